@@ -1,0 +1,85 @@
+"""Deterministic synthetic weights / frames.
+
+There is no network for datasets or checkpoints, so benchmarks and parity fixtures use
+seeded synthetic data.  Everything here is a pure function of (key name, shape, seed) on
+the CPU generator, so the golden-vector generator (which fills the *reference's* modules in
+the build container) and the GPU tests (which fill ours) get bit-identical tensors as long
+as the state-dict keys agree -- which is itself part of the drop-in contract
+(SURVEY.md Appendix B).
+"""
+import math
+import zlib
+
+import torch
+
+
+def _gen(key, seed):
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def seeded_tensor(key, shape, seed=0):
+    """Value for one state-dict entry.  Conv/linear weights: N(0, sqrt(2/fan_in)) (keeps activations
+    O(1) through ~60 ReLU layers); BN: identity (weight 1, bias 0, mean 0, var 1); biases: U(-0.1, 0.1)."""
+    g = _gen(key, seed)
+    shape = tuple(shape)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.int64)
+    is_bn = (".bn" in key) or ("downsample.1." in key) or key.startswith("backbone.bn1")
+    if is_bn:
+        if leaf in ("weight", "running_var"):
+            return torch.ones(shape)
+        return torch.zeros(shape)
+    if "conv_offset_mask" in key:
+        # reference zero-inits these (backbone.py:24-26), which would make the gather degenerate
+        if leaf == "weight":
+            return torch.randn(shape, generator=g) * 0.01
+        b = torch.zeros(shape)
+        n_off = shape[0] * 2 // 3
+        b[:n_off] = torch.rand(n_off, generator=g) * 4.0 - 2.0
+        return b
+    if key.endswith("conv_offset.weight"):  # FCB-ada 1x1 offset conv (Featurealign.py:20-25)
+        return torch.randn(shape, generator=g) * 0.5
+    if leaf == "weight":
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        return torch.randn(shape, generator=g) * math.sqrt(2.0 / max(fan_in, 1))
+    if leaf == "bias":
+        return torch.rand(shape, generator=g) * 0.2 - 0.1
+    return torch.randn(shape, generator=g)
+
+
+def detection_seeding(sd, classes=(1, 7, 13), conf_bump=6.0, centerness_bump=2.0, num_classes=41):
+    """Random heads give max class prob ~1/41 < 0.05 and centerness ~0 => zero detections.  Bump a few
+    class logits and the centerness bias so post-processing sees hundreds of candidates."""
+    for k, v in sd.items():
+        if "conf_layer" in k and k.endswith("bias") and v.numel() == num_classes:
+            for c in classes:
+                v[c] += conf_bump
+        if "centerness_layer" in k and k.endswith("bias"):
+            v += centerness_bump
+    return sd
+
+
+def fill_state_dict(module, seed=0, seed_detections=True):
+    """Overwrite every entry of module.state_dict() with its seeded value (in place) and return the dict."""
+    sd = module.state_dict()
+    new = {k: seeded_tensor(k, v.shape, seed).to(v.dtype) for k, v in sd.items()}
+    if seed_detections:
+        detection_seeding(new)
+    module.load_state_dict(new)
+    return new
+
+
+def synthetic_clip(n_frames, h=384, w=640, seed=0, device="cpu"):
+    """x_t = roll(x_0, (2t, 3t)) + 0.05 * N(0,1): real displacement for correlation / TF."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1000 + seed)
+    x0 = torch.randn(3, h, w, generator=g)
+    frames = []
+    for t in range(n_frames):
+        frames.append(torch.roll(x0, shifts=(2 * t, 3 * t), dims=(1, 2)) + 0.05 * torch.randn(3, h, w, generator=g))
+    return torch.stack(frames).to(device)

@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the REFERENCE's own Python (build container only).
+
+    python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+
+The reference (/root/reference) never travels to the GPU box; only the small .npz files
+written here do.  They hold inputs + the outputs of the reference's torch code for the
+hot-path functions:
+
+  postproc.npz   decode / center_size / jaccard / sanitize_coordinates_hw / crop /
+                 generate_candidate / Detect_TF.detect (cross-class and per-class) /
+                 generate_mask / mask_iou on seeded synthetic head outputs
+  priors.npz     PredictionModule_FC.make_priors for the five 384x640 level sizes
+  fcb_ali.npz    FeatureAlign "ali" offset construction for 3x3 / 3x5 / 5x3
+  model_*.npz    STMask.forward (eval) over a seeded 3-frame clip at reduced size for the
+                 benchmark configs, with the four third-party ops replaced by the CPU
+                 oracle (dcn_v2 / mmcv / spatial_correlation_sampler are not installed
+                 anywhere -- "parity unpinned" for those, see oracle/stm_oracle.c)
+
+The reference has no CPU path (STMask.py:15, TF_utils.py:105,109), so the stub preamble
+below fakes the CUDA-only bits; nothing of the reference is copied.
+"""
+import collections
+import collections.abc
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+import oracle  # noqa: E402
+from stmask_amd import synthetic  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- stubs
+def install_stubs():
+    sys.path.insert(0, REF)
+    collections.Sequence = collections.abc.Sequence
+    np.int = int
+    np.float = float
+    torch.cuda.current_device = lambda: "cpu"  # TF_utils.py:105,109 pass it as device=
+
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return None
+
+    def stub(name, **kw):
+        m = _Any(name)
+        m.__dict__.update(kw)
+        sys.modules[name] = m
+        return m
+
+    stub("dcn_v2", DCN=oracle.OracleDCN, DCNv2=oracle.OracleDCN)
+    mm = stub("mmcv")
+    mm.is_str = lambda x: isinstance(x, str)
+    mm.is_list_of = lambda a, b: True
+    stub("mmcv.ops", DeformConv2d=oracle.OracleDeformConv2d, roi_align=oracle.roi_align)
+    stub("mmcv.runner")
+    stub("mmcv.parallel", DataContainer=object)
+    stub("spatial_correlation_sampler", spatial_correlation_sample=oracle.spatial_correlation_sample)
+    for n in ["cocoapi", "cocoapi.PythonAPI", "cocoapi.PythonAPI.pycocotools", "pycocotools", "pycocotools.mask",
+              "cv2", "pyximport"]:
+        stub(n)
+    sys.modules["pyximport"].install = lambda *a, **k: None
+    stub("cocoapi.PythonAPI.pycocotools.ytvos", YTVOS=object)
+    stub("cocoapi.PythonAPI.pycocotools.ytvoseval", YTVOSeval=object)
+    stub("pycocotools.coco", COCO=object)
+    stub("pycocotools.cocoeval", COCOeval=object)
+    tv = stub("torchvision")
+    tv.transforms = stub("torchvision.transforms")
+    stub("utils.cython_nms", nms=None)
+    import matplotlib  # noqa: F401  (reference imports pyplot at module scope)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.ascontiguousarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, keys={sorted(out)}")
+
+
+# ----------------------------------------------------------------------------- post-processing
+def synth_head_outputs(n_priors_hw, seed, n_hot=400):
+    """Seeded synthetic head outputs shaped like forward_single's: loc, softmaxed conf, centerness,
+    mask_coeff, track; priors come from the reference's own make_priors."""
+    g = torch.Generator().manual_seed(seed)
+    N = sum(h * w for h, w in n_priors_hw) * 3
+    loc = torch.randn(N, 4, generator=g) * torch.tensor([1.0, 1.0, 1.5, 1.5])
+    logits = torch.randn(N, 41, generator=g)
+    hot = torch.randperm(N, generator=g)[:n_hot]
+    cls = torch.randint(1, 41, (n_hot,), generator=g)
+    logits[hot, cls] += torch.rand(n_hot, generator=g) * 6 + 2
+    conf = torch.softmax(logits, -1)
+    centerness = torch.tanh(torch.randn(N, 1, generator=g) + 1.0)
+    coeff = torch.randn(N, 32, generator=g)
+    track = torch.nn.functional.normalize(torch.randn(N, 128, generator=g), dim=-1)
+    return loc, conf, centerness, coeff, track
+
+
+def gen_postproc():
+    from datasets.config import cfg, set_cfg
+    set_cfg("STMask_plus_resnet50_config")
+    from layers.box_utils import decode, center_size, jaccard, sanitize_coordinates_hw, crop, mask_iou
+    from layers.mask_utils import generate_mask
+    from layers.functions import Detect_TF, generate_candidate
+    from layers.modules import PredictionModule_FC
+
+    # priors from the reference's own Python loop (prediction_head_FC.py:224-247)
+    levels = [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)]  # reduced pyramid: 1023 priors
+    pm = PredictionModule_FC.__new__(PredictionModule_FC)
+    pm.pred_aspect_ratios = cfg.backbone.pred_aspect_ratios[0]
+    pm.pred_scales = cfg.backbone.pred_scales[0]
+    priors = torch.cat([pm.make_priors(h, w, "cpu") for h, w in levels], 1)  # [1,N,4]
+
+    out = {}
+    for case, (seed, n_hot) in enumerate([(11, 300), (12, 40), (13, 900)]):
+        loc, conf, cen, coeff, track = synth_head_outputs(levels, seed, n_hot)
+        g = torch.Generator().manual_seed(100 + seed)
+        proto = torch.relu(torch.randn(24, 40, 32, generator=g))
+        boxes = decode(loc, priors[0])
+        preds = {"loc": loc[None], "conf": conf[None], "priors": priors, "mask_coeff": coeff[None],
+                 "track": track[None], "centerness": cen[None], "proto": proto[None],
+                 "T2S_feat": torch.zeros(1, 1, 2, 2), "fpn_feat": torch.zeros(1, 1, 2, 2)}
+        cand = generate_candidate(preds)[0]
+        keep_idx = torch.nonzero(conf[:, 1:].max(1)[0] > cfg.eval_conf_thresh).view(-1)
+        det = Detect_TF(cfg.num_classes, bkg_label=0, top_k=cfg.nms_top_k, conf_thresh=cfg.nms_conf_thresh,
+                        nms_thresh=cfg.nms_thresh)
+        cc = det.detect(dict(cand))
+        det.use_cross_class_nms = False
+        pc = det.detect(dict(cand))
+        masks = generate_mask(cand["proto"], cc["mask_coeff"], cc["box"])
+        masks_nocrop = generate_mask(cand["proto"], cc["mask_coeff"][:5], None)
+        bin_m = masks.gt(0.5).float()
+        miou = mask_iou(bin_m[: min(20, len(bin_m))], bin_m)
+        p = f"c{case}_"
+        out.update({
+            p + "loc": loc, p + "conf": conf, p + "centerness": cen, p + "mask_coeff": coeff,
+            p + "track": track[:, :8], p + "proto": proto, p + "boxes": boxes,
+            p + "center_size": center_size(boxes), p + "keep_idx": keep_idx,
+            p + "cand_box": cand["box"], p + "cand_conf": cand["conf"], p + "cand_centerness": cand["centerness"],
+            p + "cc_box": cc["box"], p + "cc_class": cc["class"], p + "cc_score": cc["score"],
+            p + "cc_mask_coeff": cc["mask_coeff"], p + "cc_centerness": cc["centerness"],
+            p + "pc_box": pc["box"], p + "pc_class": pc["class"], p + "pc_score": pc["score"],
+            p + "masks": masks, p + "masks_nocrop": masks_nocrop, p + "mask_iou": miou,
+            p + "jaccard": jaccard(cand["box"][:64], cand["box"][:96]),
+            p + "sanitize_hw": sanitize_coordinates_hw(cc["box"], 24, 40),
+        })
+    out["priors"] = priors[0]
+    out["levels"] = np.array(levels)
+    # crop boundary known-answer case (boxes touching 0 / 1, swapped corners)
+    kb = torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.5, 0.25, 0.25, 0.75], [0.0, 0.0, 0.024, 0.04],
+                       [0.98, 0.97, 1.0, 1.0], [0.3, 0.3, 0.3, 0.3]])
+    ones = torch.ones(24, 40, 5)
+    cm, _ = crop(ones, kb)
+    out["crop_boxes"] = kb
+    out["crop_mask"] = cm.permute(2, 0, 1).contiguous()
+    save("postproc.npz", **out)
+
+
+def gen_priors():
+    from datasets.config import cfg, set_cfg
+    set_cfg("STMask_plus_resnet50_config")
+    from layers.modules import PredictionModule_FC
+    pm = PredictionModule_FC.__new__(PredictionModule_FC)
+    pm.pred_aspect_ratios = cfg.backbone.pred_aspect_ratios[0]
+    pm.pred_scales = cfg.backbone.pred_scales[0]
+    out = {}
+    for h, w in [(48, 80), (24, 40), (12, 20), (6, 10), (3, 5)]:
+        out[f"p_{h}x{w}"] = pm.make_priors(h, w, "cpu")[0]
+    save("priors.npz", **out)
+
+
+def gen_fcb_ali():
+    from datasets.config import set_cfg
+    set_cfg("STMask_plus_resnet50_ali_config")
+    from layers.modules import FeatureAlign
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    loc = torch.randn(2, 4, 6, 10, generator=g)
+    out["loc"] = loc
+    for kh, kw in [(3, 3), (3, 5), (5, 3)]:
+        fa = FeatureAlign(8, 8, kernel_size=(kh, kw), deformable_groups=1, use_pred_offset=False)
+        captured = {}
+        fa.conv_adaption.forward = lambda x, off, _c=captured: (_c.__setitem__("off", off.clone()), x)[1]
+        fa(torch.zeros(2, 8, 6, 10), loc)
+        out[f"off_{kh}x{kw}"] = captured["off"]
+    save("fcb_ali.npz", **out)
+
+
+# ----------------------------------------------------------------------------- whole model
+def gen_model(cfg_name, tag, hw=(128, 192), n_frames=3):
+    from datasets.config import cfg, set_cfg
+    set_cfg(cfg_name)
+    import STMask as stmask_mod
+    net = stmask_mod.STMask()
+    net.eval()
+    sd = synthetic.fill_state_dict(net, seed=0)
+    frames = synthetic.synthetic_clip(n_frames, hw[0], hw[1], seed=0)
+    out = {"frames_hw": np.array(hw), "n_frames": np.array(n_frames)}
+    out["state_keys"] = np.array(sorted(sd.keys()))
+    out["state_shapes"] = np.array([str(tuple(sd[k].shape)) for k in sorted(sd.keys())])
+    with torch.no_grad():
+        fpn_outs, po = net.forward_single(frames[:1])
+        out["f0_loc"] = po["loc"][0]
+        out["f0_conf_logits"] = po["conf"][0]
+        out["f0_mask_coeff"] = po["mask_coeff"][0]
+        out["f0_centerness"] = po["centerness"][0]
+        out["f0_track_s"] = po["track"][0][::7]
+        out["f0_proto"] = po["proto"][0]
+        out["f0_priors"] = po["priors"][0]
+        out["f0_P4"] = fpn_outs[1][0, ::16]
+        for t in range(n_frames):
+            meta = [{"is_first": t == 0, "video_id": 0, "frame_id": t}]
+            res = net(frames[t:t + 1], img_meta=meta)[0]["detection"]
+            for k in ("box", "score", "class", "box_ids", "mask_coeff", "mask", "centerness"):
+                v = res.get(k, torch.zeros(0))
+                out[f"t{t}_{k}"] = v
+            print(tag, "frame", t, "n_out", len(res["box"]))
+    save(f"model_{tag}.npz", **out)
+
+
+def main():
+    install_stubs()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["postproc", "priors", "fcb_ali", "model"]
+    if "postproc" in which:
+        gen_postproc()
+    if "priors" in which:
+        gen_priors()
+    if "fcb_ali" in which:
+        gen_fcb_ali()
+    if "model" in which:
+        gen_model("STMask_plus_resnet50_config", "r50_fca")
+        gen_model("STMask_plus_resnet50_ada_config", "r50_ada")
+        gen_model("STMask_plus_resnet50_ali_config", "r50_ali")
+
+
+if __name__ == "__main__":
+    main()
