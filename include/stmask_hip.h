@@ -1,0 +1,195 @@
+/*
+ * stmask_hip.h -- flat C ABI of libstmask_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for
+ * STMask's per-frame inference hot path.
+ *
+ * This is the drop-in boundary.  The reference (MinghanLi/STMask) is pure Python; on this path it binds
+ * four un-vendored third-party CUDA extensions and a handful of torch op chains.  Each entry point below
+ * names the reference interface it replaces (file:line under the reference tree).  The Python shims in
+ * stmask_amd/ (dcn_v2.DCN, mmcv.ops.DeformConv2d / roi_align, spatial_correlation_sample, layers.*) call
+ * these through ctypes with tensor.data_ptr() and the current HIP stream; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (no allocation, no retention);
+ *   - tensors are dense, row-major, fp32 unless stated; NCHW like the reference (proto / masks NHWC / NHW
+ *     exactly as the reference lays them out);
+ *   - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*; NULL = default stream) and never
+ *     synchronise; counts that the reference obtains through a device->host sync are written to device
+ *     memory (`*_count`) so the caller decides when to read them;
+ *   - return value: STM_OK (0) or a negative STM_E* code; stm_last_error_string() (thread-local) explains it.
+ *     Nothing throws, nothing aborts;
+ *   - re-entrant: no global mutable state except the thread-local error string.
+ */
+#ifndef STMASK_HIP_H_
+#define STMASK_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STM_ABI_VERSION 1
+
+enum stm_status {
+    STM_OK = 0,
+    STM_EINVAL = -1,       /* bad dimension / unsupported combination of arguments */
+    STM_ENULL = -2,        /* required pointer is NULL */
+    STM_ELAUNCH = -3,      /* HIP reported an error when enqueuing */
+    STM_EWORKSPACE = -4,   /* workspace missing or too small (see *_workspace_bytes) */
+    STM_EUNSUPPORTED = -5  /* valid in the reference API but outside the hot path (e.g. groups != 1) */
+};
+
+typedef void* stm_stream_t; /* hipStream_t */
+
+int stm_version(void);
+const char* stm_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Deformable convolution.
+ * Replaces: dcn_v2.DCN.forward -> _backend.dcn_v2_forward (backbone.py:5,21-26,45; modulated, bias)
+ *           mmcv.ops.DeformConv2d.forward -> ext_module.deform_conv_forward
+ *                                           (Featurealign.py:3,27-31,72; no mask, no bias)
+ *
+ *   y[b,o,ho,wo] = bias[o] + sum_{c,i,j} w[o,c,i,j] * m[b,g,k,ho,wo] *
+ *                  bilinear(x[b,c], ho*sh - ph + i*dh + dy, wo*sw - pw + j*dw + dx)        k = i*kw + j
+ *   offset: channel (g*2K + 2k) = dy, (g*2K + 2k + 1) = dx;  batch stride off_bstride (elements)
+ *   mask  : channel (g*K + k); NULL -> v1 (no modulation);  batch stride mask_bstride (elements);
+ *           mask_is_logit != 0 -> sigmoid applied inside the kernel (DCN feeds the raw
+ *           conv_offset_mask output: offset = om, mask = om + 2K*Ho*Wo, both with batch stride 3K*Ho*Wo,
+ *           which fuses dcn_v2's chunk / cat / sigmoid)
+ *   a sample contributes iff -1 < y < H and -1 < x < W; out-of-range corners read 0.
+ *
+ * stm_deform_im2col_f32 writes cols[B][C*K][Ho*Wo] (row c*K + k).
+ * stm_deform_conv_fwd_f32 = im2col into `workspace` + fp32 MFMA GEMM with fused bias / optional ReLU.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct stm_deform_geom {
+    int B, C, H, W;      /* input  [B,C,H,W] */
+    int kh, kw, sh, sw;  /* kernel, stride */
+    int ph, pw, dh, dw;  /* padding, dilation */
+    int dg;              /* deformable groups (C % dg == 0) */
+    int Ho, Wo;          /* output spatial size (must match the conv arithmetic) */
+} stm_deform_geom;
+
+int stm_deform_im2col_f32(const float* x, const float* offset, int64_t off_bstride, const float* mask,
+                          int64_t mask_bstride, int mask_is_logit, float* cols, const stm_deform_geom* g,
+                          int variant, stm_stream_t stream);
+/* variant: 0 = auto, 1 = direct gather (global loads), 2 = LDS-staged input tiles */
+
+size_t stm_deform_conv_workspace_bytes(const stm_deform_geom* g);
+
+int stm_deform_conv_fwd_f32(const float* x, const float* offset, int64_t off_bstride, const float* mask,
+                            int64_t mask_bstride, int mask_is_logit, const float* weight /*[O,C,kh,kw]*/,
+                            const float* bias /*[O] or NULL*/, float* y /*[B,O,Ho,Wo]*/, int O, int relu,
+                            const stm_deform_geom* g, void* workspace, size_t workspace_bytes,
+                            stm_stream_t stream);
+
+/* Plain fp32 GEMM on the MFMA pipe (exact fp32 fmaf chain per output):
+ *   Cmat[b][M,N] = A[M,K] * Bmat[b][K,N] (+ bias[m]) (ReLU optional), b < batch, A shared by the batch.
+ * Used for the column-buffer GEMM above; exported for tests and profiling. */
+int stm_gemm_bias_f32(const float* A, const float* Bmat, const float* bias, float* Cmat, int M, int N, int K,
+                      int batch, int64_t b_bstride, int64_t c_bstride, int relu, stm_stream_t stream);
+
+/* FeatureAlign "ali" offsets (Featurealign.py:46-69): loc [B,4,H,W] -> offset [B,2*kh*kw,H,W].
+ * fp32, reference operand order, canonical exp (bit-exact against the oracle). */
+int stm_fcb_ali_offsets_f32(const float* loc, float* offset, int B, int H, int W, int kh, int kw,
+                            stm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Spatial correlation, kernel_size = 1, stride = 1, padding = 0.
+ * Replaces: spatial_correlation_sampler.spatial_correlation_sample (track_to_segment_head.py:4,53-59)
+ *           and, through scale / leaky_slope, the reference's follow-up `/ C` and leaky_relu_(0.1)
+ *           (track_to_segment_head.py:60-62).  Pass scale = 1, leaky_slope = 1 for the raw sampler.
+ *   out[b,i,j,y,x] = act(scale * sum_c f1[b,c,y,x] * f2[b,c,y+(i-P/2)*dil, x+(j-P/2)*dil])   [B,P,P,H,W]
+ * ------------------------------------------------------------------------------------------------- */
+int stm_corr_patch_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P,
+                       int dil, float scale, float leaky_slope, stm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * RoIAlign, average pooling.
+ * Replaces: mmcv.ops.roi_align -> ext_module.roi_align_forward (track_to_segment_head.py:6,86).
+ *   feat [B,C,H,W], rois [n,5] = (batch, x1, y1, x2, y2) -> out [n,C,PH,PW].
+ * ------------------------------------------------------------------------------------------------- */
+int stm_roi_align_avg_f32(const float* feat, const float* rois, float* out, int B, int C, int H, int W, int n,
+                          int PH, int PW, float spatial_scale, int sampling_ratio, int aligned,
+                          stm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Box decoding.  Replaces: layers.box_utils.decode (box_utils.py:238-283), bit-exact vs the oracle.
+ * ------------------------------------------------------------------------------------------------- */
+int stm_decode_boxes_f32(const float* loc, const float* priors, float* boxes, int64_t n,
+                         stm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Candidate generation.  Replaces: generate_candidate (TF_utils.py:54-82): decode + "max foreground
+ * confidence > thresh" + ordered boolean compaction.
+ *   loc [N,4], priors [N,4], conf [N,ncls] (soft-maxed) ->
+ *   keep_idx [N] (ascending prior indices, first *count valid), cand_box [N,4] rows compacted likewise,
+ *   count (device int).  One launch per frame; `batch` frames are processed by `batch` workgroups
+ *   (inputs / outputs strided by N rows, priors shared, count[batch]).
+ * ------------------------------------------------------------------------------------------------- */
+int stm_generate_candidates_f32(const float* loc, const float* priors, const float* conf, int N, int ncls,
+                                float thresh, int batch, int64_t* keep_idx, float* cand_box, int* count,
+                                stm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Cross-class Fast NMS.  Replaces: Detect_TF.cc_fast_nms (detection_TF.py:85-134) == Detect.cc_fast_nms
+ * (detection.py:139-187) incl. jaccard / intersect (box_utils.py:37-88).
+ *   conf [K,ncls] candidate rows (column 0 = background), boxes [K,4], centerness [K] or NULL.
+ *   score = max_{c>=1} conf * centerness; order: score desc, ties -> lower row first; top_k; IoU upper
+ *   triangle; column max; keep <= iou_thr.
+ *   Outputs (capacity top_k each): idx_out (candidate row, int64), cls_out (argmax + 1, int64),
+ *   score_out, box_out [top_k,4]; count_out (device int).
+ *   k_dev: optional device pointer holding the real K (<= K) -- lets the whole chain run without a host
+ *   sync.  `batch` independent problems are strided by K rows (outputs by top_k rows).
+ *   Indices are bit-exact against the oracle.  K <= 16384 (one workgroup sorts in LDS).
+ * ------------------------------------------------------------------------------------------------- */
+int stm_cc_fast_nms_f32(const float* conf, const float* boxes, const float* centerness, int K, int ncls,
+                        const int* k_dev, float iou_thr, int top_k, int batch, int64_t* idx_out,
+                        int64_t* cls_out, float* score_out, float* box_out, int* count_out,
+                        stm_stream_t stream);
+
+/* Per-class Fast NMS.  Replaces: Detect_TF.fast_nms (detection_TF.py:136-204) == Detect.fast_nms
+ * (detection.py:211-263).  Outputs have capacity max_det.  workspace: stm_fast_nms_workspace_bytes. */
+size_t stm_fast_nms_workspace_bytes(int K, int ncls, int top_k);
+/* Fused generate_candidate + cross-class Fast NMS (STMask.py:317-320 chain) with no host round trip.
+ *   loc [batch,N,4], priors [N,4], conf [batch,N,ncls] soft-maxed, centerness [batch,N] or NULL ->
+ *   idx_out [batch,top_k] = PRIOR index of every detection (gather mask_coeff / track rows with it),
+ *   cls / score / box likewise, count_out [batch].  Up to 16384 candidates per frame. */
+size_t stm_detect_cc_workspace_bytes(int N, int batch);
+int stm_detect_cc_f32(const float* loc, const float* priors, const float* conf, const float* centerness, int N,
+                      int ncls, float conf_thresh, float iou_thr, int top_k, int batch, int64_t* idx_out,
+                      int64_t* cls_out, float* score_out, float* box_out, int* count_out, void* workspace,
+                      size_t workspace_bytes, stm_stream_t stream);
+
+int stm_fast_nms_f32(const float* conf, const float* boxes, const float* centerness, int K, int ncls,
+                     const int* k_dev, float iou_thr, int top_k, float conf_thresh, int max_det,
+                     int64_t* idx_out, int64_t* cls_out, float* score_out, float* box_out, int* count_out,
+                     void* workspace, size_t workspace_bytes, stm_stream_t stream);
+
+/* Pairwise box IoU.  Replaces: layers.box_utils.jaccard (box_utils.py:60-88), 2-D form, bit-exact. */
+int stm_jaccard_f32(const float* a, int na, const float* b, int nb, float* out, stm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Prototype linear combination + sigmoid + crop.
+ * Replaces: generate_mask (mask_utils.py:111-128) + crop / sanitize_coordinates (box_utils.py:298-364).
+ *   proto [h,w,m] (NHWC as the reference permutes it, STMask.py:236), coeff [n,m], boxes [n,4] relative
+ *   x1y1x2y2 or NULL (no crop) -> out [n,h,w] soft masks (already in the reference's permuted layout).
+ *   apply_tanh: mask_proto_coeff_activation (config.py:447).  n_dev: optional device count (<= n).
+ * ------------------------------------------------------------------------------------------------- */
+int stm_lincomb_sigmoid_crop_f32(const float* proto, const float* coeff, const float* boxes, float* out, int h,
+                                 int w, int m, int n, int apply_tanh, const int* n_dev, stm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Binary mask IoU.  Replaces: mask_iou (box_utils.py:435-447) on m.gt(thr).float() inputs
+ * (track_TF.py:85,107).  m1 [n1,hw], m2 [n2,hw] SOFT masks (binarised `> thr` here) -> out [n1,n2].
+ * workspace: bit-packed masks, stm_mask_iou_workspace_bytes(n1, n2, hw).
+ * ------------------------------------------------------------------------------------------------- */
+size_t stm_mask_iou_workspace_bytes(int n1, int n2, int hw);
+int stm_mask_iou_f32(const float* m1, int n1, const float* m2, int n2, int hw, float thr, float* out,
+                     void* workspace, size_t workspace_bytes, stm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STMASK_HIP_H_ */

@@ -1,0 +1,61 @@
+"""ctypes binding of libstmask_hip.so (include/stmask_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstmask_hip.so")
+_lib = None
+
+c_i, c_l, c_f, c_p, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# every symbol include/stmask_hip.h declares (tests/test_abi.py checks the library exports all of them)
+ABI_SYMBOLS = [
+    "stm_version", "stm_last_error_string", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
+    "stm_deform_conv_fwd_f32", "stm_gemm_bias_f32", "stm_fcb_ali_offsets_f32", "stm_corr_patch_f32",
+    "stm_roi_align_avg_f32", "stm_decode_boxes_f32", "stm_generate_candidates_f32", "stm_cc_fast_nms_f32",
+    "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
+    "stm_jaccard_f32", "stm_lincomb_sigmoid_crop_f32", "stm_mask_iou_workspace_bytes", "stm_mask_iou_f32",
+]
+
+
+class StmError(RuntimeError):
+    pass
+
+
+class DeformGeom(ctypes.Structure):
+    _fields_ = [(n, c_i) for n in ("B", "C", "H", "W", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw", "dg", "Ho", "Wo")]
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StmError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback on the product path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.stm_last_error_string.restype = ctypes.c_char_p
+        _lib.stm_version.restype = c_i
+        for name in ("stm_deform_conv_workspace_bytes", "stm_detect_cc_workspace_bytes", "stm_fast_nms_workspace_bytes",
+                     "stm_mask_iou_workspace_bytes"):
+            getattr(_lib, name).restype = c_sz
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().stm_last_error_string().decode(errors="replace")
+        raise StmError(f"{what} failed with code {rc}: {msg}")

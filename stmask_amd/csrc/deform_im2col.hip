@@ -1,0 +1,372 @@
+// deform_im2col.hip -- modulated deformable im2col for gfx950 (MI355X).
+//
+// Replaces the im2col half of dcn_v2.DCN (backbone.py:21-26,45) and mmcv.ops.DeformConv2d
+// (Featurealign.py:27-31,72).  HBM-bound: per image it reads x (C*H*W), offsets+mask (3K*Ho*Wo) and writes
+// the column buffer (C*K*Ho*Wo floats) -- the write dominates.
+//
+// Two variants behind one entry point:
+//   1  direct   : one thread per (position, tap), loops channels, 4 global gathers per output.  Simple,
+//                 used as the cross-check and for shapes the tiled kernel does not like.
+//   2  LDS tiled: a workgroup owns TH full output rows x CCH channels.  The input rows those outputs can
+//                 touch (+/- HALO rows for the learned offsets, +1 zero column each side) are staged once
+//                 into LDS, four channels interleaved per pixel, so one ds_read_b128 per bilinear corner
+//                 serves four channels and the zero padding removes every border test from the inner loop.
+//                 Each work item is 4 consecutive output positions of one tap: offsets / mask are read as
+//                 coalesced 16-byte loads, results leave as coalesced 16-byte stores (one per channel).
+//                 Samples whose corners leave the staged rows (large offsets) fall back to global gathers,
+//                 so the result is exact for ANY offset.
+#include "stm_common.h"
+
+namespace {
+
+struct ImcolArgs {
+    const float* x;
+    const float* off;
+    const float* mask;
+    float* cols;
+    int64_t off_bs, mask_bs;
+    int mask_logit;
+    int B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, dg, Ho, Wo;
+    // tiled variant only
+    int th, cch, R, LW, halo, tiles_y;
+};
+
+__device__ __forceinline__ float sigmoidf_dev(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// Bilinear sample with the DCNv2 border rule straight from global memory (fallback / direct variant).
+__device__ __forceinline__ float sample_global(const float* __restrict__ im, int H, int W, float fy, float fx)
+{
+    if (!(fy > -1.0f && fx > -1.0f && fy < (float)H && fx < (float)W)) return 0.0f;
+    float fl_y = floorf(fy), fl_x = floorf(fx);
+    int h_low = (int)fl_y, w_low = (int)fl_x;
+    int h_high = h_low + 1, w_high = w_low + 1;
+    float lh = fy - fl_y, lw = fx - fl_x, hh = 1.0f - lh, hw = 1.0f - lw;
+    float v1 = (h_low >= 0 && w_low >= 0) ? im[h_low * W + w_low] : 0.0f;
+    float v2 = (h_low >= 0 && w_high <= W - 1) ? im[h_low * W + w_high] : 0.0f;
+    float v3 = (h_high <= H - 1 && w_low >= 0) ? im[h_high * W + w_low] : 0.0f;
+    float v4 = (h_high <= H - 1 && w_high <= W - 1) ? im[h_high * W + w_high] : 0.0f;
+    return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+}
+
+// ------------------------------------------------------------------------------------ variant 1
+// grid: x = ceil(HWo/256), y = dg * chunks_per_group * K, z = B
+__global__ __launch_bounds__(256) void deform_im2col_direct(ImcolArgs a, int cpb, int chunks_per_group)
+{
+    const int K = a.kh * a.kw;
+    const int HWo = a.Ho * a.Wo;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= HWo) return;
+    int by = blockIdx.y;
+    const int k = by % K;
+    by /= K;
+    const int chunk = by % chunks_per_group;
+    const int g = by / chunks_per_group;
+    const int b = blockIdx.z;
+    const int Cg = a.C / a.dg;
+    const int c0 = g * Cg + chunk * cpb;
+    const int c1 = min(g * Cg + Cg, c0 + cpb);
+
+    const int ho = n / a.Wo, wo = n - ho * a.Wo;
+    const int i = k / a.kw, j = k - i * a.kw;
+    const float* ob = a.off + (int64_t)b * a.off_bs + (int64_t)g * 2 * K * HWo;
+    const float dy = ob[(int64_t)(2 * k) * HWo + n];
+    const float dx = ob[(int64_t)(2 * k + 1) * HWo + n];
+    float m = 1.0f;
+    if (a.mask) {
+        m = a.mask[(int64_t)b * a.mask_bs + (int64_t)(g * K + k) * HWo + n];
+        if (a.mask_logit) m = sigmoidf_dev(m);
+    }
+    const float fy = (float)(ho * a.sh - a.ph + i * a.dh) + dy;
+    const float fx = (float)(wo * a.sw - a.pw + j * a.dw) + dx;
+
+    // corner weights (mask folded in) and clamped addresses, computed once for all channels
+    float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+    int a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    if (fy > -1.0f && fx > -1.0f && fy < (float)a.H && fx < (float)a.W) {
+        float fl_y = floorf(fy), fl_x = floorf(fx);
+        int h_low = (int)fl_y, w_low = (int)fl_x, h_high = h_low + 1, w_high = w_low + 1;
+        float lh = fy - fl_y, lw = fx - fl_x, hh = 1.0f - lh, hw = 1.0f - lw;
+        bool t = h_low >= 0, l = w_low >= 0, bt = h_high <= a.H - 1, r = w_high <= a.W - 1;
+        int hl = max(h_low, 0), wl = max(w_low, 0), hh_i = min(h_high, a.H - 1), wh_i = min(w_high, a.W - 1);
+        w1 = (t && l) ? hh * hw * m : 0.f;
+        w2 = (t && r) ? hh * lw * m : 0.f;
+        w3 = (bt && l) ? lh * hw * m : 0.f;
+        w4 = (bt && r) ? lh * lw * m : 0.f;
+        a1 = hl * a.W + wl;
+        a2 = hl * a.W + wh_i;
+        a3 = hh_i * a.W + wl;
+        a4 = hh_i * a.W + wh_i;
+    }
+    const int64_t HW = (int64_t)a.H * a.W;
+    const float* xb = a.x + ((int64_t)b * a.C + c0) * HW;
+    float* cb = a.cols + (((int64_t)b * a.C + c0) * K + k) * HWo + n;
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) {
+        float v = w1 * xb[a1] + w2 * xb[a2] + w3 * xb[a3] + w4 * xb[a4];
+        *cb = v;
+        xb += HW;
+        cb += (int64_t)K * HWo;
+    }
+}
+
+// ------------------------------------------------------------------------------------ variant 2
+// grid: x = tiles_y * (C / cch), y = B.  Dynamic LDS: (cch/4) * R * LW float4.
+template <int NP>
+__global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
+{
+    extern __shared__ float4 tile[];
+    const int K = a.kh * a.kw;
+    const int HWo = a.Ho * a.Wo;
+    const int64_t HW = (int64_t)a.H * a.W;
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x % a.tiles_y;
+    const int chunk = blockIdx.x / a.tiles_y;
+    const int b = blockIdx.y;
+    const int c0 = chunk * a.cch;
+    const int g = c0 / (a.C / a.dg);
+    const int nq = a.cch >> 2;
+    const int ho0 = ty * a.th;
+    const int rows_out = min(a.th, a.Ho - ho0);
+    const int y0 = ho0 * a.sh - a.ph - a.halo;  // input row held by LDS row 0
+    const int RL = a.R * a.LW;
+
+    // ---- stage: thread <-> pixel, 4 channel loads (each coalesced across the wave) -> one ds_write_b128
+    {
+        const float* xb = a.x + ((int64_t)b * a.C + c0) * HW;
+        for (int idx = tid; idx < nq * RL; idx += 256) {
+            int q = idx / RL;
+            int rem = idx - q * RL;
+            int r = rem / a.LW;
+            int col = rem - r * a.LW;
+            int yy = y0 + r, xx = col - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                const float* p = xb + (int64_t)(4 * q) * HW + (int64_t)yy * a.W + xx;
+                v.x = p[0];
+                v.y = p[HW];
+                v.z = p[2 * HW];
+                v.w = p[3 * HW];
+            }
+            tile[idx] = v;
+        }
+    }
+    __syncthreads();
+
+    const int n0 = ho0 * a.Wo;
+    const int NT = rows_out * a.Wo;
+    const int items_per_k = (NT + NP - 1) / NP;
+    const float* ob = a.off + (int64_t)b * a.off_bs + (int64_t)g * 2 * K * HWo;
+    const float* mb = a.mask ? a.mask + (int64_t)b * a.mask_bs + (int64_t)g * K * HWo : nullptr;
+
+    for (int item = tid; item < K * items_per_k; item += 256) {
+        const int k = item / items_per_k;
+        const int pq = item - k * items_per_k;
+        const int i = k / a.kw, j = k - i * a.kw;
+        const int nl = pq * NP;  // first position of the item, relative to the tile
+        const int nb = n0 + nl;
+
+        float dyv[NP], dxv[NP], mv[NP];
+        if (NP == 4) {
+            float4 t0 = *reinterpret_cast<const float4*>(ob + (int64_t)(2 * k) * HWo + nb);
+            float4 t1 = *reinterpret_cast<const float4*>(ob + (int64_t)(2 * k + 1) * HWo + nb);
+            dyv[0] = t0.x; dyv[1 % NP] = t0.y; dyv[2 % NP] = t0.z; dyv[3 % NP] = t0.w;
+            dxv[0] = t1.x; dxv[1 % NP] = t1.y; dxv[2 % NP] = t1.z; dxv[3 % NP] = t1.w;
+            if (mb) {
+                float4 t2 = *reinterpret_cast<const float4*>(mb + (int64_t)k * HWo + nb);
+                mv[0] = t2.x; mv[1 % NP] = t2.y; mv[2 % NP] = t2.z; mv[3 % NP] = t2.w;
+            }
+        } else {
+            dyv[0] = ob[(int64_t)(2 * k) * HWo + nb];
+            dxv[0] = ob[(int64_t)(2 * k + 1) * HWo + nb];
+            if (mb) mv[0] = mb[(int64_t)k * HWo + nb];
+        }
+
+        // per-position coefficients
+        float w1[NP], w2[NP], w3[NP], w4[NP], fyv[NP], fxv[NP];
+        int la[NP];          // LDS index of the (h_low, w_low) corner
+        unsigned farmask = 0;  // positions whose corners leave the staged rows
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float m = 1.0f;
+            if (mb) m = a.mask_logit ? sigmoidf_dev(mv[p]) : mv[p];
+            int n = nb + p;
+            int ho = n / a.Wo, wo = n - ho * a.Wo;
+            float fy = (float)(ho * a.sh - a.ph + i * a.dh) + dyv[p];
+            float fx = (float)(wo * a.sw - a.pw + j * a.dw) + dxv[p];
+            fyv[p] = fy;
+            fxv[p] = fx;
+            bool valid = fy > -1.0f && fx > -1.0f && fy < (float)a.H && fx < (float)a.W;
+            float fl_y = floorf(fy), fl_x = floorf(fx);
+            int h_low = (int)fl_y, w_low = (int)fl_x;
+            float lh = fy - fl_y, lw = fx - fl_x, hh = 1.0f - lh, hw = 1.0f - lw;
+            int r = h_low - y0;
+            bool in_rows = (r >= 0) && (r + 1 < a.R);
+            bool use = valid && in_rows;
+            w1[p] = use ? hh * hw * m : 0.f;
+            w2[p] = use ? hh * lw * m : 0.f;
+            w3[p] = use ? lh * hw * m : 0.f;
+            w4[p] = use ? lh * lw * m : 0.f;
+            la[p] = use ? (r * a.LW + w_low + 1) : 0;
+            if (valid && !in_rows) farmask |= (1u << p);
+            if (mb) mv[p] = m;
+        }
+
+        float* cb = a.cols + (((int64_t)b * a.C + c0) * K + k) * HWo + nb;
+        for (int q = 0; q < nq; ++q) {
+            const float4* tq = tile + q * RL;
+            float4 acc[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float4 v1 = tq[la[p]];
+                const float4 v2 = tq[la[p] + 1];
+                const float4 v3 = tq[la[p] + a.LW];
+                const float4 v4 = tq[la[p] + a.LW + 1];
+                acc[p].x = w1[p] * v1.x + w2[p] * v2.x + w3[p] * v3.x + w4[p] * v4.x;
+                acc[p].y = w1[p] * v1.y + w2[p] * v2.y + w3[p] * v3.y + w4[p] * v4.y;
+                acc[p].z = w1[p] * v1.z + w2[p] * v2.z + w3[p] * v3.z + w4[p] * v4.z;
+                acc[p].w = w1[p] * v1.w + w2[p] * v2.w + w3[p] * v3.w + w4[p] * v4.w;
+            }
+            if (farmask) {  // rare: offsets larger than the halo -> exact global gather
+                const float* xc = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    if (farmask & (1u << p)) {
+                        float m = mb ? mv[p] : 1.0f;
+                        acc[p].x = m * sample_global(xc, a.H, a.W, fyv[p], fxv[p]);
+                        acc[p].y = m * sample_global(xc + HW, a.H, a.W, fyv[p], fxv[p]);
+                        acc[p].z = m * sample_global(xc + 2 * HW, a.H, a.W, fyv[p], fxv[p]);
+                        acc[p].w = m * sample_global(xc + 3 * HW, a.H, a.W, fyv[p], fxv[p]);
+                    }
+            }
+            float* c_ = cb + (int64_t)(4 * q) * K * HWo;
+            const int64_t cs = (int64_t)K * HWo;
+            if (NP == 4) {
+                *reinterpret_cast<float4*>(c_) = make_float4(acc[0].x, acc[1 % NP].x, acc[2 % NP].x, acc[3 % NP].x);
+                *reinterpret_cast<float4*>(c_ + cs) = make_float4(acc[0].y, acc[1 % NP].y, acc[2 % NP].y, acc[3 % NP].y);
+                *reinterpret_cast<float4*>(c_ + 2 * cs) = make_float4(acc[0].z, acc[1 % NP].z, acc[2 % NP].z, acc[3 % NP].z);
+                *reinterpret_cast<float4*>(c_ + 3 * cs) = make_float4(acc[0].w, acc[1 % NP].w, acc[2 % NP].w, acc[3 % NP].w);
+            } else {
+                c_[0] = acc[0].x;
+                c_[cs] = acc[0].y;
+                c_[2 * cs] = acc[0].z;
+                c_[3 * cs] = acc[0].w;
+            }
+        }
+    }
+}
+
+int env_int(const char* name, int dflt)
+{
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+}  // namespace
+
+static int validate_geom(const stm_deform_geom* g, const char* who)
+{
+    STM_REQUIRE(g, STM_ENULL, "%s: geometry is NULL", who);
+    STM_REQUIRE(g->B > 0 && g->C > 0 && g->H > 0 && g->W > 0, STM_EINVAL, "%s: empty input %dx%dx%dx%d", who, g->B,
+                g->C, g->H, g->W);
+    STM_REQUIRE(g->kh > 0 && g->kw > 0 && g->sh > 0 && g->sw > 0 && g->dh > 0 && g->dw > 0 && g->ph >= 0 &&
+                    g->pw >= 0,
+                STM_EINVAL, "%s: bad kernel/stride/pad/dilation", who);
+    STM_REQUIRE(g->dg > 0 && g->C % g->dg == 0, STM_EINVAL, "%s: C=%d not divisible by deform groups %d", who, g->C,
+                g->dg);
+    int Ho = (g->H + 2 * g->ph - (g->dh * (g->kh - 1) + 1)) / g->sh + 1;
+    int Wo = (g->W + 2 * g->pw - (g->dw * (g->kw - 1) + 1)) / g->sw + 1;
+    STM_REQUIRE(Ho == g->Ho && Wo == g->Wo, STM_EINVAL, "%s: output size %dx%d does not match conv arithmetic %dx%d",
+                who, g->Ho, g->Wo, Ho, Wo);
+    return STM_OK;
+}
+
+extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_t off_bstride, const float* mask,
+                                     int64_t mask_bstride, int mask_is_logit, float* cols, const stm_deform_geom* g,
+                                     int variant, stm_stream_t stream)
+{
+    int rc = validate_geom(g, "stm_deform_im2col_f32");
+    if (rc) return rc;
+    STM_REQUIRE(x && offset && cols, STM_ENULL, "stm_deform_im2col_f32: x/offset/cols must be non-NULL");
+    const int K = g->kh * g->kw, HWo = g->Ho * g->Wo, Cg = g->C / g->dg;
+    STM_REQUIRE(off_bstride >= (int64_t)g->dg * 2 * K * HWo, STM_EINVAL,
+                "stm_deform_im2col_f32: offset batch stride %lld < %lld", (long long)off_bstride,
+                (long long)g->dg * 2 * K * HWo);
+    STM_REQUIRE(!mask || mask_bstride >= (int64_t)g->dg * K * HWo, STM_EINVAL,
+                "stm_deform_im2col_f32: mask batch stride too small");
+    STM_REQUIRE(variant >= 0 && variant <= 2, STM_EINVAL, "stm_deform_im2col_f32: variant %d not in 0..2", variant);
+
+    ImcolArgs a;
+    a.x = x; a.off = offset; a.mask = mask; a.cols = cols;
+    a.off_bs = off_bstride; a.mask_bs = mask ? mask_bstride : 0; a.mask_logit = mask_is_logit;
+    a.B = g->B; a.C = g->C; a.H = g->H; a.W = g->W; a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw;
+    a.ph = g->ph; a.pw = g->pw; a.dh = g->dh; a.dw = g->dw; a.dg = g->dg; a.Ho = g->Ho; a.Wo = g->Wo;
+    a.th = a.cch = a.R = a.LW = a.halo = a.tiles_y = 0;
+
+    if (variant == 0) variant = env_int("STM_IM2COL_VARIANT", 0);
+    bool tiled_ok = (Cg % 4 == 0);
+    if (variant == 0) variant = tiled_ok ? 2 : 1;
+    if (variant == 2 && !tiled_ok) variant = 1;
+
+    if (variant == 1) {
+        // channels per block: keep >= ~1024 blocks in flight, but amortise the coefficient set-up
+        int cpb = Cg;
+        int64_t base_blocks = (int64_t)stm_cdiv(HWo, 256) * K * g->dg * g->B;
+        while (cpb > 16 && base_blocks * (Cg / cpb) < 2048 && cpb % 2 == 0) cpb /= 2;
+        int chunks = stm_cdiv(Cg, cpb);
+        dim3 grid(stm_cdiv(HWo, 256), g->dg * chunks * K, g->B);
+        hipLaunchKernelGGL(deform_im2col_direct, grid, dim3(256), 0, stm_hs(stream), a, cpb, chunks);
+        STM_CHECK_LAUNCH("deform_im2col_direct");
+        return STM_OK;
+    }
+
+    // ---- tiled: pick rows per tile / channels per block --------------------------------------------
+    const int halo = env_int("STM_IM2COL_HALO", 2);
+    const int LW = g->W + 2;
+    bool vec = (HWo % 4 == 0) && (off_bstride % 4 == 0) && (!mask || mask_bstride % 4 == 0) &&
+               ((uintptr_t)offset % 16 == 0) && (!mask || (uintptr_t)mask % 16 == 0) && ((uintptr_t)cols % 16 == 0);
+    // rows per tile: ~512-1024 (position, tap) items per workgroup; with 16-byte stores th*Wo % 4 == 0
+    int th = env_int("STM_IM2COL_TH", 0);
+    if (th <= 0) {
+        th = 1;
+        while (th < g->Ho && (int64_t)th * g->Wo * K / (vec ? 4 : 1) < 512) ++th;
+    }
+    th = min(th, g->Ho);
+    if (vec) {
+        int step = 1;
+        while ((step * g->Wo) % 4 != 0) ++step;  // step in {1,2,4}
+        th = ((th + step - 1) / step) * step;
+        if (th > g->Ho) th = g->Ho;  // last tile = remaining rows; HWo % 4 == 0 keeps it aligned
+        if ((th * g->Wo) % 4 != 0) vec = false;
+    }
+    const int R = (th - 1) * g->sh + (g->kh - 1) * g->dh + 2 + 2 * halo;
+    const size_t quad_bytes = (size_t)R * LW * sizeof(float4);
+    const size_t lds_budget = (size_t)env_int("STM_IM2COL_LDS_KB", 48) * 1024;
+    int cch = env_int("STM_IM2COL_CCH", 0);
+    if (cch <= 0) {
+        cch = 4;
+        for (int c = 4; c <= Cg && c <= 32; c += 4)
+            if (Cg % c == 0 && (size_t)(c / 4) * quad_bytes <= lds_budget) cch = c;
+    }
+    STM_REQUIRE(cch % 4 == 0 && Cg % cch == 0, STM_EINVAL, "stm_deform_im2col_f32: channels per block %d invalid", cch);
+    size_t lds = (size_t)(cch / 4) * quad_bytes;
+    if (lds > 160 * 1024) {  // a single quad of this tile does not fit: use the direct kernel
+        return stm_deform_im2col_f32(x, offset, off_bstride, mask, mask_bstride, mask_is_logit, cols, g, 1, stream);
+    }
+    a.th = th; a.cch = cch; a.R = R; a.LW = LW; a.halo = halo; a.tiles_y = stm_cdiv(g->Ho, th);
+    dim3 grid(a.tiles_y * (g->C / cch), g->B);
+    if (vec) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(deform_im2col_lds<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(deform_im2col_lds<4>, grid, dim3(256), lds, stm_hs(stream), a);
+    } else {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(deform_im2col_lds<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(deform_im2col_lds<1>, grid, dim3(256), lds, stm_hs(stream), a);
+    }
+    STM_CHECK_LAUNCH("deform_im2col_lds");
+    return STM_OK;
+}
+
+extern "C" int stm_validate_deform_geom(const stm_deform_geom* g) { return validate_geom(g, "stm_deform_geom"); }

@@ -1,0 +1,165 @@
+// mask_ops.hip -- prototype linear combination + sigmoid + crop, and binary mask IoU, for gfx950.
+//
+// lincomb replaces generate_mask (layers/mask_utils.py:111-128) + crop / sanitize_coordinates
+// (layers/box_utils.py:298-364): the reference runs a matmul, tanh, sigmoid, 8 element-wise kernels and a
+// permute copy; here it is one write-dominated pass (bytes = proto 1.97 MB + n * 61 KB).
+//   One thread = one prototype pixel (its 32 prototype values stay in registers); a workgroup covers 256
+//   consecutive pixels x DCHUNK detections; tanh(coeff) and the crop rectangles of the chunk sit in LDS and are
+//   read as broadcasts; each output row [d][pixel] is written with coalesced stores.  Pixels outside the crop
+//   rectangle skip the dot product and store 0.
+//
+// mask_iou replaces layers/box_utils.py:435-447 applied to m.gt(0.5).float() (track_TF.py:85,107): masks are
+// bit-packed with wavefront ballots (64 pixels -> one 64-bit word), pairs are reduced with popcount.
+#include "stm_common.h"
+
+namespace {
+
+constexpr int LC_DCHUNK = 8;   // detections per workgroup
+
+template <int M>
+__global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ proto, const float* __restrict__ coeff,
+                                                      const float* __restrict__ boxes, float* __restrict__ out, int h,
+                                                      int w, int n, int apply_tanh, const int* __restrict__ n_dev)
+{
+    __shared__ float sc[LC_DCHUNK * M];
+    __shared__ float sb[LC_DCHUNK * 4];  // x1, x2, y1, y2 (float bounds, padding 1)
+    const int hw = h * w;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int d0 = blockIdx.y * LC_DCHUNK;
+    const int nd = min(LC_DCHUNK, n - d0);
+    const int n_valid = n_dev ? min(max(*n_dev, 0), n) : n;
+
+    for (int idx = threadIdx.x; idx < nd * M; idx += 256) {
+        float v = coeff[(int64_t)d0 * M + idx];
+        sc[idx] = apply_tanh ? tanhf(v) : v;
+    }
+    if (threadIdx.x < nd) {
+        float x1 = 0.f, x2 = (float)w, y1 = 0.f, y2 = (float)h;
+        if (boxes) {
+            const float* b = boxes + (int64_t)(d0 + threadIdx.x) * 4;
+            stm_sanitize(b[0], b[2], w, 1, x1, x2);
+            stm_sanitize(b[1], b[3], h, 1, y1, y2);
+        }
+        sb[threadIdx.x * 4 + 0] = x1;
+        sb[threadIdx.x * 4 + 1] = x2;
+        sb[threadIdx.x * 4 + 2] = y1;
+        sb[threadIdx.x * 4 + 3] = y2;
+    }
+    __syncthreads();
+    if (pix >= hw) return;
+
+    float p[M];
+    const float4* pr = reinterpret_cast<const float4*>(proto + (int64_t)pix * M);
+#pragma unroll
+    for (int q = 0; q < M / 4; ++q) {
+        float4 v = pr[q];
+        p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+    }
+    const int y = pix / w, x = pix - y * w;
+    const float fx = (float)x, fy = (float)y;
+    for (int d = 0; d < nd; ++d) {
+        float v = 0.0f;
+        const bool inside = (d0 + d < n_valid) && fx >= sb[d * 4] && fx < sb[d * 4 + 1] && fy >= sb[d * 4 + 2] &&
+                            fy < sb[d * 4 + 3];
+        if (inside) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < M; ++k) acc = fmaf(p[k], sc[d * M + k], acc);
+            v = 1.0f / (1.0f + expf(-acc));
+        }
+        out[(int64_t)(d0 + d) * hw + pix] = v;
+    }
+}
+
+// 64 consecutive pixels -> one 64-bit word via ballot.  grid: (ceil(words/4), n), block 256 = 4 waves = 4 words
+__global__ __launch_bounds__(256) void mask_pack_kernel(const float* __restrict__ m, unsigned long long* __restrict__ bits,
+                                                        int hw, int words, float thr)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int word = blockIdx.x * 4 + wave;
+    const int i = blockIdx.y;
+    if (word >= words) return;
+    const int pix = word * 64 + lane;
+    bool b = false;
+    if (pix < hw) b = m[(int64_t)i * hw + pix] > thr;
+    unsigned long long bal = __ballot(b);
+    if (lane == 0) bits[(int64_t)i * words + word] = bal;
+}
+
+// grid: (ceil(n2/256), n1); row i of m1 staged in LDS, one thread per column j
+__global__ __launch_bounds__(256) void mask_iou_pairs_kernel(const unsigned long long* __restrict__ b1,
+                                                             const unsigned long long* __restrict__ b2, int n2, int words,
+                                                             float* __restrict__ out)
+{
+    extern __shared__ unsigned long long arow[];
+    const int i = blockIdx.y;
+    for (int t = threadIdx.x; t < words; t += 256) arow[t] = b1[(int64_t)i * words + t];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n2) return;
+    int inter = 0, a1 = 0, a2 = 0;
+    const unsigned long long* q = b2 + (int64_t)j * words;
+    for (int t = 0; t < words; ++t) {
+        unsigned long long a = arow[t], b = q[t];
+        inter += __popcll(a & b);
+        a1 += __popcll(a);
+        a2 += __popcll(b);
+    }
+    float fi = (float)inter, uni = ((float)a1 + (float)a2) - fi;
+    out[(int64_t)i * n2 + j] = (uni == 0.0f) ? 0.0f : fi / uni;
+}
+
+}  // namespace
+
+extern "C" int stm_lincomb_sigmoid_crop_f32(const float* proto, const float* coeff, const float* boxes, float* out, int h,
+                                            int w, int m, int n, int apply_tanh, const int* n_dev, stm_stream_t stream)
+{
+    STM_REQUIRE(n >= 0, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: n=%d", n);
+    if (n == 0) return STM_OK;
+    STM_REQUIRE(proto && coeff && out, STM_ENULL, "stm_lincomb_sigmoid_crop_f32: proto/coeff/out must be non-NULL");
+    STM_REQUIRE(h > 0 && w > 0, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: bad mask size %dx%d", h, w);
+    STM_REQUIRE((uintptr_t)proto % 16 == 0, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: proto must be 16-byte aligned");
+    dim3 grid(stm_cdiv((int64_t)h * w, 256), stm_cdiv(n, LC_DCHUNK));
+    STM_REQUIRE(grid.y <= 65535, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: n=%d too large", n);
+    if (m == 32) {
+        hipLaunchKernelGGL(lincomb_kernel<32>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
+                           apply_tanh, n_dev);
+    } else if (m == 8) {
+        hipLaunchKernelGGL(lincomb_kernel<8>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
+                           apply_tanh, n_dev);
+    } else if (m == 64) {
+        hipLaunchKernelGGL(lincomb_kernel<64>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
+                           apply_tanh, n_dev);
+    } else {
+        STM_REQUIRE(false, STM_EUNSUPPORTED, "stm_lincomb_sigmoid_crop_f32: mask_dim %d not in {8,32,64}", m);
+    }
+    STM_CHECK_LAUNCH("lincomb_kernel");
+    return STM_OK;
+}
+
+extern "C" size_t stm_mask_iou_workspace_bytes(int n1, int n2, int hw)
+{
+    size_t words = (size_t)((hw + 63) / 64);
+    return ((size_t)n1 + (size_t)n2) * words * 8 + 64;
+}
+
+extern "C" int stm_mask_iou_f32(const float* m1, int n1, const float* m2, int n2, int hw, float thr, float* out,
+                                void* workspace, size_t workspace_bytes, stm_stream_t stream)
+{
+    STM_REQUIRE(n1 >= 0 && n2 >= 0 && hw > 0, STM_EINVAL, "stm_mask_iou_f32: bad sizes");
+    if (n1 == 0 || n2 == 0) return STM_OK;
+    STM_REQUIRE(m1 && m2 && out, STM_ENULL, "stm_mask_iou_f32: m1/m2/out must be non-NULL");
+    STM_REQUIRE(workspace && workspace_bytes >= stm_mask_iou_workspace_bytes(n1, n2, hw), STM_EWORKSPACE,
+                "stm_mask_iou_f32: workspace too small");
+    STM_REQUIRE(n1 <= 65535 && n2 <= 65535, STM_EINVAL, "stm_mask_iou_f32: too many masks");
+    const int words = (hw + 63) / 64;
+    unsigned long long* b1 = reinterpret_cast<unsigned long long*>(workspace);
+    unsigned long long* b2 = b1 + (size_t)n1 * words;
+    hipLaunchKernelGGL(mask_pack_kernel, dim3(stm_cdiv(words, 4), n1), dim3(256), 0, stm_hs(stream), m1, b1, hw, words, thr);
+    hipLaunchKernelGGL(mask_pack_kernel, dim3(stm_cdiv(words, 4), n2), dim3(256), 0, stm_hs(stream), m2, b2, hw, words, thr);
+    STM_CHECK_LAUNCH("mask_pack_kernel");
+    hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n2, 256), n1), dim3(256), (size_t)words * 8, stm_hs(stream), b1,
+                       b2, n2, words, out);
+    STM_CHECK_LAUNCH("mask_iou_pairs_kernel");
+    return STM_OK;
+}

@@ -1,0 +1,95 @@
+// stm_common.h -- shared helpers for the gfx950 kernels behind include/stmask_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/stmask_hip.h"
+
+#define STM_WAVE 64  // gfx950 wavefront width (hard-coded: warpSize folds to 64, no macro exists)
+
+void stm_set_error(const char* fmt, ...);
+
+#define STM_REQUIRE(cond, code, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            stm_set_error(__VA_ARGS__);   \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+#define STM_CHECK_LAUNCH(name)                                                       \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            stm_set_error("%s: launch failed: %s", (name), hipGetErrorString(e_));   \
+            return STM_ELAUNCH;                                                      \
+        }                                                                            \
+    } while (0)
+
+static inline hipStream_t stm_hs(stm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int stm_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers -----------------------------------------------------------------------------
+
+// Canonical exp (oracle/stm_oracle.c: stm_exp_f64): identical IEEE operation sequence in double, rounded
+// once to fp32.  Compiled with -ffp-contract=off; every fused step is an explicit fma().
+__device__ __forceinline__ double stm_exp_f64(double x)
+{
+    if (x > 709.0) return __longlong_as_double(0x7FF0000000000000LL);
+    if (x < -745.0) return 0.0;
+    const double LOG2E = 1.4426950408889634074;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double kf = rint(x * LOG2E);
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int k = (int)kf;
+    int k1 = k / 2, k2 = k - k1;
+    double s1 = __longlong_as_double((long long)(k1 + 1023) << 52);
+    double s2 = __longlong_as_double((long long)(k2 + 1023) << 52);
+    return p * s1 * s2;
+}
+
+__device__ __forceinline__ float stm_expf_canon(float x) { return (float)stm_exp_f64((double)x); }
+
+// box_utils.py:37-88 in fp32, reference operand order (no contraction: -ffp-contract=off).
+__device__ __forceinline__ float stm_iou(const float4 a, const float4 b)
+{
+    float mx = fminf(a.z, b.z) - fmaxf(a.x, b.x);
+    float my = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+    mx = mx < 0.0f ? 0.0f : mx;
+    my = my < 0.0f ? 0.0f : my;
+    float inter = mx * my;
+    float area_a = (a.z - a.x) * (a.w - a.y);
+    float area_b = (b.z - b.x) * (b.w - b.y);
+    float uni = area_a + area_b - inter;
+    return inter / uni;
+}
+
+// box_utils.py:298-316 (cast=False)
+__device__ __forceinline__ void stm_sanitize(float x1, float x2, int size, int padding, float& lo, float& hi)
+{
+    float a = x1 * (float)size, b = x2 * (float)size;
+    float l = fminf(a, b), h = fmaxf(a, b);
+    l = l - (float)padding;
+    h = h + (float)padding;
+    lo = l < 0.0f ? 0.0f : l;
+    hi = h > (float)size ? (float)size : h;
+}

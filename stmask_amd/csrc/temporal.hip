@@ -1,0 +1,246 @@
+// temporal.hip -- temporal-fusion kernels for gfx950: spatial correlation (patch sampler) and RoIAlign.
+//
+// Correlation replaces spatial_correlation_sampler.spatial_correlation_sample as called by
+// layers/modules/track_to_segment_head.py:53-59 (kernel_size 1, patch 11, stride 1, padding 0) plus the
+// reference's follow-up `/ C` and leaky_relu_(0.1) (:60-62).  2.4 MB of traffic and 59.5 MFLOP per frame pair:
+// bandwidth/latency bound, so the kernel is organised around LDS reuse, not MFMA.
+//
+//   One workgroup = one output row y of one image.  Work item = (4 consecutive x, one displacement row i):
+//   it needs f1[c][y][x0..x0+3] and the 14 values f2[c][y+i-5][x0-5..x0+8] -- a sliding window held in
+//   registers -- and produces 4 x 11 dot products (44 FMAs per channel for 5 ds_read_b128/b64).  Channels are
+//   staged through LDS in chunks (f2 rows zero-padded by 5 on each side so no border tests remain).  A wave
+//   carries 32 items x 2 channel halves: lanes l and l+32 work on the same item with different channels and
+//   the halves are summed at the end with a wavefront shuffle (ds_swizzle / permlane), then scaled and
+//   leaky-ReLU'd in registers before one coalesced store.
+#include "stm_common.h"
+
+namespace {
+
+constexpr int CORR_CCK = 16;  // channels staged per chunk (8 per half-wave)
+
+template <int P>
+__global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                        float* __restrict__ out, int C, int H, int W, float scale,
+                                                        float slope)
+{
+    constexpr int R = P / 2;
+    constexpr int WIN = 4 + P - 1;          // f2 values per item per channel (14 for P = 11)
+    extern __shared__ float smem[];
+    const int Wq = (W + 3) / 4;             // x quads
+    const int W4 = Wq * 4;
+    const int LW2 = ((W4 + 2 * R + 3) / 4) * 4;  // padded f2 row length (multiple of 4)
+    float* f1s = smem;                      // [CCK][W4]
+    float* f2s = smem + CORR_CCK * W4;      // [CCK][P][LW2], index x + R
+
+    const int y = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int half = lane >> 5;             // channel half handled by this lane
+    const int slot = wave * 32 + (lane & 31);  // 128 item slots per pass
+    const int items = Wq * P;
+    const int64_t HW = (int64_t)H * W;
+    const float* f1b = f1 + (int64_t)b * C * HW;
+    const float* f2b = f2 + (int64_t)b * C * HW;
+
+    for (int pass0 = 0; pass0 < items; pass0 += 128) {
+        const int item = pass0 + slot;
+        const bool active = item < items;
+        const int i = active ? item / Wq : 0;        // displacement row
+        const int xq = active ? item - i * Wq : 0;   // x quad
+        const int x0 = xq * 4;
+        float acc[4][P];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < P; ++j) acc[p][j] = 0.0f;
+
+        for (int c0 = 0; c0 < C; c0 += CORR_CCK) {
+            __syncthreads();
+            // stage f1 row y and the P rows of f2 around y for CCK channels (zero outside the image / C)
+            for (int idx = tid; idx < CORR_CCK * W4; idx += 256) {
+                int c = idx / W4, x = idx - c * W4;
+                float v = 0.0f;
+                if (c0 + c < C && x < W) v = f1b[(int64_t)(c0 + c) * HW + (int64_t)y * W + x];
+                f1s[idx] = v;
+            }
+            for (int idx = tid; idx < CORR_CCK * P * LW2; idx += 256) {
+                int c = idx / (P * LW2);
+                int rem = idx - c * (P * LW2);
+                int rr = rem / LW2, xi = rem - rr * LW2;
+                int yy = y + rr - R, xx = xi - R;
+                float v = 0.0f;
+                if (c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                    v = f2b[(int64_t)(c0 + c) * HW + (int64_t)yy * W + xx];
+                f2s[idx] = v;
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll 2
+                for (int cc = 0; cc < CORR_CCK / 2; ++cc) {
+                    const int c = half * (CORR_CCK / 2) + cc;
+                    const float4 a = *reinterpret_cast<const float4*>(&f1s[c * W4 + x0]);
+                    const float* wrow = &f2s[(c * P + i) * LW2 + x0];  // window starts at x0 - R  (index x0)
+                    float win[WIN];
+#pragma unroll
+                    for (int t = 0; t + 3 < WIN; t += 4) {
+                        float4 v = *reinterpret_cast<const float4*>(wrow + t);
+                        win[t] = v.x; win[t + 1] = v.y; win[t + 2] = v.z; win[t + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int t = (WIN / 4) * 4; t < WIN; ++t) win[t] = wrow[t];
+                    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int j = 0; j < P; ++j) acc[p][j] = fmaf(av[p], win[p + j], acc[p][j]);
+                }
+            }
+        }
+        // sum the two channel halves held by lanes l and l + 32 (wavefront shuffle), activate, store
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                float v = acc[p][j];
+                v += __shfl_xor(v, 32, 64);
+                acc[p][j] = v;
+            }
+        if (active && half == 0) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                float o[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float v = acc[p][j] * scale;
+                    o[p] = v < 0.0f ? v * slope : v;
+                }
+                float* op = out + ((((int64_t)b * P + i) * P + j) * H + y) * W + x0;
+                if ((W % 4 == 0)) {
+                    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if (x0 + p < W) op[p] = o[p];
+                }
+            }
+        }
+    }
+}
+
+// Generic fallback (any patch size / patch dilation): one thread per output, channel loop from global.
+__global__ void corr_patch_generic(const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out,
+                                   int B, int C, int H, int W, int P, int dil, float scale, float slope)
+{
+    int64_t total = (int64_t)B * P * P * H * W;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int x = t % W;
+    int64_t r = t / W;
+    int y = r % H; r /= H;
+    int j = r % P; r /= P;
+    int i = r % P;
+    int b = (int)(r / P);
+    int y2 = y + (i - P / 2) * dil, x2 = x + (j - P / 2) * dil;
+    float acc = 0.0f;
+    if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) {
+        const int64_t HW = (int64_t)H * W;
+        const float* p1 = f1 + (int64_t)b * C * HW + (int64_t)y * W + x;
+        const float* p2 = f2 + (int64_t)b * C * HW + (int64_t)y2 * W + x2;
+        for (int c = 0; c < C; ++c) acc = fmaf(p1[c * HW], p2[c * HW], acc);
+    }
+    acc *= scale;
+    out[t] = acc < 0.0f ? acc * slope : acc;
+}
+
+// ---------------------------------------------------------------------------------------- RoIAlign
+__device__ __forceinline__ float bilinear_roi(const float* __restrict__ im, int H, int W, float y, float x)
+{
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.0f;
+    if (y <= 0.0f) y = 0.0f;
+    if (x <= 0.0f) x = 0.0f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.0f - ly, hx = 1.0f - lx;
+    return hy * hx * im[y_low * W + x_low] + hy * lx * im[y_low * W + x_high] + ly * hx * im[y_high * W + x_low] +
+           ly * lx * im[y_high * W + x_high];
+}
+
+// one thread per output element; consecutive threads walk (px, py, c) so a wave shares one RoI and touches
+// neighbouring channels of one small feature window (L1/L2 resident: 633 x 24 x 40 floats = 2.4 MB)
+__global__ void roi_align_avg_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
+                                     float* __restrict__ out, int C, int H, int W, int n, int PH, int PW, float scale,
+                                     int sampling_ratio, int aligned)
+{
+    int64_t total = (int64_t)n * C * PH * PW;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int px = t % PW;
+    int64_t r = t / PW;
+    int py = r % PH; r /= PH;
+    int c = r % C;
+    int ri = (int)(r / C);
+    const float* roi = rois + 5 * ri;
+    int b = (int)roi[0];
+    float offset = aligned ? 0.5f : 0.0f;
+    float sw_ = roi[1] * scale - offset, sh_ = roi[2] * scale - offset;
+    float ew_ = roi[3] * scale - offset, eh_ = roi[4] * scale - offset;
+    float rw = ew_ - sw_, rh = eh_ - sh_;
+    if (!aligned) { rw = fmaxf(rw, 1.0f); rh = fmaxf(rh, 1.0f); }
+    float bh = rh / (float)PH, bw = rw / (float)PW;
+    int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+    int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+    float count = (float)max(gh * gw, 1);
+    const float* im = feat + ((int64_t)b * C + c) * H * W;
+    float acc = 0.0f;
+    for (int iy = 0; iy < gh; ++iy) {
+        float y = sh_ + (float)py * bh + ((float)iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+            float x = sw_ + (float)px * bw + ((float)ix + 0.5f) * bw / (float)gw;
+            acc += bilinear_roi(im, H, W, y, x);
+        }
+    }
+    out[t] = acc / count;
+}
+
+}  // namespace
+
+extern "C" int stm_corr_patch_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P,
+                                  int dil, float scale, float leaky_slope, stm_stream_t stream)
+{
+    STM_REQUIRE(f1 && f2 && out, STM_ENULL, "stm_corr_patch_f32: f1/f2/out must be non-NULL");
+    STM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, STM_EINVAL, "stm_corr_patch_f32: empty input");
+    STM_REQUIRE(P > 0 && (P & 1) && dil > 0, STM_EINVAL, "stm_corr_patch_f32: patch_size must be odd, dilation > 0");
+    const char* force = getenv("STM_CORR_VARIANT");
+    bool tiled = (P == 11 && dil == 1 && H <= 65535 && B <= 65535 && ((uintptr_t)out % 16 == 0));
+    if (force && atoi(force) == 1) tiled = false;
+    if (tiled) {
+        int Wq = (W + 3) / 4, W4 = Wq * 4, LW2 = ((W4 + 10 + 3) / 4) * 4;
+        size_t lds = (size_t)(CORR_CCK * W4 + CORR_CCK * 11 * LW2) * sizeof(float);
+        if (lds <= 64 * 1024) {
+            hipLaunchKernelGGL(corr_patch_tiled<11>, dim3(H, B), dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W,
+                               scale, leaky_slope);
+            STM_CHECK_LAUNCH("corr_patch_tiled");
+            return STM_OK;
+        }
+    }
+    int64_t total = (int64_t)B * P * P * H * W;
+    hipLaunchKernelGGL(corr_patch_generic, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), f1, f2, out, B, C, H,
+                       W, P, dil, scale, leaky_slope);
+    STM_CHECK_LAUNCH("corr_patch_generic");
+    return STM_OK;
+}
+
+extern "C" int stm_roi_align_avg_f32(const float* feat, const float* rois, float* out, int B, int C, int H, int W, int n,
+                                     int PH, int PW, float spatial_scale, int sampling_ratio, int aligned,
+                                     stm_stream_t stream)
+{
+    STM_REQUIRE(n >= 0, STM_EINVAL, "stm_roi_align_avg_f32: n=%d", n);
+    if (n == 0) return STM_OK;
+    STM_REQUIRE(feat && rois && out, STM_ENULL, "stm_roi_align_avg_f32: feat/rois/out must be non-NULL");
+    STM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0, STM_EINVAL, "stm_roi_align_avg_f32: bad sizes");
+    int64_t total = (int64_t)n * C * PH * PW;
+    hipLaunchKernelGGL(roi_align_avg_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), feat, rois, out, C,
+                       H, W, n, PH, PW, spatial_scale, sampling_ratio, aligned);
+    STM_CHECK_LAUNCH("roi_align_avg_kernel");
+    return STM_OK;
+}

@@ -1,0 +1,307 @@
+"""Tensor-level wrappers over the C ABI (include/stmask_hip.h).
+
+Each function takes CUDA(=HIP) torch tensors, allocates outputs with torch (device memory + stream plumbing only)
+and enqueues the hand-written gfx950 kernel on the current stream.  CPU tensors are rejected: the product path has
+no CPU fallback (oracle/ is test infrastructure and is never imported from here).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import DeformGeom, StmError, c_f, c_i, c_l, c_p, c_sz, check
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise StmError("stmask_amd ops need tensors on the MI355X (got a CPU tensor); there is no CPU fallback")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise StmError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return c_p(t.data_ptr()) if t is not None else c_p(0)
+
+
+def _stream():
+    return c_p(torch.cuda.current_stream().cuda_stream)
+
+
+def conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
+    return ((H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1, (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1)
+
+
+def _geom(x, kernel_size, stride, padding, dilation, dg):
+    (kh, kw), (sh, sw), (ph, pw), (dh, dw) = _pair(kernel_size), _pair(stride), _pair(padding), _pair(dilation)
+    B, C, H, W = x.shape
+    Ho, Wo = conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw)
+    return DeformGeom(B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, dg, Ho, Wo)
+
+
+def _offset_mask_views(offset, mask, g, fused_om):
+    """Returns (off_tensor, off_bstride, mask_tensor_or_None, mask_ptr, mask_bstride)."""
+    K, HWo = g.kh * g.kw, g.Ho * g.Wo
+    if fused_om is not None:
+        # raw conv_offset_mask output [B, dg*3K, Ho, Wo]: dcn_v2 chunks it into (o1, o2, mask) and uses
+        # cat(o1, o2) as the offset, i.e. channels [0, 2*dg*K) are the offsets and [2*dg*K, 3*dg*K) the mask logits
+        om = _f32c(fused_om)
+        if tuple(om.shape) != (g.B, g.dg * 3 * K, g.Ho, g.Wo):
+            raise StmError(f"conv_offset_mask output {tuple(om.shape)} != {(g.B, g.dg * 3 * K, g.Ho, g.Wo)}")
+        bs = g.dg * 3 * K * HWo
+        return om, bs, om, om.data_ptr() + 4 * g.dg * 2 * K * HWo, bs
+    offset = _f32c(offset)
+    if tuple(offset.shape) != (g.B, g.dg * 2 * K, g.Ho, g.Wo):
+        raise StmError(f"offset shape {tuple(offset.shape)} != {(g.B, g.dg * 2 * K, g.Ho, g.Wo)}")
+    if mask is not None:
+        mask = _f32c(mask)
+        if tuple(mask.shape) != (g.B, g.dg * K, g.Ho, g.Wo):
+            raise StmError(f"mask shape {tuple(mask.shape)} != {(g.B, g.dg * K, g.Ho, g.Wo)}")
+        return offset, g.dg * 2 * K * HWo, mask, mask.data_ptr(), g.dg * K * HWo
+    return offset, g.dg * 2 * K * HWo, None, 0, 0
+
+
+def deform_im2col(x, offset, mask, kernel_size, stride=1, padding=0, dilation=1, deform_groups=1, variant=0,
+                  fused_om=None, mask_is_logit=False, out=None):
+    """Modulated deformable im2col -> cols [B, C*kh*kw, Ho*Wo] (mask=None -> v1)."""
+    _dev(x, offset, mask, fused_om)
+    x = _f32c(x)
+    g = _geom(x, kernel_size, stride, padding, dilation, deform_groups)
+    off, obs, mk, mk_ptr, mbs = _offset_mask_views(offset, mask, g, fused_om)
+    cols = out if out is not None else torch.empty(g.B, g.C * g.kh * g.kw, g.Ho * g.Wo, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().stm_deform_im2col_f32(_p(x), _p(off), c_l(obs), c_p(mk_ptr), c_l(mbs),
+                                          c_i(1 if (mask_is_logit or fused_om is not None) else 0), _p(cols),
+                                          ctypes.byref(g), c_i(variant), _stream())
+    check(rc, "stm_deform_im2col_f32")
+    return cols
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag="ws"):
+    """Grow-only per-(device, stream, tag) scratch buffer (cols buffers are GBs at large batch: never per call)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def deform_conv(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, deform_groups=1, relu=False,
+                fused_om=None, mask_is_logit=False):
+    """Deformable convolution forward: hand-written im2col + fp32 MFMA GEMM (+bias, +ReLU) -> [B,O,Ho,Wo]."""
+    _dev(x, offset, mask, weight, bias, fused_om)
+    x, weight = _f32c(x), _f32c(weight)
+    O, Cw, kh, kw = weight.shape
+    if Cw != x.shape[1]:
+        raise StmError("groups != 1 is outside the hot path (STM_EUNSUPPORTED)")
+    g = _geom(x, (kh, kw), stride, padding, dilation, deform_groups)
+    off, obs, mk, mk_ptr, mbs = _offset_mask_views(offset, mask, g, fused_om)
+    bias = _f32c(bias) if bias is not None else None
+    y = torch.empty(g.B, O, g.Ho, g.Wo, device=x.device, dtype=torch.float32)
+    need = _lib.lib().stm_deform_conv_workspace_bytes(ctypes.byref(g))
+    ws = _workspace(need, x.device, "cols")
+    rc = _lib.lib().stm_deform_conv_fwd_f32(_p(x), _p(off), c_l(obs), c_p(mk_ptr), c_l(mbs),
+                                            c_i(1 if (mask_is_logit or fused_om is not None) else 0), _p(weight),
+                                            _p(bias), _p(y), c_i(O), c_i(1 if relu else 0), ctypes.byref(g), _p(ws),
+                                            c_sz(ws.numel()), _stream())
+    check(rc, "stm_deform_conv_fwd_f32")
+    return y
+
+
+def gemm_bias(A, Bm, bias=None, relu=False):
+    """C[b] = A[M,K] @ B[b][K,N] (+bias[m]) on the fp32 MFMA pipe.  Bm is [K,N] or [batch,K,N]."""
+    _dev(A, Bm, bias)
+    A, Bm = _f32c(A), _f32c(Bm)
+    squeeze = Bm.dim() == 2
+    if squeeze:
+        Bm = Bm[None]
+    batch, K, N = Bm.shape
+    M = A.shape[0]
+    assert A.shape[1] == K
+    C = torch.empty(batch, M, N, device=A.device, dtype=torch.float32)
+    rc = _lib.lib().stm_gemm_bias_f32(_p(A), _p(Bm), _p(_f32c(bias) if bias is not None else None), _p(C), c_i(M), c_i(N),
+                                      c_i(K), c_i(batch), c_l(K * N), c_l(M * N), c_i(1 if relu else 0), _stream())
+    check(rc, "stm_gemm_bias_f32")
+    return C[0] if squeeze else C
+
+
+def fcb_ali_offsets(loc, kh, kw):
+    """Featurealign.py:46-69: loc [B,4,H,W] -> offsets [B,2*kh*kw,H,W]."""
+    _dev(loc)
+    loc = _f32c(loc)
+    B, four, H, W = loc.shape
+    assert four == 4
+    off = torch.empty(B, 2 * kh * kw, H, W, device=loc.device, dtype=torch.float32)
+    check(_lib.lib().stm_fcb_ali_offsets_f32(_p(loc), _p(off), c_i(B), c_i(H), c_i(W), c_i(kh), c_i(kw), _stream()),
+          "stm_fcb_ali_offsets_f32")
+    return off
+
+
+def corr_patch(f1, f2, patch_size=11, dilation_patch=1, scale=1.0, leaky_slope=1.0):
+    """spatial_correlation_sample(kernel_size=1, stride=1, padding=0) -> [B,P,P,H,W] (optionally scaled + leaky)."""
+    _dev(f1, f2)
+    f1, f2 = _f32c(f1), _f32c(f2)
+    if f1.shape != f2.shape:
+        raise StmError(f"correlation inputs differ in shape: {tuple(f1.shape)} vs {tuple(f2.shape)}")
+    B, C, H, W = f1.shape
+    out = torch.empty(B, patch_size, patch_size, H, W, device=f1.device, dtype=torch.float32)
+    check(_lib.lib().stm_corr_patch_f32(_p(f1), _p(f2), _p(out), c_i(B), c_i(C), c_i(H), c_i(W), c_i(patch_size),
+                                        c_i(dilation_patch), c_f(scale), c_f(leaky_slope), _stream()), "stm_corr_patch_f32")
+    return out
+
+
+def roi_align(feat, rois, output_size, spatial_scale=1.0, sampling_ratio=0, aligned=True):
+    _dev(feat, rois)
+    feat, rois = _f32c(feat), _f32c(rois)
+    ph, pw = _pair(output_size)
+    B, C, H, W = feat.shape
+    n = rois.shape[0]
+    if n and rois.shape[1] != 5:
+        raise StmError("rois must be [n,5] = (batch, x1, y1, x2, y2)")
+    out = torch.empty(n, C, ph, pw, device=feat.device, dtype=torch.float32)
+    check(_lib.lib().stm_roi_align_avg_f32(_p(feat), _p(rois), _p(out), c_i(B), c_i(C), c_i(H), c_i(W), c_i(n), c_i(ph),
+                                           c_i(pw), c_f(spatial_scale), c_i(sampling_ratio), c_i(1 if aligned else 0),
+                                           _stream()), "stm_roi_align_avg_f32")
+    return out
+
+
+def decode(loc, priors):
+    """box_utils.py:238-283, bit-exact vs the oracle."""
+    _dev(loc, priors)
+    loc, priors = _f32c(loc), _f32c(priors)
+    boxes = torch.empty_like(loc)
+    check(_lib.lib().stm_decode_boxes_f32(_p(loc), _p(priors), _p(boxes), c_l(loc.shape[0]), _stream()),
+          "stm_decode_boxes_f32")
+    return boxes
+
+
+def generate_candidates(loc, priors, conf, thresh=0.05):
+    """TF_utils.py:54-82 core.  loc [B,N,4], priors [N,4], conf [B,N,ncls] soft-maxed ->
+    keep_idx [B,N] (first count[b] valid, ascending), cand_box [B,N,4], count [B] (device int32)."""
+    _dev(loc, priors, conf)
+    loc, priors, conf = _f32c(loc), _f32c(priors), _f32c(conf)
+    B, N, ncls = conf.shape
+    keep_idx = torch.empty(B, N, dtype=torch.int64, device=conf.device)
+    cand_box = torch.empty(B, N, 4, dtype=torch.float32, device=conf.device)
+    count = torch.empty(B, dtype=torch.int32, device=conf.device)
+    check(_lib.lib().stm_generate_candidates_f32(_p(loc), _p(priors), _p(conf), c_i(N), c_i(ncls), c_f(thresh), c_i(B),
+                                                 _p(keep_idx), _p(cand_box), _p(count), _stream()),
+          "stm_generate_candidates_f32")
+    return keep_idx, cand_box, count
+
+
+def cc_fast_nms(conf, boxes, centerness, iou_thr=0.5, top_k=200, k_dev=None):
+    """detection_TF.py:85-134 on candidate rows.  conf [K,ncls] or [B,K,ncls].  Returns padded
+    (idx [B,top_k] int64, cls, score, box [B,top_k,4], count [B] int32) -- all on device, no sync."""
+    _dev(conf, boxes, centerness)
+    conf, boxes = _f32c(conf), _f32c(boxes)
+    squeeze = conf.dim() == 2
+    if squeeze:
+        conf, boxes = conf[None], boxes[None]
+        centerness = centerness[None] if centerness is not None else None
+    B, K, ncls = conf.shape
+    cen = _f32c(centerness) if centerness is not None else None
+    dev = conf.device
+    idx = torch.empty(B, top_k, dtype=torch.int64, device=dev)
+    cls = torch.empty(B, top_k, dtype=torch.int64, device=dev)
+    sc = torch.empty(B, top_k, dtype=torch.float32, device=dev)
+    bx = torch.empty(B, top_k, 4, dtype=torch.float32, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    check(_lib.lib().stm_cc_fast_nms_f32(_p(conf), _p(boxes), _p(cen), c_i(K), c_i(ncls), _p(k_dev), c_f(iou_thr),
+                                         c_i(top_k), c_i(B), _p(idx), _p(cls), _p(sc), _p(bx), _p(cnt), _stream()),
+          "stm_cc_fast_nms_f32")
+    if squeeze:
+        return idx[0], cls[0], sc[0], bx[0], cnt[0]
+    return idx, cls, sc, bx, cnt
+
+
+def detect_cc(loc, priors, conf, centerness, conf_thresh=0.05, iou_thr=0.5, top_k=200):
+    """Fused generate_candidate + cc_fast_nms (STMask.py:317-320) with no host sync.
+    loc [B,N,4], priors [N,4], conf [B,N,ncls] soft-maxed, centerness [B,N] or [B,N,1] ->
+    (prior_idx [B,top_k], cls, score, box [B,top_k,4], count [B])."""
+    _dev(loc, priors, conf, centerness)
+    loc, priors, conf = _f32c(loc), _f32c(priors), _f32c(conf)
+    B, N, ncls = conf.shape
+    cen = _f32c(centerness.reshape(B, N)) if centerness is not None else None
+    dev = conf.device
+    idx = torch.empty(B, top_k, dtype=torch.int64, device=dev)
+    cls = torch.empty(B, top_k, dtype=torch.int64, device=dev)
+    sc = torch.empty(B, top_k, dtype=torch.float32, device=dev)
+    bx = torch.empty(B, top_k, 4, dtype=torch.float32, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    need = _lib.lib().stm_detect_cc_workspace_bytes(c_i(N), c_i(B))
+    ws = _workspace(need, dev, "detect")
+    check(_lib.lib().stm_detect_cc_f32(_p(loc), _p(priors), _p(conf), _p(cen), c_i(N), c_i(ncls), c_f(conf_thresh),
+                                       c_f(iou_thr), c_i(top_k), c_i(B), _p(idx), _p(cls), _p(sc), _p(bx), _p(cnt), _p(ws),
+                                       c_sz(ws.numel()), _stream()), "stm_detect_cc_f32")
+    return idx, cls, sc, bx, cnt
+
+
+def fast_nms(conf, boxes, centerness, iou_thr=0.5, top_k=200, conf_thresh=0.05, max_det=100, k_dev=None):
+    """detection_TF.py:136-204 (per-class).  Returns padded (idx, cls, score, box, count)."""
+    _dev(conf, boxes, centerness)
+    conf, boxes = _f32c(conf), _f32c(boxes)
+    K, ncls = conf.shape
+    cen = _f32c(centerness) if centerness is not None else None
+    dev = conf.device
+    idx = torch.empty(max_det, dtype=torch.int64, device=dev)
+    cls = torch.empty(max_det, dtype=torch.int64, device=dev)
+    sc = torch.empty(max_det, dtype=torch.float32, device=dev)
+    bx = torch.empty(max_det, 4, dtype=torch.float32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    need = _lib.lib().stm_fast_nms_workspace_bytes(c_i(K), c_i(ncls), c_i(top_k))
+    ws = _workspace(need, dev, "pcnms")
+    check(_lib.lib().stm_fast_nms_f32(_p(conf), _p(boxes), _p(cen), c_i(K), c_i(ncls), _p(k_dev), c_f(iou_thr), c_i(top_k),
+                                      c_f(conf_thresh), c_i(max_det), _p(idx), _p(cls), _p(sc), _p(bx), _p(cnt), _p(ws),
+                                      c_sz(ws.numel()), _stream()), "stm_fast_nms_f32")
+    return idx, cls, sc, bx, cnt[0]
+
+
+def jaccard(a, b):
+    """box_utils.py:60-88 (2-D form), bit-exact."""
+    _dev(a, b)
+    a, b = _f32c(a), _f32c(b)
+    out = torch.empty(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)
+    check(_lib.lib().stm_jaccard_f32(_p(a), c_i(a.shape[0]), _p(b), c_i(b.shape[0]), _p(out), _stream()), "stm_jaccard_f32")
+    return out
+
+
+def lincomb_sigmoid_crop(proto, coeff, boxes=None, apply_tanh=True, n_dev=None):
+    """generate_mask (mask_utils.py:111-128) + crop.  proto [h,w,m], coeff [n,m], boxes [n,4] -> [n,h,w]."""
+    _dev(proto, coeff, boxes)
+    proto, coeff = _f32c(proto), _f32c(coeff)
+    h, w, m = proto.shape
+    n = coeff.shape[0]
+    bx = _f32c(boxes) if boxes is not None else None
+    out = torch.empty(n, h, w, dtype=torch.float32, device=proto.device)
+    check(_lib.lib().stm_lincomb_sigmoid_crop_f32(_p(proto), _p(coeff), _p(bx), _p(out), c_i(h), c_i(w), c_i(m), c_i(n),
+                                                  c_i(1 if apply_tanh else 0), _p(n_dev), _stream()),
+          "stm_lincomb_sigmoid_crop_f32")
+    return out
+
+
+def mask_iou(m1, m2, thr=0.5):
+    """box_utils.py:435-447 on (m > thr).  m1 [n1,h,w], m2 [n2,h,w] soft masks -> [n1,n2]."""
+    _dev(m1, m2)
+    m1, m2 = _f32c(m1), _f32c(m2)
+    n1, n2 = m1.shape[0], m2.shape[0]
+    out = torch.zeros(n1, n2, dtype=torch.float32, device=m1.device)
+    if n1 == 0 or n2 == 0:
+        return out
+    hw = m1[0].numel()
+    need = _lib.lib().stm_mask_iou_workspace_bytes(c_i(n1), c_i(n2), c_i(hw))
+    ws = _workspace(need, m1.device, "miou")
+    check(_lib.lib().stm_mask_iou_f32(_p(m1), c_i(n1), _p(m2), c_i(n2), c_i(hw), c_f(thr), _p(out), _p(ws), c_sz(ws.numel()),
+                                      _stream()), "stm_mask_iou_f32")
+    return out

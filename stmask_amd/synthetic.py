@@ -29,7 +29,11 @@ def seeded_tensor(key, shape, seed=0):
         return torch.zeros(shape, dtype=torch.int64)
     is_bn = (".bn" in key) or ("downsample.1." in key) or key.startswith("backbone.bn1")
     if is_bn:
-        if leaf in ("weight", "running_var"):
+        if leaf == "weight":
+            # identity BN everywhere except the residual-branch BN: 0.3 keeps the variance of
+            # x + f(x) from doubling in each of the 16/33 bottlenecks (activations stay O(1))
+            return torch.full(shape, 0.3 if ".bn3." in key else 1.0)
+        if leaf == "running_var":
             return torch.ones(shape)
         return torch.zeros(shape)
     if "conv_offset_mask" in key:
@@ -46,10 +50,48 @@ def seeded_tensor(key, shape, seed=0):
         fan_in = 1
         for s in shape[1:]:
             fan_in *= s
-        return torch.randn(shape, generator=g) * math.sqrt(2.0 / max(fan_in, 1))
+        return torch.randn(shape, generator=g) * (math.sqrt(2.0 / max(fan_in, 1)) * _head_gain(key, shape))
     if leaf == "bias":
-        return torch.rand(shape, generator=g) * 0.2 - 0.1
+        return torch.rand(shape, generator=g) * 0.2 - 0.1 + _head_bias(key, shape)
     return torch.randn(shape, generator=g)
+
+
+# Output-layer calibration ("detection seeding"): plain random heads give either zero or ALL priors
+# as candidates.  Small class logits + a background bias make ~3-8 % of the priors pass the 0.05 threshold in
+# spatial clusters, so Fast NMS, lincomb and the tracker see a realistic load (hundreds of candidates, tens of
+# detections per frame).
+def _is_class_out(key, shape):
+    return "conf_layer" in key and len(shape) >= 1 and shape[0] == NUM_CLASSES and "conv_adaption" not in key
+
+
+NUM_CLASSES = 41
+
+
+def _head_gain(key, shape):
+    if _is_class_out(key, shape):
+        # FCB (FeatureAlign) class branch has one more conv + ReLU in front, which narrows the logits
+        return 0.6 if ".conv." in key else 0.35
+    if "bbox_layer" in key:
+        return 0.3
+    if "centerness_layer" in key:
+        return 0.5
+    if key.startswith("TemporalNet.fc"):
+        return 0.3
+    if key.startswith("fpn.lat_layers"):
+        return 0.2  # backbone outputs have second moment ~13: bring P3..P7 back to O(1)
+    return 1.0
+
+
+def _head_bias(key, shape):
+    b = torch.zeros(shape)
+    if _is_class_out(key, shape):
+        b[0] = BG_BIAS
+    elif "centerness_layer" in key:
+        b += 1.0
+    return b
+
+
+BG_BIAS = 6.2
 
 
 def detection_seeding(sd, classes=(1, 7, 13), conf_bump=6.0, centerness_bump=2.0, num_classes=41):
@@ -64,7 +106,7 @@ def detection_seeding(sd, classes=(1, 7, 13), conf_bump=6.0, centerness_bump=2.0
     return sd
 
 
-def fill_state_dict(module, seed=0, seed_detections=True):
+def fill_state_dict(module, seed=0, seed_detections=False):
     """Overwrite every entry of module.state_dict() with its seeded value (in place) and return the dict."""
     sd = module.state_dict()
     new = {k: seeded_tensor(k, v.shape, seed).to(v.dtype) for k, v in sd.items()}

@@ -1,0 +1,73 @@
+"""CPU-only tests of the host-side mirror: configs, state-dict compatibility with the reference, priors, synthetic data."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from stmask_amd import synthetic
+from stmask_amd.config import CONFIGS, cfg, get_cfg, set_cfg
+from stmask_amd.layers import PredictionModule_FC
+from stmask_amd.model import STMask
+
+MODEL_CASES = [("STMask_plus_resnet50_config", "r50_fca"), ("STMask_plus_resnet50_ada_config", "r50_ada"),
+               ("STMask_plus_resnet50_ali_config", "r50_ali")]
+
+
+@pytest.mark.parametrize("name,tag", MODEL_CASES)
+def test_state_dict_matches_reference(name, tag):
+    """Keys and shapes equal the reference model's (captured by gen_golden.py): its checkpoints load unchanged."""
+    net = STMask(get_cfg(name))
+    sd = net.state_dict()
+    g = load_golden(f"model_{tag}.npz")
+    assert sorted(sd.keys()) == list(g["state_keys"])
+    for k, s in zip(g["state_keys"], g["state_shapes"]):
+        assert str(tuple(sd[k].shape)) == s, k
+
+
+def test_dcn_layer_selection_rule():
+    """backbone.py:124,130 with args config.py:288,307: R50 -> 7 DCN blocks, R101 -> 11."""
+    def dcn_blocks(name):
+        net = STMask(get_cfg(name))
+        return [f"{s}.{b}" for s, layer in enumerate(net.backbone.layers) for b, blk in enumerate(layer) if blk.use_dcn]
+    assert dcn_blocks("STMask_plus_resnet50_config") == ["1.0", "1.2", "2.0", "2.2", "2.4", "3.0", "3.2"]
+    r101 = dcn_blocks("STMask_plus_base_config")
+    assert len(r101) == 11 and r101[:2] == ["1.0", "1.3"] and r101[-1] == "3.0"
+    assert dcn_blocks("STMask_resnet50_config") == []
+
+
+def test_priors_match_reference(golden_priors):
+    pm = PredictionModule_FC.__new__(PredictionModule_FC)
+    pm.pred_aspect_ratios, pm.pred_scales = cfg.pred_aspect_ratios[0], cfg.pred_scales[0]
+    for k, ref in golden_priors.items():
+        h, w = [int(v) for v in k[2:].split("x")]
+        assert torch.equal(pm.make_priors(h, w, "cpu")[0], ref), k
+    total = sum(v.shape[0] for v in golden_priors.values())
+    assert total == 15345
+
+
+def test_set_cfg_swaps_default_in_place():
+    set_cfg("STMask_plus_resnet50_ada_config")
+    assert cfg.use_pred_offset and cfg.use_dcn_class and cfg.backbone_dcn_interval == 2
+    set_cfg("STMask_plus_base_config")
+    assert not cfg.use_dcn_class and cfg.backbone_layers == [3, 4, 23, 3]
+    with pytest.raises(KeyError):
+        set_cfg("nope")
+    assert set(CONFIGS) >= {"STMask_plus_base_ali_config", "STMask_plus_resnet50_config"}
+
+
+def test_synthetic_weights_are_pure_functions_of_key():
+    a = synthetic.seeded_tensor("backbone.layers.1.0.conv2.weight", (128, 128, 3, 3), 0)
+    b = synthetic.seeded_tensor("backbone.layers.1.0.conv2.weight", (128, 128, 3, 3), 0)
+    c = synthetic.seeded_tensor("backbone.layers.1.0.conv2.weight", (128, 128, 3, 3), 1)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    om = synthetic.seeded_tensor("backbone.layers.1.0.conv2.conv_offset_mask.bias", (27,), 0)
+    assert om[:18].abs().max() <= 2 and om[18:].abs().max() == 0  # offsets U(-2,2), mask logits 0
+    clip = synthetic.synthetic_clip(3, 32, 48, seed=0)
+    assert clip.shape == (3, 3, 32, 48) and torch.equal(clip, synthetic.synthetic_clip(3, 32, 48, seed=0))
+
+
+def test_model_golden_fixtures_are_nontrivial():
+    for _, tag in MODEL_CASES:
+        g = load_golden(f"model_{tag}.npz")
+        assert g["t0_box"].shape[0] >= 3 and g["t2_box"].shape[0] >= 3, tag
+        assert np.isfinite(g["f0_proto"].numpy()).all()
