@@ -1,0 +1,32 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, bench, rocprof kernel trace.  Everything lands in gpurun_out/.
+# usage: scripts/gpu_round.sh [tests] [smoke] [bench] [prof] [pmc]   (default: tests smoke bench prof)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd $R
+WHAT=${@:-tests smoke bench prof}
+export TMPDIR=/tmp
+for w in $WHAT; do
+case $w in
+tests)
+  timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
+  echo "pytest exit $?" >> $OUT/pytest_gpu.log; tail -25 $OUT/pytest_gpu.log ;;
+smoke)
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log; tail -3 $OUT/smoke.log ;;
+bench)
+  timeout 900 python bench.py --steps 20 --warmup 4 > $OUT/bench.log 2> $OUT/bench.err; echo "bench exit $?"; tail -2 $OUT/bench.log; tail -3 $OUT/bench.err ;;
+prof)
+  cd /tmp
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof.log 2>&1
+  echo "prof exit $?"; cd $R
+  f=$(ls $OUT/prof/*/*kernel_stats.csv $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1); echo "stats: $f"; head -25 "$f"
+  # the raw per-dispatch trace is large: keep only the stats
+  find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete ;;
+pmc)
+  cd /tmp
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?"
+  cd $R; python scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt ;;
+esac
+done

@@ -97,6 +97,23 @@ def _workspace(nbytes, device, tag="ws"):
     return buf
 
 
+_im2col_timing = None  # when a list: (start_event, end_event, algorithmic_bytes) per im2col launch (bench.py roofline)
+
+
+def im2col_timing(enable):
+    """bench.py: time every im2col launch of deform_conv with HIP events on the launch stream (live roofline)."""
+    global _im2col_timing
+    old = _im2col_timing
+    _im2col_timing = [] if enable else None
+    return old
+
+
+def im2col_algorithmic_bytes(g, has_mask):
+    """4 * (C*Hin*Win + (3K | 2K)*dg*Ho*Wo + C*K*Ho*Wo) per image."""
+    K, HWo = g.kh * g.kw, g.Ho * g.Wo
+    return 4 * g.B * (g.C * g.H * g.W + (3 if has_mask else 2) * K * g.dg * HWo + g.C * K * HWo)
+
+
 def deform_conv(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, deform_groups=1, relu=False,
                 fused_om=None, mask_is_logit=False):
     """Deformable convolution forward: hand-written im2col + fp32 MFMA GEMM (+bias, +ReLU) -> [B,O,Ho,Wo]."""
@@ -111,6 +128,19 @@ def deform_conv(x, offset, mask, weight, bias=None, stride=1, padding=0, dilatio
     y = torch.empty(g.B, O, g.Ho, g.Wo, device=x.device, dtype=torch.float32)
     need = _lib.lib().stm_deform_conv_workspace_bytes(ctypes.byref(g))
     ws = _workspace(need, x.device, "cols")
+    if _im2col_timing is not None:  # same two kernels, launched separately so the im2col can be bracketed by events
+        logit = c_i(1 if (mask_is_logit or fused_om is not None) else 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.lib().stm_deform_im2col_f32(_p(x), _p(off), c_l(obs), c_p(mk_ptr), c_l(mbs), logit, _p(ws),
+                                               ctypes.byref(g), c_i(0), _stream()), "stm_deform_im2col_f32")
+        e1.record()
+        _im2col_timing.append((e0, e1, im2col_algorithmic_bytes(g, mk_ptr != 0)))
+        CK, HWo = g.C * g.kh * g.kw, g.Ho * g.Wo
+        check(_lib.lib().stm_gemm_bias_f32(_p(weight), _p(ws), _p(bias), _p(y), c_i(O), c_i(HWo), c_i(CK), c_i(g.B),
+                                           c_l(CK * HWo), c_l(O * HWo), c_i(1 if relu else 0), _stream()),
+              "stm_gemm_bias_f32")
+        return y
     rc = _lib.lib().stm_deform_conv_fwd_f32(_p(x), _p(off), c_l(obs), c_p(mk_ptr), c_l(mbs),
                                             c_i(1 if (mask_is_logit or fused_om is not None) else 0), _p(weight),
                                             _p(bias), _p(y), c_i(O), c_i(1 if relu else 0), ctypes.byref(g), _p(ws),

@@ -1,0 +1,59 @@
+"""CPU-only parity of the host-side mirror (model wiring, heads, candidate generation, Fast-NMS plumbing, stateful
+tracker) against goldens captured from the REFERENCE's own Python (tests/golden/gen_golden.py).  The four third-party
+ops and the fused kernels are served by the oracle here (oracle.cpu_path), exactly as they were when the goldens were
+generated, so any difference is a host-logic difference."""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle.cpu_path import oracle_ops
+from stmask_amd import synthetic
+from stmask_amd.config import get_cfg
+from stmask_amd.model import STMask
+
+CASES = [("STMask_plus_resnet50_config", "r50_fca"), ("STMask_plus_resnet50_ada_config", "r50_ada"),
+         ("STMask_plus_resnet50_ali_config", "r50_ali")]
+
+
+def run_clip(net, frames, dev="cpu"):
+    outs = []
+    with torch.no_grad():
+        for t in range(frames.shape[0]):
+            meta = [{"is_first": t == 0, "video_id": 0, "frame_id": t}]
+            outs.append(net(frames[t:t + 1].to(dev), img_meta=meta)[0]["detection"])
+    return outs
+
+
+def check_clip_against_golden(outs, g, tol_box=1e-4, tol_mask=1e-4, exact_ids=True):
+    for t, det in enumerate(outs):
+        n_ref = g[f"t{t}_box"].shape[0]
+        assert det["box"].shape[0] == n_ref, (t, det["box"].shape[0], n_ref)
+        if n_ref == 0:
+            continue
+        assert torch.equal(det["class"].cpu(), g[f"t{t}_class"])
+        if exact_ids:
+            assert torch.equal(det["box_ids"].cpu(), g[f"t{t}_box_ids"])
+        assert (det["box"].cpu() - g[f"t{t}_box"]).abs().max() < tol_box
+        assert (det["score"].cpu() - g[f"t{t}_score"]).abs().max() < tol_box
+        d = det["mask"].cpu() - g[f"t{t}_mask"]
+        assert d.abs().max() < tol_mask and d.pow(2).sum(dim=(1, 2)).sqrt().max() < tol_mask * 10
+
+
+@pytest.mark.parametrize("name,tag", CASES)
+def test_model_matches_reference_on_cpu(name, tag):
+    g = load_golden(f"model_{tag}.npz")
+    h, w = [int(v) for v in g["frames_hw"]]
+    net = STMask(get_cfg(name))
+    net.eval()
+    synthetic.fill_state_dict(net, seed=0)
+    frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0)
+    with oracle_ops(), torch.no_grad():
+        fpn_outs, po = net.forward_single(frames[:1])
+        assert torch.equal(po["priors"][0], g["f0_priors"])
+        for k, gk in [("loc", "f0_loc"), ("conf", "f0_conf_logits"), ("mask_coeff", "f0_mask_coeff"),
+                      ("centerness", "f0_centerness"), ("proto", "f0_proto")]:
+            assert (po[k][0] - g[gk]).abs().max() < 1e-5, k
+        assert (po["track"][0][::7] - g["f0_track_s"]).abs().max() < 1e-5
+        assert (fpn_outs[1][0, ::16] - g["f0_P4"]).abs().max() < 1e-5
+        outs = run_clip(net, frames)
+    check_clip_against_golden(outs, g, tol_box=1e-5, tol_mask=1e-5)
