@@ -60,6 +60,10 @@ def num_threads():
     return int(lib().orc_num_threads())
 
 
+def set_num_threads(n):
+    lib().orc_set_num_threads(c_i(int(n)))
+
+
 # ----------------------------------------------------------------------------- exact ops
 def expf(x):
     x = _f32(x)

@@ -23,6 +23,14 @@ prof)
   f=$(ls $OUT/prof/*/*kernel_stats.csv $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1); echo "stats: $f"; head -25 "$f"
   # the raw per-dispatch trace is large: keep only the stats
   find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete ;;
+trunk)
+  for m in "8 nobench" "8 bench" "8 bench cl"; do timeout 900 python scripts/bench_trunk.py $m >> $OUT/trunk.log 2>&1; done
+  MIOPEN_FIND_MODE=FAST timeout 600 python scripts/bench_trunk.py 8 bench >> $OUT/trunk.log 2>&1
+  grep -E "first pass|steady" $OUT/trunk.log ;;
+kernels)
+  timeout 1200 python scripts/bench_kernels.py --batch 8 > $OUT/kernels.log 2>&1; echo "kernels exit $?"; grep -E "TOTAL|gemm|corr|lincomb|nms|detect|roi|deform_conv" $OUT/kernels.log | head -70 ;;
+sweep)
+  timeout 1500 python scripts/bench_kernels.py --batch 8 --env-sweep > $OUT/sweep.log 2>&1; echo "sweep exit $?"; grep BEST $OUT/sweep.log ;;
 pmc)
   cd /tmp
   timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"

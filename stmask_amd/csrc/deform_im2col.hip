@@ -109,6 +109,34 @@ __global__ __launch_bounds__(256) void deform_im2col_direct(ImcolArgs a, int cpb
     }
 }
 
+// rare path of the tiled kernel: 4 channels of one far-away sample, same expression order as the direct kernel
+// (mask folded into the corner weights) so both variants agree bit for bit; kept out of line so it costs no
+// registers in the main loop
+__device__ __noinline__ float4 sample_global4(const float* __restrict__ xc, int64_t HW, int H, int W, float fy, float fx,
+                                              float m)
+{
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(fy > -1.0f && fx > -1.0f && fy < (float)H && fx < (float)W)) return r;
+    float fl_y = floorf(fy), fl_x = floorf(fx);
+    int h_low = (int)fl_y, w_low = (int)fl_x, h_high = h_low + 1, w_high = w_low + 1;
+    float lh = fy - fl_y, lw = fx - fl_x, hh = 1.0f - lh, hw = 1.0f - lw;
+    bool t = h_low >= 0, l = w_low >= 0, bt = h_high <= H - 1, rt = w_high <= W - 1;
+    int hl = max(h_low, 0), wl = max(w_low, 0), hh_i = min(h_high, H - 1), wh_i = min(w_high, W - 1);
+    float w1 = (t && l) ? hh * hw * m : 0.f;
+    float w2 = (t && rt) ? hh * lw * m : 0.f;
+    float w3 = (bt && l) ? lh * hw * m : 0.f;
+    float w4 = (bt && rt) ? lh * lw * m : 0.f;
+    int a1 = hl * W + wl, a2 = hl * W + wh_i, a3 = hh_i * W + wl, a4 = hh_i * W + wh_i;
+    r.x = w1 * xc[a1] + w2 * xc[a2] + w3 * xc[a3] + w4 * xc[a4];
+    xc += HW;
+    r.y = w1 * xc[a1] + w2 * xc[a2] + w3 * xc[a3] + w4 * xc[a4];
+    xc += HW;
+    r.z = w1 * xc[a1] + w2 * xc[a2] + w3 * xc[a3] + w4 * xc[a4];
+    xc += HW;
+    r.w = w1 * xc[a1] + w2 * xc[a2] + w3 * xc[a3] + w4 * xc[a4];
+    return r;
+}
+
 // ------------------------------------------------------------------------------------ variant 2
 // grid: x = tiles_y * (C / cch), y = B.  Dynamic LDS: (cch/4) * R * LW float4.
 template <int NP>
@@ -133,11 +161,11 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
     // ---- stage: thread <-> pixel, 4 channel loads (each coalesced across the wave) -> one ds_write_b128
     {
         const float* xb = a.x + ((int64_t)b * a.C + c0) * HW;
+        // (q, r, col) advance incrementally with idx += 256: no per-element integer division
+        const int step_r = 256 / a.LW, step_c = 256 - step_r * a.LW;
+        int r = tid / a.LW, col = tid - r * a.LW, q = 0;
+        while (r >= a.R) { r -= a.R; ++q; }
         for (int idx = tid; idx < nq * RL; idx += 256) {
-            int q = idx / RL;
-            int rem = idx - q * RL;
-            int r = rem / a.LW;
-            int col = rem - r * a.LW;
             int yy = y0 + r, xx = col - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
@@ -148,6 +176,10 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
                 v.w = p[3 * HW];
             }
             tile[idx] = v;
+            col += step_c;
+            r += step_r;
+            if (col >= a.LW) { col -= a.LW; ++r; }
+            while (r >= a.R) { r -= a.R; ++q; }
         }
     }
     __syncthreads();
@@ -185,12 +217,11 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
         float w1[NP], w2[NP], w3[NP], w4[NP], fyv[NP], fxv[NP];
         int la[NP];          // LDS index of the (h_low, w_low) corner
         unsigned farmask = 0;  // positions whose corners leave the staged rows
+        int ho = nb / a.Wo, wo = nb - ho * a.Wo;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             float m = 1.0f;
             if (mb) m = a.mask_logit ? sigmoidf_dev(mv[p]) : mv[p];
-            int n = nb + p;
-            int ho = n / a.Wo, wo = n - ho * a.Wo;
             float fy = (float)(ho * a.sh - a.ph + i * a.dh) + dyv[p];
             float fx = (float)(wo * a.sw - a.pw + j * a.dw) + dxv[p];
             fyv[p] = fy;
@@ -209,6 +240,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
             la[p] = use ? (r * a.LW + w_low + 1) : 0;
             if (valid && !in_rows) farmask |= (1u << p);
             if (mb) mv[p] = m;
+            if (++wo == a.Wo) { wo = 0; ++ho; }
         }
 
         float* cb = a.cols + (((int64_t)b * a.C + c0) * K + k) * HWo + nb;
@@ -230,13 +262,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
                 const float* xc = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    if (farmask & (1u << p)) {
-                        float m = mb ? mv[p] : 1.0f;
-                        acc[p].x = m * sample_global(xc, a.H, a.W, fyv[p], fxv[p]);
-                        acc[p].y = m * sample_global(xc + HW, a.H, a.W, fyv[p], fxv[p]);
-                        acc[p].z = m * sample_global(xc + 2 * HW, a.H, a.W, fyv[p], fxv[p]);
-                        acc[p].w = m * sample_global(xc + 3 * HW, a.H, a.W, fyv[p], fxv[p]);
-                    }
+                    if (farmask & (1u << p)) acc[p] = sample_global4(xc, HW, a.H, a.W, fyv[p], fxv[p], mb ? mv[p] : 1.0f);
             }
             float* c_ = cb + (int64_t)(4 * q) * K * HWo;
             const int64_t cs = (int64_t)K * HWo;

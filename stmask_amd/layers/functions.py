@@ -17,6 +17,7 @@ from .mask_utils import generate_mask
 from .modules import bbox_feat_extractor, correlate
 
 _FEATURE_KEYS = ("proto", "fpn_feat", "T2S_feat")
+ROI_BUCKET = 32
 
 
 def _empty(dev):
@@ -83,7 +84,14 @@ def CandidateShift(net, ref_candidate, next_candidate, img=None, img_meta=None, 
     box_ref = ref_candidate["box"].clone()
     feat_h, feat_w = ref_candidate["fpn_feat"].shape[2:]
     roi_feats = bbox_feat_extractor(feats, box_ref, feat_h, feat_w, 7)
+    n = roi_feats.shape[0]
+    n_pad = -(-n // ROI_BUCKET) * ROI_BUCKET
+    if n_pad != n:
+        # bucket the RoI batch: the dense-conv library (MIOpen) tunes per shape, and the tracked set grows by a few
+        # instances per frame -- padding keeps TemporalNet on a handful of shapes (rows are independent: exact)
+        roi_feats = torch.cat([roi_feats, roi_feats.new_zeros(n_pad - n, *roi_feats.shape[1:])], 0)
     loc_shift, coeff_shift = net.TemporalNet(roi_feats)
+    loc_shift, coeff_shift = loc_shift[:n], coeff_shift[:n]
     box_shift = decode(loc_shift, center_size(box_ref))
     coeff = ref_candidate["mask_coeff"] + coeff_shift
     shifted["box"] = box_shift

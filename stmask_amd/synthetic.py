@@ -19,7 +19,7 @@ def _gen(key, seed):
     return g
 
 
-def seeded_tensor(key, shape, seed=0):
+def seeded_tensor(key, shape, seed=0, bg_bias=None):
     """Value for one state-dict entry.  Conv/linear weights: N(0, sqrt(2/fan_in)) (keeps activations
     O(1) through ~60 ReLU layers); BN: identity (weight 1, bias 0, mean 0, var 1); biases: U(-0.1, 0.1)."""
     g = _gen(key, seed)
@@ -52,7 +52,7 @@ def seeded_tensor(key, shape, seed=0):
             fan_in *= s
         return torch.randn(shape, generator=g) * (math.sqrt(2.0 / max(fan_in, 1)) * _head_gain(key, shape))
     if leaf == "bias":
-        return torch.rand(shape, generator=g) * 0.2 - 0.1 + _head_bias(key, shape)
+        return torch.rand(shape, generator=g) * 0.2 - 0.1 + _head_bias(key, shape, BG_BIAS if bg_bias is None else bg_bias)
     return torch.randn(shape, generator=g)
 
 
@@ -82,16 +82,19 @@ def _head_gain(key, shape):
     return 1.0
 
 
-def _head_bias(key, shape):
+def _head_bias(key, shape, bg_bias):
     b = torch.zeros(shape)
     if _is_class_out(key, shape):
-        b[0] = BG_BIAS
+        b[0] = bg_bias
     elif "centerness_layer" in key:
         b += 1.0
     return b
 
 
+# 6.2: dense regime used by the small parity fixtures (hundreds of candidates on a 128x192 frame);
+# bench.py uses 6.9 at 384x640: ~40 candidates / ~35 detections per frame, tracked set growing to ~100 per 8-frame clip
 BG_BIAS = 6.2
+BENCH_BG_BIAS = 6.9
 
 
 def detection_seeding(sd, classes=(1, 7, 13), conf_bump=6.0, centerness_bump=2.0, num_classes=41):
@@ -106,10 +109,10 @@ def detection_seeding(sd, classes=(1, 7, 13), conf_bump=6.0, centerness_bump=2.0
     return sd
 
 
-def fill_state_dict(module, seed=0, seed_detections=False):
+def fill_state_dict(module, seed=0, seed_detections=False, bg_bias=None):
     """Overwrite every entry of module.state_dict() with its seeded value (in place) and return the dict."""
     sd = module.state_dict()
-    new = {k: seeded_tensor(k, v.shape, seed).to(v.dtype) for k, v in sd.items()}
+    new = {k: seeded_tensor(k, v.shape, seed, bg_bias).to(v.dtype) for k, v in sd.items()}
     if seed_detections:
         detection_seeding(new)
     module.load_state_dict(new)

@@ -226,7 +226,10 @@ def test_roi_align_vs_oracle_and_known_answers():
         got = ops.roi_align(feat.to(DEV), rois.to(DEV), 7, 1.0, sr, aligned).cpu()
         assert (got - ref).abs().max() < 1e-5
     const = torch.full((1, 3, 24, 40), 2.5)
-    out = ops.roi_align(const.to(DEV), rois[2:].to(DEV), 7).cpu()
+    inside = rois[2:].clone()                               # RoIs overhanging the map legitimately average in zeros
+    inside[:, 3] = inside[:, 3].clamp(max=39.0)
+    inside[:, 4] = inside[:, 4].clamp(max=23.0)
+    out = ops.roi_align(const.to(DEV), inside.to(DEV), 7).cpu()
     assert (out - 2.5).abs().max() < 1e-6                  # constant map -> constant
     ramp = torch.arange(40.0).view(1, 1, 1, 40).expand(1, 1, 24, 40).contiguous()
     r = torch.tensor([[0, 4.0, 3.0, 18.0, 17.0]])
@@ -257,7 +260,9 @@ def test_decode_bit_exact_full_size_and_extremes():
     loc[:8, 2:] = torch.tensor([[0.0, -0.0], [500.0, -500.0], [440.0, 443.5], [-430.0, -520.0], [1e-8, -1e-8],
                                 [88.0, 89.0], [3.0, 4.0], [-3.0, -4.0]])
     pri = torch.rand(n, 4, generator=g)
-    assert torch.equal(ops.decode(loc.to(DEV), pri.to(DEV)).cpu(), oracle.decode(loc, pri))
+    got, ref = ops.decode(loc.to(DEV), pri.to(DEV)).cpu(), oracle.decode(loc, pri)
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.isnan(ref).sum() <= 8   # exp overflow rows: inf - inf
+    assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(ref, nan=7.0))
     assert ops.decode(torch.zeros(0, 4, device=DEV), torch.zeros(0, 4, device=DEV)).shape == (0, 4)
 
 
