@@ -31,7 +31,7 @@ from stmask_amd import dist as sdist  # noqa: E402
 from stmask_amd import ops, synthetic  # noqa: E402
 from stmask_amd.config import get_cfg  # noqa: E402
 from stmask_amd.model import STMask  # noqa: E402
-from stmask_amd.pipeline import ClipPipeline  # noqa: E402
+from stmask_amd.pipeline import BatchedClipPipeline, ClipPipeline  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", default="batched", choices=["batched", "per-clip"],
+                    help="batched: all clips' post-processing in concatenated tensors; per-clip: reference-shaped layer API")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,11 +96,11 @@ def main():
     # clip c of this rank = global clip rank + c*world (stmask_amd.dist.shard_clips); inputs resident in HBM
     clips = torch.stack([synthetic.synthetic_clip(T, args.height, args.width, seed=rank + c * world)
                          for c in range(args.clips)]).to(dev)  # [clips, T, 3, H, W]
-    pipe = ClipPipeline(net, args.clips)
+    pipe = BatchedClipPipeline(net, args.clips) if args.pipeline == "batched" else ClipPipeline(net, args.clips)
 
     def step(t):
-        dets = pipe.step(clips[:, t % T].contiguous(), is_first=(t % T == 0))
-        packed = sdist.pack_detections(dets, top_k=net.cfg.nms_top_k, device=dev)
+        out = pipe.step(clips[:, t % T].contiguous(), is_first=(t % T == 0))
+        packed = out if args.pipeline == "batched" else sdist.pack_detections(out, top_k=net.cfg.nms_top_k, device=dev)
         return sdist.all_gather_detections(packed)
 
     for t in range(args.warmup):
@@ -137,7 +139,8 @@ def main():
             "config": {"workload": f"{args.config}: R50-DCN-FPN FCA + temporal fusion, {args.height}x{args.width} "
                                    f"tensor (360x640 padded), {args.clips} clips/GPU x 1 frame per step, random seeded weights",
                        "clips_per_gpu": args.clips, "frames_per_step": world * args.clips,
-                       "detections_last_step": n_det, "parallelism": f"clip-dp{world}"},
+                       "detections_last_step": n_det, "parallelism": f"clip-dp{world}",
+                       "pipeline": args.pipeline},
             "roofline": {"bound": "hbm", "kernel": "deform_im2col_lds (7 DCN layers, all launches of the timed region)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

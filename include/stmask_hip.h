@@ -176,9 +176,12 @@ int stm_jaccard_f32(const float* a, int na, const float* b, int nb, float* out, 
  *   proto [h,w,m] (NHWC as the reference permutes it, STMask.py:236), coeff [n,m], boxes [n,4] relative
  *   x1y1x2y2 or NULL (no crop) -> out [n,h,w] soft masks (already in the reference's permuted layout).
  *   apply_tanh: mask_proto_coeff_activation (config.py:447).  n_dev: optional device count (<= n).
+ *   row_proto: optional device int[n]: row i uses prototype set proto + row_proto[i]*h*w*m, so the rows of
+ *   several frames (clips) share one launch; NULL -> every row uses proto.
  * ------------------------------------------------------------------------------------------------- */
 int stm_lincomb_sigmoid_crop_f32(const float* proto, const float* coeff, const float* boxes, float* out, int h,
-                                 int w, int m, int n, int apply_tanh, const int* n_dev, stm_stream_t stream);
+                                 int w, int m, int n, int apply_tanh, const int* n_dev, const int* row_proto,
+                                 stm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Binary mask IoU.  Replaces: mask_iou (box_utils.py:435-447) on m.gt(thr).float() inputs

@@ -70,8 +70,14 @@ def _detect_cc(loc, priors, conf, centerness, conf_thresh=0.05, iou_thr=0.5, top
     return tuple(torch.stack([o[i] for o in outs]) for i in range(5))
 
 
-def _lincomb(proto, coeff, boxes=None, apply_tanh=True, n_dev=None):
-    out = orc.generate_mask(proto, coeff, boxes, apply_tanh)
+def _lincomb(proto, coeff, boxes=None, apply_tanh=True, n_dev=None, row_proto=None):
+    if row_proto is not None:
+        out = torch.zeros(coeff.shape[0], proto.shape[1], proto.shape[2])
+        for pi in row_proto.unique().tolist():
+            sel = torch.nonzero(row_proto == pi).view(-1)
+            out[sel] = orc.generate_mask(proto[pi], coeff[sel], boxes[sel] if boxes is not None else None, apply_tanh)
+    else:
+        out = orc.generate_mask(proto, coeff, boxes, apply_tanh)
     if n_dev is not None:
         out[int(n_dev):] = 0
     return out

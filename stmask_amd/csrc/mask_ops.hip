@@ -19,7 +19,8 @@ constexpr int LC_DCHUNK = 8;   // detections per workgroup
 template <int M>
 __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ proto, const float* __restrict__ coeff,
                                                       const float* __restrict__ boxes, float* __restrict__ out, int h,
-                                                      int w, int n, int apply_tanh, const int* __restrict__ n_dev)
+                                                      int w, int n, int apply_tanh, const int* __restrict__ n_dev,
+                                                      const int* __restrict__ row_proto)
 {
     __shared__ float sc[LC_DCHUNK * M];
     __shared__ float sb[LC_DCHUNK * 4];  // x1, x2, y1, y2 (float bounds, padding 1)
@@ -49,15 +50,20 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ 
     if (pix >= hw) return;
 
     float p[M];
-    const float4* pr = reinterpret_cast<const float4*>(proto + (int64_t)pix * M);
-#pragma unroll
-    for (int q = 0; q < M / 4; ++q) {
-        float4 v = pr[q];
-        p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
-    }
+    int cur = -1;  // prototype set currently held in registers (rows of several frames may share one launch)
     const int y = pix / w, x = pix - y * w;
     const float fx = (float)x, fy = (float)y;
     for (int d = 0; d < nd; ++d) {
+        const int want = row_proto ? row_proto[d0 + d] : 0;  // wave-uniform
+        if (want != cur) {
+            cur = want;
+            const float4* pr = reinterpret_cast<const float4*>(proto + ((int64_t)cur * hw + pix) * M);
+#pragma unroll
+            for (int q = 0; q < M / 4; ++q) {
+                float4 v = pr[q];
+                p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+            }
+        }
         float v = 0.0f;
         const bool inside = (d0 + d < n_valid) && fx >= sb[d * 4] && fx < sb[d * 4 + 1] && fy >= sb[d * 4 + 2] &&
                             fy < sb[d * 4 + 3];
@@ -112,7 +118,8 @@ __global__ __launch_bounds__(256) void mask_iou_pairs_kernel(const unsigned long
 }  // namespace
 
 extern "C" int stm_lincomb_sigmoid_crop_f32(const float* proto, const float* coeff, const float* boxes, float* out, int h,
-                                            int w, int m, int n, int apply_tanh, const int* n_dev, stm_stream_t stream)
+                                            int w, int m, int n, int apply_tanh, const int* n_dev, const int* row_proto,
+                                            stm_stream_t stream)
 {
     STM_REQUIRE(n >= 0, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: n=%d", n);
     if (n == 0) return STM_OK;
@@ -123,13 +130,13 @@ extern "C" int stm_lincomb_sigmoid_crop_f32(const float* proto, const float* coe
     STM_REQUIRE(grid.y <= 65535, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: n=%d too large", n);
     if (m == 32) {
         hipLaunchKernelGGL(lincomb_kernel<32>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
-                           apply_tanh, n_dev);
+                           apply_tanh, n_dev, row_proto);
     } else if (m == 8) {
         hipLaunchKernelGGL(lincomb_kernel<8>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
-                           apply_tanh, n_dev);
+                           apply_tanh, n_dev, row_proto);
     } else if (m == 64) {
         hipLaunchKernelGGL(lincomb_kernel<64>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
-                           apply_tanh, n_dev);
+                           apply_tanh, n_dev, row_proto);
     } else {
         STM_REQUIRE(false, STM_EUNSUPPORTED, "stm_lincomb_sigmoid_crop_f32: mask_dim %d not in {8,32,64}", m);
     }

@@ -307,16 +307,21 @@ def jaccard(a, b):
     return out
 
 
-def lincomb_sigmoid_crop(proto, coeff, boxes=None, apply_tanh=True, n_dev=None):
-    """generate_mask (mask_utils.py:111-128) + crop.  proto [h,w,m], coeff [n,m], boxes [n,4] -> [n,h,w]."""
-    _dev(proto, coeff, boxes)
+def lincomb_sigmoid_crop(proto, coeff, boxes=None, apply_tanh=True, n_dev=None, row_proto=None):
+    """generate_mask (mask_utils.py:111-128) + crop.  proto [h,w,m], coeff [n,m], boxes [n,4] -> [n,h,w].
+    With row_proto (int32 [n]) proto is [P,h,w,m] and row i uses proto[row_proto[i]] (rows of many clips, one launch)."""
+    _dev(proto, coeff, boxes, row_proto)
     proto, coeff = _f32c(proto), _f32c(coeff)
-    h, w, m = proto.shape
+    if row_proto is not None:
+        assert proto.dim() == 4 and row_proto.dtype == torch.int32 and row_proto.numel() == coeff.shape[0]
+        h, w, m = proto.shape[1:]
+    else:
+        h, w, m = proto.shape
     n = coeff.shape[0]
     bx = _f32c(boxes) if boxes is not None else None
     out = torch.empty(n, h, w, dtype=torch.float32, device=proto.device)
     check(_lib.lib().stm_lincomb_sigmoid_crop_f32(_p(proto), _p(coeff), _p(bx), _p(out), c_i(h), c_i(w), c_i(m), c_i(n),
-                                                  c_i(1 if apply_tanh else 0), _p(n_dev), _stream()),
+                                                  c_i(1 if apply_tanh else 0), _p(n_dev), _p(row_proto), _stream()),
           "stm_lincomb_sigmoid_crop_f32")
     return out
 

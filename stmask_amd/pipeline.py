@@ -1,13 +1,25 @@
 """Batched clip pipeline: many independent video clips advance one frame per step on one GPU.
 
 forward_single has no cross-frame dependence, so frame t of all local clips goes through the trunk
-and heads as ONE batch; only the temporal-fusion / tracker stage is per clip (previous-frame features and tracker
-state, track_TF.py:52-54,96-100).  This is the unit bench.py times and dist.py shards over GPUs.
+and heads as ONE batch; the temporal-fusion / tracker stage is per clip in the reference (previous-frame features and
+tracker state, track_TF.py:52-54,96-100).  Two drivers:
+
+* ``ClipPipeline``        -- reference-shaped: one ``Track_TF`` per clip, the layer API of ``stmask_amd.layers``
+                             (what a user of the reference's eval loop gets; ~4 host syncs per clip and frame).
+* ``BatchedClipPipeline`` -- same arithmetic, but the state of all clips lives in concatenated tensors and every stage
+                             is ONE launch for all clips: fused decode + threshold + Fast NMS (no sync), one lincomb
+                             launch for all detections (per-row prototype index), one correlation / RoIAlign /
+                             TemporalNet / decode / lincomb chain for all tracked instances, one cross matrix for the
+                             matching scores.  Two small device->host reads per STEP (detection counts, match ids).
 """
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .layers import Track_TF, generate_candidate
+from .layers.box_utils import center_size, sanitize_coordinates_hw
+
+ROI_BUCKET = 64
 
 
 class ClipPipeline:
@@ -36,3 +48,198 @@ class ClipPipeline:
             out.append(self.trackers[i].track(net, det, meta, img=None))
         self.t += 1
         return out
+
+
+_ROW_KEYS = ("box", "mask_coeff", "track", "class", "score", "centerness", "mask")
+
+
+class BatchedClipPipeline:
+    """All clips' tracker state concatenated (rows sorted by clip); per-clip row ranges are host integers."""
+
+    def __init__(self, net, n_clips):
+        self.net, self.cfg, self.B = net, net.cfg, n_clips
+        if not self.cfg.temporal_fusion_module:
+            raise NotImplementedError("BatchedClipPipeline drives the temporal-fusion configs")
+        self.t = 0
+        self.prev = None            # dict of concatenated row tensors
+        self.prev_n = [0] * n_clips  # tracked instances per clip
+        self.prev_feat = None       # (P4 [B,256,h,w], T2S [B,256,h,w]) of the previous frame
+        self.has_prev = [False] * n_clips
+        self.tracked = [[] for _ in range(n_clips)]  # host-side "frames since last match" counters
+
+    # -- stage helpers ------------------------------------------------------------------------------------------------
+    def _shift_prev(self, P4, T2S, proto, dev):
+        """CandidateShift (TF_utils.py:12-51) for every tracked instance of every clip in one chain."""
+        net, cfg, prev = self.net, self.cfg, self.prev
+        clip_of_row = prev["clip"]
+        P4_prev, T2S_prev = self.prev_feat
+        P = cfg.correlation_patch_size
+        corr = ops.corr_patch(P4_prev, P4, P, 1, scale=1.0 / P4.shape[1], leaky_slope=0.1)
+        corr = corr.view(P4.shape[0], P * P, P4.shape[2], P4.shape[3])
+        feats = F.relu(torch.cat([corr, T2S_prev, T2S], dim=1))
+        fh, fw = P4.shape[2:]
+        box_ref = prev["box"]
+        rois = torch.cat([clip_of_row.float().unsqueeze(1), sanitize_coordinates_hw(box_ref, fh, fw)], dim=1)
+        roi_feats = ops.roi_align(feats, rois, 7)
+        n = roi_feats.shape[0]
+        n_pad = -(-n // ROI_BUCKET) * ROI_BUCKET
+        if n_pad != n:  # keep the dense-conv library on a handful of shapes (rows are independent: exact)
+            roi_feats = torch.cat([roi_feats, roi_feats.new_zeros(n_pad - n, *roi_feats.shape[1:])], 0)
+        loc_shift, coeff_shift = net.TemporalNet(roi_feats)
+        box_shift = ops.decode(loc_shift[:n].contiguous(), center_size(box_ref))
+        coeff = prev["mask_coeff"] + coeff_shift[:n]
+        prev["box"] = box_shift
+        prev["score"] = prev["score"] * 0.95
+        prev["mask_coeff"] = coeff
+        prev["mask"] = ops.lincomb_sigmoid_crop(proto, coeff, box_shift, apply_tanh=True, row_proto=clip_of_row)
+        for b in range(self.B):
+            self.tracked[b] = [v + 1 for v in self.tracked[b]]
+
+    @torch.no_grad()
+    def step(self, frames, is_first=None):
+        """frames [B,3,H,W] -> packed detections [B, top_k, 40] (stmask_amd.dist layout) without a final sync, plus the
+        per-clip tracked-instance counts (host ints)."""
+        net, cfg, B = self.net, self.cfg, self.B
+        dev = frames.device
+        first = (self.t == 0) if is_first is None else is_first
+        if first:
+            self.prev, self.prev_n, self.prev_feat = None, [0] * B, None
+            self.tracked = [[] for _ in range(B)]
+        fpn_outs, pred = net.forward_single(frames)
+        conf = F.softmax(pred["conf"], -1)
+        P4 = fpn_outs[net.correlation_selected_layer]
+        T2S = pred["T2S_feat"][net.correlation_selected_layer]
+        proto = pred["proto"]
+        N = conf.shape[1]
+        priors = pred["priors"].squeeze(0)
+        idx, cls, score, box, cnt = ops.detect_cc(pred["loc"], priors, conf, pred["centerness"], cfg.eval_conf_thresh,
+                                                  cfg.nms_thresh, cfg.nms_top_k)
+        counts = cnt.tolist()  # host read 1 (B ints)
+        D = sum(counts)
+        top_k = cfg.nms_top_k
+        # ---- detections of all clips, concatenated (rows sorted by clip) ------------------------------------------
+        valid = torch.arange(top_k, device=dev)[None, :] < cnt[:, None]
+        offs = torch.arange(B, device=dev, dtype=torch.int64)[:, None] * N
+        flat = (idx + offs)[valid]
+        det = {
+            "box": box[valid], "class": cls[valid], "score": score[valid],
+            "mask_coeff": pred["mask_coeff"].reshape(B * N, -1).index_select(0, flat),
+            "track": pred["track"].reshape(B * N, -1).index_select(0, flat),
+            "centerness": pred["centerness"].reshape(B * N).index_select(0, flat),
+            "clip": torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32),
+                                            torch.tensor(counts, device=dev), output_size=D),
+        }
+        det["mask"] = (ops.lincomb_sigmoid_crop(proto, det["mask_coeff"], det["box"], apply_tanh=True,
+                                                row_proto=det["clip"])
+                       if D else proto.new_zeros(0, proto.shape[1], proto.shape[2]))
+
+        if self.prev is None:
+            # first frame of every clip (track_TF.py:88-93): the detections become the tracked set
+            self.prev = det
+            self.prev_n = list(counts)
+            self.tracked = [[0] * k for k in counts]
+        else:
+            Pn = sum(self.prev_n)
+            if Pn:
+                self._shift_prev(P4, T2S, proto, dev)
+            prev = self.prev
+            if D and Pn:
+                # matching scores for all clips at once; pairs from different clips can never match
+                cos = det["track"] @ prev["track"].t()
+                cos = (torch.cat([cos.new_zeros(D, 1), cos], dim=1) + 1) / 2
+                biou = ops.jaccard(det["box"], prev["box"])
+                miou = ops.mask_iou(det["mask"], prev["mask"])
+                dummy = torch.full((D, 1), 0.3, device=dev)
+                c = cfg.match_coeff
+                comp = cos + c[0] * det["score"].view(-1, 1) + c[1] * torch.cat([dummy, miou], 1) \
+                    + c[2] * torch.cat([dummy, biou], 1) \
+                    + c[3] * torch.cat([torch.ones_like(dummy), (prev["class"][None, :] == det["class"][:, None]).float()], 1)
+                same = torch.cat([torch.ones(D, 1, dtype=torch.bool, device=dev),
+                                  det["clip"][:, None] == prev["clip"][None, :]], dim=1)
+                comp = torch.where(same, comp, torch.full_like(comp, float("-inf")))
+                match = comp.argmax(dim=1)
+                host = torch.stack([match.float(), det["score"]]).cpu()  # host read 2
+                ids, scores = host[0].long().tolist(), host[1].tolist()
+            else:
+                ids, scores = [0] * D, [0.0] * D
+            # greedy resolution (track_TF.py:132-156) per clip on host scalars -> one gather plan for all clips
+            plan, new_n, new_tracked = [], [], []
+            p0 = d0 = 0
+            for b in range(B):
+                pn, dn = self.prev_n[b], counts[b]
+                src = list(range(p0, p0 + pn))
+                tm = list(self.tracked[b])
+                best = [-1.0] * pn
+                for j in range(dn):
+                    mid = ids[d0 + j]
+                    if mid == 0:
+                        src.append(Pn + d0 + j)
+                        tm.append(0)
+                    else:
+                        obj = mid - 1 - p0
+                        if scores[d0 + j] > best[obj]:
+                            best[obj] = scores[d0 + j]
+                            src[obj] = Pn + d0 + j
+                            tm[obj] = 0
+                plan += src
+                new_n.append(len(src))
+                new_tracked.append(tm)
+                p0 += pn
+                d0 += dn
+            if D:
+                plan_t = torch.tensor(plan, device=dev, dtype=torch.int64)
+                for k in _ROW_KEYS + ("clip",):
+                    prev[k] = torch.cat([prev[k], det[k]], dim=0).index_select(0, plan_t)
+            self.prev_n, self.tracked = new_n, new_tracked
+        self.prev_feat = (P4, T2S)
+        self.t += 1
+        return self._pack_outputs(dev)
+
+    def _pack_outputs(self, dev):
+        """keep rule of track_TF.py:158-165 on device, scattered into [B, top_k, 40] without a host sync."""
+        from .dist import DET_COLS
+        cfg, B, prev = self.cfg, self.B, self.prev
+        top_k = cfg.nms_top_k
+        Pn = sum(self.prev_n)
+        if Pn == 0:
+            return torch.zeros(B, top_k, DET_COLS, device=dev)
+        tm = torch.tensor([v for t in self.tracked for v in t], device=dev)
+        keep = (tm <= 10) & (prev["mask"].gt(0.5).sum([1, 2]) > 1) & (prev["score"] > cfg.eval_conf_thresh)
+        starts, ids, s = [], [], 0
+        for n in self.prev_n:
+            starts += [s] * n
+            ids += list(range(n))
+            s += n
+        starts = torch.tensor(starts, device=dev)
+        obj_id = torch.tensor(ids, device=dev)
+        csum = torch.cumsum(keep.long(), 0)
+        before = csum - keep.long()
+        pos = before - before.index_select(0, starts)  # rank among the kept rows of the same clip
+        ok = keep & (pos < top_k)
+        rows = torch.cat([prev["box"], prev["score"][:, None], prev["class"][:, None].float(), obj_id[:, None].float(),
+                          torch.ones(Pn, 1, device=dev), prev["mask_coeff"]], dim=1)
+        tgt = prev["clip"].long() * top_k + torch.where(ok, pos, torch.zeros_like(pos))
+        # rows that are not kept are routed to a scratch row past the end (no data-dependent shapes, no sync)
+        scratch = torch.zeros(B * top_k + 1, DET_COLS, device=dev)
+        tgt = torch.where(ok, tgt, torch.full_like(tgt, B * top_k))
+        scratch.index_copy_(0, tgt, rows)
+        return scratch[: B * top_k].view(B, top_k, DET_COLS)
+
+    def detections(self):
+        """Reference-shaped per-clip detection dicts of the last step (host sync; for tests and users who want them)."""
+        cfg, prev = self.cfg, self.prev
+        outs = []
+        if prev is None:
+            return [{} for _ in range(self.B)]
+        dev = prev["box"].device
+        tm = torch.tensor([v for t in self.tracked for v in t], device=dev)
+        keep = (tm <= 10) & (prev["mask"].gt(0.5).sum([1, 2]) > 1) & (prev["score"] > cfg.eval_conf_thresh)
+        p0 = 0
+        for b in range(self.B):
+            n = self.prev_n[b]
+            k = torch.nonzero(keep[p0:p0 + n]).view(-1)
+            d = {key: prev[key][p0:p0 + n].index_select(0, k) for key in _ROW_KEYS}
+            d["box_ids"] = k
+            outs.append(d)
+            p0 += n
+        return outs

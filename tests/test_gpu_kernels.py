@@ -447,6 +447,21 @@ def test_generate_mask_full_size_and_crop_boundaries(golden_postproc):
     assert ops.lincomb_sigmoid_crop(proto.to(DEV), coeff[:0].to(DEV), box[:0].to(DEV)).shape == (0, 96, 160)
 
 
+def test_generate_mask_rows_of_several_clips_in_one_launch():
+    gen = torch.Generator().manual_seed(8)
+    protos = torch.relu(torch.randn(3, 24, 40, 32, generator=gen))
+    coeff = torch.randn(37, 32, generator=gen)
+    c = torch.rand(37, 2, generator=gen)
+    wh = torch.rand(37, 2, generator=gen) * 0.6
+    box = torch.cat([c - wh / 2, c + wh / 2], 1)
+    rp = torch.tensor([0] * 5 + [1] * 20 + [2] * 12, dtype=torch.int32)   # chunk of 8 rows straddles clips
+    got = ops.lincomb_sigmoid_crop(protos.to(DEV), coeff.to(DEV), box.to(DEV), row_proto=rp.to(DEV)).cpu()
+    for pi in range(3):
+        sel = torch.nonzero(rp == pi).view(-1)
+        ref = oracle.generate_mask(protos[pi], coeff[sel], box[sel])
+        assert (got[sel] - ref).abs().max() < 5e-6
+
+
 @pytest.mark.parametrize("p", CASES)
 def test_mask_iou_bit_exact(golden_postproc, p):
     m = golden_postproc[p + "masks"]

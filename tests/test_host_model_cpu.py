@@ -57,3 +57,42 @@ def test_model_matches_reference_on_cpu(name, tag):
         assert (fpn_outs[1][0, ::16] - g["f0_P4"]).abs().max() < 1e-5
         outs = run_clip(net, frames)
     check_clip_against_golden(outs, g, tol_box=1e-5, tol_mask=1e-5)
+
+
+@pytest.mark.parametrize("name,tag", CASES[:2])
+def test_batched_pipeline_matches_reference_on_cpu(name, tag):
+    """BatchedClipPipeline (all clips in concatenated tensors, fused detect, one TF chain) == the reference's per-clip
+    Detect_TF / Track_TF on its own clip, and two different clips batched together do not interact."""
+    from stmask_amd.pipeline import BatchedClipPipeline, ClipPipeline
+    from stmask_amd.dist import unpack_detections
+    g = load_golden(f"model_{tag}.npz")
+    h, w = [int(v) for v in g["frames_hw"]]
+    net = STMask(get_cfg(name))
+    net.eval()
+    synthetic.fill_state_dict(net, seed=0)
+    T = int(g["n_frames"])
+    clip0 = synthetic.synthetic_clip(T, h, w, seed=0)
+    clip1 = synthetic.synthetic_clip(T, h, w, seed=5)
+    with oracle_ops(), torch.no_grad():
+        pipe = BatchedClipPipeline(net, 2)
+        ref_pipe = ClipPipeline(net, 2)
+        for t in range(T):
+            frames = torch.stack([clip0[t], clip1[t]])
+            packed = pipe.step(frames)
+            ref = ref_pipe.step(frames)
+            dets = pipe.detections()
+            # clip 0 against the reference golden
+            n_ref = g[f"t{t}_box"].shape[0]
+            assert dets[0]["box"].shape[0] == n_ref
+            assert torch.equal(dets[0]["box_ids"], g[f"t{t}_box_ids"]) and torch.equal(dets[0]["class"], g[f"t{t}_class"])
+            assert (dets[0]["box"] - g[f"t{t}_box"]).abs().max() < 1e-5
+            assert (dets[0]["mask"] - g[f"t{t}_mask"]).abs().max() < 1e-5
+            # both clips against the per-clip reference-shaped driver, and the packed (sync-free) output
+            for b in range(2):
+                assert torch.equal(dets[b]["box_ids"], ref[b]["box_ids"])
+                assert (dets[b]["box"] - ref[b]["box"]).abs().max() < 1e-5
+                assert (dets[b]["score"] - ref[b]["score"]).abs().max() < 1e-6
+                un = unpack_detections(packed[b])
+                n = min(len(ref[b]["box_ids"]), packed.shape[1])
+                assert torch.equal(un["box_ids"][:n], ref[b]["box_ids"][:n]) and torch.equal(un["class"][:n], ref[b]["class"][:n])
+                assert (un["box"][:n] - ref[b]["box"][:n]).abs().max() < 1e-5
