@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nchw", dest="channels_last", action="store_false", help="keep the dense convs in NCHW")
     ap.add_argument("--pipeline", default="batched", choices=["batched", "per-clip"],
                     help="batched: all clips' post-processing in concatenated tensors; per-clip: reference-shaped layer API")
     args = ap.parse_args()
@@ -87,19 +88,26 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    torch.backends.cudnn.benchmark = True  # MIOpen find mode for the dense convs
+    # MIOpen immediate mode: measured identical steady-state speed to find mode on this trunk (scripts/bench_trunk.py:
+    # 20.6 vs 21.0 ms at batch 8) without minutes of solver search per new shape
+    torch.backends.cudnn.benchmark = False
     net = STMask(get_cfg(args.config))
     net.eval()
     synthetic.fill_state_dict(net, seed=0, bg_bias=synthetic.BENCH_BG_BIAS)
     net = net.to(dev)
+    if args.channels_last:
+        net = net.to(memory_format=torch.channels_last)  # dense convs NHWC (17.0 vs 20.6 ms trunk at batch 8)
     T = 8
     # clip c of this rank = global clip rank + c*world (stmask_amd.dist.shard_clips); inputs resident in HBM
     clips = torch.stack([synthetic.synthetic_clip(T, args.height, args.width, seed=rank + c * world)
                          for c in range(args.clips)]).to(dev)  # [clips, T, 3, H, W]
     pipe = BatchedClipPipeline(net, args.clips) if args.pipeline == "batched" else ClipPipeline(net, args.clips)
 
+    fmt = torch.channels_last if args.channels_last else torch.contiguous_format
+    frames_t = [clips[:, t].contiguous(memory_format=fmt) for t in range(T)]  # resident, in the trunk's layout
+
     def step(t):
-        out = pipe.step(clips[:, t % T].contiguous(), is_first=(t % T == 0))
+        out = pipe.step(frames_t[t % T], is_first=(t % T == 0))
         packed = out if args.pipeline == "batched" else sdist.pack_detections(out, top_k=net.cfg.nms_top_k, device=dev)
         return sdist.all_gather_detections(packed)
 

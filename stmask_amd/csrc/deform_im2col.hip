@@ -137,11 +137,17 @@ __device__ __noinline__ float4 sample_global4(const float* __restrict__ xc, int6
     return r;
 }
 
+__device__ __forceinline__ void unpack(const float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void unpack(const float v, float (&o)[1]) { o[0] = v; }
+template <int NP> struct PosVec { using type = float4; };
+template <> struct PosVec<1> { using type = float; };
+
 // ------------------------------------------------------------------------------------ variant 2
 // grid: x = tiles_y * (C / cch), y = B.  Dynamic LDS: (cch/4) * R * LW float4.
 template <int NP>
 __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
 {
+    using VecT = typename PosVec<NP>::type;
     extern __shared__ float4 tile[];
     const int K = a.kh * a.kw;
     const int HWo = a.Ho * a.Wo;
@@ -158,64 +164,79 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
     const int y0 = ho0 * a.sh - a.ph - a.halo;  // input row held by LDS row 0
     const int RL = a.R * a.LW;
 
-    // ---- stage: thread <-> pixel, 4 channel loads (each coalesced across the wave) -> one ds_write_b128
+    const int n0 = ho0 * a.Wo;
+    const int NT = rows_out * a.Wo;
+    const int items_per_k = (NT + NP - 1) / NP;
+    const int n_items = K * items_per_k;
+    const float* ob = a.off + (int64_t)b * a.off_bs + (int64_t)g * 2 * K * HWo;
+    const float* mb = a.mask ? a.mask + (int64_t)b * a.mask_bs + (int64_t)g * K * HWo : nullptr;
+
+    // ---- 1. issue the offset / mask loads of this thread's first PRE items NOW: their HBM/L2 latency is hidden
+    //         behind the staging phase below (they do not depend on LDS)
+    constexpr int PRE = 3;
+    VecT pdy[PRE], pdx[PRE], pm[PRE];
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) {
+        const int item = tid + it * 256;
+        if (item < n_items) {
+            const int k = item / items_per_k;
+            const int nb = n0 + (item - k * items_per_k) * NP;
+            pdy[it] = *reinterpret_cast<const VecT*>(ob + (int64_t)(2 * k) * HWo + nb);
+            pdx[it] = *reinterpret_cast<const VecT*>(ob + (int64_t)(2 * k + 1) * HWo + nb);
+            if (mb) pm[it] = *reinterpret_cast<const VecT*>(mb + (int64_t)k * HWo + nb);
+        }
+    }
+
+    // ---- 2. stage: thread <-> pixel, 4 channel loads (each coalesced across the wave) -> one ds_write_b128.
+    //         Loads are issued in batches of SU pixels per thread before any LDS write, so SU*4 loads are in
+    //         flight per lane instead of 4 (the unbatched loop waited vmcnt(0) once per pixel).
     {
+        constexpr int SU = 4;
         const float* xb = a.x + ((int64_t)b * a.C + c0) * HW;
+        const int total = nq * RL;
         // (q, r, col) advance incrementally with idx += 256: no per-element integer division
         const int step_r = 256 / a.LW, step_c = 256 - step_r * a.LW;
         int r = tid / a.LW, col = tid - r * a.LW, q = 0;
         while (r >= a.R) { r -= a.R; ++q; }
-        for (int idx = tid; idx < nq * RL; idx += 256) {
-            int yy = y0 + r, xx = col - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-                const float* p = xb + (int64_t)(4 * q) * HW + (int64_t)yy * a.W + xx;
-                v.x = p[0];
-                v.y = p[HW];
-                v.z = p[2 * HW];
-                v.w = p[3 * HW];
+        for (int base = tid; base < total; base += 256 * SU) {
+            float4 v[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int yy = y0 + r, xx = col - 1;
+                if (base + u * 256 < total && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                    const float* p = xb + (int64_t)(4 * q) * HW + (int64_t)yy * a.W + xx;
+                    v[u].x = p[0];
+                    v[u].y = p[HW];
+                    v[u].z = p[2 * HW];
+                    v[u].w = p[3 * HW];
+                }
+                col += step_c;
+                r += step_r;
+                if (col >= a.LW) { col -= a.LW; ++r; }
+                while (r >= a.R) { r -= a.R; ++q; }
             }
-            tile[idx] = v;
-            col += step_c;
-            r += step_r;
-            if (col >= a.LW) { col -= a.LW; ++r; }
-            while (r >= a.R) { r -= a.R; ++q; }
+#pragma unroll
+            for (int u = 0; u < SU; ++u)
+                if (base + u * 256 < total) tile[base + u * 256] = v[u];
         }
     }
     __syncthreads();
 
-    const int n0 = ho0 * a.Wo;
-    const int NT = rows_out * a.Wo;
-    const int items_per_k = (NT + NP - 1) / NP;
-    const float* ob = a.off + (int64_t)b * a.off_bs + (int64_t)g * 2 * K * HWo;
-    const float* mb = a.mask ? a.mask + (int64_t)b * a.mask_bs + (int64_t)g * K * HWo : nullptr;
-
-    for (int item = tid; item < K * items_per_k; item += 256) {
+    // ---- 3. items: (4 consecutive positions) x (one tap), all channel quads of the block
+    auto process = [&](const int item, const VecT dyq, const VecT dxq, const VecT mq) {
         const int k = item / items_per_k;
         const int pq = item - k * items_per_k;
         const int i = k / a.kw, j = k - i * a.kw;
-        const int nl = pq * NP;  // first position of the item, relative to the tile
-        const int nb = n0 + nl;
-
+        const int nb = n0 + pq * NP;
         float dyv[NP], dxv[NP], mv[NP];
-        if (NP == 4) {
-            float4 t0 = *reinterpret_cast<const float4*>(ob + (int64_t)(2 * k) * HWo + nb);
-            float4 t1 = *reinterpret_cast<const float4*>(ob + (int64_t)(2 * k + 1) * HWo + nb);
-            dyv[0] = t0.x; dyv[1 % NP] = t0.y; dyv[2 % NP] = t0.z; dyv[3 % NP] = t0.w;
-            dxv[0] = t1.x; dxv[1 % NP] = t1.y; dxv[2 % NP] = t1.z; dxv[3 % NP] = t1.w;
-            if (mb) {
-                float4 t2 = *reinterpret_cast<const float4*>(mb + (int64_t)k * HWo + nb);
-                mv[0] = t2.x; mv[1 % NP] = t2.y; mv[2 % NP] = t2.z; mv[3 % NP] = t2.w;
-            }
-        } else {
-            dyv[0] = ob[(int64_t)(2 * k) * HWo + nb];
-            dxv[0] = ob[(int64_t)(2 * k + 1) * HWo + nb];
-            if (mb) mv[0] = mb[(int64_t)k * HWo + nb];
-        }
+        unpack(dyq, dyv);
+        unpack(dxq, dxv);
+        unpack(mq, mv);
 
         // per-position coefficients
         float w1[NP], w2[NP], w3[NP], w4[NP], fyv[NP], fxv[NP];
-        int la[NP];          // LDS index of the (h_low, w_low) corner
+        int la[NP];            // LDS index of the (h_low, w_low) corner
         unsigned farmask = 0;  // positions whose corners leave the staged rows
         int ho = nb / a.Wo, wo = nb - ho * a.Wo;
 #pragma unroll
@@ -239,11 +260,12 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
             w4[p] = use ? lh * lw * m : 0.f;
             la[p] = use ? (r * a.LW + w_low + 1) : 0;
             if (valid && !in_rows) farmask |= (1u << p);
-            if (mb) mv[p] = m;
+            mv[p] = m;
             if (++wo == a.Wo) { wo = 0; ++ho; }
         }
 
         float* cb = a.cols + (((int64_t)b * a.C + c0) * K + k) * HWo + nb;
+        const int64_t cs = (int64_t)K * HWo;
         for (int q = 0; q < nq; ++q) {
             const float4* tq = tile + q * RL;
             float4 acc[NP];
@@ -262,15 +284,14 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
                 const float* xc = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    if (farmask & (1u << p)) acc[p] = sample_global4(xc, HW, a.H, a.W, fyv[p], fxv[p], mb ? mv[p] : 1.0f);
+                    if (farmask & (1u << p)) acc[p] = sample_global4(xc, HW, a.H, a.W, fyv[p], fxv[p], mv[p]);
             }
-            float* c_ = cb + (int64_t)(4 * q) * K * HWo;
-            const int64_t cs = (int64_t)K * HWo;
-            if (NP == 4) {
-                *reinterpret_cast<float4*>(c_) = make_float4(acc[0].x, acc[1 % NP].x, acc[2 % NP].x, acc[3 % NP].x);
-                *reinterpret_cast<float4*>(c_ + cs) = make_float4(acc[0].y, acc[1 % NP].y, acc[2 % NP].y, acc[3 % NP].y);
-                *reinterpret_cast<float4*>(c_ + 2 * cs) = make_float4(acc[0].z, acc[1 % NP].z, acc[2 % NP].z, acc[3 % NP].z);
-                *reinterpret_cast<float4*>(c_ + 3 * cs) = make_float4(acc[0].w, acc[1 % NP].w, acc[2 % NP].w, acc[3 % NP].w);
+            float* c_ = cb + (int64_t)(4 * q) * cs;
+            if constexpr (NP == 4) {
+                *reinterpret_cast<float4*>(c_) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
+                *reinterpret_cast<float4*>(c_ + cs) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
+                *reinterpret_cast<float4*>(c_ + 2 * cs) = make_float4(acc[0].z, acc[1].z, acc[2].z, acc[3].z);
+                *reinterpret_cast<float4*>(c_ + 3 * cs) = make_float4(acc[0].w, acc[1].w, acc[2].w, acc[3].w);
             } else {
                 c_[0] = acc[0].x;
                 c_[cs] = acc[0].y;
@@ -278,6 +299,21 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
                 c_[3 * cs] = acc[0].w;
             }
         }
+    };
+
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) {
+        const int item = tid + it * 256;
+        if (item < n_items) process(item, pdy[it], pdx[it], pm[it]);
+    }
+    for (int item = tid + PRE * 256; item < n_items; item += 256) {  // tiles with more than PRE*256 items
+        const int k = item / items_per_k;
+        const int nb = n0 + (item - k * items_per_k) * NP;
+        VecT dq = *reinterpret_cast<const VecT*>(ob + (int64_t)(2 * k) * HWo + nb);
+        VecT xq = *reinterpret_cast<const VecT*>(ob + (int64_t)(2 * k + 1) * HWo + nb);
+        VecT mq = dq;
+        if (mb) mq = *reinterpret_cast<const VecT*>(mb + (int64_t)k * HWo + nb);
+        process(item, dq, xq, mq);
     }
 }
 

@@ -272,7 +272,10 @@ __global__ __launch_bounds__(NMS_THREADS) void cc_nms_kernel(const float* __rest
     }
     __syncthreads();
     const int nc = min(n_cand, Kp);
-    bitonic_sort_lds(keys, Kp, tid, NMS_THREADS);
+    // sort only as many keys as there are candidates (padding keys beyond nc are ~0 and already "sorted last")
+    int Ks = 64;
+    while (Ks < nc) Ks <<= 1;
+    bitonic_sort_lds(keys, Ks, tid, NMS_THREADS);
 
     const int n = min(nc, top_k);
     if (tid < n) {
