@@ -132,6 +132,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    if getattr(pipe, "timer", None) is not None and pipe.timer.on and rank == 0:
+        print("stage ms/step:", {k: round(v / (args.steps + args.warmup) * 1e3, 2) for k, v in pipe.timer.acc.items()},
+              file=sys.stderr, flush=True)
     frames = world * args.clips * args.steps
     n_det = int((out[..., 7] > 0).sum().item())
     if rank == 0:

@@ -139,6 +139,11 @@ __device__ __noinline__ float4 sample_global4(const float* __restrict__ xc, int6
 
 __device__ __forceinline__ void unpack(const float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 __device__ __forceinline__ void unpack(const float v, float (&o)[1]) { o[0] = v; }
+// LDS column swizzle.  A work item is 4 CONSECUTIVE output positions, so the 16 lanes of a ds_read_b128 group read
+// pixels 4*s apart (64-128 B apart): un-swizzled they fall on 4 (stride 1) or 2 (stride 2) of the 16 16-byte bank
+// groups -> 4- / 8-way conflicts.  XOR-ing column bits [5:4] into bits [1:0] spreads columns {0,4,8,...,60} over all
+// 16 groups (2-way left at stride 2).  Bijective inside every aligned 4-column block, so LW only has to be a multiple of 4.
+__device__ __forceinline__ int swz(int col) { return col ^ ((col >> 4) & 3); }
 template <int NP> struct PosVec { using type = float4; };
 template <> struct PosVec<1> { using type = float; };
 
@@ -200,9 +205,11 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
         while (r >= a.R) { r -= a.R; ++q; }
         for (int base = tid; base < total; base += 256 * SU) {
             float4 v[SU];
+            int dst[SU];
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[u] = q * RL + r * a.LW + swz(col);
                 const int yy = y0 + r, xx = col - 1;
                 if (base + u * 256 < total && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
                     const float* p = xb + (int64_t)(4 * q) * HW + (int64_t)yy * a.W + xx;
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u)
-                if (base + u * 256 < total) tile[base + u * 256] = v[u];
+                if (base + u * 256 < total) tile[dst[u]] = v[u];
         }
     }
     __syncthreads();
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
 
         // per-position coefficients
         float w1[NP], w2[NP], w3[NP], w4[NP], fyv[NP], fxv[NP];
-        int la[NP];            // LDS index of the (h_low, w_low) corner
+        int la[NP], lb[NP];    // LDS index of the (h_low, w_low) / (h_low, w_high) corners (swizzled columns)
         unsigned farmask = 0;  // positions whose corners leave the staged rows
         int ho = nb / a.Wo, wo = nb - ho * a.Wo;
 #pragma unroll
@@ -258,7 +265,8 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
             w2[p] = use ? hh * lw * m : 0.f;
             w3[p] = use ? lh * hw * m : 0.f;
             w4[p] = use ? lh * lw * m : 0.f;
-            la[p] = use ? (r * a.LW + w_low + 1) : 0;
+            la[p] = use ? (r * a.LW + swz(w_low + 1)) : 0;
+            lb[p] = use ? (r * a.LW + swz(w_low + 2)) : 0;
             if (valid && !in_rows) farmask |= (1u << p);
             mv[p] = m;
             if (++wo == a.Wo) { wo = 0; ++ho; }
@@ -272,9 +280,9 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const float4 v1 = tq[la[p]];
-                const float4 v2 = tq[la[p] + 1];
+                const float4 v2 = tq[lb[p]];
                 const float4 v3 = tq[la[p] + a.LW];
-                const float4 v4 = tq[la[p] + a.LW + 1];
+                const float4 v4 = tq[lb[p] + a.LW];
                 acc[p].x = w1[p] * v1.x + w2[p] * v2.x + w3[p] * v3.x + w4[p] * v4.x;
                 acc[p].y = w1[p] * v1.y + w2[p] * v2.y + w3[p] * v3.y + w4[p] * v4.y;
                 acc[p].z = w1[p] * v1.z + w2[p] * v2.z + w3[p] * v3.z + w4[p] * v4.z;
@@ -382,33 +390,41 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     }
 
     // ---- tiled: pick rows per tile / channels per block --------------------------------------------
-    const int halo = env_int("STM_IM2COL_HALO", 2);
-    const int LW = g->W + 2;
+    const int halo = env_int("STM_IM2COL_HALO", 3);  // learned offsets of trained DCNs rarely exceed +-3 rows
+    const int LW = ((g->W + 2 + 3) / 4) * 4;          // +1 zero column each side, rounded up for the column swizzle
     bool vec = (HWo % 4 == 0) && (off_bstride % 4 == 0) && (!mask || mask_bstride % 4 == 0) &&
                ((uintptr_t)offset % 16 == 0) && (!mask || (uintptr_t)mask % 16 == 0) && ((uintptr_t)cols % 16 == 0);
-    // rows per tile: ~512-1024 (position, tap) items per workgroup; with 16-byte stores th*Wo % 4 == 0
-    int th = env_int("STM_IM2COL_TH", 0);
-    if (th <= 0) {
-        th = 1;
-        while (th < g->Ho && (int64_t)th * g->Wo * K / (vec ? 4 : 1) < 512) ++th;
+    // Tile choice (scripts/bench_kernels.py --env-sweep on MI355X): 8 channels per workgroup and as many output rows
+    // as fit the LDS budget (up to 12) minimise halo re-reads; when 8 channels do not leave room for >= 4 rows
+    // (wide stride-2 layers) fall back to 4 channels.  With 16-byte stores th*Wo must be a multiple of 4.
+    const size_t lds_budget = (size_t)env_int("STM_IM2COL_LDS_KB", 64) * 1024;
+    auto rows_of = [&](int th_) { return (th_ - 1) * g->sh + (g->kh - 1) * g->dh + 2 + 2 * halo; };
+    auto fits = [&](int th_, int cch_) { return (size_t)(cch_ / 4) * rows_of(th_) * LW * sizeof(float4) <= lds_budget; };
+    int step = 1;
+    if (vec) while ((step * g->Wo) % 4 != 0) ++step;  // step in {1,2,4}
+    int th = env_int("STM_IM2COL_TH", 0), cch = env_int("STM_IM2COL_CCH", 0);
+    if (th <= 0 || cch <= 0) {
+        int want_c = (cch > 0) ? cch : ((Cg % 8 == 0) ? 8 : 4);
+        int t = (th > 0) ? th : min(12, g->Ho);
+        if (th <= 0) {
+            while (t > 4 && !fits(t, want_c)) --t;
+            if (!fits(t, want_c) && cch <= 0 && want_c == 8) {
+                want_c = 4;
+                t = min(8, g->Ho);
+                while (t > 1 && !fits(t, want_c)) --t;
+            }
+        }
+        th = t;
+        cch = want_c;
     }
     th = min(th, g->Ho);
     if (vec) {
-        int step = 1;
-        while ((step * g->Wo) % 4 != 0) ++step;  // step in {1,2,4}
         th = ((th + step - 1) / step) * step;
         if (th > g->Ho) th = g->Ho;  // last tile = remaining rows; HWo % 4 == 0 keeps it aligned
         if ((th * g->Wo) % 4 != 0) vec = false;
     }
-    const int R = (th - 1) * g->sh + (g->kh - 1) * g->dh + 2 + 2 * halo;
+    const int R = rows_of(th);
     const size_t quad_bytes = (size_t)R * LW * sizeof(float4);
-    const size_t lds_budget = (size_t)env_int("STM_IM2COL_LDS_KB", 48) * 1024;
-    int cch = env_int("STM_IM2COL_CCH", 0);
-    if (cch <= 0) {
-        cch = 4;
-        for (int c = 4; c <= Cg && c <= 32; c += 4)
-            if (Cg % c == 0 && (size_t)(c / 4) * quad_bytes <= lds_budget) cch = c;
-    }
     STM_REQUIRE(cch % 4 == 0 && Cg % cch == 0, STM_EINVAL, "stm_deform_im2col_f32: channels per block %d invalid", cch);
     size_t lds = (size_t)(cch / 4) * quad_bytes;
     if (lds > 160 * 1024) {  // a single quad of this tile does not fit: use the direct kernel

@@ -25,12 +25,12 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
 {
     constexpr int R = P / 2;
     constexpr int WIN = 4 + P - 1;          // f2 values per item per channel (14 for P = 11)
+    constexpr int MAXU = 8;                 // float4 staging units per thread and chunk (W <= 44 at P = 11)
     extern __shared__ float smem[];
-    const int Wq = (W + 3) / 4;             // x quads
-    const int W4 = Wq * 4;
-    const int LW2 = ((W4 + 2 * R + 3) / 4) * 4;  // padded f2 row length (multiple of 4)
-    float* f1s = smem;                      // [CCK][W4]
-    float* f2s = smem + CORR_CCK * W4;      // [CCK][P][LW2], index x + R
+    const int Wq = W / 4;                   // x quads (W % 4 == 0 on this path)
+    const int LW2 = ((W + 2 * R + 3) / 4) * 4;   // padded f2 row length (multiple of 4)
+    float* f1s = smem;                      // [CCK][W]
+    float* f2s = smem + CORR_CCK * W;       // [CCK][P][LW2], index x + R
 
     const int y = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -40,6 +40,53 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
     const int64_t HW = (int64_t)H * W;
     const float* f1b = f1 + (int64_t)b * C * HW;
     const float* f2b = f2 + (int64_t)b * C * HW;
+
+    // ---- staging plan, computed ONCE: unit u = (channel c, f2 row rr, x quad) -> one float4 global load + 4 LDS words.
+    //      Only in-image rows are ever loaded; halo columns and out-of-image rows are zeroed once and never touched again.
+    const int units = CORR_CCK * P * Wq;
+    int g_off[MAXU], l_off[MAXU];           // global offset (floats, relative to channel chunk), LDS word offset
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+        int id = tid + u * 256;
+        g_off[u] = -1;
+        l_off[u] = 0;
+        if (id < units) {
+            int c = id / (P * Wq), rem = id - c * (P * Wq);
+            int rr = rem / Wq, xq = rem - rr * Wq;
+            int yy = y + rr - R;
+            if (yy >= 0 && yy < H) {
+                g_off[u] = c * (int)HW + yy * W + xq * 4;
+                l_off[u] = (c * P + rr) * LW2 + R + xq * 4;
+            }
+        }
+    }
+    const bool f1_unit = tid < CORR_CCK * Wq;
+    const int f1_c = tid / Wq, f1_xq = tid - f1_c * Wq;
+    for (int idx = tid; idx < CORR_CCK * P * LW2; idx += 256) f2s[idx] = 0.0f;
+
+    float4 pf[MAXU], pf1;
+    auto prefetch = [&](int c0) {           // channels beyond C read as zero
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) {
+            pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g_off[u] >= 0) {
+                int c = (tid + u * 256) / (P * Wq);
+                if (c0 + c < C) pf[u] = *reinterpret_cast<const float4*>(f2b + (int64_t)c0 * HW + g_off[u]);
+            }
+        }
+        pf1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f1_unit && c0 + f1_c < C)
+            pf1 = *reinterpret_cast<const float4*>(f1b + (int64_t)(c0 + f1_c) * HW + (int64_t)y * W + f1_xq * 4);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u)
+            if (g_off[u] >= 0) {
+                float* d = f2s + l_off[u];
+                d[0] = pf[u].x; d[1] = pf[u].y; d[2] = pf[u].z; d[3] = pf[u].w;
+            }
+        if (f1_unit) *reinterpret_cast<float4*>(f1s + f1_c * W + f1_xq * 4) = pf1;
+    };
 
     for (int pass0 = 0; pass0 < items; pass0 += 128) {
         const int item = pass0 + slot;
@@ -53,31 +100,17 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < P; ++j) acc[p][j] = 0.0f;
 
+        prefetch(0);
         for (int c0 = 0; c0 < C; c0 += CORR_CCK) {
+            __syncthreads();                 // previous chunk fully consumed (and the zero fill done)
+            commit();
             __syncthreads();
-            // stage f1 row y and the P rows of f2 around y for CCK channels (zero outside the image / C)
-            for (int idx = tid; idx < CORR_CCK * W4; idx += 256) {
-                int c = idx / W4, x = idx - c * W4;
-                float v = 0.0f;
-                if (c0 + c < C && x < W) v = f1b[(int64_t)(c0 + c) * HW + (int64_t)y * W + x];
-                f1s[idx] = v;
-            }
-            for (int idx = tid; idx < CORR_CCK * P * LW2; idx += 256) {
-                int c = idx / (P * LW2);
-                int rem = idx - c * (P * LW2);
-                int rr = rem / LW2, xi = rem - rr * LW2;
-                int yy = y + rr - R, xx = xi - R;
-                float v = 0.0f;
-                if (c0 + c < C && yy >= 0 && yy < H && xx >= 0 && xx < W)
-                    v = f2b[(int64_t)(c0 + c) * HW + (int64_t)yy * W + xx];
-                f2s[idx] = v;
-            }
-            __syncthreads();
+            if (c0 + CORR_CCK < C) prefetch(c0 + CORR_CCK);   // next chunk's loads fly behind the FMAs below
             if (active) {
 #pragma unroll 2
                 for (int cc = 0; cc < CORR_CCK / 2; ++cc) {
                     const int c = half * (CORR_CCK / 2) + cc;
-                    const float4 a = *reinterpret_cast<const float4*>(&f1s[c * W4 + x0]);
+                    const float4 a = *reinterpret_cast<const float4*>(&f1s[c * W + x0]);
                     const float* wrow = &f2s[(c * P + i) * LW2 + x0];  // window starts at x0 - R  (index x0)
                     float win[WIN];
 #pragma unroll
@@ -114,13 +147,7 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
                     o[p] = v < 0.0f ? v * slope : v;
                 }
                 float* op = out + ((((int64_t)b * P + i) * P + j) * H + y) * W + x0;
-                if ((W % 4 == 0)) {
-                    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        if (x0 + p < W) op[p] = o[p];
-                }
+                *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
     }
@@ -211,11 +238,13 @@ extern "C" int stm_corr_patch_f32(const float* f1, const float* f2, float* out, 
     STM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, STM_EINVAL, "stm_corr_patch_f32: empty input");
     STM_REQUIRE(P > 0 && (P & 1) && dil > 0, STM_EINVAL, "stm_corr_patch_f32: patch_size must be odd, dilation > 0");
     const char* force = getenv("STM_CORR_VARIANT");
-    bool tiled = (P == 11 && dil == 1 && H <= 65535 && B <= 65535 && ((uintptr_t)out % 16 == 0));
+    // tiled kernel: P = 11, rows of whole float4 quads, staging plan of <= 8 units per thread (W <= 44)
+    bool tiled = (P == 11 && dil == 1 && H <= 65535 && B <= 65535 && W % 4 == 0 && CORR_CCK * 11 * (W / 4) <= 8 * 256 &&
+                  ((uintptr_t)out % 16 == 0) && ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f2 % 16 == 0));
     if (force && atoi(force) == 1) tiled = false;
     if (tiled) {
-        int Wq = (W + 3) / 4, W4 = Wq * 4, LW2 = ((W4 + 10 + 3) / 4) * 4;
-        size_t lds = (size_t)(CORR_CCK * W4 + CORR_CCK * 11 * LW2) * sizeof(float);
+        int LW2 = ((W + 10 + 3) / 4) * 4;
+        size_t lds = (size_t)(CORR_CCK * W + CORR_CCK * 11 * LW2) * sizeof(float);
         if (lds <= 64 * 1024) {
             hipLaunchKernelGGL(corr_patch_tiled<11>, dim3(H, B), dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W,
                                scale, leaky_slope);

@@ -87,11 +87,12 @@ def CandidateShift(net, ref_candidate, next_candidate, img=None, img_meta=None, 
     n = roi_feats.shape[0]
     n_pad = -(-n // ROI_BUCKET) * ROI_BUCKET
     if n_pad != n:
-        # bucket the RoI batch: the dense-conv library (MIOpen) tunes per shape, and the tracked set grows by a few
-        # instances per frame -- padding keeps TemporalNet on a handful of shapes (rows are independent: exact)
         roi_feats = torch.cat([roi_feats, roi_feats.new_zeros(n_pad - n, *roi_feats.shape[1:])], 0)
-    loc_shift, coeff_shift = net.TemporalNet(roi_feats)
-    loc_shift, coeff_shift = loc_shift[:n], coeff_shift[:n]
+    # fixed-shape blocks: the dense-conv library (MIOpen) selects / builds kernels per shape and the tracked set
+    # changes size every frame; rows are independent, so zero padding + blocking is exact
+    outs = [net.TemporalNet(roi_feats[i:i + ROI_BUCKET]) for i in range(0, n_pad, ROI_BUCKET)]
+    loc_shift = torch.cat([o[0] for o in outs], 0)[:n]
+    coeff_shift = torch.cat([o[1] for o in outs], 0)[:n]
     box_shift = decode(loc_shift, center_size(box_ref))
     coeff = ref_candidate["mask_coeff"] + coeff_shift
     shifted["box"] = box_shift

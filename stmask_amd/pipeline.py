@@ -19,7 +19,31 @@ from . import ops
 from .layers import Track_TF, generate_candidate
 from .layers.box_utils import center_size, sanitize_coordinates_hw
 
-ROI_BUCKET = 64
+ROI_CHUNK = 128  # TemporalNet always runs on [ROI_CHUNK,633,7,7] blocks: ONE dense-conv shape however many instances
+
+
+class _StageTimer:
+    """Optional per-stage wall-clock breakdown (STM_PIPE_TIMING=1): synchronises around every stage, so only for
+    diagnosis -- never enabled in a timed benchmark run."""
+
+    def __init__(self):
+        import os
+        self.on = os.environ.get("STM_PIPE_TIMING", "0") == "1"
+        self.acc, self.t0 = {}, None
+
+    def tic(self):
+        if self.on:
+            import time
+            torch.cuda.synchronize()
+            self.t0 = time.perf_counter()
+
+    def toc(self, name):
+        if self.on:
+            import time
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            self.acc[name] = self.acc.get(name, 0.0) + (t - self.t0)
+            self.t0 = t
 
 
 class ClipPipeline:
@@ -66,6 +90,7 @@ class BatchedClipPipeline:
         self.prev_feat = None       # (P4 [B,256,h,w], T2S [B,256,h,w]) of the previous frame
         self.has_prev = [False] * n_clips
         self.tracked = [[] for _ in range(n_clips)]  # host-side "frames since last match" counters
+        self.timer = _StageTimer()
 
     # -- stage helpers ------------------------------------------------------------------------------------------------
     def _shift_prev(self, P4, T2S, proto, dev):
@@ -81,17 +106,24 @@ class BatchedClipPipeline:
         box_ref = prev["box"]
         rois = torch.cat([clip_of_row.float().unsqueeze(1), sanitize_coordinates_hw(box_ref, fh, fw)], dim=1)
         roi_feats = ops.roi_align(feats, rois, 7)
+        self.timer.toc("tf_corr_roi")
         n = roi_feats.shape[0]
-        n_pad = -(-n // ROI_BUCKET) * ROI_BUCKET
-        if n_pad != n:  # keep the dense-conv library on a handful of shapes (rows are independent: exact)
+        n_pad = -(-n // ROI_CHUNK) * ROI_CHUNK
+        if n_pad != n:  # rows are independent: zero rows change nothing
             roi_feats = torch.cat([roi_feats, roi_feats.new_zeros(n_pad - n, *roi_feats.shape[1:])], 0)
-        loc_shift, coeff_shift = net.TemporalNet(roi_feats)
-        box_shift = ops.decode(loc_shift[:n].contiguous(), center_size(box_ref))
-        coeff = prev["mask_coeff"] + coeff_shift[:n]
+        # fixed-shape blocks: the dense-conv library (MIOpen) selects / builds kernels per shape, and the tracked set
+        # changes size every frame -- one shape means that cost is paid once
+        outs = [net.TemporalNet(roi_feats[i:i + ROI_CHUNK]) for i in range(0, n_pad, ROI_CHUNK)]
+        loc_shift = torch.cat([o[0] for o in outs], 0)[:n]
+        coeff_shift = torch.cat([o[1] for o in outs], 0)[:n]
+        self.timer.toc("tf_temporalnet")
+        box_shift = ops.decode(loc_shift.contiguous(), center_size(box_ref))
+        coeff = prev["mask_coeff"] + coeff_shift
         prev["box"] = box_shift
         prev["score"] = prev["score"] * 0.95
         prev["mask_coeff"] = coeff
         prev["mask"] = ops.lincomb_sigmoid_crop(proto, coeff, box_shift, apply_tanh=True, row_proto=clip_of_row)
+        self.timer.toc("tf_masks")
         for b in range(self.B):
             self.tracked[b] = [v + 1 for v in self.tracked[b]]
 
@@ -105,7 +137,10 @@ class BatchedClipPipeline:
         if first:
             self.prev, self.prev_n, self.prev_feat = None, [0] * B, None
             self.tracked = [[] for _ in range(B)]
+        tmr = self.timer
+        tmr.tic()
         fpn_outs, pred = net.forward_single(frames)
+        tmr.toc("trunk")
         conf = F.softmax(pred["conf"], -1)
         P4 = fpn_outs[net.correlation_selected_layer]
         T2S = pred["T2S_feat"][net.correlation_selected_layer]
@@ -115,6 +150,7 @@ class BatchedClipPipeline:
         idx, cls, score, box, cnt = ops.detect_cc(pred["loc"], priors, conf, pred["centerness"], cfg.eval_conf_thresh,
                                                   cfg.nms_thresh, cfg.nms_top_k)
         counts = cnt.tolist()  # host read 1 (B ints)
+        tmr.toc("detect")
         D = sum(counts)
         top_k = cfg.nms_top_k
         # ---- detections of all clips, concatenated (rows sorted by clip) ------------------------------------------
@@ -132,6 +168,7 @@ class BatchedClipPipeline:
         det["mask"] = (ops.lincomb_sigmoid_crop(proto, det["mask_coeff"], det["box"], apply_tanh=True,
                                                 row_proto=det["clip"])
                        if D else proto.new_zeros(0, proto.shape[1], proto.shape[2]))
+        tmr.toc("det_gather_masks")
 
         if self.prev is None:
             # first frame of every clip (track_TF.py:88-93): the detections become the tracked set
@@ -160,6 +197,7 @@ class BatchedClipPipeline:
                 match = comp.argmax(dim=1)
                 host = torch.stack([match.float(), det["score"]]).cpu()  # host read 2
                 ids, scores = host[0].long().tolist(), host[1].tolist()
+                tmr.toc("match_scores")
             else:
                 ids, scores = [0] * D, [0.0] * D
             # greedy resolution (track_TF.py:132-156) per clip on host scalars -> one gather plan for all clips
@@ -191,9 +229,12 @@ class BatchedClipPipeline:
                 for k in _ROW_KEYS + ("clip",):
                     prev[k] = torch.cat([prev[k], det[k]], dim=0).index_select(0, plan_t)
             self.prev_n, self.tracked = new_n, new_tracked
+            tmr.toc("tracker_update")
         self.prev_feat = (P4, T2S)
         self.t += 1
-        return self._pack_outputs(dev)
+        out = self._pack_outputs(dev)
+        tmr.toc("pack")
+        return out
 
     def _pack_outputs(self, dev):
         """keep rule of track_TF.py:158-165 on device, scattered into [B, top_k, 40] without a host sync."""

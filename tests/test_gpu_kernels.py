@@ -169,7 +169,7 @@ def test_gemm_is_exact_fmaf_chain_on_integers():
 
 
 # ------------------------------------------------------------------------------------------ temporal
-@pytest.mark.parametrize("B,C,H,W", [(1, 256, 24, 40), (2, 32, 12, 20), (1, 20, 7, 9), (1, 8, 3, 5)])
+@pytest.mark.parametrize("B,C,H,W", [(1, 256, 24, 40), (2, 32, 12, 20), (1, 20, 7, 9), (1, 8, 3, 5), (3, 20, 6, 8), (2, 40, 30, 44)])
 def test_correlation_vs_oracle(B, C, H, W):
     f1, f2 = rnd(B, C, H, W, seed=1), rnd(B, C, H, W, seed=2)
     ref = oracle.corr_patch(f1, f2, 11, 1)
