@@ -96,3 +96,44 @@ def test_batched_pipeline_matches_reference_on_cpu(name, tag):
                 n = min(len(ref[b]["box_ids"]), packed.shape[1])
                 assert torch.equal(un["box_ids"][:n], ref[b]["box_ids"][:n]) and torch.equal(un["class"][:n], ref[b]["class"][:n])
                 assert (un["box"][:n] - ref[b]["box"][:n]).abs().max() < 1e-5
+
+
+def test_batchnorm_folding_keeps_reference_parity():
+    """fuse.fold_batchnorm (53 BN kernels folded into conv / DCN weights) keeps the clip output within 1e-4 of the
+    reference goldens, and is exact algebra on a bottleneck with non-trivial BN statistics."""
+    from stmask_amd.backbone import Bottleneck
+    from stmask_amd.fuse import fold_batchnorm
+    name, tag = CASES[0]
+    g = load_golden(f"model_{tag}.npz")
+    h, w = [int(v) for v in g["frames_hw"]]
+    net = STMask(get_cfg(name))
+    net.eval()
+    synthetic.fill_state_dict(net, seed=0)
+    frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0)
+    assert fold_batchnorm(net) == 53
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in net.modules())
+    with oracle_ops(), torch.no_grad():
+        outs = run_clip(net, frames)
+    check_clip_against_golden(outs, g, tol_box=1e-4, tol_mask=1e-4)
+
+    torch.manual_seed(0)
+    blk = Bottleneck(16, 4, downsample=torch.nn.Sequential(torch.nn.Conv2d(16, 16, 1, bias=False),
+                                                           torch.nn.BatchNorm2d(16)))
+    blk.eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 2)
+            m.weight.data.normal_()
+            m.bias.data.normal_()
+    x = torch.randn(2, 16, 9, 11)
+    ref = blk(x.clone())
+
+    class _BB:
+        bn1, conv1, layers = torch.nn.Identity(), None, [[blk]]
+
+    class _Net:
+        training, backbone = False, _BB
+
+    assert fold_batchnorm(_Net) == 4
+    assert (blk(x.clone()) - ref).abs().max() < 1e-5
