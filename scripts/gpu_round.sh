@@ -31,6 +31,15 @@ kernels)
   timeout 1200 python scripts/bench_kernels.py --batch 8 > $OUT/kernels.log 2>&1; echo "kernels exit $?"; grep -E "TOTAL|gemm|corr|lincomb|nms|detect|roi|deform_conv" $OUT/kernels.log | head -70 ;;
 sweep)
   timeout 1500 python scripts/bench_kernels.py --batch 8 --env-sweep > $OUT/sweep.log 2>&1; echo "sweep exit $?"; grep BEST $OUT/sweep.log ;;
+pmcim2col)
+  cd /tmp
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_im2col/p$i -o p -- python3 $R/scripts/prof_im2col.py 8 3 > $OUT/pmc_im2col_$i.log 2>&1; echo "pmc pass $i exit $?"
+  done
+  cd $R; python scripts/summarize_pmc_kernel.py $OUT/pmc_im2col deform_im2col_lds > $OUT/pmc_im2col_summary.txt 2>&1; head -30 $OUT/pmc_im2col_summary.txt
+  find $OUT/pmc_im2col -name '*.csv' -size +5M -delete ;;
 pmc)
   cd /tmp
   timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
