@@ -74,7 +74,8 @@ typedef struct stm_deform_geom {
 int stm_deform_im2col_f32(const float* x, const float* offset, int64_t off_bstride, const float* mask,
                           int64_t mask_bstride, int mask_is_logit, float* cols, const stm_deform_geom* g,
                           int variant, stm_stream_t stream);
-/* variant: 0 = auto, 1 = direct gather (global loads), 2 = LDS-staged input tiles */
+/* variant: 0 = auto, 1 = direct gather (global loads), 2 = LDS-staged input tiles (4 or 8 channels per workgroup),
+ *          3 = LDS-staged, bilinear coefficients computed once per workgroup and reused across channel quads */
 
 size_t stm_deform_conv_workspace_bytes(const stm_deform_geom* g);
 

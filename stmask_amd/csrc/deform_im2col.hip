@@ -325,6 +325,166 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------ variant 3
+// Same tile / item geometry as variant 2 (NP = 4), but the channel loop is INSIDE the workgroup: the bilinear
+// coefficients of a thread's (<= IT) items are computed once and stay in registers while the workgroup walks the
+// channel quads of its chunk, re-staging ONE quad buffer in LDS per step.  PMC counters of variant 2 showed ~44 VALU
+// instructions per output element (coefficient set-up and 64-bit staging addresses re-done for every 4 channels) and
+// waves issuing 51 % of their lifetime: instruction-bound, not HBM-bound.  Here the set-up is amortised over cch
+// (16-64) channels and staging uses 32-bit offsets from a wave-uniform per-quad base.
+// grid: x = tiles_y * (C / cch), y = B.  Dynamic LDS: R * LW float4 (one quad).
+template <int IT>
+__global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
+{
+    extern __shared__ float4 tile[];
+    const int K = a.kh * a.kw;
+    const int HWo = a.Ho * a.Wo;
+    const int HW = a.H * a.W;
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x % a.tiles_y;
+    const int chunk = blockIdx.x / a.tiles_y;
+    const int b = blockIdx.y;
+    const int c0 = chunk * a.cch;
+    const int g = c0 / (a.C / a.dg);
+    const int nq = a.cch >> 2;
+    const int ho0 = ty * a.th;
+    const int rows_out = min(a.th, a.Ho - ho0);
+    const int y0 = ho0 * a.sh - a.ph - a.halo;
+    const int RL = a.R * a.LW;
+    const int n0 = ho0 * a.Wo;
+    const int NT = rows_out * a.Wo;
+    const int items_per_k = NT >> 2;
+    const int n_items = K * items_per_k;
+    const float* ob = a.off + (int64_t)b * a.off_bs + (int64_t)g * 2 * K * HWo;
+    const float* mb = a.mask ? a.mask + (int64_t)b * a.mask_bs + (int64_t)g * K * HWo : nullptr;
+
+    // ---- 1. per-item coefficients, once per workgroup
+    float4 wq[IT][4];        // corner weights (w1..w4) of the 4 positions, mask folded in
+    int la[IT][4], lb[IT][4];
+    int sbase[IT];           // k * HWo + first position: store offset inside one channel's K*HWo block
+    unsigned far[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int item = tid + it * 256;
+        far[it] = 0;
+        sbase[it] = -1;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { wq[it][p] = make_float4(0.f, 0.f, 0.f, 0.f); la[it][p] = 0; lb[it][p] = 0; }
+        if (item < n_items) {
+            const int k = item / items_per_k;
+            const int nb = n0 + ((item - k * items_per_k) << 2);
+            const int i = k / a.kw, j = k - i * a.kw;
+            sbase[it] = k * HWo + nb;
+            float dyv[4], dxv[4], mv[4] = {1.f, 1.f, 1.f, 1.f};
+            unpack(*reinterpret_cast<const float4*>(ob + (int64_t)(2 * k) * HWo + nb), dyv);
+            unpack(*reinterpret_cast<const float4*>(ob + (int64_t)(2 * k + 1) * HWo + nb), dxv);
+            if (mb) unpack(*reinterpret_cast<const float4*>(mb + (int64_t)k * HWo + nb), mv);
+            int ho = nb / a.Wo, wo = nb - ho * a.Wo;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float m = mv[p];
+                if (mb && a.mask_logit) m = sigmoidf_dev(m);
+                float fy = (float)(ho * a.sh - a.ph + i * a.dh) + dyv[p];
+                float fx = (float)(wo * a.sw - a.pw + j * a.dw) + dxv[p];
+                bool valid = fy > -1.0f && fx > -1.0f && fy < (float)a.H && fx < (float)a.W;
+                float fl_y = floorf(fy), fl_x = floorf(fx);
+                int h_low = (int)fl_y, w_low = (int)fl_x;
+                float lh = fy - fl_y, lw = fx - fl_x, hh = 1.0f - lh, hw = 1.0f - lw;
+                int r = h_low - y0;
+                bool in_rows = (r >= 0) && (r + 1 < a.R);
+                bool use = valid && in_rows;
+                wq[it][p].x = use ? hh * hw * m : 0.f;
+                wq[it][p].y = use ? hh * lw * m : 0.f;
+                wq[it][p].z = use ? lh * hw * m : 0.f;
+                wq[it][p].w = use ? lh * lw * m : 0.f;
+                la[it][p] = use ? (r * a.LW + swz(w_low + 1)) : 0;
+                lb[it][p] = use ? (r * a.LW + swz(w_low + 2)) : 0;
+                if (valid && !in_rows) far[it] |= (1u << p);
+                if (++wo == a.Wo) { wo = 0; ++ho; }
+            }
+        }
+    }
+
+    // ---- 2. walk the channel quads of this chunk through one LDS buffer
+    const int step_r = 256 / a.LW, step_c = 256 - step_r * a.LW;
+    const int r_first = tid / a.LW, c_first = tid - r_first * a.LW;
+    const int64_t cs = (int64_t)K * HWo;
+    for (int q = 0; q < nq; ++q) {
+        const float* xq = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;   // wave-uniform base of this quad
+        if (q) __syncthreads();                                          // previous quad fully consumed
+        {
+            constexpr int SU = 4;
+            int r = r_first, col = c_first;
+            for (int base = tid; base < RL; base += 256 * SU) {
+                float4 v[SU];
+                int dst[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    dst[u] = r * a.LW + swz(col);
+                    const int yy = y0 + r, xx = col - 1;
+                    if (base + u * 256 < RL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                        const int o = yy * a.W + xx;
+                        v[u].x = xq[o];
+                        v[u].y = xq[o + HW];
+                        v[u].z = xq[o + 2 * HW];
+                        v[u].w = xq[o + 3 * HW];
+                    }
+                    col += step_c;
+                    r += step_r;
+                    if (col >= a.LW) { col -= a.LW; ++r; }
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u)
+                    if (base + u * 256 < RL) tile[dst[u]] = v[u];
+            }
+        }
+        __syncthreads();
+        float* cq = a.cols + ((int64_t)b * a.C + c0 + 4 * q) * cs;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            if (sbase[it] < 0) continue;
+            float4 acc[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float4 v1 = tile[la[it][p]];
+                const float4 v2 = tile[lb[it][p]];
+                const float4 v3 = tile[la[it][p] + a.LW];
+                const float4 v4 = tile[lb[it][p] + a.LW];
+                const float4 w = wq[it][p];
+                acc[p].x = w.x * v1.x + w.y * v2.x + w.z * v3.x + w.w * v4.x;
+                acc[p].y = w.x * v1.y + w.y * v2.y + w.z * v3.y + w.w * v4.y;
+                acc[p].z = w.x * v1.z + w.y * v2.z + w.z * v3.z + w.w * v4.z;
+                acc[p].w = w.x * v1.w + w.y * v2.w + w.z * v3.w + w.w * v4.w;
+            }
+            if (far[it]) {  // rare: offsets larger than the halo -> exact global gather (coordinates re-derived)
+                const int k = sbase[it] / HWo;
+                const int nb = sbase[it] - k * HWo;
+                const int i = k / a.kw, j = k - i * a.kw;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (far[it] & (1u << p)) {
+                        const int n = nb + p;
+                        const int ho = n / a.Wo, wo = n - ho * a.Wo;
+                        float m = 1.0f;
+                        if (mb) {
+                            m = mb[(int64_t)k * HWo + n];
+                            if (a.mask_logit) m = sigmoidf_dev(m);
+                        }
+                        const float fy = (float)(ho * a.sh - a.ph + i * a.dh) + ob[(int64_t)(2 * k) * HWo + n];
+                        const float fx = (float)(wo * a.sw - a.pw + j * a.dw) + ob[(int64_t)(2 * k + 1) * HWo + n];
+                        acc[p] = sample_global4(xq, HW, a.H, a.W, fy, fx, m);
+                    }
+            }
+            float* c_ = cq + sbase[it];
+            *reinterpret_cast<float4*>(c_) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
+            *reinterpret_cast<float4*>(c_ + cs) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
+            *reinterpret_cast<float4*>(c_ + 2 * cs) = make_float4(acc[0].z, acc[1].z, acc[2].z, acc[3].z);
+            *reinterpret_cast<float4*>(c_ + 3 * cs) = make_float4(acc[0].w, acc[1].w, acc[2].w, acc[3].w);
+        }
+    }
+}
+
 int env_int(const char* name, int dflt)
 {
     const char* s = getenv(name);
@@ -363,7 +523,7 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
                 (long long)g->dg * 2 * K * HWo);
     STM_REQUIRE(!mask || mask_bstride >= (int64_t)g->dg * K * HWo, STM_EINVAL,
                 "stm_deform_im2col_f32: mask batch stride too small");
-    STM_REQUIRE(variant >= 0 && variant <= 2, STM_EINVAL, "stm_deform_im2col_f32: variant %d not in 0..2", variant);
+    STM_REQUIRE(variant >= 0 && variant <= 3, STM_EINVAL, "stm_deform_im2col_f32: variant %d not in 0..3", variant);
 
     ImcolArgs a;
     a.x = x; a.off = offset; a.mask = mask; a.cols = cols;
@@ -374,8 +534,8 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
 
     if (variant == 0) variant = env_int("STM_IM2COL_VARIANT", 0);
     bool tiled_ok = (Cg % 4 == 0);
-    if (variant == 0) variant = tiled_ok ? 2 : 1;
-    if (variant == 2 && !tiled_ok) variant = 1;
+    if (variant == 0) variant = tiled_ok ? 3 : 1;
+    if (variant >= 2 && !tiled_ok) variant = 1;
 
     if (variant == 1) {
         // channels per block: keep >= ~1024 blocks in flight, but amortise the coefficient set-up
@@ -394,6 +554,49 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     const int LW = ((g->W + 2 + 3) / 4) * 4;          // +1 zero column each side, rounded up for the column swizzle
     bool vec = (HWo % 4 == 0) && (off_bstride % 4 == 0) && (!mask || mask_bstride % 4 == 0) &&
                ((uintptr_t)offset % 16 == 0) && (!mask || (uintptr_t)mask % 16 == 0) && ((uintptr_t)cols % 16 == 0);
+    if (variant == 3 && vec) {
+        // ---- variant 3: coefficients once per workgroup, channel quads streamed through one LDS buffer ----------
+        // rows per tile: <= 3 items per thread (items = th*Wo/4 * K <= 768); channels per workgroup: as many as keep
+        // >= ~3 workgroups per CU in flight (the quad loop amortises the set-up, the grid must still fill 256 CUs)
+        int step3 = 1;
+        while ((step3 * g->Wo) % 4 != 0) ++step3;
+        int th3 = env_int("STM_IM2COL_TH", 0);
+        const int max_items = min(768, max(256, env_int("STM_IM2COL_ITEMS", 768)));  // 1..3 items per thread
+        if (th3 <= 0) {
+            th3 = (max_items * 4) / (g->Wo * K);
+            th3 = max(step3, (th3 / step3) * step3);
+        }
+        th3 = min(th3, g->Ho);
+        if (th3 < g->Ho) th3 = max(step3, (th3 / step3) * step3);
+        const int items3 = (th3 * g->Wo / 4) * K;
+        const int R3 = (th3 - 1) * g->sh + (g->kh - 1) * g->dh + 2 + 2 * halo;
+        const size_t lds3 = (size_t)R3 * LW * sizeof(float4);
+        if ((th3 * g->Wo) % 4 == 0 && items3 <= 768 && lds3 <= 160 * 1024) {
+            int cch3 = env_int("STM_IM2COL_CCH", 0);
+            const int tiles3 = stm_cdiv(g->Ho, th3);
+            if (cch3 <= 0) {
+                cch3 = 4;
+                for (int c = 8; c <= Cg && c <= 64; c += 4)
+                    if (Cg % c == 0 && (int64_t)tiles3 * (g->C / c) * g->B >= 768) cch3 = c;
+            }
+            STM_REQUIRE(cch3 % 4 == 0 && Cg % cch3 == 0, STM_EINVAL, "stm_deform_im2col_f32: channels per block %d invalid",
+                        cch3);
+            a.th = th3; a.cch = cch3; a.R = R3; a.LW = LW; a.halo = halo; a.tiles_y = tiles3;
+            dim3 grid3(tiles3 * (g->C / cch3), g->B);
+            const int it = stm_cdiv(items3, 256);
+            auto launch = [&](auto kern) {
+                if (lds3 > 48 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)lds3);
+                hipLaunchKernelGGL(kern, grid3, dim3(256), lds3, stm_hs(stream), a);
+            };
+            if (it <= 1) launch(deform_im2col_lds3<1>);
+            else if (it == 2) launch(deform_im2col_lds3<2>);
+            else launch(deform_im2col_lds3<3>);
+            STM_CHECK_LAUNCH("deform_im2col_lds3");
+            return STM_OK;
+        }
+    }
     // Tile choice (scripts/bench_kernels.py --env-sweep on MI355X): 8 channels per workgroup and as many output rows
     // as fit the LDS budget (up to 12) minimise halo re-reads; when 8 channels do not leave room for >= 4 rows
     // (wide stride-2 layers) fall back to 4 channels.  With 16-byte stores th*Wo must be a multiple of 4.

@@ -42,7 +42,7 @@ DEFORM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("case", DEFORM_CASES)
 def test_deform_im2col_vs_oracle(case, variant):
     B, C, H, W, kh, kw, s, ph, pw, dg, osc, wm = case
@@ -60,8 +60,9 @@ def test_deform_im2col_variants_agree_bitwise(case):
     B, C, H, W, kh, kw, s, ph, pw, dg, osc, wm = case
     x, off, mask = make_deform_case(B, C, H, W, kh, kw, s, ph, pw, dg, seed=9, off_scale=osc, with_mask=wm)
     a = ops.deform_im2col(x.to(DEV), off.to(DEV), mask.to(DEV) if wm else None, (kh, kw), s, (ph, pw), 1, dg, variant=1)
-    b = ops.deform_im2col(x.to(DEV), off.to(DEV), mask.to(DEV) if wm else None, (kh, kw), s, (ph, pw), 1, dg, variant=2)
-    assert torch.equal(a, b)
+    for v in (2, 3):
+        b = ops.deform_im2col(x.to(DEV), off.to(DEV), mask.to(DEV) if wm else None, (kh, kw), s, (ph, pw), 1, dg, variant=v)
+        assert torch.equal(a, b), v
 
 
 def test_deform_im2col_full_size_layers_variants_agree():
@@ -71,8 +72,9 @@ def test_deform_im2col_full_size_layers_variants_agree():
         x, off, mask = make_deform_case(2, C, H, W, 3, 3, s, 1, 1, 1, seed=C + s)
         xd, od, md = x.to(DEV), off.to(DEV), mask.to(DEV)
         a = ops.deform_im2col(xd, od, md, 3, s, 1, 1, 1, variant=1)
-        b = ops.deform_im2col(xd, od, md, 3, s, 1, 1, 1, variant=2)
-        assert torch.equal(a, b), (C, H, W, s)
+        for v in (2, 3):
+            b = ops.deform_im2col(xd, od, md, 3, s, 1, 1, 1, variant=v)
+            assert torch.equal(a, b), (C, H, W, s, v)
         # spot-check one image row block against the oracle (full oracle im2col at this size takes seconds)
         ref = oracle.deform_im2col(x[:1, :8], off[:1], mask[:1], 3, s, 1, 1, 1)
         assert (b[:1, :72].cpu() - ref).abs().max() < 2e-5
@@ -85,7 +87,7 @@ def test_deform_im2col_fused_offset_mask_logits():
     om = rnd(B, 27, H, W, seed=2, scale=1.5)
     o1, o2, m = torch.chunk(om, 3, dim=1)
     ref = oracle.deform_im2col(x, torch.cat((o1, o2), 1), torch.sigmoid(m), 3, 1, 1, 1, 1)
-    for v in (1, 2):
+    for v in (1, 2, 3):
         got = ops.deform_im2col(x.to(DEV), None, None, 3, 1, 1, 1, 1, variant=v, fused_om=om.to(DEV)).cpu()
         assert (got - ref).abs().max() < 2e-5
 
