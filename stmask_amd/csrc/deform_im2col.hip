@@ -29,6 +29,7 @@ struct ImcolArgs {
     int B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, dg, Ho, Wo;
     // tiled variant only
     int th, cch, R, LW, halo, tiles_y;
+    int dbg;  // ablation switch for profiling builds of variant 3 (0 = normal): 1 = no staging / LDS reads, 2 = no stores
 };
 
 __device__ __forceinline__ float sigmoidf_dev(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
     for (int q = 0; q < nq; ++q) {
         const float* xq = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;   // wave-uniform base of this quad
         if (q) __syncthreads();                                          // previous quad fully consumed
-        {
+        if (a.dbg != 1) {
             constexpr int SU = 4;
             int r = r_first, col = c_first;
             for (int base = tid; base < RL; base += 256 * SU) {
@@ -447,10 +448,15 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
             float4 acc[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const float4 v1 = tile[la[it][p]];
-                const float4 v2 = tile[lb[it][p]];
-                const float4 v3 = tile[la[it][p] + a.LW];
-                const float4 v4 = tile[lb[it][p] + a.LW];
+                float4 v1, v2, v3, v4;
+                if (a.dbg == 1) {
+                    v1 = v2 = v3 = v4 = make_float4(1.f, 2.f, 3.f, 4.f);
+                } else {
+                    v1 = tile[la[it][p]];
+                    v2 = tile[lb[it][p]];
+                    v3 = tile[la[it][p] + a.LW];
+                    v4 = tile[lb[it][p] + a.LW];
+                }
                 const float4 w = wq[it][p];
                 acc[p].x = w.x * v1.x + w.y * v2.x + w.z * v3.x + w.w * v4.x;
                 acc[p].y = w.x * v1.y + w.y * v2.y + w.z * v3.y + w.w * v4.y;
@@ -477,6 +483,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
                     }
             }
             float* c_ = cq + sbase[it];
+            if (a.dbg == 2 && acc[0].x != 123456.789f) continue;  // ablation: keep the values live, skip the stores
             *reinterpret_cast<float4*>(c_) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
             *reinterpret_cast<float4*>(c_ + cs) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
             *reinterpret_cast<float4*>(c_ + 2 * cs) = make_float4(acc[0].z, acc[1].z, acc[2].z, acc[3].z);
@@ -531,6 +538,7 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     a.B = g->B; a.C = g->C; a.H = g->H; a.W = g->W; a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw;
     a.ph = g->ph; a.pw = g->pw; a.dh = g->dh; a.dw = g->dw; a.dg = g->dg; a.Ho = g->Ho; a.Wo = g->Wo;
     a.th = a.cch = a.R = a.LW = a.halo = a.tiles_y = 0;
+    a.dbg = env_int("STM_IM2COL_DEBUG", 0);
 
     if (variant == 0) variant = env_int("STM_IM2COL_VARIANT", 0);
     bool tiled_ok = (Cg % 4 == 0);
