@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
 // waves issuing 51 % of their lifetime: instruction-bound, not HBM-bound.  Here the set-up is amortised over cch
 // (16-64) channels and staging uses 32-bit offsets from a wave-uniform per-quad base.
 // grid: x = tiles_y * (C / cch), y = B.  Dynamic LDS: R * LW float4 (one quad).
-template <int IT>
+template <int IT, int PT>
 __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
 {
     extern __shared__ float4 tile[];
@@ -342,9 +342,27 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
     const int HWo = a.Ho * a.Wo;
     const int HW = a.H * a.W;
     const int tid = threadIdx.x;
-    const int ty = blockIdx.x % a.tiles_y;
-    const int chunk = blockIdx.x / a.tiles_y;
-    const int b = blockIdx.y;
+    // XCD-aware block -> tile map (1-D grid).  Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.
+    // All row tiles of one (image, channel chunk) share halo rows and the offsets, so they are given to ONE XCD:
+    // ids congruent mod 8 walk the row tiles of a plane before moving to the next plane (speed only, any placement
+    // is correct).  Planes = B * C/cch; the tail (planes % 8) falls back to the plain order.
+    int ty, plane;
+    {
+        const int planes = a.B * (a.C / a.cch);
+        const int id = blockIdx.x;
+        const int full = (planes / 8) * 8 * a.tiles_y;   // ids covered by whole groups of 8 planes
+        if (id < full) {
+            const int xcd = id & 7, j = id >> 3;
+            ty = j % a.tiles_y;
+            plane = xcd + 8 * (j / a.tiles_y);
+        } else {
+            const int j = id - full;
+            ty = j % a.tiles_y;
+            plane = (planes / 8) * 8 + j / a.tiles_y;
+        }
+    }
+    const int chunk = plane % (a.C / a.cch);
+    const int b = plane / (a.C / a.cch);
     const int c0 = chunk * a.cch;
     const int g = c0 / (a.C / a.dg);
     const int nq = a.cch >> 2;
@@ -406,41 +424,50 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
         }
     }
 
-    // ---- 2. walk the channel quads of this chunk through one LDS buffer
+    // ---- 2. walk the channel quads of this chunk through one LDS buffer, software-pipelined: the global loads of
+    //         quad q+1 are issued into registers BEFORE the FMAs / stores of quad q, so their L2/HBM latency hides
+    //         behind that work (ablation: staging + compute alone took 51 us of a 63 us launch when serialised)
+    // PT = staged pixels per thread: R*LW <= 256*PT (host picks the instantiation)
     const int step_r = 256 / a.LW, step_c = 256 - step_r * a.LW;
     const int r_first = tid / a.LW, c_first = tid - r_first * a.LW;
     const int64_t cs = (int64_t)K * HWo;
-    for (int q = 0; q < nq; ++q) {
+    float4 pv[PT];
+    auto prefetch = [&](int q) {
         const float* xq = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;   // wave-uniform base of this quad
-        if (q) __syncthreads();                                          // previous quad fully consumed
-        if (a.dbg != 1) {
-            constexpr int SU = 4;
-            int r = r_first, col = c_first;
-            for (int base = tid; base < RL; base += 256 * SU) {
-                float4 v[SU];
-                int dst[SU];
+        int r = r_first, col = c_first;
 #pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    dst[u] = r * a.LW + swz(col);
-                    const int yy = y0 + r, xx = col - 1;
-                    if (base + u * 256 < RL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-                        const int o = yy * a.W + xx;
-                        v[u].x = xq[o];
-                        v[u].y = xq[o + HW];
-                        v[u].z = xq[o + 2 * HW];
-                        v[u].w = xq[o + 3 * HW];
-                    }
-                    col += step_c;
-                    r += step_r;
-                    if (col >= a.LW) { col -= a.LW; ++r; }
-                }
-#pragma unroll
-                for (int u = 0; u < SU; ++u)
-                    if (base + u * 256 < RL) tile[dst[u]] = v[u];
+        for (int u = 0; u < PT; ++u) {
+            pv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int yy = y0 + r, xx = col - 1;
+            if (tid + u * 256 < RL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                const int o = yy * a.W + xx;
+                pv[u].x = xq[o];
+                pv[u].y = xq[o + HW];
+                pv[u].z = xq[o + 2 * HW];
+                pv[u].w = xq[o + 3 * HW];
             }
+            col += step_c;
+            r += step_r;
+            if (col >= a.LW) { col -= a.LW; ++r; }
         }
+    };
+    auto commit = [&]() {
+        int r = r_first, col = c_first;
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            if (tid + u * 256 < RL) tile[r * a.LW + swz(col)] = pv[u];
+            col += step_c;
+            r += step_r;
+            if (col >= a.LW) { col -= a.LW; ++r; }
+        }
+    };
+    if (a.dbg != 1) prefetch(0);
+    for (int q = 0; q < nq; ++q) {
+        const float* xq = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;
+        if (q) __syncthreads();                                          // previous quad fully consumed
+        if (a.dbg != 1) commit();
         __syncthreads();
+        if (a.dbg != 1 && q + 1 < nq) prefetch(q + 1);
         float* cq = a.cols + ((int64_t)b * a.C + c0 + 4 * q) * cs;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
@@ -590,19 +617,24 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
             STM_REQUIRE(cch3 % 4 == 0 && Cg % cch3 == 0, STM_EINVAL, "stm_deform_im2col_f32: channels per block %d invalid",
                         cch3);
             a.th = th3; a.cch = cch3; a.R = R3; a.LW = LW; a.halo = halo; a.tiles_y = tiles3;
-            dim3 grid3(tiles3 * (g->C / cch3), g->B);
+            dim3 grid3(tiles3 * (g->C / cch3) * g->B);   // 1-D: the kernel maps ids to tiles XCD-aware
             const int it = stm_cdiv(items3, 256);
+            const int pt = stm_cdiv(stm_cdiv(R3 * LW, 256), 4) * 4;   // 4, 8, 12 or 16 staged pixels per thread
             auto launch = [&](auto kern) {
                 if (lds3 > 48 * 1024)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)lds3);
                 hipLaunchKernelGGL(kern, grid3, dim3(256), lds3, stm_hs(stream), a);
             };
-            if (it <= 1) launch(deform_im2col_lds3<1>);
-            else if (it == 2) launch(deform_im2col_lds3<2>);
-            else launch(deform_im2col_lds3<3>);
-            STM_CHECK_LAUNCH("deform_im2col_lds3");
-            return STM_OK;
+            if (pt <= 16) {
+#define STM_L3(I, P) launch(deform_im2col_lds3<I, P>)
+                if (it <= 1) { if (pt == 4) STM_L3(1, 4); else if (pt == 8) STM_L3(1, 8); else if (pt == 12) STM_L3(1, 12); else STM_L3(1, 16); }
+                else if (it == 2) { if (pt == 4) STM_L3(2, 4); else if (pt == 8) STM_L3(2, 8); else if (pt == 12) STM_L3(2, 12); else STM_L3(2, 16); }
+                else { if (pt == 4) STM_L3(3, 4); else if (pt == 8) STM_L3(3, 8); else if (pt == 12) STM_L3(3, 12); else STM_L3(3, 16); }
+#undef STM_L3
+                STM_CHECK_LAUNCH("deform_im2col_lds3");
+                return STM_OK;
+            }
         }
     }
     // Tile choice (scripts/bench_kernels.py --env-sweep on MI355X): 8 channels per workgroup and as many output rows
