@@ -150,8 +150,8 @@ template <> struct PosVec<1> { using type = float; };
 
 // ------------------------------------------------------------------------------------ variant 2
 // grid: x = tiles_y * (C / cch), y = B.  Dynamic LDS: (cch/4) * R * LW float4.
-template <int NP>
-__global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
+template <int NP, int NTHR>
+__global__ __launch_bounds__(NTHR) void deform_im2col_lds(ImcolArgs a)
 {
     using VecT = typename PosVec<NP>::type;
     extern __shared__ float4 tile[];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
     VecT pdy[PRE], pdx[PRE], pm[PRE];
 #pragma unroll
     for (int it = 0; it < PRE; ++it) {
-        const int item = tid + it * 256;
+        const int item = tid + it * NTHR;
         if (item < n_items) {
             const int k = item / items_per_k;
             const int nb = n0 + (item - k * items_per_k) * NP;
@@ -201,10 +201,10 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
         const float* xb = a.x + ((int64_t)b * a.C + c0) * HW;
         const int total = nq * RL;
         // (q, r, col) advance incrementally with idx += 256: no per-element integer division
-        const int step_r = 256 / a.LW, step_c = 256 - step_r * a.LW;
+        const int step_r = NTHR / a.LW, step_c = NTHR - step_r * a.LW;
         int r = tid / a.LW, col = tid - r * a.LW, q = 0;
         while (r >= a.R) { r -= a.R; ++q; }
-        for (int base = tid; base < total; base += 256 * SU) {
+        for (int base = tid; base < total; base += NTHR * SU) {
             float4 v[SU];
             int dst[SU];
 #pragma unroll
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 dst[u] = q * RL + r * a.LW + swz(col);
                 const int yy = y0 + r, xx = col - 1;
-                if (base + u * 256 < total && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                if (base + u * NTHR < total && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
                     const float* p = xb + (int64_t)(4 * q) * HW + (int64_t)yy * a.W + xx;
                     v[u].x = p[0];
                     v[u].y = p[HW];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u)
-                if (base + u * 256 < total) tile[dst[u]] = v[u];
+                if (base + u * NTHR < total) tile[dst[u]] = v[u];
         }
     }
     __syncthreads();
@@ -312,10 +312,10 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
 
 #pragma unroll
     for (int it = 0; it < PRE; ++it) {
-        const int item = tid + it * 256;
+        const int item = tid + it * NTHR;
         if (item < n_items) process(item, pdy[it], pdx[it], pm[it]);
     }
-    for (int item = tid + PRE * 256; item < n_items; item += 256) {  // tiles with more than PRE*256 items
+    for (int item = tid + PRE * NTHR; item < n_items; item += NTHR) {  // tiles with more than PRE*256 items
         const int k = item / items_per_k;
         const int nb = n0 + (item - k * items_per_k) * NP;
         VecT dq = *reinterpret_cast<const VecT*>(ob + (int64_t)(2 * k) * HWo + nb);
@@ -333,8 +333,11 @@ __global__ __launch_bounds__(256) void deform_im2col_lds(ImcolArgs a)
 // instructions per output element (coefficient set-up and 64-bit staging addresses re-done for every 4 channels) and
 // waves issuing 51 % of their lifetime: instruction-bound, not HBM-bound.  Here the set-up is amortised over cch
 // (16-64) channels and staging uses 32-bit offsets from a wave-uniform per-quad base.
-// grid: x = tiles_y * (C / cch), y = B.  Dynamic LDS: R * LW float4 (one quad).
-template <int IT, int PT>
+// A register-prefetch pipeline over the quads (loads of quad q+1 issued before the FMAs of quad q) was measured and
+// REJECTED: the prefetch registers pushed the kernel to 256 VGPR + 172 AGPR (1 wave/SIMD) and it ran 1.4x slower --
+// on this kernel occupancy hides latency better than software pipelining.
+// grid: 1-D, tiles_y * (C / cch) * B, XCD-aware id -> tile map.  Dynamic LDS: R * LW float4 (one quad).
+template <int IT>
 __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
 {
     extern __shared__ float4 tile[];
@@ -424,50 +427,41 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
         }
     }
 
-    // ---- 2. walk the channel quads of this chunk through one LDS buffer, software-pipelined: the global loads of
-    //         quad q+1 are issued into registers BEFORE the FMAs / stores of quad q, so their L2/HBM latency hides
-    //         behind that work (ablation: staging + compute alone took 51 us of a 63 us launch when serialised)
-    // PT = staged pixels per thread: R*LW <= 256*PT (host picks the instantiation)
+    // ---- 2. walk the channel quads of this chunk through one LDS buffer
     const int step_r = 256 / a.LW, step_c = 256 - step_r * a.LW;
     const int r_first = tid / a.LW, c_first = tid - r_first * a.LW;
     const int64_t cs = (int64_t)K * HWo;
-    float4 pv[PT];
-    auto prefetch = [&](int q) {
-        const float* xq = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;   // wave-uniform base of this quad
-        int r = r_first, col = c_first;
-#pragma unroll
-        for (int u = 0; u < PT; ++u) {
-            pv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int yy = y0 + r, xx = col - 1;
-            if (tid + u * 256 < RL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-                const int o = yy * a.W + xx;
-                pv[u].x = xq[o];
-                pv[u].y = xq[o + HW];
-                pv[u].z = xq[o + 2 * HW];
-                pv[u].w = xq[o + 3 * HW];
-            }
-            col += step_c;
-            r += step_r;
-            if (col >= a.LW) { col -= a.LW; ++r; }
-        }
-    };
-    auto commit = [&]() {
-        int r = r_first, col = c_first;
-#pragma unroll
-        for (int u = 0; u < PT; ++u) {
-            if (tid + u * 256 < RL) tile[r * a.LW + swz(col)] = pv[u];
-            col += step_c;
-            r += step_r;
-            if (col >= a.LW) { col -= a.LW; ++r; }
-        }
-    };
-    if (a.dbg != 1) prefetch(0);
     for (int q = 0; q < nq; ++q) {
-        const float* xq = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;
+        const float* xq = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;   // wave-uniform base of this quad
         if (q) __syncthreads();                                          // previous quad fully consumed
-        if (a.dbg != 1) commit();
+        if (a.dbg != 1) {
+            constexpr int SU = 4;
+            int r = r_first, col = c_first;
+            for (int base = tid; base < RL; base += 256 * SU) {
+                float4 v[SU];
+                int dst[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    dst[u] = r * a.LW + swz(col);
+                    const int yy = y0 + r, xx = col - 1;
+                    if (base + u * 256 < RL && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                        const int o = yy * a.W + xx;
+                        v[u].x = xq[o];
+                        v[u].y = xq[o + HW];
+                        v[u].z = xq[o + 2 * HW];
+                        v[u].w = xq[o + 3 * HW];
+                    }
+                    col += step_c;
+                    r += step_r;
+                    if (col >= a.LW) { col -= a.LW; ++r; }
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u)
+                    if (base + u * 256 < RL) tile[dst[u]] = v[u];
+            }
+        }
         __syncthreads();
-        if (a.dbg != 1 && q + 1 < nq) prefetch(q + 1);
         float* cq = a.cols + ((int64_t)b * a.C + c0 + 4 * q) * cs;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
@@ -587,7 +581,7 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     // ---- tiled: pick rows per tile / channels per block --------------------------------------------
     const int halo = env_int("STM_IM2COL_HALO", 3);  // learned offsets of trained DCNs rarely exceed +-3 rows
     const int LW = ((g->W + 2 + 3) / 4) * 4;          // +1 zero column each side, rounded up for the column swizzle
-    bool vec = (HWo % 4 == 0) && (off_bstride % 4 == 0) && (!mask || mask_bstride % 4 == 0) &&
+    bool vec = !env_int("STM_IM2COL_NP1", 0) && (HWo % 4 == 0) && (off_bstride % 4 == 0) && (!mask || mask_bstride % 4 == 0) &&
                ((uintptr_t)offset % 16 == 0) && (!mask || (uintptr_t)mask % 16 == 0) && ((uintptr_t)cols % 16 == 0);
     if (variant == 3 && vec) {
         // ---- variant 3: coefficients once per workgroup, channel quads streamed through one LDS buffer ----------
@@ -619,19 +613,16 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
             a.th = th3; a.cch = cch3; a.R = R3; a.LW = LW; a.halo = halo; a.tiles_y = tiles3;
             dim3 grid3(tiles3 * (g->C / cch3) * g->B);   // 1-D: the kernel maps ids to tiles XCD-aware
             const int it = stm_cdiv(items3, 256);
-            const int pt = stm_cdiv(stm_cdiv(R3 * LW, 256), 4) * 4;   // 4, 8, 12 or 16 staged pixels per thread
             auto launch = [&](auto kern) {
                 if (lds3 > 48 * 1024)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)lds3);
                 hipLaunchKernelGGL(kern, grid3, dim3(256), lds3, stm_hs(stream), a);
             };
-            if (pt <= 16) {
-#define STM_L3(I, P) launch(deform_im2col_lds3<I, P>)
-                if (it <= 1) { if (pt == 4) STM_L3(1, 4); else if (pt == 8) STM_L3(1, 8); else if (pt == 12) STM_L3(1, 12); else STM_L3(1, 16); }
-                else if (it == 2) { if (pt == 4) STM_L3(2, 4); else if (pt == 8) STM_L3(2, 8); else if (pt == 12) STM_L3(2, 12); else STM_L3(2, 16); }
-                else { if (pt == 4) STM_L3(3, 4); else if (pt == 8) STM_L3(3, 8); else if (pt == 12) STM_L3(3, 12); else STM_L3(3, 16); }
-#undef STM_L3
+            {
+                if (it <= 1) launch(deform_im2col_lds3<1>);
+                else if (it == 2) launch(deform_im2col_lds3<2>);
+                else launch(deform_im2col_lds3<3>);
                 STM_CHECK_LAUNCH("deform_im2col_lds3");
                 return STM_OK;
             }
@@ -675,16 +666,19 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     }
     a.th = th; a.cch = cch; a.R = R; a.LW = LW; a.halo = halo; a.tiles_y = stm_cdiv(g->Ho, th);
     dim3 grid(a.tiles_y * (g->C / cch), g->B);
+    const int nthr = env_int("STM_IM2COL_THREADS", 256);
+    auto launch2 = [&](auto kern, int threads) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stm_hs(stream), a);
+    };
     if (vec) {
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(deform_im2col_lds<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(deform_im2col_lds<4>, grid, dim3(256), lds, stm_hs(stream), a);
+        if (nthr == 512) launch2(deform_im2col_lds<4, 512>, 512);
+        else launch2(deform_im2col_lds<4, 256>, 256);
     } else {
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(deform_im2col_lds<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(deform_im2col_lds<1>, grid, dim3(256), lds, stm_hs(stream), a);
+        if (nthr == 1024) launch2(deform_im2col_lds<1, 1024>, 1024);
+        else if (nthr == 512) launch2(deform_im2col_lds<1, 512>, 512);
+        else launch2(deform_im2col_lds<1, 256>, 256);
     }
     STM_CHECK_LAUNCH("deform_im2col_lds");
     return STM_OK;
