@@ -563,7 +563,16 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
 
     if (variant == 0) variant = env_int("STM_IM2COL_VARIANT", 0);
     bool tiled_ok = (Cg % 4 == 0);
-    if (variant == 0) variant = tiled_ok ? 3 : 1;
+    const bool auto_variant = (variant == 0);
+    if (variant == 0) {
+        // measured on MI355X (scripts/exp_im2col.sh, true kernel durations at batch 8): variant 2 wins on every R50 layer
+        // except the wide stride-2 one (96x160 input), where its LDS tile only leaves room for 4 channels per workgroup
+        // and variant 3 (set-up amortised over 32 channels, XCD-aware tile map) is 1.25x faster.
+        const int halo0 = env_int("STM_IM2COL_HALO", 3);
+        const size_t quad4 = (size_t)(3 * g->sh + (g->kh - 1) * g->dh + 2 + 2 * halo0) * (((g->W + 2 + 3) / 4) * 4) * 16;
+        const bool wide = 2 * quad4 > (size_t)env_int("STM_IM2COL_LDS_KB", 64) * 1024;  // 8 channels x 4 rows do not fit
+        variant = !tiled_ok ? 1 : ((wide && Cg % 32 == 0) ? 3 : 2);
+    }
     if (variant >= 2 && !tiled_ok) variant = 1;
 
     if (variant == 1) {
@@ -607,6 +616,7 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
                 cch3 = 4;
                 for (int c = 8; c <= Cg && c <= 64; c += 4)
                     if (Cg % c == 0 && (int64_t)tiles3 * (g->C / c) * g->B >= 768) cch3 = c;
+                if (auto_variant && Cg % 32 == 0) cch3 = 32;  // sweep optimum for the wide layers this path is chosen for
             }
             STM_REQUIRE(cch3 % 4 == 0 && Cg % cch3 == 0, STM_EINVAL, "stm_deform_im2col_f32: channels per block %d invalid",
                         cch3);
