@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nchw", dest="channels_last", action="store_false", help="keep the dense convs in NCHW")
+    ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="keep BatchNorm / bias / ReLU as separate kernels")
     ap.add_argument("--pipeline", default="batched", choices=["batched", "per-clip"],
                     help="batched: all clips' post-processing in concatenated tensors; per-clip: reference-shaped layer API")
     args = ap.parse_args()
@@ -95,8 +96,13 @@ def main():
     net.eval()
     synthetic.fill_state_dict(net, seed=0, bg_bias=synthetic.BENCH_BG_BIAS)
     net = net.to(dev)
+    if args.fuse:
+        from stmask_amd.fuse import optimize_for_inference
+        optimize_for_inference(net)  # BN folded into conv / DCN weights, bias (+residual) + ReLU as one epilogue pass
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)  # dense convs NHWC (17.0 vs 20.6 ms trunk at batch 8)
+        # ... except TemporalNet: on 7x7 RoI tiles MIOpen is 1.5x faster in NCHW (scripts/bench_temporalnet.py)
+        net.TemporalNet = net.TemporalNet.to(memory_format=torch.contiguous_format)
     T = 8
     # clip c of this rank = global clip rank + c*world (stmask_amd.dist.shard_clips); inputs resident in HBM
     clips = torch.stack([synthetic.synthetic_clip(T, args.height, args.width, seed=rank + c * world)
@@ -151,7 +157,9 @@ def main():
                                    f"tensor (360x640 padded), {args.clips} clips/GPU x 1 frame per step, random seeded weights",
                        "clips_per_gpu": args.clips, "frames_per_step": world * args.clips,
                        "detections_last_step": n_det, "parallelism": f"clip-dp{world}",
-                       "pipeline": args.pipeline},
+                       "pipeline": args.pipeline,
+                       "inference_graph": "bn-folded+fused-epilogues" if args.fuse else "reference-ops",
+                       "memory_format": "channels_last" if args.channels_last else "nchw"},
             "roofline": {"bound": "hbm", "kernel": "deform_im2col_lds (7 DCN layers, all launches of the timed region)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

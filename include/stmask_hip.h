@@ -193,6 +193,15 @@ size_t stm_mask_iou_workspace_bytes(int n1, int n2, int hw);
 int stm_mask_iou_f32(const float* m1, int n1, const float* m2, int n2, int hw, float thr, float* out,
                      void* workspace, size_t workspace_bytes, stm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Fused dense-conv epilogue, in place: y = act(y + bias[c] (+ residual)).
+ * Replaces: the BatchNorm / ReLU / residual-add passes around every trunk convolution (backbone.py:38-58,
+ * make_net.py ReLUs, prediction_head_FC.py extras) once BN is folded into the conv weights (stmask_amd/fuse.py).
+ *   channel of element i = (i / inner) % C; inner = H*W for NCHW, 1 for NHWC.  relu != 0 -> max(., 0).
+ * ------------------------------------------------------------------------------------------------- */
+int stm_bias_act_f32(float* y, const float* bias, const float* residual, int64_t n, int C, int64_t inner,
+                     int relu, stm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

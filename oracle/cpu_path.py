@@ -83,7 +83,17 @@ def _lincomb(proto, coeff, boxes=None, apply_tanh=True, n_dev=None, row_proto=No
     return out
 
 
+def _bias_act_(y, bias, residual=None, relu=True):
+    y.add_(bias.view(1, -1, 1, 1))
+    if residual is not None:
+        y.add_(residual)
+    if relu:
+        y.clamp_(min=0)
+    return y
+
+
 _PATCH = {
+    "bias_act_": _bias_act_,
     "deform_conv": _deform_conv,
     "deform_im2col": lambda x, offset, mask, kernel_size, stride=1, padding=0, dilation=1, deform_groups=1, variant=0,
     fused_om=None, mask_is_logit=False, out=None: orc.deform_im2col(x, offset, mask, kernel_size, stride, padding, dilation,

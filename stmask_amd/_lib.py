@@ -19,6 +19,7 @@ ABI_SYMBOLS = [
     "stm_roi_align_avg_f32", "stm_decode_boxes_f32", "stm_generate_candidates_f32", "stm_cc_fast_nms_f32",
     "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
     "stm_jaccard_f32", "stm_lincomb_sigmoid_crop_f32", "stm_mask_iou_workspace_bytes", "stm_mask_iou_f32",
+    "stm_bias_act_f32",
 ]
 
 

@@ -170,3 +170,54 @@ extern "C" int stm_mask_iou_f32(const float* m1, int n1, const float* m2, int n2
     STM_CHECK_LAUNCH("mask_iou_pairs_kernel");
     return STM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused conv epilogue for the dense trunk: y = act(y + bias[c] (+ residual)), in place.
+// The reference runs conv -> BatchNorm -> ReLU (-> += residual -> ReLU) as separate full passes over the activations
+// (backbone.py:38-58); with BN folded into the conv weights (stmask_amd/fuse.py) what is left is one bias add, an
+// optional residual add and a ReLU -- one HBM pass here instead of three to five.
+// Layout: channel index = (i / inner) % C; inner = H*W for NCHW, 1 for NHWC (channels_last).
+namespace {
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                       const float* __restrict__ res, int64_t n4, int C, int64_t inner,
+                                                       int relu)
+{
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= n4) return;
+    float4 v = reinterpret_cast<float4*>(y)[i4];
+    float4 b;
+    if (inner == 1) {  // NHWC: 4 consecutive channels
+        b = *reinterpret_cast<const float4*>(bias + (int)((i4 * 4) % C));
+    } else {           // NCHW: 4 consecutive pixels of one channel (inner % 4 == 0)
+        const float s = bias[(int)(((i4 * 4) / inner) % C)];
+        b = make_float4(s, s, s, s);
+    }
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (res) {
+        const float4 r = reinterpret_cast<const float4*>(res)[i4];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    reinterpret_cast<float4*>(y)[i4] = v;
+}
+}  // namespace
+
+extern "C" int stm_bias_act_f32(float* y, const float* bias, const float* residual, int64_t n, int C, int64_t inner,
+                                int relu, stm_stream_t stream)
+{
+    STM_REQUIRE(n >= 0, STM_EINVAL, "stm_bias_act_f32: n < 0");
+    if (n == 0) return STM_OK;
+    STM_REQUIRE(y && bias, STM_ENULL, "stm_bias_act_f32: y/bias must be non-NULL");
+    STM_REQUIRE(C > 0 && inner > 0 && n % ((int64_t)C * inner) == 0, STM_EINVAL, "stm_bias_act_f32: n not a multiple of C*inner");
+    STM_REQUIRE((inner == 1 && C % 4 == 0) || (inner > 1 && inner % 4 == 0), STM_EUNSUPPORTED,
+                "stm_bias_act_f32: needs C %% 4 == 0 (NHWC) or H*W %% 4 == 0 (NCHW)");
+    STM_REQUIRE(((uintptr_t)y % 16 == 0) && ((uintptr_t)bias % 16 == 0) && (!residual || (uintptr_t)residual % 16 == 0),
+                STM_EINVAL, "stm_bias_act_f32: pointers must be 16-byte aligned");
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(bias_act_kernel, dim3(stm_cdiv(n4, 256)), dim3(256), 0, stm_hs(stream), y, bias, residual, n4, C, inner,
+                       relu);
+    STM_CHECK_LAUNCH("bias_act_kernel");
+    return STM_OK;
+}

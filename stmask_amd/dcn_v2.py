@@ -53,6 +53,7 @@ class DCN(DCNv2):
         ch = self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1]
         self.conv_offset_mask = nn.Conv2d(in_channels, ch, kernel_size=self.kernel_size, stride=self.stride,
                                           padding=self.padding, bias=True)
+        self.fuse_relu = False  # fuse.optimize_for_inference: apply the following ReLU in the GEMM epilogue
         self.init_offset()
 
     def init_offset(self):
@@ -64,4 +65,4 @@ class DCN(DCNv2):
         om = self.conv_offset_mask(input)
         # offsets = om[:, :2*dg*K], mask = sigmoid(om[:, 2*dg*K:]) -- read in place by the kernel
         return ops.deform_conv(input, None, None, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                               self.deformable_groups, fused_om=om)
+                               self.deformable_groups, relu=self.fuse_relu, fused_om=om)

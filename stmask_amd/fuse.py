@@ -8,7 +8,10 @@ relative); tests/test_host_model_cpu.py checks the folded model against the refe
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from . import ops
+from .backbone import Bottleneck
 from .dcn_v2 import DCN
 
 
@@ -47,3 +50,83 @@ def fold_batchnorm(net):
                 blk.downsample[1] = nn.Identity()
                 n += 1
     return n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Fused epilogues: after BN folding every trunk conv is followed by (bias add [+ residual add] + ReLU).  MIOpen runs
+# the bias add as its own kernel and torch runs the add / ReLU as further kernels; the modules below run the conv
+# without bias and finish with ONE in-place HIP pass (stm_bias_act_f32).  Classes are swapped in place
+# (instance.__class__), so parameter names / state-dict keys do not change.
+def _epilogue(y, bias, residual=None, relu=True):
+    B, C, H, W = y.shape
+    nhwc = (not y.is_contiguous()) and y.is_contiguous(memory_format=torch.channels_last)
+    if y.is_cuda and ((nhwc and C % 4 == 0) or (y.is_contiguous() and (H * W) % 4 == 0)):
+        return ops.bias_act_(y, bias, residual, relu)
+    y = y + bias.view(1, -1, 1, 1)          # shapes the kernel does not cover (e.g. 3x5 maps in NCHW)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+class _ConvBiasReLU(nn.Conv2d):
+    def forward(self, x):
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
+        return _epilogue(y, self.bias, None, True)
+
+
+class _FusedBottleneck(Bottleneck):
+    def forward(self, x):
+        c1, c2, c3 = self.conv1, self.conv2, self.conv3
+        out = _epilogue(F.conv2d(x, c1.weight, None, c1.stride, c1.padding), c1.bias)
+        if isinstance(c2, DCN):
+            out = c2(out)                    # bias + ReLU already in the GEMM epilogue (c2.fuse_relu)
+        else:
+            out = _epilogue(F.conv2d(out, c2.weight, None, c2.stride, c2.padding, c2.dilation), c2.bias)
+        out = F.conv2d(out, c3.weight, None, c3.stride, c3.padding)
+        if self.downsample is not None:
+            d = self.downsample[0]
+            res = F.conv2d(x, d.weight, None, d.stride, d.padding)
+        else:
+            res = x
+        return _epilogue(out, self.bias3, res, True)
+
+
+def optimize_for_inference(net):
+    """fold_batchnorm + fused conv epilogues on the backbone, FPN prediction layers, proto-net and the head towers.
+    In place, eval mode only; call after the weights are loaded and the model is on its device."""
+    n_bn = fold_batchnorm(net)
+    n_fused = 0
+    bb = net.backbone
+    for layer in bb.layers:
+        for blk in layer:
+            b3 = blk.conv3.bias.detach().clone()
+            if blk.downsample is not None:
+                b3 = b3 + blk.downsample[0].bias.detach()
+            blk.register_buffer("bias3", b3, persistent=False)
+            if isinstance(blk.conv2, DCN):
+                blk.conv2.fuse_relu = True
+            blk.__class__ = _FusedBottleneck
+            n_fused += 3
+    # stem: conv1 (+ folded bn1) + ReLU
+    bb.conv1.__class__ = _ConvBiasReLU
+    bb.relu = nn.Identity()
+    n_fused += 1
+
+    def fuse_sequential(seq):
+        nonlocal n_fused
+        mods = list(seq.children())
+        for i in range(len(mods) - 1):
+            if type(mods[i]) is nn.Conv2d and isinstance(mods[i + 1], nn.ReLU) and mods[i].bias is not None:
+                mods[i].__class__ = _ConvBiasReLU
+                seq[i + 1] = nn.Identity()
+                n_fused += 1
+
+    fuse_sequential(net.proto_net)
+    head = net.prediction_layers[0]
+    for name in ("upfeature", "bbox_extra", "conf_extra", "mask_extra", "track_extra"):
+        fuse_sequential(getattr(head, name))
+    for pred in net.fpn.pred_layers:
+        pred.__class__ = _ConvBiasReLU
+        n_fused += 1
+    net.fpn.pred_relu_fused = True
+    return n_bn, n_fused

@@ -55,6 +55,7 @@ class FPN(nn.Module):
         self.downsample_layers = nn.ModuleList([nn.Conv2d(nf, nf, kernel_size=3, padding=1, stride=2)
                                                 for _ in range(cfg.fpn_num_downsample)])
         self.interpolation_mode = cfg.fpn_interpolation_mode
+        self.pred_relu_fused = False  # set by fuse.optimize_for_inference: the pred conv applies bias + ReLU itself
 
     def forward(self, convouts):
         n = len(convouts)
@@ -71,7 +72,7 @@ class FPN(nn.Module):
             out[j] = x
         for i, pred in enumerate(self.pred_layers):
             j = n - 1 - i
-            out[j] = F.relu(pred(out[j]))
+            out[j] = pred(out[j]) if self.pred_relu_fused else F.relu(pred(out[j]))
         for ds in self.downsample_layers:
             out.append(ds(out[-1]))
         return out

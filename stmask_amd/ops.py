@@ -340,3 +340,24 @@ def mask_iou(m1, m2, thr=0.5):
     check(_lib.lib().stm_mask_iou_f32(_p(m1), c_i(n1), _p(m2), c_i(n2), c_i(hw), c_f(thr), _p(out), _p(ws), c_sz(ws.numel()),
                                       _stream()), "stm_mask_iou_f32")
     return out
+
+
+def bias_act_(y, bias, residual=None, relu=True):
+    """In place y = act(y + bias[c] (+ residual)) for a 4-D activation in NCHW-contiguous or channels_last layout
+    (fused BN-folded conv epilogue).  Returns y."""
+    _dev(y, bias, residual)
+    if y.dtype != torch.float32 or y.dim() != 4:
+        raise StmError("bias_act_ expects a 4-D float32 activation")
+    B, C, H, W = y.shape
+    if y.is_contiguous():
+        inner = H * W
+    elif y.is_contiguous(memory_format=torch.channels_last):
+        inner = 1
+    else:
+        raise StmError("bias_act_: activation must be NCHW-contiguous or channels_last")
+    if residual is not None:
+        if residual.shape != y.shape or residual.stride() != y.stride():
+            residual = residual.contiguous(memory_format=torch.channels_last if inner == 1 else torch.contiguous_format)
+    check(_lib.lib().stm_bias_act_f32(_p(y), _p(_f32c(bias)), _p(residual), c_l(y.numel()), c_i(C), c_l(inner),
+                                      c_i(1 if relu else 0), _stream()), "stm_bias_act_f32")
+    return y

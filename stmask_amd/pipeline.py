@@ -19,7 +19,7 @@ from . import ops
 from .layers import Track_TF, generate_candidate
 from .layers.box_utils import center_size, sanitize_coordinates_hw
 
-ROI_CHUNK = 128  # TemporalNet always runs on [ROI_CHUNK,633,7,7] blocks: ONE dense-conv shape however many instances
+ROI_CHUNKS = (256, 128, 64)  # TemporalNet only ever sees these RoI batch sizes: three dense-conv shapes in total
 
 
 class _StageTimer:
@@ -108,12 +108,16 @@ class BatchedClipPipeline:
         roi_feats = ops.roi_align(feats, rois, 7)
         self.timer.toc("tf_corr_roi")
         n = roi_feats.shape[0]
-        n_pad = -(-n // ROI_CHUNK) * ROI_CHUNK
+        n_pad = -(-n // ROI_CHUNKS[-1]) * ROI_CHUNKS[-1]
         if n_pad != n:  # rows are independent: zero rows change nothing
             roi_feats = torch.cat([roi_feats, roi_feats.new_zeros(n_pad - n, *roi_feats.shape[1:])], 0)
-        # fixed-shape blocks: the dense-conv library (MIOpen) selects / builds kernels per shape, and the tracked set
-        # changes size every frame -- one shape means that cost is paid once
-        outs = [net.TemporalNet(roi_feats[i:i + ROI_CHUNK]) for i in range(0, n_pad, ROI_CHUNK)]
+        # fixed-shape blocks (greedy 256 / 128 / 64): the dense-conv library (MIOpen) selects / builds kernels per shape
+        # and the tracked set changes size every frame -- three shapes mean that cost is paid three times in total
+        outs, i = [], 0
+        while i < n_pad:
+            c = next(c for c in ROI_CHUNKS if c <= n_pad - i)
+            outs.append(net.TemporalNet(roi_feats[i:i + c]))
+            i += c
         loc_shift = torch.cat([o[0] for o in outs], 0)[:n]
         coeff_shift = torch.cat([o[1] for o in outs], 0)[:n]
         self.timer.toc("tf_temporalnet")

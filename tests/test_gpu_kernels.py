@@ -475,6 +475,27 @@ def test_mask_iou_bit_exact(golden_postproc, p):
     assert torch.equal(ops.mask_iou(a.to(DEV), a.to(DEV)).cpu(), oracle.mask_iou(a, a))
 
 
+@pytest.mark.parametrize("fmt", ["nchw", "nhwc"])
+def test_bias_act_epilogue(fmt):
+    y = rnd(3, 64, 12, 20, seed=1)
+    bias, res = rnd(64, seed=2), rnd(3, 64, 12, 20, seed=3)
+    mf = torch.channels_last if fmt == "nhwc" else torch.contiguous_format
+    for use_res in (False, True):
+        for relu in (False, True):
+            ref = y + bias.view(1, -1, 1, 1) + (res if use_res else 0)
+            ref = ref.clamp(min=0) if relu else ref
+            yd = y.to(DEV).contiguous(memory_format=mf).clone()
+            rd = res.to(DEV).contiguous(memory_format=mf) if use_res else None
+            out = ops.bias_act_(yd, bias.to(DEV), rd, relu)
+            assert out.data_ptr() == yd.data_ptr()
+            assert torch.equal(out.cpu(), ref), (fmt, use_res, relu)   # same IEEE ops, same order: bit-exact
+    # residual in the other memory format is converted, not misread
+    yd = y.to(DEV).contiguous(memory_format=mf).clone()
+    other = torch.contiguous_format if fmt == "nhwc" else torch.channels_last
+    out = ops.bias_act_(yd, bias.to(DEV), res.to(DEV).contiguous(memory_format=other), True)
+    assert torch.equal(out.cpu(), (y + bias.view(1, -1, 1, 1) + res).clamp(min=0))
+
+
 def test_bad_arguments_raise():
     x = torch.zeros(1, 8, 8, 8, device=DEV)
     with pytest.raises(StmError):

@@ -114,3 +114,23 @@ def test_batched_pipeline_equals_per_clip_driver_on_gpu():
             assert (d[b]["mask"] - r[b]["mask"]).abs().max() < 1e-3
             un = unpack_detections(packed[b])
             assert torch.equal(un["box_ids"], r[b]["box_ids"][:200])
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_optimized_inference_graph_on_gpu(channels_last):
+    """fuse.optimize_for_inference (BN folded, one-pass conv epilogues, ReLU in the DCN GEMM) changes head outputs only
+    by fp32 rounding, in NCHW and channels_last."""
+    from stmask_amd.fuse import optimize_for_inference
+    ref_net = build("STMask_plus_resnet50_config")
+    opt_net = build("STMask_plus_resnet50_config")
+    optimize_for_inference(opt_net)
+    x = synthetic.synthetic_clip(2, 128, 192, seed=3).cuda()
+    if channels_last:
+        opt_net = opt_net.to(memory_format=torch.channels_last)
+        opt_net.TemporalNet = opt_net.TemporalNet.to(memory_format=torch.contiguous_format)
+    with torch.no_grad():
+        _, a = ref_net.forward_single(x)
+        _, b = opt_net.forward_single(x.contiguous(memory_format=torch.channels_last) if channels_last else x)
+    for k in ("loc", "conf", "mask_coeff", "centerness", "proto", "track"):
+        scale = max(1.0, a[k].abs().max().item())
+        assert (a[k] - b[k]).abs().max().item() < 2e-4 * scale, k

@@ -137,3 +137,24 @@ def test_batchnorm_folding_keeps_reference_parity():
 
     assert fold_batchnorm(_Net) == 4
     assert (blk(x.clone()) - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("name,tag", CASES[:2])
+def test_optimized_inference_graph_keeps_reference_parity(name, tag):
+    """fuse.optimize_for_inference (BN folded, conv bias + residual + ReLU as one epilogue pass) against the goldens."""
+    from stmask_amd.fuse import optimize_for_inference
+    g = load_golden(f"model_{tag}.npz")
+    h, w = [int(v) for v in g["frames_hw"]]
+    net = STMask(get_cfg(name))
+    net.eval()
+    synthetic.fill_state_dict(net, seed=0)
+    keys_before = sorted(net.state_dict().keys())
+    n_bn, n_fused = optimize_for_inference(net)
+    assert n_bn == 53 and n_fused >= 60
+    frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0)
+    with oracle_ops(), torch.no_grad():
+        outs = run_clip(net, frames)
+    check_clip_against_golden(outs, g, tol_box=1e-4, tol_mask=1e-4)
+    # parameter names survive (only BatchNorm entries disappear, conv biases appear)
+    keys_after = set(net.state_dict().keys())
+    assert all(k in keys_after for k in keys_before if ".bn" not in k and "downsample.1" not in k and "bn1" not in k)
