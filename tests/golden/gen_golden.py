@@ -200,9 +200,10 @@ def gen_fcb_ali():
 
 
 # ----------------------------------------------------------------------------- whole model
-def gen_model(cfg_name, tag, hw=(128, 192), n_frames=3):
+def gen_model(cfg_name, tag, hw=(128, 192), n_frames=3, temporal_fusion=True):
     from datasets.config import cfg, set_cfg
     set_cfg(cfg_name)
+    cfg.temporal_fusion_module = temporal_fusion  # False: the reference's Detect / Track path (STMask.py:323-327)
     import STMask as stmask_mod
     net = stmask_mod.STMask()
     net.eval()
@@ -226,6 +227,7 @@ def gen_model(cfg_name, tag, hw=(128, 192), n_frames=3):
             res = net(frames[t:t + 1], img_meta=meta)[0]["detection"]
             for k in ("box", "score", "class", "box_ids", "mask_coeff", "mask", "centerness"):
                 v = res.get(k, torch.zeros(0))
+                v = torch.zeros(0) if v is None else v
                 out[f"t{t}_{k}"] = v
             print(tag, "frame", t, "n_out", len(res["box"]))
     save(f"model_{tag}.npz", **out)
@@ -246,6 +248,10 @@ def main():
         gen_model("STMask_plus_resnet50_config", "r50_fca")
         gen_model("STMask_plus_resnet50_ada_config", "r50_ada")
         gen_model("STMask_plus_resnet50_ali_config", "r50_ali")
+    if "model_extra" in which:
+        # NB: the reference's non-TF path (Detect/Track, STMask.py:323-327) cannot produce a golden: Detect.__call__
+        # reads result['bbox_idx'] (detection.py:93), a key its cc_fast_nms never sets -> KeyError on the first frame.
+        gen_model("STMask_plus_base_ali_config", "r101_ali", hw=(96, 160), n_frames=2)
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ from stmask_amd.layers import PredictionModule_FC
 from stmask_amd.model import STMask
 
 MODEL_CASES = [("STMask_plus_resnet50_config", "r50_fca"), ("STMask_plus_resnet50_ada_config", "r50_ada"),
-               ("STMask_plus_resnet50_ali_config", "r50_ali")]
+               ("STMask_plus_resnet50_ali_config", "r50_ali"), ("STMask_plus_base_ali_config", "r101_ali")]
 
 
 @pytest.mark.parametrize("name,tag", MODEL_CASES)
@@ -69,5 +69,6 @@ def test_synthetic_weights_are_pure_functions_of_key():
 def test_model_golden_fixtures_are_nontrivial():
     for _, tag in MODEL_CASES:
         g = load_golden(f"model_{tag}.npz")
-        assert g["t0_box"].shape[0] >= 3 and g["t2_box"].shape[0] >= 3, tag
+        last = int(g["n_frames"]) - 1
+        assert g["t0_box"].shape[0] >= 3 and g[f"t{last}_box"].shape[0] >= 3, tag
         assert np.isfinite(g["f0_proto"].numpy()).all()

