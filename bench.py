@@ -36,6 +36,17 @@ from stmask_amd.pipeline import BatchedClipPipeline, ClipPipeline  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+def pmc_traffic():
+    """HBM bytes per im2col launch from the committed rocprofv3 PMC passes (bench.py cannot collect PMC counters about
+    itself): profiles/r01_pmc_traffic.json, produced by `scripts/gpu_round.sh pmc` on the same command and batch."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return int(json.load(fh)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg_name, h, w, budget_s=25.0):
     """Oracle path on the host cores: same model / weights / clip, CPU tensors, oracle kernels."""
     import oracle
@@ -162,7 +173,9 @@ def main():
                        "memory_format": "channels_last" if args.channels_last else "nchw"},
             "roofline": {"bound": "hbm", "kernel": "deform_im2col_lds (7 DCN layers, all launches of the timed region)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic() if (args.clips == 8 and args.config == "STMask_plus_resnet50_config") else None,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)",
                          "launches": len(timing), "avg_launch_us": round(ker_ms * 1e3 / n_launch, 2),
                          "algorithmic_bytes_per_launch": int(ker_bytes / n_launch)},
         }
