@@ -29,6 +29,8 @@ struct ImcolArgs {
     int B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, dg, Ho, Wo;
     // tiled variant only
     int th, cch, R, LW, halo, tiles_y;
+    int blk;  // 1: tile-blocked column buffer cols[b][row tile][C*K][tile positions] (each workgroup writes one
+              // contiguous region); 0: plain cols[b][C*K][Ho*Wo]
     int dbg;  // ablation switch for profiling builds of variant 3 (0 = normal): 1 = no staging / LDS reads, 2 = no stores
 };
 
@@ -273,8 +275,11 @@ __global__ __launch_bounds__(NTHR) void deform_im2col_lds(ImcolArgs a)
             if (++wo == a.Wo) { wo = 0; ++ho; }
         }
 
-        float* cb = a.cols + (((int64_t)b * a.C + c0) * K + k) * HWo + nb;
-        const int64_t cs = (int64_t)K * HWo;
+        // plain: row (c*K + k) has HWo positions; blocked: tile ty owns [C*K][NT] floats at offset ty * C*K*(th*Wo)
+        const int64_t cs = a.blk ? (int64_t)K * NT : (int64_t)K * HWo;
+        float* cb = a.blk ? a.cols + (int64_t)b * a.C * K * HWo + (int64_t)ty * a.C * K * (a.th * a.Wo) +
+                                ((int64_t)c0 * K + k) * NT + (nb - n0)
+                          : a.cols + (((int64_t)b * a.C + c0) * K + k) * HWo + nb;
         for (int q = 0; q < nq; ++q) {
             const float4* tq = tile + q * RL;
             float4 acc[NP];
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
             const int k = item / items_per_k;
             const int nb = n0 + ((item - k * items_per_k) << 2);
             const int i = k / a.kw, j = k - i * a.kw;
-            sbase[it] = k * HWo + nb;
+            sbase[it] = a.blk ? k * NT + (nb - n0) : k * HWo + nb;
             float dyv[4], dxv[4], mv[4] = {1.f, 1.f, 1.f, 1.f};
             unpack(*reinterpret_cast<const float4*>(ob + (int64_t)(2 * k) * HWo + nb), dyv);
             unpack(*reinterpret_cast<const float4*>(ob + (int64_t)(2 * k + 1) * HWo + nb), dxv);
@@ -430,7 +435,9 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
     // ---- 2. walk the channel quads of this chunk through one LDS buffer
     const int step_r = 256 / a.LW, step_c = 256 - step_r * a.LW;
     const int r_first = tid / a.LW, c_first = tid - r_first * a.LW;
-    const int64_t cs = (int64_t)K * HWo;
+    const int64_t cs = a.blk ? (int64_t)K * NT : (int64_t)K * HWo;
+    float* const cbase = a.blk ? a.cols + (int64_t)b * a.C * K * HWo + (int64_t)ty * a.C * K * (a.th * a.Wo) + (int64_t)c0 * cs
+                               : a.cols + ((int64_t)b * a.C + c0) * cs;
     for (int q = 0; q < nq; ++q) {
         const float* xq = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;   // wave-uniform base of this quad
         if (q) __syncthreads();                                          // previous quad fully consumed
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
             }
         }
         __syncthreads();
-        float* cq = a.cols + ((int64_t)b * a.C + c0 + 4 * q) * cs;
+        float* cq = cbase + (int64_t)(4 * q) * cs;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             if (sbase[it] < 0) continue;
@@ -485,8 +492,8 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
                 acc[p].w = w.x * v1.w + w.y * v2.w + w.z * v3.w + w.w * v4.w;
             }
             if (far[it]) {  // rare: offsets larger than the halo -> exact global gather (coordinates re-derived)
-                const int k = sbase[it] / HWo;
-                const int nb = sbase[it] - k * HWo;
+                const int k = a.blk ? sbase[it] / NT : sbase[it] / HWo;
+                const int nb = a.blk ? n0 + (sbase[it] - k * NT) : sbase[it] - k * HWo;
                 const int i = k / a.kw, j = k - i * a.kw;
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
@@ -560,6 +567,7 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     a.ph = g->ph; a.pw = g->pw; a.dh = g->dh; a.dw = g->dw; a.dg = g->dg; a.Ho = g->Ho; a.Wo = g->Wo;
     a.th = a.cch = a.R = a.LW = a.halo = a.tiles_y = 0;
     a.dbg = env_int("STM_IM2COL_DEBUG", 0);
+    a.blk = env_int("STM_IM2COL_BLOCKED", 0);
 
     if (variant == 0) variant = env_int("STM_IM2COL_VARIANT", 0);
     bool tiled_ok = (Cg % 4 == 0);
