@@ -36,6 +36,14 @@ struct ImcolArgs {
 
 __device__ __forceinline__ float sigmoidf_dev(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// The one bilinear blend every variant uses: an explicit 1-mul + 3-fma chain (the file is built with
+// -ffp-contract=off and -fno-slp-vectorize: left to itself hipcc turned the mul/add form into v_pk_mul / v_pk_add pairs
+// plus 48 v_mov shuffles per 16 outputs).  Identical in all variants, so they agree bit for bit.
+__device__ __forceinline__ float bilerp(float w1, float w2, float w3, float w4, float v1, float v2, float v3, float v4)
+{
+    return fmaf(w4, v4, fmaf(w3, v3, fmaf(w2, v2, w1 * v1)));
+}
+
 // Bilinear sample with the DCNv2 border rule straight from global memory (fallback / direct variant).
 __device__ __forceinline__ float sample_global(const float* __restrict__ im, int H, int W, float fy, float fx)
 {
@@ -48,7 +56,7 @@ __device__ __forceinline__ float sample_global(const float* __restrict__ im, int
     float v2 = (h_low >= 0 && w_high <= W - 1) ? im[h_low * W + w_high] : 0.0f;
     float v3 = (h_high <= H - 1 && w_low >= 0) ? im[h_high * W + w_low] : 0.0f;
     float v4 = (h_high <= H - 1 && w_high <= W - 1) ? im[h_high * W + w_high] : 0.0f;
-    return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+    return bilerp(hh * hw, hh * lw, lh * hw, lh * lw, v1, v2, v3, v4);
 }
 
 // ------------------------------------------------------------------------------------ variant 1
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256) void deform_im2col_direct(ImcolArgs a, int cpb
     float* cb = a.cols + (((int64_t)b * a.C + c0) * K + k) * HWo + n;
 #pragma unroll 4
     for (int c = c0; c < c1; ++c) {
-        float v = w1 * xb[a1] + w2 * xb[a2] + w3 * xb[a3] + w4 * xb[a4];
+        float v = bilerp(w1, w2, w3, w4, xb[a1], xb[a2], xb[a3], xb[a4]);
         *cb = v;
         xb += HW;
         cb += (int64_t)K * HWo;
@@ -130,13 +138,13 @@ __device__ __noinline__ float4 sample_global4(const float* __restrict__ xc, int6
     float w3 = (bt && l) ? lh * hw * m : 0.f;
     float w4 = (bt && rt) ? lh * lw * m : 0.f;
     int a1 = hl * W + wl, a2 = hl * W + wh_i, a3 = hh_i * W + wl, a4 = hh_i * W + wh_i;
-    r.x = w1 * xc[a1] + w2 * xc[a2] + w3 * xc[a3] + w4 * xc[a4];
+    r.x = bilerp(w1, w2, w3, w4, xc[a1], xc[a2], xc[a3], xc[a4]);
     xc += HW;
-    r.y = w1 * xc[a1] + w2 * xc[a2] + w3 * xc[a3] + w4 * xc[a4];
+    r.y = bilerp(w1, w2, w3, w4, xc[a1], xc[a2], xc[a3], xc[a4]);
     xc += HW;
-    r.z = w1 * xc[a1] + w2 * xc[a2] + w3 * xc[a3] + w4 * xc[a4];
+    r.z = bilerp(w1, w2, w3, w4, xc[a1], xc[a2], xc[a3], xc[a4]);
     xc += HW;
-    r.w = w1 * xc[a1] + w2 * xc[a2] + w3 * xc[a3] + w4 * xc[a4];
+    r.w = bilerp(w1, w2, w3, w4, xc[a1], xc[a2], xc[a3], xc[a4]);
     return r;
 }
 
@@ -152,8 +160,8 @@ template <> struct PosVec<1> { using type = float; };
 
 // ------------------------------------------------------------------------------------ variant 2
 // grid: x = tiles_y * (C / cch), y = B.  Dynamic LDS: (cch/4) * R * LW float4.
-template <int NP, int NTHR>
-__global__ __launch_bounds__(NTHR) void deform_im2col_lds(ImcolArgs a)
+template <int NP, int NTHR, int MINW = 1>
+__global__ __launch_bounds__(NTHR, MINW) void deform_im2col_lds(ImcolArgs a)
 {
     using VecT = typename PosVec<NP>::type;
     extern __shared__ float4 tile[];
@@ -289,10 +297,10 @@ __global__ __launch_bounds__(NTHR) void deform_im2col_lds(ImcolArgs a)
                 const float4 v2 = tq[lb[p]];
                 const float4 v3 = tq[la[p] + a.LW];
                 const float4 v4 = tq[lb[p] + a.LW];
-                acc[p].x = w1[p] * v1.x + w2[p] * v2.x + w3[p] * v3.x + w4[p] * v4.x;
-                acc[p].y = w1[p] * v1.y + w2[p] * v2.y + w3[p] * v3.y + w4[p] * v4.y;
-                acc[p].z = w1[p] * v1.z + w2[p] * v2.z + w3[p] * v3.z + w4[p] * v4.z;
-                acc[p].w = w1[p] * v1.w + w2[p] * v2.w + w3[p] * v3.w + w4[p] * v4.w;
+                acc[p].x = bilerp(w1[p], w2[p], w3[p], w4[p], v1.x, v2.x, v3.x, v4.x);
+                acc[p].y = bilerp(w1[p], w2[p], w3[p], w4[p], v1.y, v2.y, v3.y, v4.y);
+                acc[p].z = bilerp(w1[p], w2[p], w3[p], w4[p], v1.z, v2.z, v3.z, v4.z);
+                acc[p].w = bilerp(w1[p], w2[p], w3[p], w4[p], v1.w, v2.w, v3.w, v4.w);
             }
             if (farmask) {  // rare: offsets larger than the halo -> exact global gather
                 const float* xc = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;
@@ -486,10 +494,10 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
                     v4 = tile[lb[it][p] + a.LW];
                 }
                 const float4 w = wq[it][p];
-                acc[p].x = w.x * v1.x + w.y * v2.x + w.z * v3.x + w.w * v4.x;
-                acc[p].y = w.x * v1.y + w.y * v2.y + w.z * v3.y + w.w * v4.y;
-                acc[p].z = w.x * v1.z + w.y * v2.z + w.z * v3.z + w.w * v4.z;
-                acc[p].w = w.x * v1.w + w.y * v2.w + w.z * v3.w + w.w * v4.w;
+                acc[p].x = bilerp(w.x, w.y, w.z, w.w, v1.x, v2.x, v3.x, v4.x);
+                acc[p].y = bilerp(w.x, w.y, w.z, w.w, v1.y, v2.y, v3.y, v4.y);
+                acc[p].z = bilerp(w.x, w.y, w.z, w.w, v1.z, v2.z, v3.z, v4.z);
+                acc[p].w = bilerp(w.x, w.y, w.z, w.w, v1.w, v2.w, v3.w, v4.w);
             }
             if (far[it]) {  // rare: offsets larger than the halo -> exact global gather (coordinates re-derived)
                 const int k = a.blk ? sbase[it] / NT : sbase[it] / HWo;
@@ -692,6 +700,7 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     };
     if (vec) {
         if (nthr == 512) launch2(deform_im2col_lds<4, 512>, 512);
+        else if (env_int("STM_IM2COL_OCC", 0) == 4) launch2(deform_im2col_lds<4, 256, 4>, 256);
         else launch2(deform_im2col_lds<4, 256>, 256);
     } else {
         if (nthr == 1024) launch2(deform_im2col_lds<1, 1024>, 1024);
