@@ -580,14 +580,15 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     if (variant == 0) variant = env_int("STM_IM2COL_VARIANT", 0);
     bool tiled_ok = (Cg % 4 == 0);
     const bool auto_variant = (variant == 0);
+    int auto_items = 0;
     if (variant == 0) {
-        // measured on MI355X (scripts/exp_im2col.sh, true kernel durations at batch 8): variant 2 wins on every R50 layer
-        // except the wide stride-2 one (96x160 input), where its LDS tile only leaves room for 4 channels per workgroup
-        // and variant 3 (set-up amortised over 32 channels, XCD-aware tile map) is 1.25x faster.
-        const int halo0 = env_int("STM_IM2COL_HALO", 3);
-        const size_t quad4 = (size_t)(3 * g->sh + (g->kh - 1) * g->dh + 2 + 2 * halo0) * (((g->W + 2 + 3) / 4) * 4) * 16;
-        const bool wide = 2 * quad4 > (size_t)env_int("STM_IM2COL_LDS_KB", 64) * 1024;  // 8 channels x 4 rows do not fit
-        variant = !tiled_ok ? 1 : ((wide && Cg % 32 == 0) ? 3 : 2);
+        // measured on MI355X (scripts/exp_im2col.sh, true kernel durations, batch 8): variant 3 (coefficients once per
+        // workgroup, 32 channels streamed through LDS, XCD-aware tiles) wins on the large layers -- 2 items per thread
+        // for >= 3840 output positions, 1 item per thread for the mid-size stride-2 layer -- variant 2 on the small ones.
+        if (!tiled_ok) variant = 1;
+        else if (Cg % 32 == 0 && (int64_t)HWo * K >= 3840 * 9) { variant = 3; auto_items = 512; }
+        else if (Cg % 32 == 0 && g->sh == 2 && HWo >= 960) { variant = 3; auto_items = 256; }
+        else variant = 2;
     }
     if (variant >= 2 && !tiled_ok) variant = 1;
 
@@ -615,7 +616,7 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
         int step3 = 1;
         while ((step3 * g->Wo) % 4 != 0) ++step3;
         int th3 = env_int("STM_IM2COL_TH", 0);
-        const int max_items = min(768, max(256, env_int("STM_IM2COL_ITEMS", 768)));  // 1..3 items per thread
+        const int max_items = min(768, max(256, env_int("STM_IM2COL_ITEMS", auto_items ? auto_items : 768)));  // 1..3 items per thread
         if (th3 <= 0) {
             th3 = (max_items * 4) / (g->Wo * K);
             th3 = max(step3, (th3 / step3) * step3);
