@@ -97,8 +97,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+    if use_dist:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
 
     # MIOpen immediate mode: measured identical steady-state speed to find mode on this trunk (scripts/bench_trunk.py:
     # 20.6 vs 21.0 ms at batch 8) without minutes of solver search per new shape
@@ -131,7 +132,7 @@ def main():
     for t in range(args.warmup):
         step(t)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     ops.im2col_timing(True)
     torch.cuda.synchronize()
@@ -139,12 +140,12 @@ def main():
     for t in range(args.warmup, args.warmup + args.steps):
         out = step(t)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timing = ops.im2col_timing(False)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -182,7 +183,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.config, args.height, args.width)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

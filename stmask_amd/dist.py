@@ -43,7 +43,7 @@ def unpack_detections(packed):
 def all_gather_detections(packed):
     """[local_clips, top_k, DET_COLS] on every rank -> [world * local_clips, top_k, DET_COLS] (rank-major).
     Every rank must pass the same local_clips (pad the last shard)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return packed
     world = dist.get_world_size()
     out = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
