@@ -161,8 +161,171 @@ __global__ __launch_bounds__(256) void gemm_bias_f32_kernel(const float* __restr
 
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// 128 x 128 x 32 tile, double-buffered LDS, one barrier per K-slab, optional split-K (deterministic two-pass reduce).
+//
+// Why a second kernel: at 1-2 waves per SIMD the instruction stream, not the MFMA pipe, sets the pace (same finding
+// as for the im2col kernel).  This one keeps the per-wave stream lean: A stays [m][k] in LDS (no transposing stores)
+// and each lane fetches its 16 k-values of a slab with 4 ds_read_b128 thanks to a K permutation -- MFMA step s of
+// lane-half h uses k = 16h + s for BOTH operands, which is legal because a GEMM is invariant under any permutation of
+// K applied to A and B alike; the next slab's global loads are issued before the 64 MFMAs of the current one and land
+// in the other LDS buffer afterwards.  A row = 36 floats (144 B): the 16 rows of a ds_read_b128 group fall on 16
+// distinct 16-byte bank groups.  Small grids (M x N / 128^2 x batch < 256 workgroups) are split along K.
+namespace {
+
+constexpr int G2_BM = 128, G2_BN = 128, G2_BK = 32, G2_LDA = G2_BK + 4;
+
+__global__ __launch_bounds__(256) void gemm128_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                          const float* __restrict__ bias, float* __restrict__ Cm, int M,
+                                                          int N, int Kd, int64_t b_bs, int64_t c_bs, int relu, int n_tiles,
+                                                          int splitk, int k_per_split, float* __restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][G2_BM * G2_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][G2_BK * G2_BN];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+    const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
+    const int batch = blockIdx.y, ks = blockIdx.z;
+    const int k_begin = ks * k_per_split, k_end = min(Kd, k_begin + k_per_split);
+    const float* Bp = Bm + (int64_t)batch * b_bs;
+
+    // global -> register staging: A: 128 rows x 8 float4 (row = tid/8 + 32 i, kq = tid%8); B: 32 rows x 32 float4
+    const int a_row = tid >> 3, a_kq = tid & 7;
+    const int b_row = tid >> 5, b_nq = tid & 31;
+    float4 ra[4], rb[4];
+    auto load_slab = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = m0 + a_row + 32 * i, gk = k0 + a_kq * 4;
+            ra[i] = (gm < M && gk < k_end) ? *reinterpret_cast<const float4*>(A + (int64_t)gm * Kd + gk)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gk = k0 + b_row + 8 * i, gn = n0 + b_nq * 4;
+            rb[i] = (gk < k_end && gn < N) ? *reinterpret_cast<const float4*>(Bp + (int64_t)gk * N + gn)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&As[buf][(a_row + 32 * i) * G2_LDA + a_kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&Bs[buf][(b_row + 8 * i) * G2_BN + b_nq * 4]) = rb[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    load_slab(k_begin);
+    store_slab(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += G2_BK) {
+        const bool more = k0 + G2_BK < k_end;
+        if (more) load_slab(k0 + G2_BK);   // in flight behind the MFMAs below
+        // A fragments: 16 consecutive k of row (wm*64 + i*32 + lrow), lane-half lh -> k = 16 lh .. 16 lh + 15
+        float af[2][16], bf[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* ap = &As[buf][(wm * 64 + i * 32 + lrow) * G2_LDA + lh * 16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(ap + 4 * q);
+                af[i][4 * q] = v.x; af[i][4 * q + 1] = v.y; af[i][4 * q + 2] = v.z; af[i][4 * q + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* bp = &Bs[buf][(lh * 16) * G2_BN + wn * 64 + j * 32 + lrow];
+#pragma unroll
+            for (int s_ = 0; s_ < 16; ++s_) bf[j][s_] = bp[s_ * G2_BN];
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s_], bf[j][s_], acc[i][j], 0, 0, 0);
+        if (more) store_slab(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    float* Cp = (splitk > 1) ? partial + ((int64_t)ks * gridDim.y + batch) * (int64_t)M * N : Cm + (int64_t)batch * c_bs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gn = n0 + wn * 64 + j * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (gm < M && gn < N) {
+                    float v = acc[i][j][r];
+                    if (splitk == 1) {
+                        if (bias) v = v + bias[gm];
+                        if (relu) v = v > 0.0f ? v : 0.0f;
+                    }
+                    Cp[(int64_t)gm * N + gn] = v;
+                }
+            }
+        }
+}
+
+// sums the split-K partials in a fixed order (deterministic), adds bias, applies ReLU
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                            float* __restrict__ Cm, int M, int N, int batch, int64_t c_bs,
+                                                            int splitk, int relu)
+{
+    const int64_t mn4 = (int64_t)M * N / 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= mn4) return;
+    const int64_t stride = (int64_t)batch * M * N;
+    const float* p = partial + (int64_t)b * M * N + t * 4;
+    float4 v = *reinterpret_cast<const float4*>(p);
+    for (int s_ = 1; s_ < splitk; ++s_) {
+        const float4 u = *reinterpret_cast<const float4*>(p + s_ * stride);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (bias) {
+        const float bb = bias[(t * 4) / N];   // N % 4 == 0: the 4 elements share a row
+        v.x += bb; v.y += bb; v.z += bb; v.w += bb;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(Cm + (int64_t)b * c_bs + t * 4) = v;
+}
+
+}  // namespace
+
+// internal entry with workspace for split-K partials (ws may be NULL: then no split)
+static int gemm_dispatch(const float* A, const float* Bmat, const float* bias, float* Cmat, int M, int N, int K, int batch,
+                         int64_t b_bstride, int64_t c_bstride, int relu, void* ws, size_t ws_bytes, stm_stream_t stream);
+
+extern "C" size_t stm_gemm_workspace_bytes(int M, int N, int batch) { return (size_t)8 * batch * M * N * sizeof(float); }
+
 extern "C" int stm_gemm_bias_f32(const float* A, const float* Bmat, const float* bias, float* Cmat, int M, int N, int K,
                                  int batch, int64_t b_bstride, int64_t c_bstride, int relu, stm_stream_t stream)
+{
+    return gemm_dispatch(A, Bmat, bias, Cmat, M, N, K, batch, b_bstride, c_bstride, relu, nullptr, 0, stream);
+}
+
+static int gemm_dispatch(const float* A, const float* Bmat, const float* bias, float* Cmat, int M, int N, int K, int batch,
+                         int64_t b_bstride, int64_t c_bstride, int relu, void* ws, size_t ws_bytes, stm_stream_t stream)
 {
     STM_REQUIRE(A && Bmat && Cmat, STM_ENULL, "stm_gemm_bias_f32: A/B/C must be non-NULL");
     STM_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, STM_EINVAL, "stm_gemm_bias_f32: bad sizes M=%d N=%d K=%d batch=%d",
@@ -170,10 +333,34 @@ extern "C" int stm_gemm_bias_f32(const float* A, const float* Bmat, const float*
     STM_REQUIRE(batch <= 65535, STM_EINVAL, "stm_gemm_bias_f32: batch %d > 65535", batch);
     STM_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)Bmat % 16 == 0) && (b_bstride % 4 == 0 || N % 4 != 0),
                 STM_EINVAL, "stm_gemm_bias_f32: A and B must be 16-byte aligned");
-    // tile choice: big tiles when the grid still fills 256 CUs, otherwise 64x64 for parallelism
-    int64_t big = (int64_t)stm_cdiv(M, 128) * stm_cdiv(N, 128) * batch;
     const char* force = getenv("STM_GEMM_TILE");
-    int tile = force ? atoi(force) : (big >= 512 && M >= 128 ? 128 : 64);
+    const int forced = force ? atoi(force) : 0;
+    // 128^2 double-buffered kernel: needs whole 128-row tiles, float4-loadable A and B rows
+    const bool ok128 = (M % 128 == 0) && (K % 4 == 0) && (N % 4 == 0) && (c_bstride % 4 == 0) && ((uintptr_t)Cmat % 16 == 0);
+    if ((forced == 0 || forced == 256) && ok128) {
+        const int nt = stm_cdiv(N, G2_BN);
+        const int64_t blocks = (int64_t)nt * (M / G2_BM) * batch;
+        int splitk = 1;
+        const char* fs = getenv("STM_GEMM_SPLITK");
+        if (fs) splitk = atoi(fs);
+        else while (splitk < 8 && blocks * splitk < 224 && K / (splitk * 2) >= 256) splitk *= 2;
+        if (splitk > 1 && (!ws || ws_bytes < (size_t)splitk * batch * M * N * sizeof(float))) splitk = 1;
+        int kps = stm_cdiv(stm_cdiv(K, splitk), G2_BK) * G2_BK;
+        splitk = stm_cdiv(K, kps);
+        dim3 grid(nt * (M / G2_BM), batch, splitk);
+        hipLaunchKernelGGL(gemm128_f32_kernel, grid, dim3(256), 0, stm_hs(stream), A, Bmat, bias, Cmat, M, N, K, b_bstride,
+                           c_bstride, relu, nt, splitk, kps, static_cast<float*>(ws));
+        STM_CHECK_LAUNCH("gemm128_f32_kernel");
+        if (splitk > 1) {
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stm_cdiv((int64_t)M * N / 4, 256), batch), dim3(256), 0, stm_hs(stream),
+                               static_cast<const float*>(ws), bias, Cmat, M, N, batch, c_bstride, splitk, relu);
+            STM_CHECK_LAUNCH("splitk_reduce_kernel");
+        }
+        return STM_OK;
+    }
+    // general shapes: 64x64 (or 128x128 single-buffered) tiles with full edge handling
+    int64_t big = (int64_t)stm_cdiv(M, 128) * stm_cdiv(N, 128) * batch;
+    int tile = (forced == 64 || forced == 128) ? forced : (big >= 512 && M >= 128 ? 128 : 64);
     if (tile == 128) {
         int nt = stm_cdiv(N, 128);
         dim3 grid(nt * stm_cdiv(M, 128), batch);
@@ -192,7 +379,11 @@ extern "C" int stm_gemm_bias_f32(const float* A, const float* Bmat, const float*
 extern "C" size_t stm_deform_conv_workspace_bytes(const stm_deform_geom* g)
 {
     if (!g) return 0;
-    return (size_t)g->B * g->C * g->kh * g->kw * g->Ho * g->Wo * sizeof(float);
+    // column buffer + room for up to 8 split-K partial outputs of at most C output channels... the output channel
+    // count is not part of the geometry, so reserve for O <= 4*C (covers every STMask layer: O == C)
+    size_t cols = (size_t)g->B * g->C * g->kh * g->kw * g->Ho * g->Wo * sizeof(float);
+    size_t part = (size_t)8 * g->B * (4 * (size_t)g->C) * g->Ho * g->Wo * sizeof(float);
+    return cols + part + 256;
 }
 
 extern "C" int stm_deform_conv_fwd_f32(const float* x, const float* offset, int64_t off_bstride, const float* mask,
@@ -210,5 +401,9 @@ extern "C" int stm_deform_conv_fwd_f32(const float* x, const float* offset, int6
     int rc = stm_deform_im2col_f32(x, offset, off_bstride, mask, mask_bstride, mask_is_logit, cols, g, 0, stream);
     if (rc) return rc;
     const int CK = g->C * g->kh * g->kw, HWo = g->Ho * g->Wo;
-    return stm_gemm_bias_f32(weight, cols, bias, y, O, HWo, CK, g->B, (int64_t)CK * HWo, (int64_t)O * HWo, relu, stream);
+    const size_t cols_bytes = (((size_t)g->B * CK * HWo * sizeof(float)) + 255) / 256 * 256;
+    void* part = static_cast<char*>(workspace) + cols_bytes;
+    const size_t part_bytes = workspace_bytes > cols_bytes ? workspace_bytes - cols_bytes : 0;
+    return gemm_dispatch(weight, cols, bias, y, O, HWo, CK, g->B, (int64_t)CK * HWo, (int64_t)O * HWo, relu, part, part_bytes,
+                         stream);
 }
