@@ -70,7 +70,7 @@ def bench_gemm(B):
         bias = torch.randn(M, device=DEV)
         fl = 2.0 * M * N * K * B
         line = f"gemm {name} M={M} N={N} K={K} batch={B}: "
-        for tile in ("64", "128"):
+        for tile in ("64", "128", "256"):
             os.environ["STM_GEMM_TILE"] = tile
             ms = timeit(lambda: ops.gemm_bias(A, Bm, bias))
             line += f"| tile{tile} {ms * 1e3:8.1f} us {fl / ms / 1e9:6.1f} TF "

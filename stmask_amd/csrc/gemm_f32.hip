@@ -316,7 +316,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static int gemm_dispatch(const float* A, const float* Bmat, const float* bias, float* Cmat, int M, int N, int K, int batch,
                          int64_t b_bstride, int64_t c_bstride, int relu, void* ws, size_t ws_bytes, stm_stream_t stream);
 
-extern "C" size_t stm_gemm_workspace_bytes(int M, int N, int batch) { return (size_t)8 * batch * M * N * sizeof(float); }
 
 extern "C" int stm_gemm_bias_f32(const float* A, const float* Bmat, const float* bias, float* Cmat, int M, int N, int K,
                                  int batch, int64_t b_bstride, int64_t c_bstride, int relu, stm_stream_t stream)
@@ -379,10 +378,10 @@ static int gemm_dispatch(const float* A, const float* Bmat, const float* bias, f
 extern "C" size_t stm_deform_conv_workspace_bytes(const stm_deform_geom* g)
 {
     if (!g) return 0;
-    // column buffer + room for up to 8 split-K partial outputs of at most C output channels... the output channel
-    // count is not part of the geometry, so reserve for O <= 4*C (covers every STMask layer: O == C)
+    // column buffer + room for the split-K partial outputs (up to 8 x [B, O, Ho*Wo], O <= 4*C; capped at 64 MB)
     size_t cols = (size_t)g->B * g->C * g->kh * g->kw * g->Ho * g->Wo * sizeof(float);
     size_t part = (size_t)8 * g->B * (4 * (size_t)g->C) * g->Ho * g->Wo * sizeof(float);
+    if (part > ((size_t)64 << 20)) part = (size_t)64 << 20;  // split-K only runs on small outputs (grid < 224 tiles)
     return cols + part + 256;
 }
 
