@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nchw", dest="channels_last", action="store_false", help="keep the dense convs in NCHW")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="keep BatchNorm / bias / ReLU as separate kernels")
+    ap.add_argument("--fp16-backbone", action="store_true",
+                    help="BASELINE config 5 flavour: ResNet trunk under fp16 autocast (implies --no-fuse); NOT the headline metric")
     ap.add_argument("--pipeline", default="batched", choices=["batched", "per-clip"],
                     help="batched: all clips' post-processing in concatenated tensors; per-clip: reference-shaped layer API")
     args = ap.parse_args()
@@ -108,6 +110,9 @@ def main():
     net.eval()
     synthetic.fill_state_dict(net, seed=0, bg_bias=synthetic.BENCH_BG_BIAS)
     net = net.to(dev)
+    if args.fp16_backbone:
+        args.fuse = False
+        net.backbone_fp16 = True
     if args.fuse:
         from stmask_amd.fuse import optimize_for_inference
         optimize_for_inference(net)  # BN folded into conv / DCN weights, bias (+residual) + ReLU as one epilogue pass
@@ -164,7 +169,7 @@ def main():
             "metric": "frames/sec at 360x640 R50-DCN-FPN (STMask hot path, fp32)", "value": round(frames / elapsed, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if not args.fp16_backbone else "f16-backbone/f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: R50-DCN-FPN FCA + temporal fusion, {args.height}x{args.width} "
                                    f"tensor (360x640 padded), {args.clips} clips/GPU x 1 frame per step, random seeded weights",
                        "clips_per_gpu": args.clips, "frames_per_step": world * args.clips,

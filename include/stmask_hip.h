@@ -90,6 +90,12 @@ int stm_deform_conv_fwd_f32(const float* x, const float* offset, int64_t off_bst
  * Used for the column-buffer GEMM above; exported for tests and profiling. */
 int stm_gemm_bias_f32(const float* A, const float* Bmat, const float* bias, float* Cmat, int M, int N, int K,
                       int batch, int64_t b_bstride, int64_t c_bstride, int relu, stm_stream_t stream);
+/* Same, with scratch for deterministic split-K (small M x N grids are split along K so that >= ~256 workgroups run;
+ * partial sums are reduced in a fixed order).  workspace may be NULL (then no split). */
+size_t stm_gemm_workspace_bytes(int M, int N, int batch);
+int stm_gemm_bias_ws_f32(const float* A, const float* Bmat, const float* bias, float* Cmat, int M, int N, int K,
+                         int batch, int64_t b_bstride, int64_t c_bstride, int relu, void* workspace,
+                         size_t workspace_bytes, stm_stream_t stream);
 
 /* FeatureAlign "ali" offsets (Featurealign.py:46-69): loc [B,4,H,W] -> offset [B,2*kh*kw,H,W].
  * fp32, reference operand order, canonical exp (bit-exact against the oracle). */

@@ -15,7 +15,7 @@ c_i, c_l, c_f, c_p, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.
 # every symbol include/stmask_hip.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
     "stm_version", "stm_last_error_string", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
-    "stm_deform_conv_fwd_f32", "stm_gemm_bias_f32", "stm_fcb_ali_offsets_f32", "stm_corr_patch_f32",
+    "stm_deform_conv_fwd_f32", "stm_gemm_bias_f32", "stm_gemm_workspace_bytes", "stm_gemm_bias_ws_f32", "stm_fcb_ali_offsets_f32", "stm_corr_patch_f32",
     "stm_roi_align_avg_f32", "stm_decode_boxes_f32", "stm_generate_candidates_f32", "stm_cc_fast_nms_f32",
     "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
     "stm_jaccard_f32", "stm_lincomb_sigmoid_crop_f32", "stm_mask_iou_workspace_bytes", "stm_mask_iou_f32",
@@ -50,7 +50,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.stm_last_error_string.restype = ctypes.c_char_p
         _lib.stm_version.restype = c_i
-        for name in ("stm_deform_conv_workspace_bytes", "stm_detect_cc_workspace_bytes", "stm_fast_nms_workspace_bytes",
+        for name in ("stm_deform_conv_workspace_bytes", "stm_gemm_workspace_bytes", "stm_detect_cc_workspace_bytes", "stm_fast_nms_workspace_bytes",
                      "stm_mask_iou_workspace_bytes"):
             getattr(_lib, name).restype = c_sz
     return _lib

@@ -323,6 +323,19 @@ extern "C" int stm_gemm_bias_f32(const float* A, const float* Bmat, const float*
     return gemm_dispatch(A, Bmat, bias, Cmat, M, N, K, batch, b_bstride, c_bstride, relu, nullptr, 0, stream);
 }
 
+extern "C" size_t stm_gemm_workspace_bytes(int M, int N, int batch)
+{
+    size_t b = (size_t)8 * batch * M * N * sizeof(float);
+    return b > ((size_t)64 << 20) ? ((size_t)64 << 20) : b;
+}
+
+extern "C" int stm_gemm_bias_ws_f32(const float* A, const float* Bmat, const float* bias, float* Cmat, int M, int N, int K,
+                                    int batch, int64_t b_bstride, int64_t c_bstride, int relu, void* workspace,
+                                    size_t workspace_bytes, stm_stream_t stream)
+{
+    return gemm_dispatch(A, Bmat, bias, Cmat, M, N, K, batch, b_bstride, c_bstride, relu, workspace, workspace_bytes, stream);
+}
+
 static int gemm_dispatch(const float* A, const float* Bmat, const float* bias, float* Cmat, int M, int N, int K, int batch,
                          int64_t b_bstride, int64_t c_bstride, int relu, void* ws, size_t ws_bytes, stm_stream_t stream)
 {

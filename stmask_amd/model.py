@@ -42,6 +42,9 @@ class STMask(nn.Module):
             self.Detect_TF = Detect_TF(cfg.num_classes, bkg_label=0, top_k=cfg.nms_top_k,
                                        conf_thresh=cfg.nms_conf_thresh, nms_thresh=cfg.nms_thresh, cfg=cfg)
             self.Track_TF = Track_TF(cfg=cfg)
+        # BASELINE config 5 ("fp16 MFMA backbone convs"): run the ResNet trunk under fp16 autocast (MIOpen fp16 MFMA kernels,
+        # fp32 accumulate); the deformable convs, FPN, proto-net, heads and all post-processing stay fp32
+        self.backbone_fp16 = False
         self.detect = Detect(cfg.num_classes, bkg_label=0, top_k=cfg.nms_top_k, conf_thresh=cfg.nms_conf_thresh,
                              nms_thresh=cfg.nms_thresh, cfg=cfg)
         self.Track = Track(cfg=cfg)
@@ -63,7 +66,12 @@ class STMask(nn.Module):
 
     # -- trunk + heads (reference STMask.py:205-282) ----------------------------------------------------------------
     def forward_single(self, x):
-        bb_outs = self.backbone(x)
+        if self.backbone_fp16 and x.is_cuda:
+            with torch.autocast("cuda", dtype=torch.float16):
+                bb_outs = self.backbone(x)
+            bb_outs = tuple(o.float() for o in bb_outs)
+        else:
+            bb_outs = self.backbone(x)
         fpn_outs = self.fpn([bb_outs[i] for i in self.backbone_selected])
         proto = F.relu(self.proto_net(fpn_outs[self.proto_src]))
         proto = proto.permute(0, 2, 3, 1).contiguous()

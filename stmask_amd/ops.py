@@ -137,9 +137,11 @@ def deform_conv(x, offset, mask, weight, bias=None, stride=1, padding=0, dilatio
         e1.record()
         _im2col_timing.append((e0, e1, im2col_algorithmic_bytes(g, mk_ptr != 0)))
         CK, HWo = g.C * g.kh * g.kw, g.Ho * g.Wo
-        check(_lib.lib().stm_gemm_bias_f32(_p(weight), _p(ws), _p(bias), _p(y), c_i(O), c_i(HWo), c_i(CK), c_i(g.B),
-                                           c_l(CK * HWo), c_l(O * HWo), c_i(1 if relu else 0), _stream()),
-              "stm_gemm_bias_f32")
+        cols_bytes = (g.B * CK * HWo * 4 + 255) // 256 * 256   # same split of the workspace as stm_deform_conv_fwd_f32
+        part = ws[cols_bytes:]
+        check(_lib.lib().stm_gemm_bias_ws_f32(_p(weight), _p(ws), _p(bias), _p(y), c_i(O), c_i(HWo), c_i(CK), c_i(g.B),
+                                              c_l(CK * HWo), c_l(O * HWo), c_i(1 if relu else 0), _p(part),
+                                              c_sz(part.numel()), _stream()), "stm_gemm_bias_ws_f32")
         return y
     rc = _lib.lib().stm_deform_conv_fwd_f32(_p(x), _p(off), c_l(obs), c_p(mk_ptr), c_l(mbs),
                                             c_i(1 if (mask_is_logit or fused_om is not None) else 0), _p(weight),
@@ -160,9 +162,11 @@ def gemm_bias(A, Bm, bias=None, relu=False):
     M = A.shape[0]
     assert A.shape[1] == K
     C = torch.empty(batch, M, N, device=A.device, dtype=torch.float32)
-    rc = _lib.lib().stm_gemm_bias_f32(_p(A), _p(Bm), _p(_f32c(bias) if bias is not None else None), _p(C), c_i(M), c_i(N),
-                                      c_i(K), c_i(batch), c_l(K * N), c_l(M * N), c_i(1 if relu else 0), _stream())
-    check(rc, "stm_gemm_bias_f32")
+    ws = _workspace(_lib.lib().stm_gemm_workspace_bytes(c_i(M), c_i(N), c_i(batch)), A.device, "gemm")
+    rc = _lib.lib().stm_gemm_bias_ws_f32(_p(A), _p(Bm), _p(_f32c(bias) if bias is not None else None), _p(C), c_i(M),
+                                         c_i(N), c_i(K), c_i(batch), c_l(K * N), c_l(M * N), c_i(1 if relu else 0),
+                                         _p(ws), c_sz(ws.numel()), _stream())
+    check(rc, "stm_gemm_bias_ws_f32")
     return C[0] if squeeze else C
 
 

@@ -134,3 +134,19 @@ def test_optimized_inference_graph_on_gpu(channels_last):
     for k in ("loc", "conf", "mask_coeff", "centerness", "proto", "track"):
         scale = max(1.0, a[k].abs().max().item())
         assert (a[k] - b[k]).abs().max().item() < 2e-4 * scale, k
+
+
+def test_fp16_backbone_option_config5():
+    """BASELINE config 5 flavour: fp16 autocast ResNet trunk (DCN, FPN, heads fp32).  fp16 trunk activations carry ~1e-3
+    relative error, so only closeness of the prototypes / box regression to the fp32 run is asserted."""
+    net = build("STMask_plus_resnet50_config")
+    x = synthetic.synthetic_clip(1, 128, 192, seed=4).cuda()
+    with torch.no_grad():
+        _, a = net.forward_single(x)
+        net.backbone_fp16 = True
+        _, b = net.forward_single(x)
+    assert b["proto"].dtype == torch.float32
+    for k in ("proto", "loc", "mask_coeff"):
+        rel = (a[k] - b[k]).abs().max().item() / max(1e-6, a[k].abs().max().item())
+        assert rel < 3e-2, (k, rel)
+    net.backbone_fp16 = False
