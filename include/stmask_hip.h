@@ -208,6 +208,19 @@ int stm_mask_iou_f32(const float* m1, int n1, const float* m2, int n2, int hw, f
 int stm_bias_act_f32(float* y, const float* bias, const float* residual, int64_t n, int C, int64_t inner,
                      int relu, stm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Output stage (next row after the hot path): mask leg of postprocess_ytbvis (output_utils.py:85-106).
+ * Replaces: masks[:, :crop_h, :crop_w] -> F.interpolate(bilinear, align_corners=False) to out_h x out_w -> gt(0.5)
+ *           -> per-mask .cpu() -> pycocotools.mask.encode (COCO RLE of the column-major binary image).
+ *   masks [n, mh, mw] soft masks -> counts [n, max_runs] uint32 run lengths (first run = zeros, possibly 0),
+ *   n_runs [n] (true number of runs; > max_runs means the row overflowed).  The 5-bit string packing of COCO RLE
+ *   (maskApi.c rleToString) is a few hundred bytes per mask and is done by the caller on the host.
+ * ------------------------------------------------------------------------------------------------- */
+size_t stm_mask_rle_workspace_bytes(int n, int out_h, int out_w, int max_runs);
+int stm_mask_resize_rle_f32(const float* masks, int n, int mh, int mw, int crop_h, int crop_w, int out_h, int out_w,
+                            float thr, uint32_t* counts, int max_runs, int* n_runs, void* workspace,
+                            size_t workspace_bytes, stm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

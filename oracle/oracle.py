@@ -250,6 +250,48 @@ def roi_align(feat, rois, output_size, spatial_scale=1.0, sampling_ratio=0, pool
     return out
 
 
+# ------------------------------------------------------------------------------ output stage
+def mask_resize_threshold(mask, crop_h, crop_w, out_h, out_w, thr=0.5):
+    """output_utils.py:85-95 for one mask [mh,mw] -> uint8 [out_h,out_w]"""
+    mask = _f32(mask)
+    mh, mw = mask.shape
+    out = torch.empty(out_h, out_w, dtype=torch.uint8)
+    lib().orc_mask_resize_threshold(_ptr(mask), c_i(mh), c_i(mw), c_i(crop_h), c_i(crop_w), c_i(out_h), c_i(out_w), c_f(thr),
+                                    _ptr(out))
+    return out
+
+
+def rle_encode(img):
+    """COCO RLE counts (column-major, starting with the zero run) of a binary [h,w] image -> int64 tensor"""
+    img = img.to(torch.uint8).contiguous()
+    h, w = img.shape
+    counts = torch.empty(h * w + 1, dtype=torch.int32)
+    lib().orc_rle_encode.restype = c_l
+    n = lib().orc_rle_encode(_ptr(img), c_i(h), c_i(w), _ptr(counts), c_l(counts.numel()))
+    return counts[:n].to(torch.int64)
+
+
+def rle_to_string(counts):
+    c = counts.to(torch.int32).contiguous()
+    buf = ctypes.create_string_buffer(6 * c.numel() + 1)
+    lib().orc_rle_to_string.restype = c_l
+    n = lib().orc_rle_to_string(_ptr(c), c_l(c.numel()), buf)
+    return buf.raw[:n]
+
+
+def rle_from_string(s, max_runs=1 << 22):
+    counts = torch.empty(max_runs, dtype=torch.int32)
+    lib().orc_rle_from_string.restype = c_l
+    n = lib().orc_rle_from_string(ctypes.c_char_p(bytes(s)), _ptr(counts), c_l(max_runs))
+    return counts[:n].to(torch.int64)
+
+
+def rle_decode(counts, h, w):
+    """inverse of rle_encode -> uint8 [h,w]"""
+    flat = torch.repeat_interleave(torch.arange(len(counts)) % 2, counts.to(torch.int64)).to(torch.uint8)
+    return flat.view(w, h).t().contiguous()
+
+
 # --------------------------------------------------------------- reference-import stand-ins
 class OracleDCN(nn.Module):
     """CPU stand-in for dcn_v2.DCN (backbone.py:21-26,45): same parameters and state-dict keys."""

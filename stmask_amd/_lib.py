@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "stm_roi_align_avg_f32", "stm_decode_boxes_f32", "stm_generate_candidates_f32", "stm_cc_fast_nms_f32",
     "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
     "stm_jaccard_f32", "stm_lincomb_sigmoid_crop_f32", "stm_mask_iou_workspace_bytes", "stm_mask_iou_f32",
-    "stm_bias_act_f32",
+    "stm_bias_act_f32", "stm_mask_rle_workspace_bytes", "stm_mask_resize_rle_f32",
 ]
 
 
@@ -50,7 +50,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.stm_last_error_string.restype = ctypes.c_char_p
         _lib.stm_version.restype = c_i
-        for name in ("stm_deform_conv_workspace_bytes", "stm_gemm_workspace_bytes", "stm_detect_cc_workspace_bytes", "stm_fast_nms_workspace_bytes",
+        for name in ("stm_deform_conv_workspace_bytes", "stm_gemm_workspace_bytes", "stm_mask_rle_workspace_bytes", "stm_detect_cc_workspace_bytes", "stm_fast_nms_workspace_bytes",
                      "stm_mask_iou_workspace_bytes"):
             getattr(_lib, name).restype = c_sz
     return _lib

@@ -365,3 +365,21 @@ def bias_act_(y, bias, residual=None, relu=True):
     check(_lib.lib().stm_bias_act_f32(_p(y), _p(_f32c(bias)), _p(residual), c_l(y.numel()), c_i(C), c_l(inner),
                                       c_i(1 if relu else 0), _stream()), "stm_bias_act_f32")
     return y
+
+
+def mask_resize_rle(masks, crop_h, crop_w, out_h, out_w, thr=0.5, max_runs=4096):
+    """Mask leg of postprocess_ytbvis on the device: [n,mh,mw] soft masks -> (counts [n,max_runs] int32, n_runs [n] int32)
+    = COCO run lengths of the un-padded, bilinearly resized, thresholded masks (column-major)."""
+    _dev(masks)
+    masks = _f32c(masks)
+    n, mh, mw = masks.shape
+    counts = torch.zeros(n, max_runs, dtype=torch.int32, device=masks.device)
+    n_runs = torch.zeros(n, dtype=torch.int32, device=masks.device)
+    if n == 0:
+        return counts, n_runs
+    need = _lib.lib().stm_mask_rle_workspace_bytes(c_i(n), c_i(out_h), c_i(out_w), c_i(max_runs))
+    ws = _workspace(need, masks.device, "rle")
+    check(_lib.lib().stm_mask_resize_rle_f32(_p(masks), c_i(n), c_i(mh), c_i(mw), c_i(crop_h), c_i(crop_w), c_i(out_h),
+                                             c_i(out_w), c_f(thr), _p(counts), c_i(max_runs), _p(n_runs), _p(ws),
+                                             c_sz(ws.numel()), _stream()), "stm_mask_resize_rle_f32")
+    return counts, n_runs
