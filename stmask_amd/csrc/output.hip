@@ -43,6 +43,13 @@ __global__ __launch_bounds__(256) void resize_threshold_pack_kernel(const float*
     if (lane == 0) bits[(int64_t)i * words + word] = bal;
 }
 
+// bits of word w that are real pixels (the last word is zero-padded: a 1 -> padding "transition" is not a run boundary)
+__device__ __forceinline__ unsigned long long valid_bits(int w, int64_t n_px)
+{
+    const int64_t rem = n_px - (int64_t)w * 64;
+    return rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+}
+
 // one workgroup per mask; counts[i][0..n_runs[i]) (capacity max_runs; n_runs reports the true number)
 __global__ __launch_bounds__(1024) void rle_runs_kernel(const unsigned long long* __restrict__ bits, int words, int64_t n_px,
                                                         unsigned int* __restrict__ counts, int max_runs, int* __restrict__ n_runs,
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(1024) void rle_runs_kernel(const unsigned long long
     for (int w = w0; w < w1; ++w) {
         const unsigned long long cur = bw[w];
         const unsigned long long prev = w ? (bw[w - 1] >> 63) : 0ull;
-        mine += __popcll(cur ^ ((cur << 1) | prev));
+        mine += __popcll((cur ^ ((cur << 1) | prev)) & valid_bits(w, n_px));
     }
     // exclusive scan over the 1024 threads (wave scan + wave totals)
     int incl = mine;
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(1024) void rle_runs_kernel(const unsigned long long
     for (int w = w0; w < w1; ++w) {
         const unsigned long long cur = bw[w];
         const unsigned long long prev = w ? (bw[w - 1] >> 63) : 0ull;
-        unsigned long long d = cur ^ ((cur << 1) | prev);
+        unsigned long long d = (cur ^ ((cur << 1) | prev)) & valid_bits(w, n_px);
         while (d) {
             const int b = __ffsll((long long)d) - 1;
             if (pos < max_runs) T[pos] = (unsigned int)(w * 64 + b);
