@@ -192,32 +192,41 @@ __global__ __launch_bounds__(256) void gemm128_f32_kernel(const float* __restric
     const int k_begin = ks * k_per_split, k_end = min(Kd, k_begin + k_per_split);
     const float* Bp = Bm + (int64_t)batch * b_bs;
 
-    // global -> register staging: A: 128 rows x 8 float4 (row = tid/8 + 32 i, kq = tid%8); B: 32 rows x 32 float4
+    // global -> register staging: A: 128 rows x 8 float4 (row = tid/8 + 32 i, kq = tid%8); B: 32 rows x 32 float4.
+    // No bounds tests in the loop: M % 128 == 0 and K % 32 == 0 are launch conditions, and B columns beyond N are read
+    // from a clamped (valid) address -- they only feed output columns that are never stored.
     const int a_row = tid >> 3, a_kq = tid & 7;
     const int b_row = tid >> 5, b_nq = tid & 31;
-    float4 ra[4], rb[4];
-    auto load_slab = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gm = m0 + a_row + 32 * i, gk = k0 + a_kq * 4;
-            ra[i] = (gm < M && gk < k_end) ? *reinterpret_cast<const float4*>(A + (int64_t)gm * Kd + gk)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gk = k0 + b_row + 8 * i, gn = n0 + b_nq * 4;
-            rb[i] = (gk < k_end && gn < N) ? *reinterpret_cast<const float4*>(Bp + (int64_t)gk * N + gn)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_slab = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&As[buf][(a_row + 32 * i) * G2_LDA + a_kq * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&Bs[buf][(b_row + 8 * i) * G2_BN + b_nq * 4]) = rb[i];
-    };
+    const float* ap0 = A + (int64_t)(m0 + a_row) * Kd + k_begin + a_kq * 4;
+    const float* bp0 = Bp + (int64_t)(k_begin + b_row) * N + min(n0 + b_nq * 4, N - 4);
+    const int64_t a_step = (int64_t)32 * Kd, b_step = (int64_t)8 * N;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;   // named scalars: an array captured by a lambda went to scratch
+#define G2_LOAD_SLAB(slab)                                                            \
+    {                                                                                 \
+        const float* ap_ = ap0 + (int64_t)(slab) * G2_BK;                             \
+        const float* bp_ = bp0 + (int64_t)(slab) * G2_BK * N;                         \
+        ra0 = *reinterpret_cast<const float4*>(ap_);                                  \
+        ra1 = *reinterpret_cast<const float4*>(ap_ + a_step);                         \
+        ra2 = *reinterpret_cast<const float4*>(ap_ + 2 * a_step);                     \
+        ra3 = *reinterpret_cast<const float4*>(ap_ + 3 * a_step);                     \
+        rb0 = *reinterpret_cast<const float4*>(bp_);                                  \
+        rb1 = *reinterpret_cast<const float4*>(bp_ + b_step);                         \
+        rb2 = *reinterpret_cast<const float4*>(bp_ + 2 * b_step);                     \
+        rb3 = *reinterpret_cast<const float4*>(bp_ + 3 * b_step);                     \
+    }
+#define G2_STORE_SLAB(buf_)                                                                            \
+    {                                                                                                  \
+        float* as_ = &As[buf_][a_row * G2_LDA + a_kq * 4];                                             \
+        float* bs_ = &Bs[buf_][b_row * G2_BN + b_nq * 4];                                              \
+        *reinterpret_cast<float4*>(as_) = ra0;                                                         \
+        *reinterpret_cast<float4*>(as_ + 32 * G2_LDA) = ra1;                                           \
+        *reinterpret_cast<float4*>(as_ + 64 * G2_LDA) = ra2;                                           \
+        *reinterpret_cast<float4*>(as_ + 96 * G2_LDA) = ra3;                                           \
+        *reinterpret_cast<float4*>(bs_) = rb0;                                                         \
+        *reinterpret_cast<float4*>(bs_ + 8 * G2_BN) = rb1;                                             \
+        *reinterpret_cast<float4*>(bs_ + 16 * G2_BN) = rb2;                                            \
+        *reinterpret_cast<float4*>(bs_ + 24 * G2_BN) = rb3;                                            \
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -228,14 +237,16 @@ __global__ __launch_bounds__(256) void gemm128_f32_kernel(const float* __restric
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int lrow = lane & 31, lh = lane >> 5;
-    load_slab(k_begin);
-    store_slab(0);
+    const int n_slabs = (k_end - k_begin) / G2_BK;
+    G2_LOAD_SLAB(0);
+    G2_STORE_SLAB(0);
     __syncthreads();
     int buf = 0;
-    for (int k0 = k_begin; k0 < k_end; k0 += G2_BK) {
-        const bool more = k0 + G2_BK < k_end;
-        if (more) load_slab(k0 + G2_BK);   // in flight behind the MFMAs below
-        // A fragments: 16 consecutive k of row (wm*64 + i*32 + lrow), lane-half lh -> k = 16 lh .. 16 lh + 15
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        // next slab in flight behind the MFMAs below (the last iteration re-reads its own slab: no branch)
+        G2_LOAD_SLAB(min(sl + 1, n_slabs - 1));
+        // all fragments of this slab first (8 ds_read_b128 + 32 ds_read_b32), then 64 back-to-back MFMAs: left to
+        // itself the compiler fetched each B fragment right before its MFMA group and stalled on LDS latency 16 times
         float af[2][16], bf[2][16];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -252,6 +263,7 @@ __global__ __launch_bounds__(256) void gemm128_f32_kernel(const float* __restric
 #pragma unroll
             for (int s_ = 0; s_ < 16; ++s_) bf[j][s_] = bp[s_ * G2_BN];
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s_ = 0; s_ < 16; ++s_)
 #pragma unroll
@@ -259,7 +271,8 @@ __global__ __launch_bounds__(256) void gemm128_f32_kernel(const float* __restric
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s_], bf[j][s_], acc[i][j], 0, 0, 0);
-        if (more) store_slab(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        G2_STORE_SLAB(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
@@ -348,7 +361,7 @@ static int gemm_dispatch(const float* A, const float* Bmat, const float* bias, f
     const char* force = getenv("STM_GEMM_TILE");
     const int forced = force ? atoi(force) : 0;
     // 128^2 double-buffered kernel: needs whole 128-row tiles, float4-loadable A and B rows
-    const bool ok128 = (M % 128 == 0) && (K % 4 == 0) && (N % 4 == 0) && (c_bstride % 4 == 0) && ((uintptr_t)Cmat % 16 == 0);
+    const bool ok128 = (M % 128 == 0) && (K % 32 == 0) && (N % 4 == 0) && (N >= 4) && (c_bstride % 4 == 0) && ((uintptr_t)Cmat % 16 == 0);
     if ((forced == 0 || forced == 256) && ok128) {
         const int nt = stm_cdiv(N, G2_BN);
         const int64_t blocks = (int64_t)nt * (M / G2_BM) * batch;
