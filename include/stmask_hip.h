@@ -221,6 +221,40 @@ int stm_mask_resize_rle_f32(const float* masks, int n, int mh, int mw, int crop_
                             float thr, uint32_t* counts, int max_runs, int* n_runs, void* workspace,
                             size_t workspace_bytes, stm_stream_t stream);
 
+/* ---- dense convolution on the bf16 matrix cores with fp32-equivalent accuracy (row f4 and the dense part of a2-a5) ----
+ * Replaces torch.nn.Conv2d (+ folded eval BatchNorm + ReLU + residual add) as the reference uses it in
+ * Bottleneck.forward (backbone.py:38-58), FPN.forward (FPN.py:68-108), the proto-net (make_net.py:5-59) and the
+ * PredictionModule_FC tower (prediction_head_FC.py:146-195).  Activations are NHWC fp32 (a torch channels_last tensor
+ * is exactly this); every fp32 operand is split into `planes` bf16 terms (3: six products, error ~2^-24, the default;
+ * 2: three products, error ~2^-16) and accumulated in fp32.  Input channels must be a multiple of 32. */
+typedef struct stm_conv_geom {
+    int B, H, W, C;       /* input  [B, H, W, C] (NHWC) */
+    int Ho, Wo, Cout;     /* output [B, Ho, Wo, Cout] */
+    int kh, kw, sh, sw, ph, pw;
+    int x_ld, out_ld, res_ld; /* floats between consecutive pixels of x / out / residual; 0 = dense (C / Cout / Cout) */
+    int planes;           /* 3 or 2, must match the packed weights */
+} stm_conv_geom;
+
+/* bytes of the packed (pre-split, pre-tiled) weight image; 0 on bad arguments */
+size_t stm_conv_packed_weight_bytes(int Cout, int Cin, int kh, int kw, int planes);
+/* weight [Cout, Cin, kh, kw] fp32 (torch OIHW, contiguous) -> packed image; done once per layer */
+int stm_conv_pack_weights_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int planes,
+                              stm_stream_t stream);
+/* out = act(conv(x, weight) + bias + residual); bias [Cout] or NULL, residual NHWC or NULL, relu 0/1 */
+int stm_conv2d_nhwc_f32(const float* x, const void* packed_weight, const float* bias, const float* residual, float* out,
+                        const stm_conv_geom* g, int relu, stm_stream_t stream);
+
+/* Planar form of the same convolution: activations travel between layers ALREADY split, as bf16 planes
+ * [planes][B*H*W][ld] (plane p of element i at planes + (p * B*H*W*ld + i) * 2 bytes; fp32 value = sum of the planes,
+ * exactly).  Staging a K-slab is then pure LDS-DMA -- each element is split once, by its producer's epilogue, instead of
+ * kh*kw*(Cout/128) times by its consumers.  stm_split_bf16_planes_f32 enters the format from an fp32 tensor (n % 8 == 0);
+ * the convolution writes fp32 NHWC (out_f32), three planes (out_planes), or both; the residual may be given in either
+ * form.  g->planes selects how many input planes take part in the products (3 or 2); outputs always carry three. */
+int stm_split_bf16_planes_f32(const float* x, void* planes, int64_t n, stm_stream_t stream);
+int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
+                          const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu,
+                          stm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

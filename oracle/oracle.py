@@ -221,6 +221,23 @@ def deform_conv(x, offset, mask, weight, bias=None, stride=1, padding=0, dilatio
     return y
 
 
+def conv2d_nhwc(x, weight, bias=None, residual=None, stride=1, padding=0, relu=False):
+    """nn.Conv2d semantics on an NHWC activation [B,H,W,C] with OIHW weights; y = act(conv + bias + residual), NHWC."""
+    x, weight = _f32(x), _f32(weight)
+    bs = _f32(bias) if bias is not None else None
+    rs = _f32(residual) if residual is not None else None
+    B, H, W, C = x.shape
+    O, Cw, kh, kw = weight.shape
+    assert Cw == C
+    (sh, sw), (ph, pw) = _pair(stride), _pair(padding)
+    Ho, Wo = _out_hw(H, W, kh, kw, sh, sw, ph, pw, 1, 1)
+    y = torch.empty(B, Ho, Wo, O, dtype=torch.float32)
+    lib().orc_conv2d_nhwc(_ptr(x), _ptr(weight), _ptr(bs), _ptr(rs), c_i(B), c_i(H), c_i(W), c_i(C), c_i(O), c_i(kh),
+                          c_i(kw), c_i(sh), c_i(sw), c_i(ph), c_i(pw), c_i(Ho), c_i(Wo), c_i(C), c_i(O), c_i(O),
+                          c_i(1 if relu else 0), _ptr(y))
+    return y
+
+
 def corr_patch(f1, f2, patch_size=11, dilation_patch=1, scale=1.0, leaky=1.0):
     """spatial_correlation_sample(kernel_size=1, stride=1, padding=0) -> [B,P,P,H,W]"""
     f1, f2 = _f32(f1), _f32(f2)

@@ -1,0 +1,812 @@
+// conv_bf16x.hip -- dense 2-D convolution (NHWC, fp32 in / fp32 out) as an implicit GEMM on the bf16 matrix cores,
+// with every fp32 operand carried as THREE bf16 planes (x = p0 + p1 + p2, each plane round-to-nearest of the running
+// residual) and six plane products per fp32 product:
+//      x*w ~= x0 w0 + x0 w1 + x1 w0 + x1 w1 + x0 w2 + x2 w0          (dropped terms <= 2^-24 |x w|)
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The result carries fp32-level error (measured: 2e-7 relative to the
+// fp64 oracle, the same as an fp32 FMA chain) while the six bf16 MFMAs cost 6/16 of the one fp32 MFMA they replace
+// (fp32 matrix peak 157 TFLOP/s, bf16 2.5 PFLOP/s).  `planes == 2` keeps only x0 w0 + x0 w1 + x1 w0 (error 2^-16, three
+// MFMAs) for callers that state a looser tolerance.
+//
+// This is the reference's nn.Conv2d on the hot path -- Bottleneck 1x1/3x3 (backbone.py:38-58), FPN (FPN.py:68-108),
+// proto-net (make_net.py:5-59) and the PredictionModule_FC tower (prediction_head_FC.py:146-195), SURVEY.md section 8
+// rows a2-a5 / f4 -- with the eval-mode BatchNorm folded into the weights, and bias, residual add and ReLU fused into
+// the epilogue.
+//
+// Tiling: one 256-thread workgroup (4 waves as 2x2) produces 128 output pixels x 128 output channels; K runs over
+// (tap, 32 input channels).  Per K-slab the activation tile (128 pixels x 32 channels fp32, one 128-B line per pixel in
+// NHWC, fetched with buffer loads whose out-of-range offsets return 0 = the zero padding) is split into planes in
+// registers and written to LDS; the weight tile arrives pre-split and pre-tiled (stm_conv_pack_weights_f32) so it is a
+// linear 24 KB copy.  LDS rows are 64 B (32 bf16) with the 16-B chunk index XORed by (row>>2)&3, which makes the
+// ds_read_b128 fragment reads of both operands conflict-free without padding.  48 KB LDS and < 256 VGPRs per thread:
+// two workgroups per CU, so one workgroup's split/stage phase runs under the other's MFMA phase.
+#include "stm_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CV_BM = 128;            // output pixels per workgroup
+constexpr int CV_BN = 128;            // output channels per workgroup
+constexpr int CV_BK = 32;             // input channels per K-slab (one tap)
+constexpr int CV_PLANE_B = 128 * 64;  // bytes of one bf16 plane of a 128 x 32 tile
+constexpr unsigned CV_OOB = 0x80000000u;
+
+struct ConvArgs {
+    const float* x;
+    const uint8_t* wp;
+    const float* bias;
+    const float* res;
+    float* out;
+    int B, H, W, C, Ho, Wo, Cout;
+    int kh, kw, sh, sw, ph, pw;
+    int x_ld, out_ld, res_ld;
+    int relu;
+    int M;        // B * Ho * Wo
+    int n_tiles;  // ceil(Cout / 128)
+    int m_tiles;
+    int slabs;    // kh * kw * C / 32
+    unsigned x_bytes;
+    long long* trace;  // timing instrumentation (stm_debug_conv_set_trace): per-phase clock stamps of workgroup 0
+    int dbg;      // STM_CONV_DEBUG ablation bits (timing experiments only): 1 no MFMA, 2 no global loads, 4 no split, 8 no LDS writes
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// two fp32 -> three packed bf16 pairs (round-to-nearest of the running residual; the subtractions are exact)
+__device__ __forceinline__ void split2(f32x2 v, unsigned& p0, unsigned& p1, unsigned& p2)
+{
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+    const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+    const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+    p0 = __builtin_bit_cast(unsigned, h);
+    p1 = __builtin_bit_cast(unsigned, m);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256, 2) void conv_bf16x_kernel(const ConvArgs a)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint8_t* xs = smem;                      // [NPL][128 rows][64 B]
+    uint8_t* ws = smem + NPL * CV_PLANE_B;   // [NPL][128 rows][64 B]
+
+    // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of
+    // tiles; the n-tiles of one pixel tile sit next to each other (same activations, same L2).
+    const int tiles = a.m_tiles * a.n_tiles;
+    const int per_xcd = (tiles + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= tiles) return;
+    const int nt = logical % a.n_tiles;
+    const int mt = logical / a.n_tiles;
+    const int m0 = mt * CV_BM, n0 = nt * CV_BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // activation staging: thread -> rows (tid>>2) and (tid>>2)+64, channels 8*(tid&3) .. +7 of the slab
+    const int oct = tid & 3;
+    int iy0[2], ix0[2], pbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + (tid >> 2) + 64 * i;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / (a.Ho * a.Wo);
+        const int rem = mm - b * (a.Ho * a.Wo);
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        iy0[i] = ok ? oy * a.sh - a.ph : -(1 << 20);
+        ix0[i] = ox * a.sw - a.pw;
+        pbase[i] = b * a.H * a.W;
+    }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * (NPL * CV_PLANE_B);
+
+    u32x4 xv[2][2];
+    u32x4 wv[2 * NPL];
+    const int taps = a.kh * a.kw;
+    int s_tap = 0, s_c = 0;   // (tap, channel slab) of the slab being FETCHED; K runs channel-slab outer, tap inner, so the
+                              // kh*kw shifted re-reads of one 32-channel slice of the pixel neighbourhood hit L2
+    auto fetch = [&](int slab) {
+        if (a.dbg & 2) return;
+        const int ky = s_tap / a.kw, kx = s_tap - ky * a.kw;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned off = in ? (unsigned)(((pbase[i] + iy * a.W + ix) * a.x_ld + s_c * CV_BK + oct * 8) * 4) : CV_OOB;
+            xv[i][0] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+            xv[i][1] = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 16, 0, 0);
+        }
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wtile + (size_t)min(slab, a.slabs - 1) * (NPL * CV_PLANE_B));
+#pragma unroll
+        for (int j = 0; j < 2 * NPL; ++j) wv[j] = wsrc[tid + 256 * j];
+        if (++s_tap == taps) { s_tap = 0; ++s_c; }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x4 p0, p1, p2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // (whole-vector bit cast: __builtin_bit_cast of a single vector ELEMENT reads element 0 on this compiler)
+                const f32x4 f = __builtin_bit_cast(f32x4, xv[i][h]);
+                const f32x2 v0 = {f.x, f.y};
+                const f32x2 v1 = {f.z, f.w};
+                unsigned q0, q1, q2, r0, r1, r2;
+                if (a.dbg & 4) {
+                    q0 = q1 = q2 = xv[i][h].x; r0 = r1 = r2 = xv[i][h].z;
+                } else {
+                    split2(v0, q0, q1, q2);
+                    split2(v1, r0, r1, r2);
+                }
+                if (h == 0) { p0.x = q0; p0.y = r0; p1.x = q1; p1.y = r1; p2.x = q2; p2.y = r2; }
+                else        { p0.z = q0; p0.w = r0; p1.z = q1; p1.w = r1; p2.z = q2; p2.w = r2; }
+            }
+            if (a.dbg & 8) continue;
+            const int row = (tid >> 2) + 64 * i;
+            uint8_t* dst = xs + lds_off(row, oct);
+            *reinterpret_cast<u32x4*>(dst) = p0;
+            *reinterpret_cast<u32x4*>(dst + CV_PLANE_B) = p1;
+            if (NPL == 3) *reinterpret_cast<u32x4*>(dst + 2 * CV_PLANE_B) = p2;
+        }
+        if (a.dbg & 8) return;
+#pragma unroll
+        for (int j = 0; j < 2 * NPL; ++j) *reinterpret_cast<u32x4*>(ws + (tid + 256 * j) * 16) = wv[j];
+    };
+
+    // two accumulators per tile: the leading product x0 w0 in one, the five correction products (2^-8 and smaller) in
+    // the other, so the corrections are not rounded at the magnitude of the running sum
+    f32x16 acc[2][2], accl[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    fetch(0);
+    for (int s = 0; s < a.slabs; ++s) {
+        if (a.dbg & 32) __builtin_amdgcn_s_setprio(1);
+        stage();
+        if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        fetch(s + 1);   // in flight behind the MFMAs (past the end: a harmless re-read, no branch)
+        if (a.dbg & 16) __builtin_amdgcn_s_setprio(1);
+        if (!(a.dbg & 1))
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2][NPL], bf[2][NPL];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+                    af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * CV_PLANE_B + lds_off(wm * 64 + i * 32 + lrow, 2 * ks + lh));
+                    bf[i][p] = *reinterpret_cast<const bf16x8*>(ws + p * CV_PLANE_B + lds_off(wn * 64 + i * 32 + lrow, 2 * ks + lh));
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = accl[i][j];
+                    if constexpr (NPL == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                    accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (a.dbg & 16) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + j * 32 + lrow;
+        if (co >= a.Cout) continue;
+        const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = (acc[i][j][r] + accl[i][j][r]) + bv;
+                if (a.res) v += a.res[(size_t)m * a.res_ld + co];
+                if (a.relu) v = v > 0.0f ? v : 0.0f;
+                a.out[(size_t)m * a.out_ld + co] = v;
+            }
+    }
+}
+
+// ---- ping-pong variant: 512 threads = two groups of four waves (one wave of each group per SIMD), each group owning a
+// 128-pixel half of a 256 x 128 output tile and both sharing the weight tile.  The groups run half a K-slab apart: in
+// every phase one group issues its 48 (x6) MFMAs while the other splits and stages its next activation slab plus half
+// of the next weight slab, then a workgroup barrier swaps the roles.  Two independent 256-thread workgroups on a CU do
+// NOT settle into this alternation by themselves (measured: their MFMA phases coincide and the staging time adds to,
+// instead of hiding under, the matrix time); the barrier-enforced anti-phase does.
+//   group 0: stage slab s in phase 2s,     compute it in phase 2s+1
+//   group 1: stage slab s in phase 2s+1,   compute it in phase 2s+2      (phase 0: its half of weight slab 0)
+// weight slab s lives in buffer s&1 from the end of phase 2s to the end of phase 2s+2.  Global fetches for the next
+// stage are issued at the END of a stage phase, so they fly for the barrier wait plus the whole compute phase.
+template <int NPL>
+__global__ __launch_bounds__(512, 1) void conv_bf16x_pp_kernel(const ConvArgs a)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wq = (tid >> 6) & 3;
+    uint8_t* xs = smem + grp * (NPL * CV_PLANE_B);        // this group's activation tile [NPL][128][64 B]
+    uint8_t* wsm = smem + 2 * (NPL * CV_PLANE_B);         // weight tiles [2][NPL][128][64 B]
+
+    const int tiles = a.m_tiles * a.n_tiles;              // m_tiles counts 256-pixel tiles here
+    const int per_xcd = (tiles + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= tiles) return;
+    const int nt = logical % a.n_tiles;
+    const int mt = logical / a.n_tiles;
+    const int m0 = mt * (2 * CV_BM) + grp * CV_BM, n0 = nt * CV_BN;
+    const int wm = wq & 1, wn = wq >> 1;
+
+    const int oct = t & 3;
+    int iy0[2], ix0[2], pbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + (t >> 2) + 64 * i;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / (a.Ho * a.Wo);
+        const int rem = mm - b * (a.Ho * a.Wo);
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        iy0[i] = ok ? oy * a.sh - a.ph : -(1 << 20);
+        ix0[i] = ox * a.sw - a.pw;
+        pbase[i] = b * a.H * a.W;
+    }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * (NPL * CV_PLANE_B);
+    const int taps = a.kh * a.kw, S = a.slabs;
+
+    u32x4 xv0, xv1, xv2, xv3;   // rows 0/1 x halves 0/1 (named: arrays captured by reference have gone to scratch before)
+    u32x4 wv[NPL];
+    int s_tap = 0, s_c = 0;
+#define PP_FETCH_X()                                                                                                      \
+    {                                                                                                                     \
+        const int ky = s_tap / a.kw, kx = s_tap - ky * a.kw;                                                              \
+        {                                                                                                                 \
+            const int iy = iy0[0] + ky, ix = ix0[0] + kx;                                                                 \
+            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;                                 \
+            const unsigned off = in ? (unsigned)(((pbase[0] + iy * a.W + ix) * a.x_ld + s_c * CV_BK + oct * 8) * 4) : CV_OOB; \
+            xv0 = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);                                                   \
+            xv1 = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 16, 0, 0);                                              \
+        }                                                                                                                 \
+        {                                                                                                                 \
+            const int iy = iy0[1] + ky, ix = ix0[1] + kx;                                                                 \
+            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;                                 \
+            const unsigned off = in ? (unsigned)(((pbase[1] + iy * a.W + ix) * a.x_ld + s_c * CV_BK + oct * 8) * 4) : CV_OOB; \
+            xv2 = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);                                                   \
+            xv3 = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 16, 0, 0);                                              \
+        }                                                                                                                 \
+        if (++s_tap == taps) { s_tap = 0; ++s_c; }                                                                        \
+    }
+#define PP_FETCH_W(slab)                                                                                                  \
+    {                                                                                                                     \
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wtile + (size_t)min((slab), S - 1) * (NPL * CV_PLANE_B)) +      \
+                            grp * (256 * NPL) + t;                                                                        \
+        _Pragma("unroll") for (int j = 0; j < NPL; ++j) wv[j] = wsrc[256 * j];                                            \
+    }
+#define PP_STAGE_ROW(row, va, vb)                                                                                         \
+    {                                                                                                                     \
+        const f32x4 fa = __builtin_bit_cast(f32x4, va), fb = __builtin_bit_cast(f32x4, vb);                               \
+        unsigned q0[4], q1[4], q2[4];                                                                                     \
+        split2(f32x2{fa.x, fa.y}, q0[0], q1[0], q2[0]);                                                                   \
+        split2(f32x2{fa.z, fa.w}, q0[1], q1[1], q2[1]);                                                                   \
+        split2(f32x2{fb.x, fb.y}, q0[2], q1[2], q2[2]);                                                                   \
+        split2(f32x2{fb.z, fb.w}, q0[3], q1[3], q2[3]);                                                                   \
+        const u32x4 p0 = {q0[0], q0[1], q0[2], q0[3]}, p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]}; \
+        uint8_t* dst = xs + lds_off((row), oct);                                                                          \
+        *reinterpret_cast<u32x4*>(dst) = p0;                                                                              \
+        *reinterpret_cast<u32x4*>(dst + CV_PLANE_B) = p1;                                                                 \
+        if (NPL == 3) *reinterpret_cast<u32x4*>(dst + 2 * CV_PLANE_B) = p2;                                               \
+    }
+#define PP_STAGE_W(buf)                                                                                                   \
+    {                                                                                                                     \
+        u32x4* wdst = reinterpret_cast<u32x4*>(wsm + (buf) * (NPL * CV_PLANE_B)) + grp * (256 * NPL) + t;                 \
+        _Pragma("unroll") for (int j = 0; j < NPL; ++j) wdst[256 * j] = wv[j];                                            \
+    }
+
+    f32x16 acc[2][2], accl[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    // prologue fetches: group 0 needs X(0) and its half of W(0); group 1 its half of W(0) first
+    if (grp == 0) PP_FETCH_X();
+    PP_FETCH_W(0);
+
+    const bool tr = a.trace != nullptr && blockIdx.x == 0 && (tid & 255) == 0;
+#define PP_STAMP(k) if (tr && p < 64) a.trace[(grp * 64 + p) * 8 + (k)] = clock64();
+    for (int p = 0; p <= 2 * S; ++p) {
+        const int q = p - grp;
+        PP_STAMP(0);
+        if (q < 0) {                                   // group 1, phase 0: its half of weight slab 0
+            PP_STAGE_W(0);
+            PP_FETCH_X();
+            PP_FETCH_W(1);
+        } else if ((q & 1) == 0) {                     // stage slab s = q/2 (+ this group's half of weight slab s+grp)
+            const int sl = q >> 1;
+            if (sl < S) {
+                if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(1); }
+                if (a.dbg & 32) __builtin_amdgcn_s_setprio(2);
+                PP_STAGE_ROW(t >> 2, xv0, xv1);
+                PP_STAGE_ROW((t >> 2) + 64, xv2, xv3);
+                if (sl + grp < S) PP_STAGE_W((sl + grp) & 1);
+                if (tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_STAMP(2); }
+                PP_FETCH_X();
+                PP_FETCH_W(sl + 1 + grp);
+                if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
+                PP_STAMP(3);
+            }
+        } else if (!(a.dbg & 1)) {                     // compute slab s = (q-1)/2
+            const uint8_t* ws = wsm + ((q >> 1) & 1) * (NPL * CV_PLANE_B);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[2][NPL], bf[2][NPL];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) {
+                        af[i][pl] = *reinterpret_cast<const bf16x8*>(xs + pl * CV_PLANE_B + lds_off(wm * 64 + i * 32 + lrow, 2 * ks + lh));
+                        bf[i][pl] = *reinterpret_cast<const bf16x8*>(ws + pl * CV_PLANE_B + lds_off(wn * 64 + i * 32 + lrow, 2 * ks + lh));
+                    }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x16 c = accl[i][j];
+                        if constexpr (NPL == 3) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                        }
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                        accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+            PP_STAMP(4);
+        }
+        PP_STAMP(5);
+        __syncthreads();
+        PP_STAMP(6);
+    }
+#undef PP_STAMP
+#undef PP_FETCH_X
+#undef PP_FETCH_W
+#undef PP_STAGE_ROW
+#undef PP_STAGE_W
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + j * 32 + lrow;
+        if (co >= a.Cout) continue;
+        const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = (acc[i][j][r] + accl[i][j][r]) + bv;
+                if (a.res) v += a.res[(size_t)m * a.res_ld + co];
+                if (a.relu) v = v > 0.0f ? v : 0.0f;
+                a.out[(size_t)m * a.out_ld + co] = v;
+            }
+    }
+}
+
+// ---- planar variant: the activation arrives ALREADY split, as NPL bf16 planes [NPL][B*H*W][x_ld] (the format the
+// epilogue below writes), so staging a K-slab is pure data movement: LDS-DMA (buffer_load ... lds, 16 B per lane,
+// out-of-range offsets deliver the zero padding) for the activation rows and global_load_lds for the pre-tiled weights,
+// no registers and no VALU beyond a handful of address operations.  Each element is split once, where it is produced,
+// instead of kh*kw*n_tiles times in the consumers' loaders -- measured on the register-staged kernels above, the
+// split's VALU stream crawls (2.8x slower) whenever the SIMD's other wave is issuing MFMAs, and that, not the matrix
+// pipe, set their speed.  Two LDS buffers; slab s+1 streams in while the MFMAs run on slab s; one barrier per slab.
+// Workgroup = 4*MG waves as (2*MG) x 2, tile = 128*MG pixels x 128 channels.
+struct PlanarArgs {
+    const uint8_t* xp;      // [NPL][B*H*W][x_ld] bf16
+    const uint8_t* wp;
+    const float* bias;
+    const float* res_f32;   // [M][res_ld] or null
+    const uint8_t* res_pl;  // [3][M][res_ld] bf16 or null
+    float* out_f32;         // [M][out_ld] or null
+    uint8_t* out_pl;        // [3][M][out_ld] bf16 or null
+    int B, H, W, C, Ho, Wo, Cout;
+    int kh, kw, sh, sw, ph, pw;
+    int x_ld, out_ld, res_ld;
+    int relu;
+    int M, n_tiles, m_tiles, slabs;
+    unsigned plane_bytes;   // B*H*W*x_ld*2
+};
+
+template <int NPL, int MG>
+__global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr int BM = CV_BM * MG;
+    constexpr int XBUF = NPL * BM * 64, WBUF = NPL * CV_PLANE_B, BUF = XBUF + WBUF;
+    constexpr int NWAVES = 4 * MG;
+    constexpr int WDMA = 8 * NPL / NWAVES;   // weight DMA instructions per wave per slab (6 or 4 | 3 or 2)
+
+    const int tiles = a.m_tiles * a.n_tiles;
+    const int per_xcd = (tiles + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= tiles) return;
+    const int nt = logical % a.n_tiles;
+    const int mt = logical / a.n_tiles;
+    const int m0 = mt * BM, n0 = nt * CV_BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % (2 * MG), wn = wave / (2 * MG);
+
+    // DMA duties of this lane: activation row groups 2*wave and 2*wave+1 (16 rows x 64 B each, all planes)
+    int iy0[2], ix0[2], pbase[2];
+    const int slot = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (2 * wave + i) * 16 + (lane >> 2);
+        const int m = m0 + r;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / (a.Ho * a.Wo);
+        const int rem = mm - b * (a.Ho * a.Wo);
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        iy0[i] = ok ? oy * a.sh - a.ph : -(1 << 20);
+        ix0[i] = ox * a.sw - a.pw;
+        // byte offset of (pixel, logical chunk) within a plane, minus the tap / channel-slab terms
+        pbase[i] = (b * a.H * a.W) * a.x_ld * 2 + ((slot ^ ((r >> 2) & 3)) << 4);
+    }
+    __amdgpu_buffer_rsrc_t xr[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+        xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.plane_bytes, 0, (int)a.plane_bytes, 0x00020000);
+    const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * WBUF;
+    const int taps = a.kh * a.kw, S = a.slabs;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+    int s_tap = 0, s_c = 0;
+    auto dma = [&](int slab, int buf) {
+        uint8_t* xb = smem + buf * BUF;
+        const int ky = s_tap / a.kw, kx = s_tap - ky * a.kw;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned off = in ? (unsigned)(pbase[i] + ((iy * a.W + ix) * a.x_ld + s_c * CV_BK) * 2) : CV_OOB;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(xb + p * (BM * 64) + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
+        }
+        const uint8_t* wsrc = wtile + (size_t)slab * WBUF;
+#pragma unroll
+        for (int j = 0; j < WDMA; ++j) {
+            const int wi = wave + NWAVES * j;
+            __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + wi * 1024 + lane * 16), (lds_ptr)(xb + XBUF + wi * 1024), 16, 0, 0);
+        }
+        if (++s_tap == taps) { s_tap = 0; ++s_c; }
+    };
+
+    f32x16 acc[2][2], accl[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    dma(0, 0);
+    for (int s = 0; s < S; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of slab s has landed
+        __syncthreads();                                     // ... everyone's has, and buffer (s+1)&1 is no longer read
+        if (s + 1 < S) dma(s + 1, (s + 1) & 1);
+        const uint8_t* xs = smem + (s & 1) * BUF;
+        const uint8_t* ws = xs + XBUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2][NPL], bf[2][NPL];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+                    af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + i * 32 + lrow, 2 * ks + lh));
+                    bf[i][p] = *reinterpret_cast<const bf16x8*>(ws + p * CV_PLANE_B + lds_off(wn * 64 + i * 32 + lrow, 2 * ks + lh));
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = accl[i][j];
+                    if constexpr (NPL == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                    accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // epilogue: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes of the result
+    const size_t opl = (size_t)a.M * a.out_ld, rpl = (size_t)a.M * a.res_ld;
+    __bf16* outp = reinterpret_cast<__bf16*>(a.out_pl);
+    const __bf16* resp = reinterpret_cast<const __bf16*>(a.res_pl);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = n0 + wn * 64 + j * 32 + lrow;
+        if (co >= a.Cout) continue;
+        const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = (acc[i][j][r] + accl[i][j][r]) + bv;
+                if (a.res_f32) v += a.res_f32[(size_t)m * a.res_ld + co];
+                if (resp) {
+                    const size_t ri = (size_t)m * a.res_ld + co;
+                    v += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
+                }
+                if (a.relu) v = v > 0.0f ? v : 0.0f;
+                if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co] = v;
+                if (outp) {
+                    const size_t oi = (size_t)m * a.out_ld + co;
+                    const __bf16 h = (__bf16)v;
+                    const float r1 = v - (float)h;
+                    const __bf16 mid = (__bf16)r1;
+                    const float r2 = r1 - (float)mid;
+                    outp[oi] = h;
+                    outp[oi + opl] = mid;
+                    outp[oi + 2 * opl] = (__bf16)r2;
+                }
+            }
+    }
+#endif
+}
+
+// fp32 -> three bf16 planes [3][n] (entry into the planar format from a foreign producer); 8 elements per thread
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint8_t* __restrict__ planes, int64_t n)
+{
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    if (i + 8 <= n) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + i), a1 = *reinterpret_cast<const f32x4*>(x + i + 4);
+        unsigned q0[4], q1[4], q2[4];
+        split2(f32x2{a0.x, a0.y}, q0[0], q1[0], q2[0]);
+        split2(f32x2{a0.z, a0.w}, q0[1], q1[1], q2[1]);
+        split2(f32x2{a1.x, a1.y}, q0[2], q1[2], q2[2]);
+        split2(f32x2{a1.z, a1.w}, q0[3], q1[3], q2[3]);
+        *reinterpret_cast<u32x4*>(planes + i * 2) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        *reinterpret_cast<u32x4*>(planes + (n + i) * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        *reinterpret_cast<u32x4*>(planes + (2 * n + i) * 2) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+    } else {
+        __bf16* pl = reinterpret_cast<__bf16*>(planes);
+        for (int64_t k = i; k < n; ++k) {
+            const float v = x[k];
+            const __bf16 h = (__bf16)v;
+            const float r1 = v - (float)h;
+            const __bf16 mid = (__bf16)r1;
+            pl[k] = h; pl[n + k] = mid; pl[2 * n + k] = (__bf16)(r1 - (float)mid);
+        }
+    }
+}
+
+// Weights [Cout][Cin][kh][kw] fp32 -> packed [n_tile][slab][plane][row 0..127][swizzled 16-B chunk][8 bf16]; rows past
+// Cout are zero.  One thread per (n_tile, slab, row, chunk).
+__global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp, int Cout,
+                                                                int C, int kh, int kw, int slabs, int n_tiles, int npl)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n_tiles * slabs * 512;
+    if (idx >= total) return;
+    const int chunk = (int)(idx & 3), row = (int)((idx >> 2) & 127);
+    const int slab = (int)((idx >> 9) % slabs), nt = (int)((idx >> 9) / slabs);
+    const int taps = kh * kw;
+    const int cs = slab / taps, tap = slab - cs * taps, c0 = cs * CV_BK + chunk * 8;   // K order: channel slab outer, tap inner
+    const int co = nt * CV_BN + row;
+    unsigned pl[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f32x2 v = {0.0f, 0.0f};
+        if (co < Cout) {
+            v.x = w[((size_t)co * C + c0 + 2 * e) * (kh * kw) + tap];
+            v.y = w[((size_t)co * C + c0 + 2 * e + 1) * (kh * kw) + tap];
+        }
+        split2(v, pl[0][e], pl[1][e], pl[2][e]);
+    }
+    uint8_t* dst = wp + ((size_t)nt * slabs + slab) * (npl * CV_PLANE_B) + lds_off(row, chunk);
+    for (int p = 0; p < npl; ++p) {
+        u32x4 o = {pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
+        *reinterpret_cast<u32x4*>(dst + p * CV_PLANE_B) = o;
+    }
+}
+
+template <int NPL, int MG>
+int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
+{
+    const size_t lds = (size_t)2 * (NPL * CV_BM * MG * 64 + NPL * CV_PLANE_B);
+    STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
+    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
+    STM_CHECK_LAUNCH("conv_planar_kernel");
+    return STM_OK;
+}
+
+bool geom_ok(const stm_conv_geom* g, const char* who)
+{
+    if (!g) { stm_set_error("%s: geometry is NULL", who); return false; }
+    if (g->B <= 0 || g->H <= 0 || g->W <= 0 || g->C <= 0 || g->Cout <= 0 || g->kh <= 0 || g->kw <= 0 || g->sh <= 0 ||
+        g->sw <= 0 || g->ph < 0 || g->pw < 0 || g->Ho <= 0 || g->Wo <= 0) {
+        stm_set_error("%s: bad geometry", who);
+        return false;
+    }
+    if (g->C % CV_BK != 0) { stm_set_error("%s: input channels (%d) must be a multiple of 32", who, g->C); return false; }
+    if (g->Ho != (g->H + 2 * g->ph - g->kh) / g->sh + 1 || g->Wo != (g->W + 2 * g->pw - g->kw) / g->sw + 1) {
+        stm_set_error("%s: Ho/Wo do not match the convolution arithmetic", who);
+        return false;
+    }
+    if (g->planes != 2 && g->planes != 3) { stm_set_error("%s: planes must be 2 or 3", who); return false; }
+    return true;
+}
+
+}  // namespace
+
+static long long* g_conv_trace = nullptr;
+// debugging aid (not part of include/stmask_hip.h): device buffer of 2*64*8 int64 receiving workgroup 0's per-phase clocks
+extern "C" void stm_debug_conv_set_trace(void* dev_buf) { g_conv_trace = static_cast<long long*>(dev_buf); }
+
+extern "C" size_t stm_conv_packed_weight_bytes(int Cout, int Cin, int kh, int kw, int planes)
+{
+    if (Cout <= 0 || Cin <= 0 || Cin % CV_BK || kh <= 0 || kw <= 0 || (planes != 2 && planes != 3)) return 0;
+    return (size_t)stm_cdiv(Cout, CV_BN) * (kh * kw * (Cin / CV_BK)) * planes * CV_PLANE_B;
+}
+
+extern "C" int stm_conv_pack_weights_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int planes,
+                                         stm_stream_t stream)
+{
+    STM_REQUIRE(weight && packed, STM_ENULL, "stm_conv_pack_weights_f32: weight/packed must be non-NULL");
+    STM_REQUIRE(stm_conv_packed_weight_bytes(Cout, Cin, kh, kw, planes) > 0, STM_EINVAL,
+                "stm_conv_pack_weights_f32: bad sizes Cout=%d Cin=%d (multiple of 32) k=%dx%d planes=%d", Cout, Cin, kh, kw, planes);
+    STM_REQUIRE((uintptr_t)packed % 16 == 0, STM_EINVAL, "stm_conv_pack_weights_f32: packed buffer must be 16-byte aligned");
+    const int slabs = kh * kw * (Cin / CV_BK), n_tiles = stm_cdiv(Cout, CV_BN);
+    const int64_t total = (int64_t)n_tiles * slabs * 512;
+    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), weight,
+                       static_cast<uint8_t*>(packed), Cout, Cin, kh, kw, slabs, n_tiles, planes);
+    STM_CHECK_LAUNCH("conv_pack_weights_kernel");
+    return STM_OK;
+}
+
+extern "C" int stm_conv2d_nhwc_f32(const float* x, const void* packed_weight, const float* bias, const float* residual,
+                                   float* out, const stm_conv_geom* g, int relu, stm_stream_t stream)
+{
+    STM_REQUIRE(x && packed_weight && out, STM_ENULL, "stm_conv2d_nhwc_f32: x/packed_weight/out must be non-NULL");
+    if (!geom_ok(g, "stm_conv2d_nhwc_f32")) return STM_EINVAL;
+    const int x_ld = g->x_ld ? g->x_ld : g->C, out_ld = g->out_ld ? g->out_ld : g->Cout, res_ld = g->res_ld ? g->res_ld : g->Cout;
+    STM_REQUIRE(x_ld >= g->C && x_ld % 4 == 0 && out_ld >= g->Cout && res_ld >= g->Cout, STM_EINVAL,
+                "stm_conv2d_nhwc_f32: bad leading dimensions x_ld=%d out_ld=%d res_ld=%d", x_ld, out_ld, res_ld);
+    STM_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)packed_weight % 16 == 0, STM_EINVAL,
+                "stm_conv2d_nhwc_f32: x and packed_weight must be 16-byte aligned");
+    const int64_t x_bytes = ((int64_t)g->B * g->H * g->W - 1) * x_ld * 4 + (int64_t)g->C * 4;
+    STM_REQUIRE(x_bytes < ((int64_t)1 << 31), STM_EUNSUPPORTED, "stm_conv2d_nhwc_f32: input larger than 2 GiB (%lld bytes)",
+                (long long)x_bytes);
+    ConvArgs a;
+    a.x = x; a.wp = static_cast<const uint8_t*>(packed_weight); a.bias = bias; a.res = residual; a.out = out;
+    a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout;
+    a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw;
+    a.x_ld = x_ld; a.out_ld = out_ld; a.res_ld = res_ld; a.relu = relu;
+    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
+    STM_REQUIRE(M < ((int64_t)1 << 30), STM_EUNSUPPORTED, "stm_conv2d_nhwc_f32: too many output pixels");
+    a.M = (int)M;
+    a.n_tiles = stm_cdiv(g->Cout, CV_BN);
+    a.m_tiles = stm_cdiv(M, CV_BM);
+    a.slabs = g->kh * g->kw * (g->C / CV_BK);
+    a.x_bytes = (unsigned)x_bytes;
+    const char* dbg = getenv("STM_CONV_DEBUG");
+    a.dbg = dbg ? atoi(dbg) : 0;
+    a.trace = g_conv_trace;
+    // 256-pixel ping-pong tiles when they still give every CU work; 128-pixel tiles (two workgroups per CU) otherwise
+    const char* fk = getenv("STM_CONV_KERNEL");
+    const int forced = fk ? atoi(fk) : 0;
+    const int64_t pp_tiles = (int64_t)stm_cdiv(M, 2 * CV_BM) * a.n_tiles;
+    const bool use_pp = forced ? forced == 2 : pp_tiles >= 192;
+    if (use_pp) {
+        a.m_tiles = stm_cdiv(M, 2 * CV_BM);
+        const dim3 grid(8 * stm_cdiv(pp_tiles, 8));
+        const size_t lds = (size_t)4 * g->planes * CV_PLANE_B;
+        if (g->planes == 3) {
+            STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x_pp_kernel<3>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                        STM_ELAUNCH, "stm_conv2d_nhwc_f32: cannot reserve %zu bytes of LDS", lds);
+            hipLaunchKernelGGL(conv_bf16x_pp_kernel<3>, grid, dim3(512), lds, stm_hs(stream), a);
+        } else {
+            STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x_pp_kernel<2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                        STM_ELAUNCH, "stm_conv2d_nhwc_f32: cannot reserve %zu bytes of LDS", lds);
+            hipLaunchKernelGGL(conv_bf16x_pp_kernel<2>, grid, dim3(512), lds, stm_hs(stream), a);
+        }
+        STM_CHECK_LAUNCH("conv_bf16x_pp_kernel");
+        return STM_OK;
+    }
+    const int tiles = a.m_tiles * a.n_tiles;
+    const dim3 grid(8 * stm_cdiv(tiles, 8));
+    const size_t lds = (size_t)2 * g->planes * CV_PLANE_B + ((a.dbg & 64) ? (48 << 10) : 0);
+    if (g->planes == 3)
+        hipLaunchKernelGGL(conv_bf16x_kernel<3>, grid, dim3(256), lds, stm_hs(stream), a);
+    else
+        hipLaunchKernelGGL(conv_bf16x_kernel<2>, grid, dim3(256), lds, stm_hs(stream), a);
+    STM_CHECK_LAUNCH("conv_bf16x_kernel");
+    return STM_OK;
+}
+
+extern "C" int stm_split_bf16_planes_f32(const float* x, void* planes, int64_t n, stm_stream_t stream)
+{
+    STM_REQUIRE(x && planes, STM_ENULL, "stm_split_bf16_planes_f32: x/planes must be non-NULL");
+    STM_REQUIRE(n > 0 && n % 8 == 0, STM_EINVAL, "stm_split_bf16_planes_f32: n (%lld) must be a positive multiple of 8", (long long)n);
+    STM_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)planes % 16 == 0, STM_EINVAL, "stm_split_bf16_planes_f32: 16-byte alignment required");
+    hipLaunchKernelGGL(split_planes_kernel, dim3(stm_cdiv(n / 8, 256)), dim3(256), 0, stm_hs(stream), x, static_cast<uint8_t*>(planes), n);
+    STM_CHECK_LAUNCH("split_planes_kernel");
+    return STM_OK;
+}
+
+extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
+                                     const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
+                                     int relu, stm_stream_t stream)
+{
+    STM_REQUIRE(x_planes && packed_weight && (out_f32 || out_planes), STM_ENULL,
+                "stm_conv2d_planar_f32: x_planes/packed_weight and at least one output must be non-NULL");
+    if (!geom_ok(g, "stm_conv2d_planar_f32")) return STM_EINVAL;
+    const int x_ld = g->x_ld ? g->x_ld : g->C, out_ld = g->out_ld ? g->out_ld : g->Cout, res_ld = g->res_ld ? g->res_ld : g->Cout;
+    STM_REQUIRE(x_ld >= g->C && x_ld % 8 == 0 && out_ld >= g->Cout && res_ld >= g->Cout, STM_EINVAL,
+                "stm_conv2d_planar_f32: bad leading dimensions x_ld=%d out_ld=%d res_ld=%d", x_ld, out_ld, res_ld);
+    STM_REQUIRE((uintptr_t)x_planes % 16 == 0 && (uintptr_t)packed_weight % 16 == 0, STM_EINVAL,
+                "stm_conv2d_planar_f32: x_planes and packed_weight must be 16-byte aligned");
+    const int64_t plane_bytes = (int64_t)g->B * g->H * g->W * x_ld * 2;
+    STM_REQUIRE(plane_bytes < ((int64_t)1 << 31), STM_EUNSUPPORTED, "stm_conv2d_planar_f32: plane larger than 2 GiB");
+    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
+    STM_REQUIRE(M < ((int64_t)1 << 30), STM_EUNSUPPORTED, "stm_conv2d_planar_f32: too many output pixels");
+    PlanarArgs a;
+    a.xp = static_cast<const uint8_t*>(x_planes); a.wp = static_cast<const uint8_t*>(packed_weight); a.bias = bias;
+    a.res_f32 = residual_f32; a.res_pl = static_cast<const uint8_t*>(residual_planes);
+    a.out_f32 = out_f32; a.out_pl = static_cast<uint8_t*>(out_planes);
+    a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout;
+    a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw;
+    a.x_ld = x_ld; a.out_ld = out_ld; a.res_ld = res_ld; a.relu = relu;
+    a.M = (int)M; a.n_tiles = stm_cdiv(g->Cout, CV_BN); a.slabs = g->kh * g->kw * (g->C / CV_BK);
+    a.plane_bytes = (unsigned)plane_bytes;
+    const char* fk = getenv("STM_CONV_MG");
+    const int forced = fk ? atoi(fk) : 0;
+    const int64_t big_tiles = (int64_t)stm_cdiv(M, 2 * CV_BM) * a.n_tiles;
+    const int mg = forced ? forced : (big_tiles >= 192 ? 2 : 1);
+    a.m_tiles = stm_cdiv(M, CV_BM * mg);
+    const int tiles = a.m_tiles * a.n_tiles;
+    if (g->planes == 3) return mg == 2 ? launch_planar<3, 2>(a, tiles, stream) : launch_planar<3, 1>(a, tiles, stream);
+    return mg == 2 ? launch_planar<2, 2>(a, tiles, stream) : launch_planar<2, 1>(a, tiles, stream);
+}

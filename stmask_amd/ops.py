@@ -383,3 +383,81 @@ def mask_resize_rle(masks, crop_h, crop_w, out_h, out_w, thr=0.5, max_runs=4096)
                                              c_i(out_w), c_f(thr), _p(counts), c_i(max_runs), _p(n_runs), _p(ws),
                                              c_sz(ws.numel()), _stream()), "stm_mask_resize_rle_f32")
     return counts, n_runs
+
+
+def conv_pack_weights(weight, planes=3):
+    """OIHW fp32 weights -> the pre-split, pre-tiled bf16 image stm_conv2d_nhwc_f32 streams (done once per layer)."""
+    _dev(weight)
+    weight = _f32c(weight)
+    O, C, kh, kw = weight.shape
+    nbytes = _lib.lib().stm_conv_packed_weight_bytes(c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes))
+    if nbytes == 0:
+        raise StmError(f"conv_pack_weights: unsupported weight shape {tuple(weight.shape)} (Cin must be a multiple of 32)")
+    packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
+    check(_lib.lib().stm_conv_pack_weights_f32(_p(weight), _p(packed), c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes),
+                                               _stream()), "stm_conv_pack_weights_f32")
+    return packed
+
+
+def conv2d_nhwc(x, packed, weight_shape, bias=None, residual=None, stride=1, padding=0, relu=False, planes=3, out=None):
+    """y = act(conv2d(x, w) + bias + residual) on NHWC fp32 tensors ([B,H,W,C] contiguous, i.e. the storage of a torch
+    channels_last tensor); `packed` from conv_pack_weights, `weight_shape` the original (O, C, kh, kw)."""
+    _dev(x, packed, bias, residual)
+    x = _f32c(x)
+    O, C, kh, kw = weight_shape
+    B, H, W, Cx = x.shape
+    if Cx != C:
+        raise StmError(f"conv2d_nhwc: input has {Cx} channels, weights expect {C}")
+    (sh, sw), (ph, pw) = _pair(stride), _pair(padding)
+    Ho, Wo = conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, 1, 1)
+    if out is None:
+        out = torch.empty(B, Ho, Wo, O, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        residual = _f32c(residual)
+        if tuple(residual.shape) != (B, Ho, Wo, O):
+            raise StmError(f"conv2d_nhwc: residual {tuple(residual.shape)} != output {(B, Ho, Wo, O)}")
+    g = _lib.ConvGeom(B, H, W, C, Ho, Wo, O, kh, kw, sh, sw, ph, pw, 0, 0, 0, planes)
+    check(_lib.lib().stm_conv2d_nhwc_f32(_p(x), _p(packed), _p(_f32c(bias) if bias is not None else None), _p(residual),
+                                         _p(out), ctypes.byref(g), c_i(1 if relu else 0), _stream()), "stm_conv2d_nhwc_f32")
+    return out
+
+
+def split_planes(x):
+    """fp32 tensor (any shape, numel % 8 == 0) -> [3, *shape] bf16 planes whose fp32 sum is x exactly."""
+    _dev(x)
+    x = _f32c(x)
+    planes = torch.empty((3,) + tuple(x.shape), device=x.device, dtype=torch.bfloat16)
+    check(_lib.lib().stm_split_bf16_planes_f32(_p(x), _p(planes), c_l(x.numel()), _stream()), "stm_split_bf16_planes_f32")
+    return planes
+
+
+def conv2d_planar(xp, packed, weight_shape, bias=None, residual=None, stride=1, padding=0, relu=False, planes=3,
+                  out="planes"):
+    """The same convolution on the planar activation format: xp [3,B,H,W,C] bf16 (split_planes / a previous layer's
+    output).  `residual` may be fp32 [B,Ho,Wo,O] or planes [3,B,Ho,Wo,O].  out: "planes" | "f32" | "both"."""
+    _dev(xp, packed, bias, residual)
+    if xp.dtype != torch.bfloat16 or xp.dim() != 5 or xp.shape[0] != 3 or not xp.is_contiguous():
+        raise StmError(f"conv2d_planar: expected contiguous bf16 planes [3,B,H,W,C], got {xp.dtype} {tuple(xp.shape)}")
+    O, C, kh, kw = weight_shape
+    _, B, H, W, Cx = xp.shape
+    if Cx != C:
+        raise StmError(f"conv2d_planar: input has {Cx} channels, weights expect {C}")
+    (sh, sw), (ph, pw) = _pair(stride), _pair(padding)
+    Ho, Wo = conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, 1, 1)
+    y32 = torch.empty(B, Ho, Wo, O, device=xp.device, dtype=torch.float32) if out in ("f32", "both") else None
+    ypl = torch.empty(3, B, Ho, Wo, O, device=xp.device, dtype=torch.bfloat16) if out in ("planes", "both") else None
+    r32 = rpl = None
+    if residual is not None:
+        if residual.dtype == torch.bfloat16:
+            if tuple(residual.shape) != (3, B, Ho, Wo, O) or not residual.is_contiguous():
+                raise StmError(f"conv2d_planar: residual planes {tuple(residual.shape)} != {(3, B, Ho, Wo, O)}")
+            rpl = residual
+        else:
+            r32 = _f32c(residual)
+            if tuple(r32.shape) != (B, Ho, Wo, O):
+                raise StmError(f"conv2d_planar: residual {tuple(r32.shape)} != output {(B, Ho, Wo, O)}")
+    g = _lib.ConvGeom(B, H, W, C, Ho, Wo, O, kh, kw, sh, sw, ph, pw, 0, 0, 0, planes)
+    check(_lib.lib().stm_conv2d_planar_f32(_p(xp), _p(packed), _p(_f32c(bias) if bias is not None else None), _p(r32), _p(rpl),
+                                           _p(y32), _p(ypl), ctypes.byref(g), c_i(1 if relu else 0), _stream()),
+          "stm_conv2d_planar_f32")
+    return (y32, ypl) if out == "both" else (y32 if out == "f32" else ypl)

@@ -1,0 +1,175 @@
+"""GPU parity of the bf16-split implicit-GEMM convolution (stm_conv2d_nhwc_f32, include/stmask_hip.h) against the fp64
+CPU oracle (oracle.conv2d_nhwc) and torch's fp32 convolution on the same seeded inputs.
+
+Tolerance, stated: with three bf16 planes per operand (six products) every fp32 product is reproduced to ~2^-24 and the
+sum is accumulated in fp32, so the result must sit within a few fp32 ULPs of the reduction's magnitude:
+|y - y_fp64| <= 2e-6 * sum_k |x_k w_k|  (observed ~2e-7).  With two planes (three products) the bound is 4e-5.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from stmask_amd import ops
+from stmask_amd._lib import StmError
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # B, H,  W,  C, Cout, kh, kw, stride, pad(h,w), bias, residual, relu
+    (2, 12, 20, 32, 64, 3, 3, 1, (1, 1), True, False, True),      # head-tower-like 3x3
+    (1, 24, 40, 64, 256, 1, 1, 1, (0, 0), True, True, True),      # bottleneck conv3 + residual
+    (2, 13, 17, 32, 27, 3, 3, 2, (1, 1), True, False, False),     # conv_offset_mask-like: stride 2, Cout 27, odd sizes
+    (1, 6, 10, 64, 41, 3, 5, 1, (1, 2), True, False, False),      # FCB trailing conv 3x5 -> 41 classes
+    (1, 3, 5, 32, 130, 5, 3, 1, (2, 1), False, False, True),      # P7: 15 pixels, 5x3, Cout just over one tile
+    (3, 9, 11, 96, 4, 3, 3, 1, (1, 1), True, False, False),       # bbox layer: Cout 4
+    (1, 48, 80, 256, 256, 3, 3, 1, (1, 1), True, False, True),    # the P3 tower layer at full size
+]
+
+
+def run_case(B, H, W, C, O, kh, kw, s, pad, has_bias, has_res, relu, planes=3, seed=0):
+    x = rnd(B, H, W, C, seed=seed)
+    w = rnd(O, C, kh, kw, seed=seed + 1, scale=(C * kh * kw) ** -0.5)
+    b = rnd(O, seed=seed + 2) if has_bias else None
+    Ho, Wo = ops.conv_out_hw(H, W, kh, kw, s, s, pad[0], pad[1], 1, 1)
+    r = rnd(B, Ho, Wo, O, seed=seed + 3) if has_res else None
+    ref = oracle.conv2d_nhwc(x, w, b, r, stride=s, padding=pad, relu=relu)
+    mag = oracle.conv2d_nhwc(x.abs(), w.abs(), b.abs() if has_bias else None, r.abs() if has_res else None, stride=s, padding=pad)
+    packed = ops.conv_pack_weights(w.to(DEV), planes)
+    y = ops.conv2d_nhwc(x.to(DEV), packed, tuple(w.shape), b.to(DEV) if has_bias else None, r.to(DEV) if has_res else None,
+                        stride=s, padding=pad, relu=relu, planes=planes)
+    torch.cuda.synchronize()
+    return y.cpu(), ref, mag
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bf16x6_vs_oracle(case):
+    y, ref, mag = run_case(*case)
+    assert y.shape == ref.shape
+    err = ((y - ref).abs() / mag.clamp_min(1e-6)).max().item()
+    assert err < 2e-6, err
+    assert (y - ref).abs().max().item() < 1e-4      # the north star's absolute mask tolerance, far from binding here
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_pingpong_kernel_vs_oracle(case, monkeypatch):
+    """The 512-thread ping-pong kernel (256-pixel tiles; picked automatically for large layers) forced on every case,
+    and bit-identical to the 128-pixel kernel: same products, same accumulation order."""
+    monkeypatch.setenv("STM_CONV_KERNEL", "2")
+    y, ref, mag = run_case(*case)
+    err = ((y - ref).abs() / mag.clamp_min(1e-6)).max().item()
+    assert err < 2e-6, err
+    monkeypatch.setenv("STM_CONV_KERNEL", "1")
+    y1, _, _ = run_case(*case)
+    assert torch.equal(y, y1)
+
+
+@pytest.mark.parametrize("case", CONV_CASES[:4])
+def test_conv_bf16x3_looser_mode(case):
+    y, ref, mag = run_case(*case, planes=2)
+    err = ((y - ref).abs() / mag.clamp_min(1e-6)).max().item()
+    assert err < 4e-5, err
+
+
+def test_conv_matches_torch_fp32_conv_and_is_no_worse():
+    """Against torch's own fp32 convolution (MIOpen): both sit at fp32 rounding distance from the fp64 oracle."""
+    B, H, W, C, O = 2, 24, 40, 128, 128
+    x, w, b = rnd(B, H, W, C, seed=5), rnd(O, C, 3, 3, seed=6, scale=0.03), rnd(O, seed=7)
+    ref = oracle.conv2d_nhwc(x, w, b, None, stride=1, padding=1)
+    packed = ops.conv_pack_weights(w.to(DEV))
+    y = ops.conv2d_nhwc(x.to(DEV), packed, tuple(w.shape), b.to(DEV), None, stride=1, padding=1).cpu()
+    yt = F.conv2d(x.permute(0, 3, 1, 2).to(DEV), w.to(DEV), b.to(DEV), padding=1).permute(0, 2, 3, 1).cpu()
+    e_ours, e_torch = (y - ref).abs().max().item(), (yt - ref).abs().max().item()
+    assert e_ours < 5e-6 and e_ours < 4 * e_torch + 1e-6, (e_ours, e_torch)
+
+
+def test_conv_known_answers_and_linearity():
+    # identity 1x1 kernel returns the input; a one-hot 3x3 tap shifts the image with zero padding
+    C = 32
+    x = rnd(1, 7, 9, C, seed=1)
+    w = torch.eye(C).reshape(C, C, 1, 1)
+    y = ops.conv2d_nhwc(x.to(DEV), ops.conv_pack_weights(w.to(DEV)), (C, C, 1, 1)).cpu()
+    assert torch.equal(y, x)                                   # x = p0 + p1 + p2 exactly, times 1.0
+    w3 = torch.zeros(C, C, 3, 3)
+    w3[:, :, 0, 2] = torch.eye(C)                              # tap (ky=0, kx=2): y[oy, ox] = x[oy - 1, ox + 1]
+    y = ops.conv2d_nhwc(x.to(DEV), ops.conv_pack_weights(w3.to(DEV)), (C, C, 3, 3), padding=1).cpu()
+    exp = torch.zeros_like(x)
+    exp[:, 1:, :-1] = x[:, :-1, 1:]
+    assert torch.equal(y, exp)
+    # linearity at a BASELINE-size layer: conv(a x1 + x2) == a conv(x1) + conv(x2) within fp32 rounding
+    x1, x2 = rnd(8, 48, 80, 256, seed=2).to(DEV), rnd(8, 48, 80, 256, seed=3).to(DEV)
+    w = rnd(256, 256, 3, 3, seed=4, scale=0.02).to(DEV)
+    pk = ops.conv_pack_weights(w)
+    f = lambda t: ops.conv2d_nhwc(t, pk, (256, 256, 3, 3), padding=1)
+    lhs, rhs = f(0.5 * x1 + x2), 0.5 * f(x1) + f(x2)
+    assert (lhs - rhs).abs().max().item() < 2e-5
+
+
+def test_conv_rejects_bad_arguments():
+    w = rnd(8, 20, 3, 3).to(DEV)
+    with pytest.raises(StmError):
+        ops.conv_pack_weights(w)                               # Cin not a multiple of 32
+    w = rnd(8, 32, 3, 3).to(DEV)
+    pk = ops.conv_pack_weights(w)
+    with pytest.raises(StmError):
+        ops.conv2d_nhwc(rnd(1, 5, 5, 64).to(DEV), pk, (8, 32, 3, 3))   # channel mismatch
+    with pytest.raises(StmError):
+        ops.conv2d_nhwc(rnd(1, 5, 5, 32), pk, (8, 32, 3, 3))          # CPU tensor: no fallback
+
+
+def planes_to_f32(pl):
+    return (pl[0].float() + pl[1].float()) + pl[2].float()
+
+
+def test_split_planes_is_exact():
+    x = rnd(3, 5, 8, 64, seed=11) * torch.logspace(-6, 6, 64)
+    pl = ops.split_planes(x.to(DEV)).cpu()
+    assert pl.shape == (3, 3, 5, 8, 64) and pl.dtype == torch.bfloat16
+    assert torch.equal(planes_to_f32(pl), x)          # 8+8+8 mantissa bits: the fp32 value is recovered exactly
+
+
+@pytest.mark.parametrize("mg", ["1", "2"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_planar_vs_oracle(case, mg, monkeypatch):
+    """Planar (pre-split, LDS-DMA staged) kernel, both tile heights, fp32 and planar outputs, both residual forms."""
+    monkeypatch.setenv("STM_CONV_MG", mg)
+    B, H, W, C, O, kh, kw, s, pad, has_bias, has_res, relu = case
+    x = rnd(B, H, W, C, seed=0)
+    w = rnd(O, C, kh, kw, seed=1, scale=(C * kh * kw) ** -0.5)
+    b = rnd(O, seed=2) if has_bias else None
+    Ho, Wo = ops.conv_out_hw(H, W, kh, kw, s, s, pad[0], pad[1], 1, 1)
+    r = rnd(B, Ho, Wo, O, seed=3) if has_res else None
+    ref = oracle.conv2d_nhwc(x, w, b, r, stride=s, padding=pad, relu=relu)
+    mag = oracle.conv2d_nhwc(x.abs(), w.abs(), b.abs() if has_bias else None, r.abs() if has_res else None, stride=s, padding=pad)
+    pk = ops.conv_pack_weights(w.to(DEV))
+    xp = ops.split_planes(x.to(DEV))
+    bd = b.to(DEV) if has_bias else None
+    y32, ypl = ops.conv2d_planar(xp, pk, tuple(w.shape), bd, r.to(DEV) if has_res else None, stride=s, padding=pad, relu=relu, out="both")
+    y32, ypl = y32.cpu(), ypl.cpu()
+    assert ((y32 - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
+    assert torch.equal(planes_to_f32(ypl), y32)        # the planar output IS the fp32 output, split
+    # same inputs through the register-staged fp32-in kernel: identical products and accumulation order
+    y_ref_kernel = ops.conv2d_nhwc(x.to(DEV), pk, tuple(w.shape), bd, r.to(DEV) if has_res else None, stride=s, padding=pad, relu=relu).cpu()
+    assert torch.equal(y32, y_ref_kernel)
+    if has_res:                                        # residual handed over as planes gives the same result
+        y2 = ops.conv2d_planar(xp, pk, tuple(w.shape), bd, ops.split_planes(r.to(DEV)), stride=s, padding=pad, relu=relu, out="f32").cpu()
+        assert torch.equal(y2, y32)
+
+
+def test_conv_planar_chain_of_layers():
+    """Two stacked layers handing planes to each other == the fp64 oracle applied twice (error stays at fp32 level)."""
+    x = rnd(2, 24, 40, 64, seed=21)
+    w1, w2 = rnd(64, 64, 3, 3, seed=22, scale=0.05), rnd(96, 64, 1, 1, seed=23, scale=0.1)
+    b1 = rnd(64, seed=24)
+    h_ref = oracle.conv2d_nhwc(x, w1, b1, None, padding=1, relu=True)
+    y_ref = oracle.conv2d_nhwc(h_ref, w2, None, None)
+    h = ops.conv2d_planar(ops.split_planes(x.to(DEV)), ops.conv_pack_weights(w1.to(DEV)), (64, 64, 3, 3), b1.to(DEV), padding=1, relu=True)
+    y = ops.conv2d_planar(h, ops.conv_pack_weights(w2.to(DEV)), (96, 64, 1, 1), out="f32").cpu()
+    assert (y - y_ref).abs().max().item() < 1e-5
