@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nchw", dest="channels_last", action="store_false", help="keep the dense convs in NCHW")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="keep BatchNorm / bias / ReLU as separate kernels")
+    ap.add_argument("--no-planar", dest="planar", action="store_false",
+                    help="FPN / proto-net / head convolutions through MIOpen instead of the bf16-split matrix-core kernel")
     ap.add_argument("--fp16-backbone", action="store_true",
                     help="BASELINE config 5 flavour: ResNet trunk under fp16 autocast (implies --no-fuse); NOT the headline metric")
     ap.add_argument("--pipeline", default="batched", choices=["batched", "per-clip"],
@@ -115,7 +117,9 @@ def main():
         net.backbone_fp16 = True
     if args.fuse:
         from stmask_amd.fuse import optimize_for_inference
-        optimize_for_inference(net)  # BN folded into conv / DCN weights, bias (+residual) + ReLU as one epilogue pass
+        # BN folded into conv / DCN weights, bias (+residual) + ReLU as one epilogue pass; FPN / proto-net / shared head
+        # on stm_conv2d_planar_f32 (fp32-equivalent bf16-split MFMA convolution, all FPN levels per launch)
+        optimize_for_inference(net, planar=args.planar and args.channels_last)
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)  # dense convs NHWC (17.0 vs 20.6 ms trunk at batch 8)
         # ... except TemporalNet: on 7x7 RoI tiles MIOpen is 1.5x faster in NCHW (scripts/bench_temporalnet.py)

@@ -231,8 +231,17 @@ typedef struct stm_conv_geom {
     int B, H, W, C;       /* input  [B, H, W, C] (NHWC) */
     int Ho, Wo, Cout;     /* output [B, Ho, Wo, Cout] */
     int kh, kw, sh, sw, ph, pw;
-    int x_ld, out_ld, res_ld; /* floats between consecutive pixels of x / out / residual; 0 = dense (C / Cout / Cout) */
+    int x_ld, out_ld, res_ld; /* elements between consecutive pixels of x / out / residual; 0 = dense (groups*C / Cout / Cout) */
     int planes;           /* 3 or 2, must match the packed weights */
+    /* --- the fields below are read by stm_conv2d_planar_f32 only; all zero = one dense ungrouped image batch --- */
+    int groups;           /* grouped convolution: C input channels and Cout/groups output channels PER GROUP (0 = 1);
+                             Cout/groups must be a multiple of 128 when groups > 1 */
+    int n_levels;         /* > 0: the pixel axis is the concatenation of n_levels (<= 8) image batches of different
+                             sizes -- the FPN levels a shared prediction head runs over in ONE launch.  Level l holds
+                             pixels [lvl_start[l], lvl_start[l+1]) = B images of lvl_h[l] x lvl_w[l]; stride 1 and
+                             "same" padding only; B/H/W/Ho/Wo are then ignored */
+    int lvl_start[9], lvl_h[8], lvl_w[8];
+    long long x_plane_stride, out_plane_stride, res_plane_stride; /* elements between bf16 planes; 0 = dense (pixels*ld) */
 } stm_conv_geom;
 
 /* bytes of the packed (pre-split, pre-tiled) weight image; 0 on bad arguments */

@@ -21,6 +21,8 @@
 // two workgroups per CU, so one workgroup's split/stage phase runs under the other's MFMA phase.
 #include "stm_common.h"
 
+static long long* g_conv_trace = nullptr;   // see stm_debug_conv_set_trace
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -438,7 +440,13 @@ struct PlanarArgs {
     int x_ld, out_ld, res_ld;
     int relu;
     int M, n_tiles, m_tiles, slabs;
-    unsigned plane_bytes;   // B*H*W*x_ld*2
+    unsigned plane_bytes;   // bytes of one input plane that may be addressed (buffer range)
+    long long x_pstride, out_pstride, res_pstride;   // bytes between planes
+    int groups, ntpg, cout_g;                        // grouped conv: n-tiles per group, output channels per group
+    int n_levels;                                    // > 0: pixels are the concatenation of n_levels images sizes
+    int lvl_start[9], lvl_h[8], lvl_w[8];
+    int vec_epilogue;       // Cout, out_ld, res_ld multiples of 8 and 16-byte aligned pointers: vector epilogue
+    long long* trace;
 };
 
 template <int NPL, int MG>
@@ -457,14 +465,17 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     if (logical >= tiles) return;
     const int nt = logical % a.n_tiles;
     const int mt = logical / a.n_tiles;
-    const int m0 = mt * BM, n0 = nt * CV_BN;
+    const int m0 = mt * BM;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % (2 * MG), wn = wave / (2 * MG);
 
+    // grouped convolution: n-tile -> group; the group reads its own C input channels and writes its own cout_g outputs
+    const int grp = nt / a.ntpg;
+    const int n0g = (nt - grp * a.ntpg) * CV_BN;           // first output channel of this tile within its group
     // DMA duties of this lane: activation row groups 2*wave and 2*wave+1 (16 rows x 64 B each, all planes)
-    int iy0[2], ix0[2], pbase[2];
+    int iy0[2], ix0[2], pbase[2], hl[2], wl[2];
     const int slot = lane & 3;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -472,43 +483,57 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         const int m = m0 + r;
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
-        const int b = mm / (a.Ho * a.Wo);
-        const int rem = mm - b * (a.Ho * a.Wo);
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, first = 0, local = mm;
+        if (a.n_levels > 0) {
+            // the pixel axis concatenates several image sizes (the FPN levels a shared head runs over): find this
+            // pixel's level; stride 1 / same padding there, so input and output pixel indices coincide
+#pragma unroll
+            for (int l = 0; l < 8; ++l)
+                if (l < a.n_levels && mm >= a.lvl_start[l]) { first = a.lvl_start[l]; H = a.lvl_h[l]; W = a.lvl_w[l]; }
+            Ho = H; Wo = W; local = mm - first;
+        }
+        const int b = local / (Ho * Wo);
+        const int rem = local - b * (Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
         iy0[i] = ok ? oy * a.sh - a.ph : -(1 << 20);
         ix0[i] = ox * a.sw - a.pw;
-        // byte offset of (pixel, logical chunk) within a plane, minus the tap / channel-slab terms
-        pbase[i] = (b * a.H * a.W) * a.x_ld * 2 + ((slot ^ ((r >> 2) & 3)) << 4);
+        hl[i] = H; wl[i] = W;
+        // byte offset of (image origin, group channel base, logical chunk) within a plane
+        pbase[i] = ((first + b * H * W) * a.x_ld + grp * a.C) * 2 + ((slot ^ ((r >> 2) & 3)) << 4);
     }
     __amdgpu_buffer_rsrc_t xr[NPL];
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
-        xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.plane_bytes, 0, (int)a.plane_bytes, 0x00020000);
+        xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
     const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * WBUF;
     const int taps = a.kh * a.kw, S = a.slabs;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
 
     int s_tap = 0, s_c = 0;
-    auto dma = [&](int slab, int buf) {
+    auto dma_x = [&](int buf) {
         uint8_t* xb = smem + buf * BUF;
         const int ky = s_tap / a.kw, kx = s_tap - ky * a.kw;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned off = in ? (unsigned)(pbase[i] + ((iy * a.W + ix) * a.x_ld + s_c * CV_BK) * 2) : CV_OOB;
+            // branch-free (a select the compiler turns into an exec-masked branch would split the MFMA block)
+            const unsigned oob = ((unsigned)iy >= (unsigned)hl[i]) | ((unsigned)ix >= (unsigned)wl[i]);
+            const unsigned off = (unsigned)(pbase[i] + ((iy * wl[i] + ix) * a.x_ld + s_c * CV_BK) * 2) | (oob << 31);
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(xb + p * (BM * 64) + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
         }
+        if (++s_tap == taps) { s_tap = 0; ++s_c; }
+    };
+    auto dma_w = [&](int slab, int buf) {
+        uint8_t* wb = smem + buf * BUF + XBUF;
         const uint8_t* wsrc = wtile + (size_t)slab * WBUF;
 #pragma unroll
         for (int j = 0; j < WDMA; ++j) {
             const int wi = wave + NWAVES * j;
-            __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + wi * 1024 + lane * 16), (lds_ptr)(xb + XBUF + wi * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + wi * 1024 + lane * 16), (lds_ptr)(wb + wi * 1024), 16, 0, 0);
         }
-        if (++s_tap == taps) { s_tap = 0; ++s_c; }
     };
 
     f32x16 acc[2][2], accl[2][2];
@@ -520,13 +545,28 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
 
     const int lrow = lane & 31, lh = lane >> 5;
-    dma(0, 0);
+#ifdef STM_CONV_TRACE
+    const bool tr = a.trace != nullptr && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4 * MG - 1);
+#define PL_STAMP(k) if (tr && s < 64) a.trace[((wave != 0) * 64 + s) * 8 + (k)] = clock64();
+#else
+    const bool tr = false;
+#define PL_STAMP(k)
+#endif
+    dma_x(0);
+    dma_w(0, 0);
     for (int s = 0; s < S; ++s) {
+        PL_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of slab s has landed
+        PL_STAMP(1);
         __syncthreads();                                     // ... everyone's has, and buffer (s+1)&1 is no longer read
-        if (s + 1 < S) dma(s + 1, (s + 1) & 1);
+        PL_STAMP(2);
         const uint8_t* xs = smem + (s & 1) * BUF;
         const uint8_t* ws = xs + XBUF;
+        // Source order matters: an LDS-DMA is an LDS store to the compiler, so fragment reads cannot move above it.
+        // Each half (k-step) therefore reads its fragments first and is followed by its share of slab s+1's DMA, and the
+        // schedule directives deal the DMA's address arithmetic and issue out between that half's MFMAs.  Issued as one
+        // block ahead of the MFMAs the same ~60 instructions took 850-2800 cycles: the SIMD's other wave is issuing
+        // MFMAs then and takes the issue slots.  Past the last slab the DMA re-reads it into the idle buffer (no branch).
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[2][NPL], bf[2][NPL];
@@ -537,6 +577,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                     af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + i * 32 + lrow, 2 * ks + lh));
                     bf[i][p] = *reinterpret_cast<const bf16x8*>(ws + p * CV_PLANE_B + lds_off(wn * 64 + i * 32 + lrow, 2 * ks + lh));
                 }
+            if (ks == 0) dma_x((s + 1) & 1);
+            else dma_w(min(s + 1, S - 1), (s + 1) & 1);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -551,44 +593,122 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                     accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                 }
-        }
-    }
-
-    // epilogue: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes of the result
-    const size_t opl = (size_t)a.M * a.out_ld, rpl = (size_t)a.M * a.res_ld;
-    __bf16* outp = reinterpret_cast<__bf16*>(a.out_pl);
-    const __bf16* resp = reinterpret_cast<const __bf16*>(a.res_pl);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = n0 + wn * 64 + j * 32 + lrow;
-        if (co >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[co] : 0.0f;
+            for (int k = 0; k < 8 * NPL; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA
+                if (ks == 0) __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);       // VALU / SALU of the DMA addresses
+                else __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
+                if (k % 3 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // a DMA
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PL_STAMP(4);
+    }
+#undef PL_STAMP
+    if (tr) a.trace[(wave != 0) * 512 + 7] = clock64();
+
+    // epilogue: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes of the result.
+    // Fast path (Cout, leading dimensions multiples of 8): each wave parks its 64 x 64 accumulator tile in LDS (free
+    // now) and re-reads it pixel-major, 8 consecutive channels per lane, so every global access is a 16-byte vector
+    // (24 stores per thread for the three planes instead of 192 two-byte ones).
+    const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
+    if (a.vec_epilogue) {
+        __syncthreads();                                   // all fragment reads of the last slab are done
+        constexpr int EP_LD = 68;                          // floats per parked pixel row (64 + 4 pad)
+        float* park = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
-                float v = (acc[i][j][r] + accl[i][j][r]) + bv;
-                if (a.res_f32) v += a.res_f32[(size_t)m * a.res_ld + co];
-                if (resp) {
-                    const size_t ri = (size_t)m * a.res_ld + co;
-                    v += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
-                }
-                if (a.relu) v = v > 0.0f ? v : 0.0f;
-                if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co] = v;
-                if (outp) {
-                    const size_t oi = (size_t)m * a.out_ld + co;
-                    const __bf16 h = (__bf16)v;
-                    const float r1 = v - (float)h;
-                    const __bf16 mid = (__bf16)r1;
-                    const float r2 = r1 - (float)mid;
-                    outp[oi] = h;
-                    outp[oi + opl] = mid;
-                    outp[oi + 2 * opl] = (__bf16)r2;
-                }
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    park[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP_LD + j * 32 + lrow] = acc[i][j][r] + accl[i][j][r];
+        // same wave reads back what it wrote: no workgroup barrier needed, only the LDS counter
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int seg = lane & 7, prow = lane >> 3;
+        const int cog = n0g + wn * 64 + seg * 8;           // channel within the group
+        const int co = grp * a.cout_g + cog;
+        const bool co_ok = cog < a.cout_g;                 // cout_g % 8 == 0: the whole 8-channel segment is in or out
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && co_ok) ? a.bias[co + e] : 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int pr = pass * 8 + prow;
+            const int m = m0 + wm * 64 + pr;
+            if (m >= a.M || !co_ok) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
+            float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+            if (a.res_f32) {
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co);
+                const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co + 4);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
             }
+            if (a.res_pl) {
+                const size_t ri = ((size_t)m * a.res_ld + co) * 2;
+                const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri);
+                const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 2);
+                const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += ((float)p0[e] + (float)p1[e]) + (float)p2[e];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+            }
+            if (a.out_f32) {
+                float* o = a.out_f32 + (size_t)m * a.out_ld + co;
+                *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+            if (a.out_pl) {
+                unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
+                uint8_t* o = a.out_pl + ((size_t)m * a.out_ld + co) * 2;
+                *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+                *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+                *reinterpret_cast<u32x4*>(o + opl * 4) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+            }
+        }
+    } else {
+        __bf16* outp = reinterpret_cast<__bf16*>(a.out_pl);
+        const __bf16* resp = reinterpret_cast<const __bf16*>(a.res_pl);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cog = n0g + wn * 64 + j * 32 + lrow;
+            if (cog >= a.cout_g) continue;
+            const int co = grp * a.cout_g + cog;
+            const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m >= a.M) continue;
+                    float v = (acc[i][j][r] + accl[i][j][r]) + bv;
+                    if (a.res_f32) v += a.res_f32[(size_t)m * a.res_ld + co];
+                    if (resp) {
+                        const size_t ri = (size_t)m * a.res_ld + co;
+                        v += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
+                    }
+                    if (a.relu) v = v > 0.0f ? v : 0.0f;
+                    if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co] = v;
+                    if (outp) {
+                        const size_t oi = (size_t)m * a.out_ld + co;
+                        const __bf16 h = (__bf16)v;
+                        const float r1 = v - (float)h;
+                        const __bf16 mid = (__bf16)r1;
+                        const float r2 = r1 - (float)mid;
+                        outp[oi] = h;
+                        outp[oi + opl] = mid;
+                        outp[oi + 2 * opl] = (__bf16)r2;
+                    }
+                }
+        }
     }
+    if (tr) a.trace[(wave != 0) * 512 + 15] = clock64();
 #endif
 }
 
@@ -652,7 +772,9 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
 template <int NPL, int MG>
 int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
 {
-    const size_t lds = (size_t)2 * (NPL * CV_BM * MG * 64 + NPL * CV_PLANE_B);
+    size_t lds = (size_t)2 * (NPL * CV_BM * MG * 64 + NPL * CV_PLANE_B);
+    const size_t park = (size_t)4 * MG * 64 * 68 * sizeof(float);   // the epilogue parks one 64 x 64 tile per wave
+    if (lds < park) lds = park;
     STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
     hipLaunchKernelGGL((conv_planar_kernel<NPL, MG>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
@@ -679,7 +801,6 @@ bool geom_ok(const stm_conv_geom* g, const char* who)
 
 }  // namespace
 
-static long long* g_conv_trace = nullptr;
 // debugging aid (not part of include/stmask_hip.h): device buffer of 2*64*8 int64 receiving workgroup 0's per-phase clocks
 extern "C" void stm_debug_conv_set_trace(void* dev_buf) { g_conv_trace = static_cast<long long*>(dev_buf); }
 
@@ -780,18 +901,43 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
                                      const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
                                      int relu, stm_stream_t stream)
 {
+    const char* who = "stm_conv2d_planar_f32";
     STM_REQUIRE(x_planes && packed_weight && (out_f32 || out_planes), STM_ENULL,
-                "stm_conv2d_planar_f32: x_planes/packed_weight and at least one output must be non-NULL");
-    if (!geom_ok(g, "stm_conv2d_planar_f32")) return STM_EINVAL;
-    const int x_ld = g->x_ld ? g->x_ld : g->C, out_ld = g->out_ld ? g->out_ld : g->Cout, res_ld = g->res_ld ? g->res_ld : g->Cout;
-    STM_REQUIRE(x_ld >= g->C && x_ld % 8 == 0 && out_ld >= g->Cout && res_ld >= g->Cout, STM_EINVAL,
-                "stm_conv2d_planar_f32: bad leading dimensions x_ld=%d out_ld=%d res_ld=%d", x_ld, out_ld, res_ld);
+                "%s: x_planes/packed_weight and at least one output must be non-NULL", who);
+    STM_REQUIRE(g, STM_ENULL, "%s: geometry is NULL", who);
+    const int groups = g->groups > 0 ? g->groups : 1;
+    STM_REQUIRE(g->C > 0 && g->C % CV_BK == 0 && g->Cout > 0 && g->Cout % groups == 0 && g->kh > 0 && g->kw > 0 &&
+                (g->planes == 2 || g->planes == 3), STM_EINVAL, "%s: bad channel / kernel / planes arguments", who);
+    const int cout_g = g->Cout / groups;
+    STM_REQUIRE(groups == 1 || cout_g % CV_BN == 0, STM_EINVAL, "%s: Cout per group (%d) must be a multiple of 128", who, cout_g);
+    int64_t M, in_pixels;
+    if (g->n_levels > 0) {
+        STM_REQUIRE(g->n_levels <= 8 && g->sh == 1 && g->sw == 1 && 2 * g->ph == g->kh - 1 && 2 * g->pw == g->kw - 1, STM_EINVAL,
+                    "%s: multi-level launches need stride 1 and same padding (<= 8 levels)", who);
+        STM_REQUIRE(g->lvl_start[0] == 0, STM_EINVAL, "%s: lvl_start[0] must be 0", who);
+        for (int l = 0; l < g->n_levels; ++l) {
+            const int n = g->lvl_start[l + 1] - g->lvl_start[l];
+            STM_REQUIRE(g->lvl_h[l] > 0 && g->lvl_w[l] > 0 && n > 0 && n % (g->lvl_h[l] * g->lvl_w[l]) == 0, STM_EINVAL,
+                        "%s: level %d: %d pixels is not a whole number of %dx%d images", who, l, n, g->lvl_h[l], g->lvl_w[l]);
+        }
+        M = in_pixels = g->lvl_start[g->n_levels];
+    } else {
+        if (!geom_ok(g, who)) return STM_EINVAL;
+        M = (int64_t)g->B * g->Ho * g->Wo;
+        in_pixels = (int64_t)g->B * g->H * g->W;
+    }
+    const int x_ld = g->x_ld ? g->x_ld : groups * g->C, out_ld = g->out_ld ? g->out_ld : g->Cout, res_ld = g->res_ld ? g->res_ld : g->Cout;
+    STM_REQUIRE(x_ld >= groups * g->C && x_ld % 8 == 0 && out_ld >= g->Cout && res_ld >= g->Cout, STM_EINVAL,
+                "%s: bad leading dimensions x_ld=%d out_ld=%d res_ld=%d", who, x_ld, out_ld, res_ld);
     STM_REQUIRE((uintptr_t)x_planes % 16 == 0 && (uintptr_t)packed_weight % 16 == 0, STM_EINVAL,
-                "stm_conv2d_planar_f32: x_planes and packed_weight must be 16-byte aligned");
-    const int64_t plane_bytes = (int64_t)g->B * g->H * g->W * x_ld * 2;
-    STM_REQUIRE(plane_bytes < ((int64_t)1 << 31), STM_EUNSUPPORTED, "stm_conv2d_planar_f32: plane larger than 2 GiB");
-    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
-    STM_REQUIRE(M < ((int64_t)1 << 30), STM_EUNSUPPORTED, "stm_conv2d_planar_f32: too many output pixels");
+                "%s: x_planes and packed_weight must be 16-byte aligned", who);
+    const int64_t plane_bytes = in_pixels * x_ld * 2;
+    STM_REQUIRE(plane_bytes < ((int64_t)1 << 31), STM_EUNSUPPORTED, "%s: plane larger than 2 GiB", who);
+    STM_REQUIRE(M < ((int64_t)1 << 30), STM_EUNSUPPORTED, "%s: too many output pixels", who);
+    const int64_t xps = g->x_plane_stride ? g->x_plane_stride : in_pixels * x_ld;
+    const int64_t ops = g->out_plane_stride ? g->out_plane_stride : M * out_ld;
+    const int64_t rps = g->res_plane_stride ? g->res_plane_stride : M * res_ld;
+    STM_REQUIRE(xps % 8 == 0, STM_EINVAL, "%s: x_plane_stride must be a multiple of 8 elements", who);
     PlanarArgs a;
     a.xp = static_cast<const uint8_t*>(x_planes); a.wp = static_cast<const uint8_t*>(packed_weight); a.bias = bias;
     a.res_f32 = residual_f32; a.res_pl = static_cast<const uint8_t*>(residual_planes);
@@ -801,6 +947,15 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     a.x_ld = x_ld; a.out_ld = out_ld; a.res_ld = res_ld; a.relu = relu;
     a.M = (int)M; a.n_tiles = stm_cdiv(g->Cout, CV_BN); a.slabs = g->kh * g->kw * (g->C / CV_BK);
     a.plane_bytes = (unsigned)plane_bytes;
+    a.x_pstride = xps * 2; a.out_pstride = ops * 2; a.res_pstride = rps * 2;
+    a.groups = groups; a.cout_g = cout_g; a.ntpg = stm_cdiv(cout_g, CV_BN);
+    a.n_levels = g->n_levels > 0 ? g->n_levels : 0;
+    for (int l = 0; l < 8; ++l) { a.lvl_start[l] = g->lvl_start[l]; a.lvl_h[l] = g->lvl_h[l]; a.lvl_w[l] = g->lvl_w[l]; }
+    a.lvl_start[8] = g->lvl_start[8];
+    a.vec_epilogue = (cout_g % 8 == 0) && (out_ld % 8 == 0) && (res_ld % 8 == 0) && ((uintptr_t)out_f32 % 16 == 0) &&
+                     ((uintptr_t)out_planes % 16 == 0) && ((uintptr_t)residual_f32 % 16 == 0) && ((uintptr_t)residual_planes % 16 == 0) &&
+                     (ops % 8 == 0) && (rps % 8 == 0) && !getenv("STM_CONV_SCALAR_EPILOGUE");
+    a.trace = g_conv_trace;
     const char* fk = getenv("STM_CONV_MG");
     const int forced = fk ? atoi(fk) : 0;
     const int64_t big_tiles = (int64_t)stm_cdiv(M, 2 * CV_BM) * a.n_tiles;

@@ -91,9 +91,11 @@ class _FusedBottleneck(Bottleneck):
         return _epilogue(out, self.bias3, res, True)
 
 
-def optimize_for_inference(net):
+def optimize_for_inference(net, planar=False):
     """fold_batchnorm + fused conv epilogues on the backbone, FPN prediction layers, proto-net and the head towers.
-    In place, eval mode only; call after the weights are loaded and the model is on its device."""
+    In place, eval mode only; call after the weights are loaded and the model is on its device.
+    planar=True (GPU only) additionally routes FPN prediction/downsample layers, proto-net and the shared head through
+    the bf16-split matrix-core convolution (stmask_amd/planar.py)."""
     n_bn = fold_batchnorm(net)
     n_fused = 0
     bb = net.backbone
@@ -129,4 +131,7 @@ def optimize_for_inference(net):
         pred.__class__ = _ConvBiasReLU
         n_fused += 1
     net.fpn.pred_relu_fused = True
+    if planar:
+        from .planar import PlanarGraph
+        net._planar = PlanarGraph(net)
     return n_bn, n_fused

@@ -72,6 +72,8 @@ class STMask(nn.Module):
             bb_outs = tuple(o.float() for o in bb_outs)
         else:
             bb_outs = self.backbone(x)
+        if getattr(self, "_planar", None) is not None:     # fuse.optimize_for_inference(net, planar=True)
+            return self._planar.run([bb_outs[i] for i in self.backbone_selected])
         fpn_outs = self.fpn([bb_outs[i] for i in self.backbone_selected])
         proto = F.relu(self.proto_net(fpn_outs[self.proto_src]))
         proto = proto.permute(0, 2, 3, 1).contiguous()

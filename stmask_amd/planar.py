@@ -1,0 +1,306 @@
+"""Planar inference graph: FPN prediction / downsample layers, the proto-net and the shared prediction head run on
+stm_conv2d_planar_f32 (include/stmask_hip.h) -- activations stay in the three-plane bf16 split between layers, the
+five FPN levels of the shared head go through every layer in ONE launch (pixel axis = concatenated levels), the four
+branch towers are one Cout=1024 layer followed by one grouped layer, and the per-kernel-shape output layers are one
+grouped launch each.  Values are those of the reference's fp32 convolutions to fp32 rounding (tests/test_gpu_conv.py,
+tests/test_gpu_model.py); what changes is the schedule:
+
+    reference (prediction_head_FC.py:146-195, per level, 5 levels): 1 + 8 + 15 convolutions, each + bias + ReLU kernels
+    here: 1 + 1 + 1 + 3 launches for all levels together.
+
+Built by fuse.optimize_for_inference(net, planar=True) from the (BN-folded) modules; parameters are read once and packed
+(stm_conv_pack_weights_f32).  Heads with FCB branches (use_dcn_class / track / mask) keep their module path for the
+head; FPN and proto-net still run planar.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import StmError, c_i, check
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class PlanarConv:
+    """One packed convolution layer.  x / outputs are described by raw (tensor, pixel offset) pairs so that a layer can
+    read from and write into slices of larger plane buffers."""
+
+    def __init__(self, weight, bias, stride=1, padding=0, relu=False, groups=1, planes=3):
+        weight = weight.detach().float().contiguous()
+        self.O, self.C, self.kh, self.kw = weight.shape
+        (self.sh, self.sw), (self.ph, self.pw) = _pair(stride), _pair(padding)
+        self.relu, self.groups, self.planes = relu, groups, planes
+        self.packed = ops.conv_pack_weights(weight, planes)
+        self.bias = bias.detach().float().contiguous() if bias is not None else None
+
+    def __call__(self, xp, shape, out="planes", x_off=0, out_planes=None, out_f32=None, out_off=0, residual=None):
+        """xp: [3, N, x_ld] bf16.  shape: ("img", B, H, W) -> pixels [x_off, x_off + B*H*W) of xp are one image batch;
+        ("levels", B, [(H, W), ...]) -> all of xp, concatenated levels.  out: "planes" | "f32" | "both" allocates dense
+        outputs unless out_planes / out_f32 ([3, N', ld] / [N', ld]) are given, then rows [out_off, ...) are written."""
+        if xp.dtype != torch.bfloat16 or xp.dim() != 3 or xp.shape[0] != 3 or not xp.is_contiguous():
+            raise StmError(f"PlanarConv: expected contiguous bf16 planes [3, N, C], got {xp.dtype} {tuple(xp.shape)}")
+        x_ld = xp.shape[2]
+        g = _lib.ConvGeom()
+        g.C, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw = self.C, self.O, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw
+        g.planes, g.groups, g.x_ld = self.planes, self.groups, x_ld
+        if x_ld != self.groups * self.C:
+            raise StmError(f"PlanarConv: input has {x_ld} channels, layer expects {self.groups} x {self.C}")
+        if shape[0] == "levels":
+            _, B, sizes = shape
+            g.n_levels = len(sizes)
+            start = 0
+            for l, (h, w) in enumerate(sizes):
+                g.lvl_start[l], g.lvl_h[l], g.lvl_w[l] = start, h, w
+                start += B * h * w
+            g.lvl_start[len(sizes)] = start
+            M = n_in = start
+            if x_off or xp.shape[1] != start:
+                raise StmError("PlanarConv: a multi-level launch covers the whole plane buffer")
+        else:
+            _, B, H, W = shape
+            Ho, Wo = ops.conv_out_hw(H, W, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, 1, 1)
+            g.B, g.H, g.W, g.Ho, g.Wo = B, H, W, Ho, Wo
+            M, n_in = B * Ho * Wo, B * H * W
+            if x_off + n_in > xp.shape[1]:
+                raise StmError("PlanarConv: input slice runs past the plane buffer")
+        g.x_plane_stride = xp.shape[1] * x_ld
+        dev = xp.device
+        if out in ("planes", "both") and out_planes is None:
+            out_planes, out_off_p = torch.empty(3, M, self.O, device=dev, dtype=torch.bfloat16), 0
+        else:
+            out_off_p = out_off
+        if out in ("f32", "both") and out_f32 is None:
+            out_f32, out_off_f = torch.empty(M, self.O, device=dev, dtype=torch.float32), 0
+        else:
+            out_off_f = out_off
+        if out == "planes":
+            out_f32 = None
+        if out == "f32":
+            out_planes = None
+        ld = None
+        for t in (out_planes, out_f32):
+            if t is not None:
+                if ld is not None and t.shape[-1] != ld:
+                    raise StmError("PlanarConv: fp32 and planar outputs must share their leading dimension")
+                ld = t.shape[-1]
+        g.out_ld = ld
+        p_pl = p_f32 = 0
+        if out_planes is not None:
+            g.out_plane_stride = out_planes.shape[1] * ld
+            p_pl = out_planes.data_ptr() + out_off_p * ld * 2
+        if out_f32 is not None:
+            p_f32 = out_f32.data_ptr() + out_off_f * ld * 4
+        r32 = rpl = 0
+        if residual is not None:
+            if residual.dtype == torch.bfloat16:
+                g.res_ld, g.res_plane_stride = residual.shape[2], residual.shape[1] * residual.shape[2]
+                rpl = residual.data_ptr()
+            else:
+                g.res_ld = residual.shape[-1]
+                r32 = residual.data_ptr()
+        rc = _lib.lib().stm_conv2d_planar_f32(ctypes.c_void_p(xp.data_ptr() + x_off * x_ld * 2), ops._p(self.packed),
+                                              ops._p(self.bias), ctypes.c_void_p(r32), ctypes.c_void_p(rpl),
+                                              ctypes.c_void_p(p_f32), ctypes.c_void_p(p_pl), ctypes.byref(g),
+                                              c_i(1 if self.relu else 0), ops._stream())
+        check(rc, "stm_conv2d_planar_f32")
+        if out == "both":
+            return out_f32, out_planes
+        return out_f32 if out == "f32" else out_planes
+
+
+def _nhwc(t):
+    """[B, C, H, W] (any strides) -> contiguous [B, H, W, C] (a free view when t is channels_last)."""
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _split(t_nhwc):
+    """fp32 [B, H, W, C] -> planes [3, B*H*W, C]."""
+    B, H, W, C = t_nhwc.shape
+    return ops.split_planes(t_nhwc).view(3, B * H * W, C)
+
+
+class PlanarGraph:
+    GROUP_PAD = 128   # output channels per group of the final (grouped) layers
+
+    def __init__(self, net):
+        cfg = net.cfg
+        self.net = net
+        fpn = net.fpn
+        self.n_lat = len(fpn.lat_layers)
+        # FPN prediction convs always end in ReLU (FPN.py:96-100); downsample convs do not
+        self.fpn_pred = [PlanarConv(m.weight, m.bias, m.stride, m.padding, relu=True) for m in fpn.pred_layers]
+        self.fpn_down = [PlanarConv(m.weight, m.bias, m.stride, m.padding, relu=False) for m in fpn.downsample_layers]
+        # proto-net: Conv2d / ReLU / InterpolateModule sequence, then F.relu in STMask.forward_single
+        self.proto = []
+        mods = [m for m in net.proto_net.children() if not isinstance(m, (torch.nn.ReLU, torch.nn.Identity))]
+        for m in mods:
+            if isinstance(m, torch.nn.Conv2d):
+                self.proto.append(PlanarConv(m.weight, m.bias, m.stride, m.padding, relu=True))
+            else:
+                self.proto.append(m)   # the bilinear upsample
+        self.cor_idx = net.correlation_selected_layer if cfg.temporal_fusion_module else None
+        head = net.prediction_layers[0]
+        self.head_planar = not (cfg.use_dcn_class or cfg.use_dcn_track or cfg.use_dcn_mask) and cfg.share_prediction_module
+        if not self.head_planar:
+            return
+        convs = lambda seq: [m for m in seq.children() if isinstance(m, torch.nn.Conv2d)]
+        up = convs(head.upfeature)
+        assert len(up) == 1
+        self.up = PlanarConv(up[0].weight, up[0].bias, 1, up[0].padding, relu=True)
+        towers = [convs(head.conf_extra), convs(head.bbox_extra), convs(head.mask_extra), convs(head.track_extra)]
+        assert all(len(t) == 2 for t in towers), "extra_layers (2,2,2,2) is the only head layout on the hot path"
+        w1 = torch.cat([t[0].weight for t in towers], 0)
+        b1 = torch.cat([t[0].bias for t in towers], 0)
+        self.tower1 = PlanarConv(w1, b1, 1, towers[0][0].padding, relu=True)               # 256 -> 4 x 256, shared input
+        w2 = torch.cat([t[1].weight for t in towers], 0)
+        b2 = torch.cat([t[1].bias for t in towers], 0)
+        self.tower2 = PlanarConv(w2, b2, 1, towers[0][1].padding, relu=True, groups=4)     # 4 x (256 -> 256)
+        self.finals = []
+        P = self.GROUP_PAD
+        self.dims = (head.num_priors * head.num_classes, head.num_priors * 4, head.num_priors * head.mask_dim,
+                     head.num_priors * head.embed_dim)
+        for k in range(len(cfg.head_layer_params)):
+            mods = [[head.conf_layer[k]], [head.centerness_layer[k], head.bbox_layer[k]], [head.mask_layer[k]], [head.track_layer[k]]]
+            ws, bs = [], []
+            for grp in mods:
+                w = torch.cat([m.weight for m in grp], 0)
+                b = torch.cat([m.bias for m in grp], 0)
+                assert w.shape[0] <= P
+                ws.append(F.pad(w, (0, 0, 0, 0, 0, 0, 0, P - w.shape[0])))
+                bs.append(F.pad(b, (0, P - b.shape[0])))
+            m0 = mods[0][0]
+            self.finals.append(PlanarConv(torch.cat(ws, 0), torch.cat(bs, 0), 1, m0.padding, relu=False, groups=4))
+        self.head = head
+
+    # ------------------------------------------------------------------------------------------------------------
+    def run(self, bb_outs):
+        """bb_outs: the selected backbone outputs (C3, C4, C5).  Returns (fpn_outs, pred) as STMask.forward_single."""
+        net, fpn = self.net, self.net.fpn
+        n = self.n_lat
+        B = bb_outs[0].shape[0]
+        # laterals + top-down pathway in fp32 (1x1 convs on the widest tensors: left to the GEMM library)
+        lat, x = [None] * n, None
+        for i, layer in enumerate(fpn.lat_layers):
+            j = n - 1 - i
+            lateral = layer(bb_outs[j])
+            if x is None:
+                x = lateral
+            else:
+                h, w = bb_outs[j].shape[2:]
+                x = F.interpolate(x, size=(h, w), mode=fpn.interpolation_mode, align_corners=False) + lateral
+            lat[j] = x
+        sizes = [tuple(t.shape[2:]) for t in lat]
+        for d in self.fpn_down:
+            h, w = sizes[-1]
+            sizes.append(ops.conv_out_hw(h, w, d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, 1, 1))
+        starts = [0]
+        for h, w in sizes:
+            starts.append(starts[-1] + B * h * w)
+        ntot, nf = starts[-1], self.fpn_pred[0].O
+        dev = lat[0].device
+        feat = torch.empty(3, ntot, nf, device=dev, dtype=torch.bfloat16)    # P3..P7, all levels, planar
+        feat32 = torch.empty(ntot, nf, device=dev, dtype=torch.float32) if not self.head_planar else None
+        fpn_outs = [None] * len(sizes)
+        for i, conv in enumerate(self.fpn_pred):
+            j = n - 1 - i
+            h, w = sizes[j]
+            xp = _split(_nhwc(lat[j]))
+            if feat32 is not None:     # module-path head: it wants every level in fp32 as well
+                conv(xp, ("img", B, h, w), out="both", out_planes=feat, out_f32=feat32, out_off=starts[j])
+                fpn_outs[j] = feat32[starts[j]:starts[j + 1]].view(B, h, w, nf).permute(0, 3, 1, 2)
+            else:
+                conv(xp, ("img", B, h, w), out="planes", out_planes=feat, out_off=starts[j])
+        for i, conv in enumerate(self.fpn_down):
+            j = n + i
+            h, w = sizes[j - 1]
+            if feat32 is not None:
+                conv(feat, ("img", B, h, w), out="both", x_off=starts[j - 1], out_planes=feat, out_f32=feat32, out_off=starts[j])
+                fpn_outs[j] = feat32[starts[j]:starts[j + 1]].view(B, *sizes[j], nf).permute(0, 3, 1, 2)
+            else:
+                conv(feat, ("img", B, h, w), out="planes", x_off=starts[j - 1], out_planes=feat, out_off=starts[j])
+        if feat32 is None and self.cor_idx is not None:
+            # fp32 NCHW view of the correlation level, rebuilt from its planes (exact)
+            j = self.cor_idx
+            pl = feat[:, starts[j]:starts[j + 1]].float()
+            fpn_outs[j] = ((pl[0] + pl[1]) + pl[2]).view(B, *sizes[j], nf).permute(0, 3, 1, 2)
+
+        # ---- proto-net on P3 (mask_proto_src) ------------------------------------------------------------------
+        src = net.proto_src
+        h, w = sizes[src]
+        xp, x_off, cur = feat, starts[src], None
+        n_layers = len(self.proto)
+        for li, layer in enumerate(self.proto):
+            last = li == n_layers - 1
+            if isinstance(layer, PlanarConv):
+                nxt_is_interp = (not last) and not isinstance(self.proto[li + 1], PlanarConv)
+                if cur is not None:            # fp32 NHWC tensor pending a split
+                    xp, x_off = _split(cur), 0
+                    cur = None
+                if last or nxt_is_interp:
+                    y = layer(xp, ("img", B, h, w), out="f32", x_off=x_off)
+                    cur = y.view(B, h, w, layer.O)
+                else:
+                    xp, x_off = layer(xp, ("img", B, h, w), out="planes", x_off=x_off), 0
+            else:                              # bilinear upsample, fp32
+                t = layer(cur.permute(0, 3, 1, 2))
+                h, w = t.shape[2:]
+                cur = _nhwc(t)
+        proto = cur                            # [B, 2h, 2w, 32], ReLU applied by the last layer (STMask.py:227)
+
+        keys = ("mask_coeff", "priors", "loc", "T2S_feat", "centerness", "conf", "track")
+        pred = {k: [] for k in keys}
+        if not self.head_planar:
+            for idx, layer in zip(net.selected_layers, net.prediction_layers):
+                p = layer(fpn_outs[idx])
+                for k in keys:
+                    pred[k].append(p[k])
+            for k in keys:
+                if k != "T2S_feat":
+                    pred[k] = torch.cat(pred[k], 1)
+            pred["proto"] = proto
+            return fpn_outs, pred
+
+        # ---- shared prediction head, all levels per launch -------------------------------------------------------
+        lv = ("levels", B, sizes)
+        head = self.head
+        if self.cor_idx is not None:
+            up32, up = self.up(feat, lv, out="both")
+        else:
+            up32, up = None, self.up(feat, lv, out="planes")
+        t1 = self.tower1(up, lv, out="planes")
+        t2 = self.tower2(t1, lv, out="planes")
+        outs = [f(t2, lv, out="f32") for f in self.finals]          # each [ntot, 4 * GROUP_PAD]
+        P = self.GROUP_PAD
+        ncls, nbox, nmask, ntrk = self.dims
+        K = len(outs)
+        conf, loc, mask, track, cen, t2s = [], [], [], [], [], []
+        for l, (hh, ww) in enumerate(sizes):
+            sl = slice(starts[l], starts[l + 1])
+            per_k = [o[sl].view(B, hh * ww, 4 * P) for o in outs]
+            cat = torch.stack(per_k, dim=2)                                           # [B, HW, K, 4P]
+            conf.append(cat[..., 0:ncls].reshape(B, -1, head.num_classes))
+            # group 1 = centerness (1 per prior) then bbox (4 per prior)
+            npri = head.num_priors
+            loc.append(cat[..., P + npri:P + npri + nbox].reshape(B, -1, 4))
+            mask.append(cat[..., 2 * P:2 * P + nmask].reshape(B, -1, head.mask_dim))
+            track.append(cat[..., 3 * P:3 * P + ntrk].reshape(B, -1, head.embed_dim))
+            # the reference concatenates centerness along H (prediction_head_FC.py:189): order (k, y, x)
+            cen.append(torch.stack([pk[..., P:P + npri] for pk in per_k], dim=1).reshape(B, -1, 1))
+            pred["priors"].append(head.make_priors(hh, ww, dev))
+            if up32 is not None and l == self.cor_idx:
+                t2s.append(up32[sl].view(B, hh, ww, -1).permute(0, 3, 1, 2))
+            else:
+                t2s.append(None)
+        pred["conf"] = torch.cat(conf, 1)
+        pred["loc"] = torch.cat(loc, 1)
+        pred["mask_coeff"] = torch.cat(mask, 1)
+        pred["track"] = F.normalize(torch.cat(track, 1), dim=-1)
+        pred["centerness"] = torch.tanh(torch.cat(cen, 1))
+        pred["priors"] = torch.cat(pred["priors"], 1)
+        pred["T2S_feat"] = t2s
+        pred["proto"] = proto
+        return fpn_outs, pred

@@ -136,6 +136,48 @@ def test_optimized_inference_graph_on_gpu(channels_last):
         assert (a[k] - b[k]).abs().max().item() < 2e-4 * scale, k
 
 
+@pytest.mark.parametrize("name,tag", CASES[:3])
+def test_planar_graph_matches_module_path_and_reference(name, tag):
+    """fuse.optimize_for_inference(planar=True): FPN pred/downsample layers, proto-net and (FCA-only configs) the whole
+    shared head on the bf16-split matrix-core convolution, all five levels per launch.  Same tensors as the module
+    path to fp32 rounding (5e-5 relative, the convolutions themselves are at 2e-6), the reference goldens to the
+    tolerance the module path is held to, and the clip's detections as before."""
+    from stmask_amd.fuse import optimize_for_inference
+    g = load_golden(f"model_{tag}.npz")
+    h, w = [int(v) for v in g["frames_hw"]]
+    ref_net = build(name)
+    opt_net = build(name)
+    optimize_for_inference(opt_net, planar=True)
+    opt_net = opt_net.to(memory_format=torch.channels_last)
+    opt_net.TemporalNet = opt_net.TemporalNet.to(memory_format=torch.contiguous_format)
+    assert opt_net._planar.head_planar == (tag == "r50_fca")
+    frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0)
+    x = frames[:2].cuda()
+    with torch.no_grad():
+        fa, a = ref_net.forward_single(x)
+        fb, b = opt_net.forward_single(x.contiguous(memory_format=torch.channels_last))
+    assert torch.equal(a["priors"], b["priors"])
+    for k in ("loc", "conf", "mask_coeff", "centerness", "proto", "track"):
+        assert a[k].shape == b[k].shape, k
+        scale = max(1.0, a[k].abs().max().item())
+        assert (a[k] - b[k]).abs().max().item() < 5e-5 * scale, (k, (a[k] - b[k]).abs().max().item())
+    ci = opt_net.correlation_selected_layer
+    assert (fa[ci] - fb[ci]).abs().max().item() < 5e-5 * max(1.0, fa[ci].abs().max().item())
+    assert (a["T2S_feat"][ci] - b["T2S_feat"][ci]).abs().max().item() < 5e-5 * max(1.0, a["T2S_feat"][ci].abs().max().item())
+    for k, gk in [("loc", "f0_loc"), ("conf", "f0_conf_logits"), ("mask_coeff", "f0_mask_coeff"),
+                  ("centerness", "f0_centerness"), ("proto", "f0_proto")]:
+        ref = g[gk]
+        assert (b[k][0].cpu() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), k
+    outs = run_clip(opt_net, frames.contiguous(memory_format=torch.channels_last), "cuda")
+    for t, det in enumerate(outs):
+        ref_ids = g[f"t{t}_box_ids"].tolist()
+        got_ids = det["box_ids"].cpu().tolist() if det["box"].numel() else []
+        assert abs(len(got_ids) - len(ref_ids)) <= max(2, len(ref_ids) // 10)
+        if got_ids == ref_ids and torch.equal(det["class"].cpu(), g[f"t{t}_class"]):
+            d = det["mask"].cpu() - g[f"t{t}_mask"]
+            assert d.pow(2).mean(dim=(1, 2)).sqrt().median() < 1e-4
+
+
 def test_fp16_backbone_option_config5():
     """BASELINE config 5 flavour: fp16 autocast ResNet trunk (DCN, FPN, heads fp32).  fp16 trunk activations carry ~1e-3
     relative error, so only closeness of the prototypes / box regression to the fp32 run is asserted."""
