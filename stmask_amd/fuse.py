@@ -132,6 +132,8 @@ def optimize_for_inference(net, planar=False):
         n_fused += 1
     net.fpn.pred_relu_fused = True
     if planar:
-        from .planar import PlanarGraph
+        from .planar import PlanarGraph, PlanarTemporalNet
         net._planar = PlanarGraph(net)
+        if getattr(net, "TemporalNet", None) is not None:
+            net._planar_temporal = PlanarTemporalNet(net.TemporalNet)
     return n_bn, n_fused

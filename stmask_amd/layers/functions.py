@@ -85,14 +85,18 @@ def CandidateShift(net, ref_candidate, next_candidate, img=None, img_meta=None, 
     feat_h, feat_w = ref_candidate["fpn_feat"].shape[2:]
     roi_feats = bbox_feat_extractor(feats, box_ref, feat_h, feat_w, 7)
     n = roi_feats.shape[0]
-    n_pad = -(-n // ROI_BUCKET) * ROI_BUCKET
-    if n_pad != n:
-        roi_feats = torch.cat([roi_feats, roi_feats.new_zeros(n_pad - n, *roi_feats.shape[1:])], 0)
-    # fixed-shape blocks: the dense-conv library (MIOpen) selects / builds kernels per shape and the tracked set
-    # changes size every frame; rows are independent, so zero padding + blocking is exact
-    outs = [net.TemporalNet(roi_feats[i:i + ROI_BUCKET]) for i in range(0, n_pad, ROI_BUCKET)]
-    loc_shift = torch.cat([o[0] for o in outs], 0)[:n]
-    coeff_shift = torch.cat([o[1] for o in outs], 0)[:n]
+    ptn = getattr(net, "_planar_temporal", None)    # fuse.optimize_for_inference(net, planar=True)
+    if ptn is not None and n > 0:
+        loc_shift, coeff_shift = ptn(roi_feats)
+    else:
+        n_pad = -(-n // ROI_BUCKET) * ROI_BUCKET
+        if n_pad != n:
+            roi_feats = torch.cat([roi_feats, roi_feats.new_zeros(n_pad - n, *roi_feats.shape[1:])], 0)
+        # fixed-shape blocks: the dense-conv library (MIOpen) selects / builds kernels per shape and the tracked set
+        # changes size every frame; rows are independent, so zero padding + blocking is exact
+        outs = [net.TemporalNet(roi_feats[i:i + ROI_BUCKET]) for i in range(0, n_pad, ROI_BUCKET)]
+        loc_shift = torch.cat([o[0] for o in outs], 0)[:n]
+        coeff_shift = torch.cat([o[1] for o in outs], 0)[:n]
     box_shift = decode(loc_shift, center_size(box_ref))
     coeff = ref_candidate["mask_coeff"] + coeff_shift
     shifted["box"] = box_shift

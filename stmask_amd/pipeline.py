@@ -108,18 +108,22 @@ class BatchedClipPipeline:
         roi_feats = ops.roi_align(feats, rois, 7)
         self.timer.toc("tf_corr_roi")
         n = roi_feats.shape[0]
-        n_pad = -(-n // ROI_CHUNKS[-1]) * ROI_CHUNKS[-1]
-        if n_pad != n:  # rows are independent: zero rows change nothing
-            roi_feats = torch.cat([roi_feats, roi_feats.new_zeros(n_pad - n, *roi_feats.shape[1:])], 0)
-        # fixed-shape blocks (greedy 256 / 128 / 64): the dense-conv library (MIOpen) selects / builds kernels per shape
-        # and the tracked set changes size every frame -- three shapes mean that cost is paid three times in total
-        outs, i = [], 0
-        while i < n_pad:
-            c = next(c for c in ROI_CHUNKS if c <= n_pad - i)
-            outs.append(net.TemporalNet(roi_feats[i:i + c]))
-            i += c
-        loc_shift = torch.cat([o[0] for o in outs], 0)[:n]
-        coeff_shift = torch.cat([o[1] for o in outs], 0)[:n]
+        ptn = getattr(net, "_planar_temporal", None)
+        if ptn is not None:      # planar convolution: any RoI count, one launch per layer
+            loc_shift, coeff_shift = ptn(roi_feats)
+        else:
+            n_pad = -(-n // ROI_CHUNKS[-1]) * ROI_CHUNKS[-1]
+            if n_pad != n:  # rows are independent: zero rows change nothing
+                roi_feats = torch.cat([roi_feats, roi_feats.new_zeros(n_pad - n, *roi_feats.shape[1:])], 0)
+            # fixed-shape blocks (greedy 256 / 128 / 64): the dense-conv library (MIOpen) selects / builds kernels per
+            # shape and the tracked set changes size every frame -- three shapes mean that cost is paid three times
+            outs, i = [], 0
+            while i < n_pad:
+                c = next(c for c in ROI_CHUNKS if c <= n_pad - i)
+                outs.append(net.TemporalNet(roi_feats[i:i + c]))
+                i += c
+            loc_shift = torch.cat([o[0] for o in outs], 0)[:n]
+            coeff_shift = torch.cat([o[1] for o in outs], 0)[:n]
         self.timer.toc("tf_temporalnet")
         box_shift = ops.decode(loc_shift.contiguous(), center_size(box_ref))
         coeff = prev["mask_coeff"] + coeff_shift
@@ -143,6 +147,8 @@ class BatchedClipPipeline:
             self.tracked = [[] for _ in range(B)]
         tmr = self.timer
         tmr.tic()
+        if getattr(net, "_planar", None) is not None and tmr.on:
+            net._planar.timer = tmr      # finer stages inside the trunk
         fpn_outs, pred = net.forward_single(frames)
         tmr.toc("trunk")
         conf = F.softmax(pred["conf"], -1)

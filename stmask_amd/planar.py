@@ -143,6 +143,7 @@ class PlanarGraph:
             else:
                 self.proto.append(m)   # the bilinear upsample
         self.cor_idx = net.correlation_selected_layer if cfg.temporal_fusion_module else None
+        self.timer = None      # a pipeline._StageTimer (STM_PIPE_TIMING=1 diagnosis runs only)
         head = net.prediction_layers[0]
         self.head_planar = not (cfg.use_dcn_class or cfg.use_dcn_track or cfg.use_dcn_mask) and cfg.share_prediction_module
         if not self.head_planar:
@@ -182,6 +183,8 @@ class PlanarGraph:
         net, fpn = self.net, self.net.fpn
         n = self.n_lat
         B = bb_outs[0].shape[0]
+        toc = self.timer.toc if self.timer is not None else (lambda name: None)
+        toc("backbone")
         # laterals + top-down pathway in fp32 (1x1 convs on the widest tensors: left to the GEMM library)
         lat, x = [None] * n, None
         for i, layer in enumerate(fpn.lat_layers):
@@ -193,6 +196,7 @@ class PlanarGraph:
                 h, w = bb_outs[j].shape[2:]
                 x = F.interpolate(x, size=(h, w), mode=fpn.interpolation_mode, align_corners=False) + lateral
             lat[j] = x
+        toc("fpn_lateral")
         sizes = [tuple(t.shape[2:]) for t in lat]
         for d in self.fpn_down:
             h, w = sizes[-1]
@@ -228,6 +232,7 @@ class PlanarGraph:
             pl = feat[:, starts[j]:starts[j + 1]].float()
             fpn_outs[j] = ((pl[0] + pl[1]) + pl[2]).view(B, *sizes[j], nf).permute(0, 3, 1, 2)
 
+        toc("fpn_pred_down")
         # ---- proto-net on P3 (mask_proto_src) ------------------------------------------------------------------
         src = net.proto_src
         h, w = sizes[src]
@@ -250,6 +255,7 @@ class PlanarGraph:
                 h, w = t.shape[2:]
                 cur = _nhwc(t)
         proto = cur                            # [B, 2h, 2w, 32], ReLU applied by the last layer (STMask.py:227)
+        toc("proto_net")
 
         keys = ("mask_coeff", "priors", "loc", "T2S_feat", "centerness", "conf", "track")
         pred = {k: [] for k in keys}
@@ -273,7 +279,9 @@ class PlanarGraph:
             up32, up = None, self.up(feat, lv, out="planes")
         t1 = self.tower1(up, lv, out="planes")
         t2 = self.tower2(t1, lv, out="planes")
+        toc("head_towers")
         outs = [f(t2, lv, out="f32") for f in self.finals]          # each [ntot, 4 * GROUP_PAD]
+        toc("head_finals")
         P = self.GROUP_PAD
         ncls, nbox, nmask, ntrk = self.dims
         K = len(outs)
@@ -303,4 +311,32 @@ class PlanarGraph:
         pred["priors"] = torch.cat(pred["priors"], 1)
         pred["T2S_feat"] = t2s
         pred["proto"] = proto
+        toc("head_assemble")
         return fpn_outs, pred
+
+
+class PlanarTemporalNet:
+    """TemporalNet (track_to_segment_head.py:10-37: 3 x (3x3 conv + ReLU) on 7x7 RoI features, 7x7 average pool, two
+    linear layers) on the planar convolution.  The 633 input channels (121 correlation + 2 x 256 features) are padded to
+    640 with zero weights; any number of RoIs goes through in one launch per layer, so the fixed-shape RoI blocks the
+    dense-conv library needed (one kernel selection per shape) disappear."""
+
+    def __init__(self, tn):
+        w1 = tn.conv1.weight.detach()
+        self.cin = w1.shape[1]
+        self.cpad = -(-self.cin // 32) * 32
+        w1 = F.pad(w1, (0, 0, 0, 0, 0, self.cpad - self.cin))
+        self.c1 = PlanarConv(w1, tn.conv1.bias, 1, tn.conv1.padding, relu=True)
+        self.c2 = PlanarConv(tn.conv2.weight, tn.conv2.bias, 1, tn.conv2.padding, relu=True)
+        self.c3 = PlanarConv(tn.conv3.weight, tn.conv3.bias, 1, tn.conv3.padding, relu=True)
+        self.fc, self.fc_coeff = tn.fc, tn.fc_coeff
+
+    def __call__(self, roi_feats):
+        """roi_feats [n, 633, 7, 7] fp32 -> (loc shift [n, 4], coeff shift [n, 32])."""
+        n, c, h, w = roi_feats.shape
+        x = F.pad(roi_feats.permute(0, 2, 3, 1), (0, self.cpad - c)).contiguous()       # NHWC, channels padded
+        xp = ops.split_planes(x).view(3, n * h * w, self.cpad)
+        shape = ("img", n, h, w)
+        y = self.c3(self.c2(self.c1(xp, shape), shape), shape, out="f32")                # [n*h*w, 1024]
+        pooled = y.view(n, h * w, -1).mean(dim=1)                                        # AvgPool2d((7, 7)) on a 7x7 map
+        return self.fc(pooled), self.fc_coeff(pooled)

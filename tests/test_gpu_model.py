@@ -178,6 +178,20 @@ def test_planar_graph_matches_module_path_and_reference(name, tag):
             assert d.pow(2).mean(dim=(1, 2)).sqrt().median() < 1e-4
 
 
+def test_planar_temporalnet_matches_module():
+    """PlanarTemporalNet (633 -> 640 zero-padded channels, any RoI count per launch) == the nn.Module TemporalNet."""
+    from stmask_amd.planar import PlanarTemporalNet
+    net = build("STMask_plus_resnet50_config")
+    ptn = PlanarTemporalNet(net.TemporalNet)
+    for n in (1, 37, 200):
+        x = torch.relu(torch.randn(n, 633, 7, 7, generator=torch.Generator().manual_seed(n))).cuda()
+        with torch.no_grad():
+            la, ca = net.TemporalNet(x)
+            lb, cb = ptn(x)
+        assert (la - lb).abs().max().item() < 2e-5 * max(1.0, la.abs().max().item())
+        assert (ca - cb).abs().max().item() < 2e-5 * max(1.0, ca.abs().max().item())
+
+
 def test_fp16_backbone_option_config5():
     """BASELINE config 5 flavour: fp16 autocast ResNet trunk (DCN, FPN, heads fp32).  fp16 trunk activations carry ~1e-3
     relative error, so only closeness of the prototypes / box regression to the fp32 run is asserted."""
