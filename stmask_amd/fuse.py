@@ -132,8 +132,9 @@ def optimize_for_inference(net, planar=False):
         n_fused += 1
     net.fpn.pred_relu_fused = True
     if planar:
-        from .planar import PlanarGraph, PlanarTemporalNet
+        from .planar import PlanarBackbone, PlanarGraph, PlanarTemporalNet
         net._planar = PlanarGraph(net)
+        net._planar_backbone = PlanarBackbone(net.backbone)
         if getattr(net, "TemporalNet", None) is not None:
             net._planar_temporal = PlanarTemporalNet(net.TemporalNet)
     return n_bn, n_fused

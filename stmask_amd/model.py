@@ -70,6 +70,8 @@ class STMask(nn.Module):
             with torch.autocast("cuda", dtype=torch.float16):
                 bb_outs = self.backbone(x)
             bb_outs = tuple(o.float() for o in bb_outs)
+        elif getattr(self, "_planar_backbone", None) is not None:
+            bb_outs = self._planar_backbone(x)
         else:
             bb_outs = self.backbone(x)
         if getattr(self, "_planar", None) is not None:     # fuse.optimize_for_inference(net, planar=True)

@@ -340,3 +340,60 @@ class PlanarTemporalNet:
         y = self.c3(self.c2(self.c1(xp, shape), shape), shape, out="f32")                # [n*h*w, 1024]
         pooled = y.view(n, h * w, -1).mean(dim=1)                                        # AvgPool2d((7, 7)) on a 7x7 map
         return self.fc(pooled), self.fc_coeff(pooled)
+
+
+class PlanarBackbone:
+    """ResNet bottlenecks (backbone.py:38-58 of the reference, eval BatchNorm folded) with every 1x1 convolution, the
+    plain 3x3 convolutions and the stride-s downsample projections on the planar convolution; residual add + ReLU in
+    conv3's epilogue.  The stem (7x7, 3 input channels) stays on the dense-conv library; the deformable 3x3 layers stay on
+    deform im2col + fp32 MFMA GEMM (they take / return NCHW fp32: one layout change either side)."""
+
+    def __init__(self, bb):
+        from .dcn_v2 import DCN
+        self.bb = bb
+        self.blocks = []
+        for layer in bb.layers:
+            blks = []
+            for blk in layer:
+                c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+                e = {"c1": PlanarConv(c1.weight, c1.bias, 1, 0, relu=True),
+                     "c3": PlanarConv(c3.weight, c3.bias, 1, 0, relu=True)}
+                if isinstance(c2, DCN):
+                    c2.fuse_relu = True
+                    e["dcn"] = c2
+                else:
+                    e["c2"] = PlanarConv(c2.weight, c2.bias, c2.stride, c2.padding, relu=True)
+                if blk.downsample is not None:
+                    d = blk.downsample[0]
+                    e["ds"] = PlanarConv(d.weight, d.bias, d.stride, 0, relu=False)
+                e["stride"] = _pair(c2.stride)
+                blks.append(e)
+            self.blocks.append(blks)
+
+    def __call__(self, x):
+        bb = self.bb
+        x = bb.maxpool(bb.relu(bb.bn1(bb.conv1(x))))        # conv1 carries the folded BN + ReLU after fuse
+        B, C, H, W = x.shape
+        xp = _split(_nhwc(x))
+        outs = []
+        for blks in self.blocks:
+            y32 = None
+            for bi, e in enumerate(blks):
+                last = bi == len(blks) - 1
+                shape = ("img", B, H, W)
+                sh, sw = e["stride"]
+                Ho, Wo = (H - 1) // sh + 1, (W - 1) // sw + 1
+                if "dcn" in e:
+                    t = e["c1"](xp, shape, out="f32")                                    # [B*H*W, P] NHWC
+                    t = e["dcn"](t.view(B, H, W, -1).permute(0, 3, 1, 2))                # NCHW fp32, bias + ReLU fused
+                    mid = _split(_nhwc(t))
+                else:
+                    mid = e["c2"](e["c1"](xp, shape), shape)
+                res = e["ds"](xp, shape) if "ds" in e else xp
+                H, W = Ho, Wo
+                if last:
+                    y32, xp = e["c3"](mid, ("img", B, H, W), out="both", residual=res)
+                else:
+                    xp = e["c3"](mid, ("img", B, H, W), residual=res)
+            outs.append(y32.view(B, H, W, -1).permute(0, 3, 1, 2))                       # channels_last NCHW view
+        return tuple(outs)
