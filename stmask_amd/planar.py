@@ -359,8 +359,9 @@ class PlanarBackbone:
                 e = {"c1": PlanarConv(c1.weight, c1.bias, 1, 0, relu=True),
                      "c3": PlanarConv(c3.weight, c3.bias, 1, 0, relu=True)}
                 if isinstance(c2, DCN):
-                    c2.fuse_relu = True
                     e["dcn"] = c2
+                    om = c2.conv_offset_mask
+                    e["om"] = PlanarConv(om.weight, om.bias, om.stride, om.padding, relu=False)
                 else:
                     e["c2"] = PlanarConv(c2.weight, c2.bias, c2.stride, c2.padding, relu=True)
                 if blk.downsample is not None:
@@ -384,8 +385,14 @@ class PlanarBackbone:
                 sh, sw = e["stride"]
                 Ho, Wo = (H - 1) // sh + 1, (W - 1) // sw + 1
                 if "dcn" in e:
-                    t = e["c1"](xp, shape, out="f32")                                    # [B*H*W, P] NHWC
-                    t = e["dcn"](t.view(B, H, W, -1).permute(0, 3, 1, 2))                # NCHW fp32, bias + ReLU fused
+                    # conv1 -> fp32 (NCHW copy for the deformable sampler) and planes (offset / mask convolution);
+                    # the sampler reads the raw conv_offset_mask output (sigmoid folded in), GEMM adds bias + ReLU
+                    d = e["dcn"]
+                    t32, tpl = e["c1"](xp, shape, out="both")
+                    om = e["om"](tpl, shape, out="f32").view(B, Ho, Wo, -1).permute(0, 3, 1, 2).contiguous()
+                    xin = t32.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+                    t = ops.deform_conv(xin, None, None, d.weight, d.bias, d.stride, d.padding, d.dilation,
+                                        d.deformable_groups, relu=True, fused_om=om)
                     mid = _split(_nhwc(t))
                 else:
                     mid = e["c2"](e["c1"](xp, shape), shape)
