@@ -33,6 +33,7 @@ from stmask_amd.config import get_cfg  # noqa: E402
 from stmask_amd.model import STMask  # noqa: E402
 from stmask_amd.pipeline import BatchedClipPipeline, ClipPipeline  # noqa: E402
 
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -144,6 +145,7 @@ def main():
     if use_dist:
         dist.barrier()
     ops.im2col_timing(True)
+    ops.conv_timing(True)
     if getattr(pipe, "timer", None) is not None and pipe.timer.on:
         pipe.timer.acc.clear()   # diagnosis runs: stage times of the timed steps only
     torch.cuda.synchronize()
@@ -156,6 +158,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timing = ops.im2col_timing(False)
+    conv_t = ops.conv_timing(False) or []
     if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -181,16 +184,37 @@ def main():
                        "clips_per_gpu": args.clips, "frames_per_step": world * args.clips,
                        "detections_last_step": n_det, "parallelism": f"clip-dp{world}",
                        "pipeline": args.pipeline,
-                       "inference_graph": "bn-folded+fused-epilogues" if args.fuse else "reference-ops",
+                       "inference_graph": ("bn-folded+fused-epilogues" + ("+planar-bf16x6-convs" if (args.planar and args.channels_last) else ""))
+                                          if args.fuse else "reference-ops",
+                       "arithmetic": "fp32 in / fp32 out / fp32 accumulate; dense convs as 3 bf16 planes x 6 MFMA products "
+                                     "(max error 2e-6 of sum|x w| vs fp64, tests/test_gpu_conv.py)" if (args.fuse and args.planar and args.channels_last)
+                                     else "fp32",
                        "memory_format": "channels_last" if args.channels_last else "nchw"},
-            "roofline": {"bound": "hbm", "kernel": "deform_im2col_lds (7 DCN layers, all launches of the timed region)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic() if (args.clips == 8 and args.config == "STMask_plus_resnet50_config") else None,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)",
-                         "launches": len(timing), "avg_launch_us": round(ker_ms * 1e3 / n_launch, 2),
-                         "algorithmic_bytes_per_launch": int(ker_bytes / n_launch)},
         }
+        im2col_roof = {"bound": "hbm", "kernel": "deform_im2col_lds (7 DCN layers, all launches of the timed region)",
+                       "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(achieved / HBM_PEAK_GBS, 4),
+                       "traffic": pmc_traffic() if (args.clips == 8 and args.config == "STMask_plus_resnet50_config") else None,
+                       "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)",
+                       "launches": len(timing), "avg_launch_us": round(ker_ms * 1e3 / n_launch, 2),
+                       "algorithmic_bytes_per_launch": int(ker_bytes / n_launch)}
+        if conv_t:
+            # dominant kernel of the step: the bf16-split convolution.  achieved = fp32-equivalent algorithmic flops
+            # (2*M*Cout*Cin*kh*kw of the reference layers, zero-padded channels excluded) / launch time; peak = dense bf16
+            # MFMA peak / 6, because each fp32 product is carried by six bf16 MFMA products.
+            c_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in conv_t)
+            c_fl = sum(f for _, _, f in conv_t)
+            tf = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
+            res["roofline"] = {"bound": "mfma", "kernel": "conv_planar_kernel (bf16x3-plane split conv: backbone 1x1/3x3, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
+                               "achieved": round(tf, 1), "peak": round(BF16_MFMA_PEAK_TF / 6.0, 1), "unit": "TFLOP/s",
+                               "frac": round(tf / (BF16_MFMA_PEAK_TF / 6.0), 4), "traffic": None,
+                               "peak_note": "fp32-equivalent: 2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 product (fp32 MFMA peak is 157)",
+                               "launches": len(conv_t), "avg_launch_us": round(c_ms * 1e3 / len(conv_t), 2),
+                               "ms_per_step": round(c_ms / args.steps, 3),
+                               "algorithmic_gflop_per_launch": round(c_fl / len(conv_t) / 1e9, 2)}
+            res["roofline_im2col"] = im2col_roof
+        else:
+            res["roofline"] = im2col_roof
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.config, args.height, args.width)
         print(json.dumps(res), flush=True)

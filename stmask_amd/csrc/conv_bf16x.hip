@@ -775,8 +775,12 @@ int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
     size_t lds = (size_t)2 * (NPL * CV_BM * MG * 64 + NPL * CV_PLANE_B);
     const size_t park = (size_t)4 * MG * 64 * 68 * sizeof(float);   // the epilogue parks one 64 x 64 tile per wave
     if (lds < park) lds = park;
-    STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
+    static bool lds_reserved = false;   // per instantiation; the attribute is sticky, setting it again each launch only costs host time
+    if (!lds_reserved) {
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
+        lds_reserved = true;
+    }
     hipLaunchKernelGGL((conv_planar_kernel<NPL, MG>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kernel");
     return STM_OK;

@@ -108,6 +108,17 @@ def im2col_timing(enable):
     return old
 
 
+_conv_timing = None  # when a list: (start_event, end_event, algorithmic_flops) per planar-conv launch (bench.py roofline)
+
+
+def conv_timing(enable):
+    """bench.py: time every stm_conv2d_planar_f32 launch with HIP events on the launch stream (live MFMA roofline)."""
+    global _conv_timing
+    old = _conv_timing
+    _conv_timing = [] if enable else None
+    return old
+
+
 def im2col_algorithmic_bytes(g, has_mask):
     """4 * (C*Hin*Win + (3K | 2K)*dg*Ho*Wo + C*K*Ho*Wo) per image."""
     K, HWo = g.kh * g.kw, g.Ho * g.Wo

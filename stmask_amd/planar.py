@@ -29,8 +29,11 @@ class PlanarConv:
     """One packed convolution layer.  x / outputs are described by raw (tensor, pixel offset) pairs so that a layer can
     read from and write into slices of larger plane buffers."""
 
-    def __init__(self, weight, bias, stride=1, padding=0, relu=False, groups=1, planes=3):
+    def __init__(self, weight, bias, stride=1, padding=0, relu=False, groups=1, planes=3, algo_frac=1.0):
+        """algo_frac: share of the packed layer that is the reference's own arithmetic (zero-padded channels excluded);
+        only used for the flop count of the live roofline measurement."""
         weight = weight.detach().float().contiguous()
+        self.algo_frac = algo_frac
         self.O, self.C, self.kh, self.kw = weight.shape
         (self.sh, self.sw), (self.ph, self.pw) = _pair(stride), _pair(padding)
         self.relu, self.groups, self.planes = relu, groups, planes
@@ -102,11 +105,18 @@ class PlanarConv:
             else:
                 g.res_ld = residual.shape[-1]
                 r32 = residual.data_ptr()
+        timing = ops._conv_timing
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         rc = _lib.lib().stm_conv2d_planar_f32(ctypes.c_void_p(xp.data_ptr() + x_off * x_ld * 2), ops._p(self.packed),
                                               ops._p(self.bias), ctypes.c_void_p(r32), ctypes.c_void_p(rpl),
                                               ctypes.c_void_p(p_f32), ctypes.c_void_p(p_pl), ctypes.byref(g),
                                               c_i(1 if self.relu else 0), ops._stream())
         check(rc, "stm_conv2d_planar_f32")
+        if timing is not None:
+            e1.record()
+            timing.append((e0, e1, 2.0 * M * self.O * self.C * self.kh * self.kw * self.algo_frac))
         if out == "both":
             return out_f32, out_planes
         return out_f32 if out == "f32" else out_planes
@@ -174,7 +184,9 @@ class PlanarGraph:
                 ws.append(F.pad(w, (0, 0, 0, 0, 0, 0, 0, P - w.shape[0])))
                 bs.append(F.pad(b, (0, P - b.shape[0])))
             m0 = mods[0][0]
-            self.finals.append(PlanarConv(torch.cat(ws, 0), torch.cat(bs, 0), 1, m0.padding, relu=False, groups=4))
+            real = sum(m.weight.shape[0] for grp in mods for m in grp)
+            self.finals.append(PlanarConv(torch.cat(ws, 0), torch.cat(bs, 0), 1, m0.padding, relu=False, groups=4,
+                                          algo_frac=real / (4.0 * P)))
         self.head = head
 
     # ------------------------------------------------------------------------------------------------------------
@@ -326,7 +338,7 @@ class PlanarTemporalNet:
         self.cin = w1.shape[1]
         self.cpad = -(-self.cin // 32) * 32
         w1 = F.pad(w1, (0, 0, 0, 0, 0, self.cpad - self.cin))
-        self.c1 = PlanarConv(w1, tn.conv1.bias, 1, tn.conv1.padding, relu=True)
+        self.c1 = PlanarConv(w1, tn.conv1.bias, 1, tn.conv1.padding, relu=True, algo_frac=self.cin / self.cpad)
         self.c2 = PlanarConv(tn.conv2.weight, tn.conv2.bias, 1, tn.conv2.padding, relu=True)
         self.c3 = PlanarConv(tn.conv3.weight, tn.conv3.bias, 1, tn.conv3.padding, relu=True)
         self.fc, self.fc_coeff = tn.fc, tn.fc_coeff
