@@ -242,6 +242,9 @@ typedef struct stm_conv_geom {
                              "same" padding only; B/H/W/Ho/Wo are then ignored */
     int lvl_start[9], lvl_h[8], lvl_w[8];
     long long x_plane_stride, out_plane_stride, res_plane_stride; /* elements between bf16 planes; 0 = dense (pixels*ld) */
+    int tile_n;           /* output-channel tile the weights were packed for: 0 / 128 (stm_conv_pack_weights_f32) or 64
+                             (stm_conv_pack_weights_tiled_f32): 128 x 64 tiles, two workgroups per CU -- narrow layers
+                             (few output channels) and layers with few pixel tiles */
 } stm_conv_geom;
 
 /* bytes of the packed (pre-split, pre-tiled) weight image; 0 on bad arguments */
@@ -249,6 +252,10 @@ size_t stm_conv_packed_weight_bytes(int Cout, int Cin, int kh, int kw, int plane
 /* weight [Cout, Cin, kh, kw] fp32 (torch OIHW, contiguous) -> packed image; done once per layer */
 int stm_conv_pack_weights_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int planes,
                               stm_stream_t stream);
+/* the same with an explicit output-channel tile width (64 or 128); planar convolution only */
+size_t stm_conv_packed_weight_bytes_tiled(int Cout, int Cin, int kh, int kw, int planes, int tile_n);
+int stm_conv_pack_weights_tiled_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int planes,
+                                    int tile_n, stm_stream_t stream);
 /* out = act(conv(x, weight) + bias + residual); bias [Cout] or NULL, residual NHWC or NULL, relu 0/1 */
 int stm_conv2d_nhwc_f32(const float* x, const void* packed_weight, const float* bias, const float* residual, float* out,
                         const stm_conv_geom* g, int relu, stm_stream_t stream);

@@ -21,7 +21,8 @@ ABI_SYMBOLS = [
     "stm_jaccard_f32", "stm_lincomb_sigmoid_crop_f32", "stm_mask_iou_workspace_bytes", "stm_mask_iou_f32",
     "stm_bias_act_f32", "stm_mask_rle_workspace_bytes", "stm_mask_resize_rle_f32",
     "stm_conv_packed_weight_bytes", "stm_conv_pack_weights_f32", "stm_conv2d_nhwc_f32",
-    "stm_split_bf16_planes_f32", "stm_conv2d_planar_f32",
+    "stm_split_bf16_planes_f32", "stm_conv2d_planar_f32", "stm_conv_packed_weight_bytes_tiled",
+    "stm_conv_pack_weights_tiled_f32",
 ]
 
 
@@ -37,7 +38,7 @@ class ConvGeom(ctypes.Structure):
     _fields_ = ([(n, c_i) for n in ("B", "H", "W", "C", "Ho", "Wo", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "x_ld",
                                     "out_ld", "res_ld", "planes", "groups", "n_levels")] +
                 [("lvl_start", c_i * 9), ("lvl_h", c_i * 8), ("lvl_w", c_i * 8),
-                 ("x_plane_stride", c_l), ("out_plane_stride", c_l), ("res_plane_stride", c_l)])
+                 ("x_plane_stride", c_l), ("out_plane_stride", c_l), ("res_plane_stride", c_l), ("tile_n", c_i)])
 
 
 def build(force=False):
@@ -60,7 +61,7 @@ def lib():
         _lib.stm_last_error_string.restype = ctypes.c_char_p
         _lib.stm_version.restype = c_i
         for name in ("stm_deform_conv_workspace_bytes", "stm_gemm_workspace_bytes", "stm_mask_rle_workspace_bytes", "stm_detect_cc_workspace_bytes", "stm_fast_nms_workspace_bytes",
-                     "stm_mask_iou_workspace_bytes", "stm_conv_packed_weight_bytes"):
+                     "stm_mask_iou_workspace_bytes", "stm_conv_packed_weight_bytes", "stm_conv_packed_weight_bytes_tiled"):
             getattr(_lib, name).restype = c_sz
     return _lib
 

@@ -449,15 +449,18 @@ struct PlanarArgs {
     long long* trace;
 };
 
-template <int NPL, int MG>
+template <int NPL, int MG, int NJ>
 __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int BM = CV_BM * MG;
-    constexpr int XBUF = NPL * BM * 64, WBUF = NPL * CV_PLANE_B, BUF = XBUF + WBUF;
+    constexpr int BN = 64 * NJ;                      // output channels per workgroup: waves 2 wide, 32*NJ columns each
+    constexpr int WPL = BN * 64;                     // bytes of one weight plane of a slab
+    constexpr int XBUF = NPL * BM * 64, WBUF = NPL * WPL, BUF = XBUF + WBUF;
     constexpr int NWAVES = 4 * MG;
-    constexpr int WDMA = 8 * NPL / NWAVES;   // weight DMA instructions per wave per slab (6 or 4 | 3 or 2)
+    constexpr int WDMA = (BN / 16) * NPL / NWAVES;   // weight DMA instructions (1 KB each) per wave per slab
+    static_assert((BN / 16) * NPL % NWAVES == 0, "weight tile must split evenly over the waves");
 
     const int tiles = a.m_tiles * a.n_tiles;
     const int per_xcd = (tiles + 7) >> 3;
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 
     // grouped convolution: n-tile -> group; the group reads its own C input channels and writes its own cout_g outputs
     const int grp = nt / a.ntpg;
-    const int n0g = (nt - grp * a.ntpg) * CV_BN;           // first output channel of this tile within its group
+    const int n0g = (nt - grp * a.ntpg) * BN;           // first output channel of this tile within its group
     // DMA duties of this lane: activation row groups 2*wave and 2*wave+1 (16 rows x 64 B each, all planes)
     int iy0[2], ix0[2], pbase[2], hl[2], wl[2];
     const int slot = lane & 3;
@@ -536,11 +539,11 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         }
     };
 
-    f32x16 acc[2][2], accl[2][2];
+    f32x16 acc[2][NJ], accl[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
 
@@ -569,20 +572,23 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         // MFMAs then and takes the issue slots.  Past the last slab the DMA re-reads it into the idle buffer (no branch).
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][NPL], bf[2][NPL];
+            bf16x8 af[2][NPL], bf[NJ][NPL];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) {
+                for (int p = 0; p < NPL; ++p)
                     af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + i * 32 + lrow, 2 * ks + lh));
-                    bf[i][p] = *reinterpret_cast<const bf16x8*>(ws + p * CV_PLANE_B + lds_off(wn * 64 + i * 32 + lrow, 2 * ks + lh));
-                }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p)
+                    bf[j][p] = *reinterpret_cast<const bf16x8*>(ws + p * WPL + lds_off(wn * (32 * NJ) + j * 32 + lrow, 2 * ks + lh));
             if (ks == 0) dma_x((s + 1) & 1);
             else dma_w(min(s + 1, S - 1), (s + 1) & 1);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     f32x16 c = accl[i][j];
                     if constexpr (NPL == 3) {
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                 }
 #pragma unroll
-            for (int k = 0; k < 8 * NPL; ++k) {
+            for (int k = 0; k < 4 * NJ * NPL; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA
                 if (ks == 0) __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);       // VALU / SALU of the DMA addresses
                 else __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
@@ -614,27 +620,28 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
     if (a.vec_epilogue) {
         __syncthreads();                                   // all fragment reads of the last slab are done
-        constexpr int EP_LD = 68;                          // floats per parked pixel row (64 + 4 pad)
+        constexpr int EP_LD = 32 * NJ + 4;                 // floats per parked pixel row (+ 4 pad)
+        constexpr int LPR = 4 * NJ;                        // lanes per pixel row (8 channels each)
         float* park = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     park[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP_LD + j * 32 + lrow] = acc[i][j][r] + accl[i][j][r];
         // same wave reads back what it wrote: no workgroup barrier needed, only the LDS counter
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int seg = lane & 7, prow = lane >> 3;
-        const int cog = n0g + wn * 64 + seg * 8;           // channel within the group
+        const int seg = lane % LPR, prow = lane / LPR;
+        const int cog = n0g + wn * (32 * NJ) + seg * 8;    // channel within the group
         const int co = grp * a.cout_g + cog;
         const bool co_ok = cog < a.cout_g;                 // cout_g % 8 == 0: the whole 8-channel segment is in or out
         float bv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = (a.bias && co_ok) ? a.bias[co + e] : 0.0f;
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int pr = pass * 8 + prow;
+        for (int pass = 0; pass < LPR; ++pass) {
+            const int pr = pass * (64 / LPR) + prow;
             const int m = m0 + wm * 64 + pr;
             if (m >= a.M || !co_ok) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
@@ -676,8 +683,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         __bf16* outp = reinterpret_cast<__bf16*>(a.out_pl);
         const __bf16* resp = reinterpret_cast<const __bf16*>(a.res_pl);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int cog = n0g + wn * 64 + j * 32 + lrow;
+        for (int j = 0; j < NJ; ++j) {
+            const int cog = n0g + wn * (32 * NJ) + j * 32 + lrow;
             if (cog >= a.cout_g) continue;
             const int co = grp * a.cout_g + cog;
             const float bv = a.bias ? a.bias[co] : 0.0f;
@@ -742,16 +749,17 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 // Weights [Cout][Cin][kh][kw] fp32 -> packed [n_tile][slab][plane][row 0..127][swizzled 16-B chunk][8 bf16]; rows past
 // Cout are zero.  One thread per (n_tile, slab, row, chunk).
 __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp, int Cout,
-                                                                int C, int kh, int kw, int slabs, int n_tiles, int npl)
+                                                                int C, int kh, int kw, int slabs, int n_tiles, int npl, int bn)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)n_tiles * slabs * 512;
+    const int per_tile = bn * 4;                       // (row, chunk) pairs of one slab tile
+    const int64_t total = (int64_t)n_tiles * slabs * per_tile;
     if (idx >= total) return;
-    const int chunk = (int)(idx & 3), row = (int)((idx >> 2) & 127);
-    const int slab = (int)((idx >> 9) % slabs), nt = (int)((idx >> 9) / slabs);
+    const int chunk = (int)(idx & 3), row = (int)((idx >> 2) % bn);
+    const int slab = (int)((idx / per_tile) % slabs), nt = (int)((idx / per_tile) / slabs);
     const int taps = kh * kw;
     const int cs = slab / taps, tap = slab - cs * taps, c0 = cs * CV_BK + chunk * 8;   // K order: channel slab outer, tap inner
-    const int co = nt * CV_BN + row;
+    const int co = nt * bn + row;
     unsigned pl[3][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -762,26 +770,27 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
         }
         split2(v, pl[0][e], pl[1][e], pl[2][e]);
     }
-    uint8_t* dst = wp + ((size_t)nt * slabs + slab) * (npl * CV_PLANE_B) + lds_off(row, chunk);
+    const int wpl = bn * 64;
+    uint8_t* dst = wp + ((size_t)nt * slabs + slab) * (npl * wpl) + lds_off(row, chunk);
     for (int p = 0; p < npl; ++p) {
         u32x4 o = {pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
-        *reinterpret_cast<u32x4*>(dst + p * CV_PLANE_B) = o;
+        *reinterpret_cast<u32x4*>(dst + p * wpl) = o;
     }
 }
 
-template <int NPL, int MG>
+template <int NPL, int MG, int NJ>
 int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
 {
-    size_t lds = (size_t)2 * (NPL * CV_BM * MG * 64 + NPL * CV_PLANE_B);
-    const size_t park = (size_t)4 * MG * 64 * 68 * sizeof(float);   // the epilogue parks one 64 x 64 tile per wave
+    size_t lds = (size_t)2 * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
+    const size_t park = (size_t)4 * MG * 64 * (32 * NJ + 4) * sizeof(float);   // the epilogue parks one 64 x 32NJ tile per wave
     if (lds < park) lds = park;
     static bool lds_reserved = false;   // per instantiation; the attribute is sticky, setting it again each launch only costs host time
     if (!lds_reserved) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
         lds_reserved = true;
     }
-    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
+    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kernel");
     return STM_OK;
 }
@@ -808,25 +817,38 @@ bool geom_ok(const stm_conv_geom* g, const char* who)
 // debugging aid (not part of include/stmask_hip.h): device buffer of 2*64*8 int64 receiving workgroup 0's per-phase clocks
 extern "C" void stm_debug_conv_set_trace(void* dev_buf) { g_conv_trace = static_cast<long long*>(dev_buf); }
 
+extern "C" size_t stm_conv_packed_weight_bytes_tiled(int Cout, int Cin, int kh, int kw, int planes, int tile_n)
+{
+    if (Cout <= 0 || Cin <= 0 || Cin % CV_BK || kh <= 0 || kw <= 0 || (planes != 2 && planes != 3) || (tile_n != 64 && tile_n != 128))
+        return 0;
+    return (size_t)stm_cdiv(Cout, tile_n) * (kh * kw * (Cin / CV_BK)) * planes * (tile_n * 64);
+}
+
 extern "C" size_t stm_conv_packed_weight_bytes(int Cout, int Cin, int kh, int kw, int planes)
 {
-    if (Cout <= 0 || Cin <= 0 || Cin % CV_BK || kh <= 0 || kw <= 0 || (planes != 2 && planes != 3)) return 0;
-    return (size_t)stm_cdiv(Cout, CV_BN) * (kh * kw * (Cin / CV_BK)) * planes * CV_PLANE_B;
+    return stm_conv_packed_weight_bytes_tiled(Cout, Cin, kh, kw, planes, CV_BN);
+}
+
+extern "C" int stm_conv_pack_weights_tiled_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int planes,
+                                               int tile_n, stm_stream_t stream)
+{
+    STM_REQUIRE(weight && packed, STM_ENULL, "stm_conv_pack_weights_f32: weight/packed must be non-NULL");
+    STM_REQUIRE(stm_conv_packed_weight_bytes_tiled(Cout, Cin, kh, kw, planes, tile_n) > 0, STM_EINVAL,
+                "stm_conv_pack_weights_f32: bad sizes Cout=%d Cin=%d (multiple of 32) k=%dx%d planes=%d tile_n=%d (64 or 128)", Cout,
+                Cin, kh, kw, planes, tile_n);
+    STM_REQUIRE((uintptr_t)packed % 16 == 0, STM_EINVAL, "stm_conv_pack_weights_f32: packed buffer must be 16-byte aligned");
+    const int slabs = kh * kw * (Cin / CV_BK), n_tiles = stm_cdiv(Cout, tile_n);
+    const int64_t total = (int64_t)n_tiles * slabs * tile_n * 4;
+    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), weight,
+                       static_cast<uint8_t*>(packed), Cout, Cin, kh, kw, slabs, n_tiles, planes, tile_n);
+    STM_CHECK_LAUNCH("conv_pack_weights_kernel");
+    return STM_OK;
 }
 
 extern "C" int stm_conv_pack_weights_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int planes,
                                          stm_stream_t stream)
 {
-    STM_REQUIRE(weight && packed, STM_ENULL, "stm_conv_pack_weights_f32: weight/packed must be non-NULL");
-    STM_REQUIRE(stm_conv_packed_weight_bytes(Cout, Cin, kh, kw, planes) > 0, STM_EINVAL,
-                "stm_conv_pack_weights_f32: bad sizes Cout=%d Cin=%d (multiple of 32) k=%dx%d planes=%d", Cout, Cin, kh, kw, planes);
-    STM_REQUIRE((uintptr_t)packed % 16 == 0, STM_EINVAL, "stm_conv_pack_weights_f32: packed buffer must be 16-byte aligned");
-    const int slabs = kh * kw * (Cin / CV_BK), n_tiles = stm_cdiv(Cout, CV_BN);
-    const int64_t total = (int64_t)n_tiles * slabs * 512;
-    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), weight,
-                       static_cast<uint8_t*>(packed), Cout, Cin, kh, kw, slabs, n_tiles, planes);
-    STM_CHECK_LAUNCH("conv_pack_weights_kernel");
-    return STM_OK;
+    return stm_conv_pack_weights_tiled_f32(weight, packed, Cout, Cin, kh, kw, planes, CV_BN, stream);
 }
 
 extern "C" int stm_conv2d_nhwc_f32(const float* x, const void* packed_weight, const float* bias, const float* residual,
@@ -913,7 +935,9 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     STM_REQUIRE(g->C > 0 && g->C % CV_BK == 0 && g->Cout > 0 && g->Cout % groups == 0 && g->kh > 0 && g->kw > 0 &&
                 (g->planes == 2 || g->planes == 3), STM_EINVAL, "%s: bad channel / kernel / planes arguments", who);
     const int cout_g = g->Cout / groups;
-    STM_REQUIRE(groups == 1 || cout_g % CV_BN == 0, STM_EINVAL, "%s: Cout per group (%d) must be a multiple of 128", who, cout_g);
+    const int bn = g->tile_n ? g->tile_n : CV_BN;      // must be the tile width the weights were packed for
+    STM_REQUIRE(bn == 64 || bn == 128, STM_EINVAL, "%s: tile_n must be 64 or 128", who);
+    STM_REQUIRE(groups == 1 || cout_g % bn == 0, STM_EINVAL, "%s: Cout per group (%d) must be a multiple of the tile width %d", who, cout_g, bn);
     int64_t M, in_pixels;
     if (g->n_levels > 0) {
         STM_REQUIRE(g->n_levels <= 8 && g->sh == 1 && g->sw == 1 && 2 * g->ph == g->kh - 1 && 2 * g->pw == g->kw - 1, STM_EINVAL,
@@ -949,10 +973,10 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout;
     a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw;
     a.x_ld = x_ld; a.out_ld = out_ld; a.res_ld = res_ld; a.relu = relu;
-    a.M = (int)M; a.n_tiles = stm_cdiv(g->Cout, CV_BN); a.slabs = g->kh * g->kw * (g->C / CV_BK);
+    a.M = (int)M; a.n_tiles = stm_cdiv(g->Cout, bn); a.slabs = g->kh * g->kw * (g->C / CV_BK);
     a.plane_bytes = (unsigned)plane_bytes;
     a.x_pstride = xps * 2; a.out_pstride = ops * 2; a.res_pstride = rps * 2;
-    a.groups = groups; a.cout_g = cout_g; a.ntpg = stm_cdiv(cout_g, CV_BN);
+    a.groups = groups; a.cout_g = cout_g; a.ntpg = stm_cdiv(cout_g, bn);
     a.n_levels = g->n_levels > 0 ? g->n_levels : 0;
     for (int l = 0; l < 8; ++l) { a.lvl_start[l] = g->lvl_start[l]; a.lvl_h[l] = g->lvl_h[l]; a.lvl_w[l] = g->lvl_w[l]; }
     a.lvl_start[8] = g->lvl_start[8];
@@ -960,12 +984,19 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
                      ((uintptr_t)out_planes % 16 == 0) && ((uintptr_t)residual_f32 % 16 == 0) && ((uintptr_t)residual_planes % 16 == 0) &&
                      (ops % 8 == 0) && (rps % 8 == 0) && !getenv("STM_CONV_SCALAR_EPILOGUE");
     a.trace = g_conv_trace;
+    if (bn == 64) {
+        // 128 x 64 tiles, 72 KB of LDS: two independent workgroups per CU, each one's barrier / staging gaps filled by
+        // the other's MFMAs
+        a.m_tiles = stm_cdiv(M, CV_BM);
+        const int tiles = a.m_tiles * a.n_tiles;
+        return g->planes == 3 ? launch_planar<3, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1>(a, tiles, stream);
+    }
     const char* fk = getenv("STM_CONV_MG");
     const int forced = fk ? atoi(fk) : 0;
     const int64_t big_tiles = (int64_t)stm_cdiv(M, 2 * CV_BM) * a.n_tiles;
     const int mg = forced ? forced : (big_tiles >= 192 ? 2 : 1);
     a.m_tiles = stm_cdiv(M, CV_BM * mg);
     const int tiles = a.m_tiles * a.n_tiles;
-    if (g->planes == 3) return mg == 2 ? launch_planar<3, 2>(a, tiles, stream) : launch_planar<3, 1>(a, tiles, stream);
-    return mg == 2 ? launch_planar<2, 2>(a, tiles, stream) : launch_planar<2, 1>(a, tiles, stream);
+    if (g->planes == 3) return mg == 2 ? launch_planar<3, 2, 2>(a, tiles, stream) : launch_planar<3, 1, 2>(a, tiles, stream);
+    return mg == 2 ? launch_planar<2, 2, 2>(a, tiles, stream) : launch_planar<2, 1, 2>(a, tiles, stream);
 }

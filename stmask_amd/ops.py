@@ -396,17 +396,18 @@ def mask_resize_rle(masks, crop_h, crop_w, out_h, out_w, thr=0.5, max_runs=4096)
     return counts, n_runs
 
 
-def conv_pack_weights(weight, planes=3):
-    """OIHW fp32 weights -> the pre-split, pre-tiled bf16 image stm_conv2d_nhwc_f32 streams (done once per layer)."""
+def conv_pack_weights(weight, planes=3, tile_n=128):
+    """OIHW fp32 weights -> the pre-split, pre-tiled bf16 image the convolution kernels stream (done once per layer).
+    tile_n = 64 packs for the 128 x 64-tile planar kernel (stm_conv_geom.tile_n must say so too)."""
     _dev(weight)
     weight = _f32c(weight)
     O, C, kh, kw = weight.shape
-    nbytes = _lib.lib().stm_conv_packed_weight_bytes(c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes))
+    nbytes = _lib.lib().stm_conv_packed_weight_bytes_tiled(c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes), c_i(tile_n))
     if nbytes == 0:
         raise StmError(f"conv_pack_weights: unsupported weight shape {tuple(weight.shape)} (Cin must be a multiple of 32)")
     packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
-    check(_lib.lib().stm_conv_pack_weights_f32(_p(weight), _p(packed), c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes),
-                                               _stream()), "stm_conv_pack_weights_f32")
+    check(_lib.lib().stm_conv_pack_weights_tiled_f32(_p(weight), _p(packed), c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes),
+                                                     c_i(tile_n), _stream()), "stm_conv_pack_weights_tiled_f32")
     return packed
 
 
@@ -443,7 +444,7 @@ def split_planes(x):
 
 
 def conv2d_planar(xp, packed, weight_shape, bias=None, residual=None, stride=1, padding=0, relu=False, planes=3,
-                  out="planes"):
+                  out="planes", tile_n=128):
     """The same convolution on the planar activation format: xp [3,B,H,W,C] bf16 (split_planes / a previous layer's
     output).  `residual` may be fp32 [B,Ho,Wo,O] or planes [3,B,Ho,Wo,O].  out: "planes" | "f32" | "both"."""
     _dev(xp, packed, bias, residual)
@@ -468,6 +469,7 @@ def conv2d_planar(xp, packed, weight_shape, bias=None, residual=None, stride=1, 
             if tuple(r32.shape) != (B, Ho, Wo, O):
                 raise StmError(f"conv2d_planar: residual {tuple(r32.shape)} != output {(B, Ho, Wo, O)}")
     g = _lib.ConvGeom(B, H, W, C, Ho, Wo, O, kh, kw, sh, sw, ph, pw, 0, 0, 0, planes)
+    g.tile_n = tile_n
     check(_lib.lib().stm_conv2d_planar_f32(_p(xp), _p(packed), _p(_f32c(bias) if bias is not None else None), _p(r32), _p(rpl),
                                            _p(y32), _p(ypl), ctypes.byref(g), c_i(1 if relu else 0), _stream()),
           "stm_conv2d_planar_f32")

@@ -29,18 +29,38 @@ class PlanarConv:
     """One packed convolution layer.  x / outputs are described by raw (tensor, pixel offset) pairs so that a layer can
     read from and write into slices of larger plane buffers."""
 
-    def __init__(self, weight, bias, stride=1, padding=0, relu=False, groups=1, planes=3, algo_frac=1.0):
+    def __init__(self, weight, bias, stride=1, padding=0, relu=False, groups=1, planes=3, algo_frac=1.0, tile_n=None):
         """algo_frac: share of the packed layer that is the reference's own arithmetic (zero-padded channels excluded);
-        only used for the flop count of the live roofline measurement."""
-        weight = weight.detach().float().contiguous()
+        only used for the flop count of the live roofline measurement.  tile_n: 64 / 128 forces the output-channel tile,
+        None picks per call from the problem size (weights are packed once per tile width used)."""
+        self.weight = weight.detach().float().contiguous()
         self.algo_frac = algo_frac
-        self.O, self.C, self.kh, self.kw = weight.shape
+        self.O, self.C, self.kh, self.kw = self.weight.shape
         (self.sh, self.sw), (self.ph, self.pw) = _pair(stride), _pair(padding)
-        self.relu, self.groups, self.planes = relu, groups, planes
-        self.packed = ops.conv_pack_weights(weight, planes)
+        self.relu, self.groups, self.planes, self.tile_n = relu, groups, planes, tile_n
+        self._packed = {}
         self.bias = bias.detach().float().contiguous() if bias is not None else None
 
-    def __call__(self, xp, shape, out="planes", x_off=0, out_planes=None, out_f32=None, out_off=0, residual=None):
+    def packed(self, tile_n):
+        if tile_n not in self._packed:
+            self._packed[tile_n] = ops.conv_pack_weights(self.weight, self.planes, tile_n)
+        return self._packed[tile_n]
+
+    def pick_tile(self, M):
+        """Measured on the R50 layer shapes at batch 8 (scripts/bench_conv.py): 128-channel tiles (256 or 128 pixels, one
+        workgroup per CU) win once the grid has a few hundred of them; 128 x 64 tiles (two workgroups per CU) win for
+        narrow layers and for grids that would leave CUs idle."""
+        if self.tile_n is not None:
+            return self.tile_n
+        cg = self.O // self.groups
+        if self.groups > 1 and cg % 128 != 0:
+            return 64
+        if cg <= 64 or (cg % 128 != 0 and cg % 128 <= 64 and cg < 256):
+            return 64
+        tiles128 = -(-M // 128) * -(-self.O // 128)
+        return 64 if tiles128 < 400 else 128
+
+    def __call__(self, xp, shape, out="planes", x_off=0, out_planes=None, out_f32=None, out_off=0, residual=None, x_ch_off=0):
         """xp: [3, N, x_ld] bf16.  shape: ("img", B, H, W) -> pixels [x_off, x_off + B*H*W) of xp are one image batch;
         ("levels", B, [(H, W), ...]) -> all of xp, concatenated levels.  out: "planes" | "f32" | "both" allocates dense
         outputs unless out_planes / out_f32 ([3, N', ld] / [N', ld]) are given, then rows [out_off, ...) are written."""
@@ -50,8 +70,8 @@ class PlanarConv:
         g = _lib.ConvGeom()
         g.C, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw = self.C, self.O, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw
         g.planes, g.groups, g.x_ld = self.planes, self.groups, x_ld
-        if x_ld != self.groups * self.C:
-            raise StmError(f"PlanarConv: input has {x_ld} channels, layer expects {self.groups} x {self.C}")
+        if x_ld < x_ch_off + self.groups * self.C or x_ch_off % 8:
+            raise StmError(f"PlanarConv: input has {x_ld} channels, layer reads {self.groups} x {self.C} from channel {x_ch_off}")
         if shape[0] == "levels":
             _, B, sizes = shape
             g.n_levels = len(sizes)
@@ -71,6 +91,7 @@ class PlanarConv:
             if x_off + n_in > xp.shape[1]:
                 raise StmError("PlanarConv: input slice runs past the plane buffer")
         g.x_plane_stride = xp.shape[1] * x_ld
+        g.tile_n = self.pick_tile(M)
         dev = xp.device
         if out in ("planes", "both") and out_planes is None:
             out_planes, out_off_p = torch.empty(3, M, self.O, device=dev, dtype=torch.bfloat16), 0
@@ -109,7 +130,7 @@ class PlanarConv:
         if timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rc = _lib.lib().stm_conv2d_planar_f32(ctypes.c_void_p(xp.data_ptr() + x_off * x_ld * 2), ops._p(self.packed),
+        rc = _lib.lib().stm_conv2d_planar_f32(ctypes.c_void_p(xp.data_ptr() + (x_off * x_ld + x_ch_off) * 2), ops._p(self.packed(g.tile_n)),
                                               ops._p(self.bias), ctypes.c_void_p(r32), ctypes.c_void_p(rpl),
                                               ctypes.c_void_p(p_f32), ctypes.c_void_p(p_pl), ctypes.byref(g),
                                               c_i(1 if self.relu else 0), ops._stream())
@@ -134,7 +155,7 @@ def _split(t_nhwc):
 
 
 class PlanarGraph:
-    GROUP_PAD = 128   # output channels per group of the final (grouped) layers
+    GROUP_PAD = 64    # output channels per group of the grouped output layers (41 / 5 / 32 real ones)
 
     def __init__(self, net):
         cfg = net.cfg
@@ -170,12 +191,15 @@ class PlanarGraph:
         w2 = torch.cat([t[1].weight for t in towers], 0)
         b2 = torch.cat([t[1].bias for t in towers], 0)
         self.tower2 = PlanarConv(w2, b2, 1, towers[0][1].padding, relu=True, groups=4)     # 4 x (256 -> 256)
+        # output layers, per kernel shape k: the conf / centerness+bbox / mask layers read three consecutive 256-channel
+        # groups of the tower output -> one grouped launch with 64 output channels per group (41 / 5 / 32 real ones);
+        # the track layer (128 channels) reads the fourth group -> its own launch
         self.finals = []
         P = self.GROUP_PAD
         self.dims = (head.num_priors * head.num_classes, head.num_priors * 4, head.num_priors * head.mask_dim,
                      head.num_priors * head.embed_dim)
         for k in range(len(cfg.head_layer_params)):
-            mods = [[head.conf_layer[k]], [head.centerness_layer[k], head.bbox_layer[k]], [head.mask_layer[k]], [head.track_layer[k]]]
+            mods = [[head.conf_layer[k]], [head.centerness_layer[k], head.bbox_layer[k]], [head.mask_layer[k]]]
             ws, bs = [], []
             for grp in mods:
                 w = torch.cat([m.weight for m in grp], 0)
@@ -185,8 +209,10 @@ class PlanarGraph:
                 bs.append(F.pad(b, (0, P - b.shape[0])))
             m0 = mods[0][0]
             real = sum(m.weight.shape[0] for grp in mods for m in grp)
-            self.finals.append(PlanarConv(torch.cat(ws, 0), torch.cat(bs, 0), 1, m0.padding, relu=False, groups=4,
-                                          algo_frac=real / (4.0 * P)))
+            small = PlanarConv(torch.cat(ws, 0), torch.cat(bs, 0), 1, m0.padding, relu=False, groups=3,
+                               algo_frac=real / (3.0 * P), tile_n=64)
+            tr = head.track_layer[k]
+            self.finals.append((small, PlanarConv(tr.weight, tr.bias, 1, tr.padding, relu=False)))
         self.head = head
 
     # ------------------------------------------------------------------------------------------------------------
@@ -292,22 +318,22 @@ class PlanarGraph:
         t1 = self.tower1(up, lv, out="planes")
         t2 = self.tower2(t1, lv, out="planes")
         toc("head_towers")
-        outs = [f(t2, lv, out="f32") for f in self.finals]          # each [ntot, 4 * GROUP_PAD]
+        cw = self.tower2.O // 4                                       # channels per branch in t2 (conf, bbox, mask, track)
+        outs = [(small(t2, lv, out="f32"), trk(t2, lv, out="f32", x_ch_off=3 * cw)) for small, trk in self.finals]
         toc("head_finals")
         P = self.GROUP_PAD
         ncls, nbox, nmask, ntrk = self.dims
-        K = len(outs)
+        npri = head.num_priors
         conf, loc, mask, track, cen, t2s = [], [], [], [], [], []
         for l, (hh, ww) in enumerate(sizes):
             sl = slice(starts[l], starts[l + 1])
-            per_k = [o[sl].view(B, hh * ww, 4 * P) for o in outs]
-            cat = torch.stack(per_k, dim=2)                                           # [B, HW, K, 4P]
+            per_k = [o[0][sl].view(B, hh * ww, 3 * P) for o in outs]
+            cat = torch.stack(per_k, dim=2)                                           # [B, HW, K, 3P]
             conf.append(cat[..., 0:ncls].reshape(B, -1, head.num_classes))
             # group 1 = centerness (1 per prior) then bbox (4 per prior)
-            npri = head.num_priors
             loc.append(cat[..., P + npri:P + npri + nbox].reshape(B, -1, 4))
             mask.append(cat[..., 2 * P:2 * P + nmask].reshape(B, -1, head.mask_dim))
-            track.append(cat[..., 3 * P:3 * P + ntrk].reshape(B, -1, head.embed_dim))
+            track.append(torch.stack([o[1][sl].view(B, hh * ww, ntrk) for o in outs], dim=2).reshape(B, -1, head.embed_dim))
             # the reference concatenates centerness along H (prediction_head_FC.py:189): order (k, y, x)
             cen.append(torch.stack([pk[..., P:P + npri] for pk in per_k], dim=1).reshape(B, -1, 1))
             pred["priors"].append(head.make_priors(hh, ww, dev))

@@ -135,11 +135,14 @@ def test_split_planes_is_exact():
     assert torch.equal(planes_to_f32(pl), x)          # 8+8+8 mantissa bits: the fp32 value is recovered exactly
 
 
-@pytest.mark.parametrize("mg", ["1", "2"])
+@pytest.mark.parametrize("mg", ["1", "2", "n64"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_planar_vs_oracle(case, mg, monkeypatch):
-    """Planar (pre-split, LDS-DMA staged) kernel, both tile heights, fp32 and planar outputs, both residual forms."""
-    monkeypatch.setenv("STM_CONV_MG", mg)
+    """Planar (pre-split, LDS-DMA staged) kernel: 128- and 256-pixel tiles of 128 channels and the 128 x 64 tile, fp32
+    and planar outputs, both residual forms."""
+    tile_n = 64 if mg == "n64" else 128
+    if mg != "n64":
+        monkeypatch.setenv("STM_CONV_MG", mg)
     B, H, W, C, O, kh, kw, s, pad, has_bias, has_res, relu = case
     x = rnd(B, H, W, C, seed=0)
     w = rnd(O, C, kh, kw, seed=1, scale=(C * kh * kw) ** -0.5)
@@ -149,9 +152,11 @@ def test_conv_planar_vs_oracle(case, mg, monkeypatch):
     ref = oracle.conv2d_nhwc(x, w, b, r, stride=s, padding=pad, relu=relu)
     mag = oracle.conv2d_nhwc(x.abs(), w.abs(), b.abs() if has_bias else None, r.abs() if has_res else None, stride=s, padding=pad)
     pk = ops.conv_pack_weights(w.to(DEV))
+    pkt = ops.conv_pack_weights(w.to(DEV), tile_n=tile_n)
     xp = ops.split_planes(x.to(DEV))
     bd = b.to(DEV) if has_bias else None
-    y32, ypl = ops.conv2d_planar(xp, pk, tuple(w.shape), bd, r.to(DEV) if has_res else None, stride=s, padding=pad, relu=relu, out="both")
+    y32, ypl = ops.conv2d_planar(xp, pkt, tuple(w.shape), bd, r.to(DEV) if has_res else None, stride=s, padding=pad, relu=relu,
+                                 out="both", tile_n=tile_n)
     y32, ypl = y32.cpu(), ypl.cpu()
     assert ((y32 - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
     assert torch.equal(planes_to_f32(ypl), y32)        # the planar output IS the fp32 output, split
@@ -159,7 +164,8 @@ def test_conv_planar_vs_oracle(case, mg, monkeypatch):
     y_ref_kernel = ops.conv2d_nhwc(x.to(DEV), pk, tuple(w.shape), bd, r.to(DEV) if has_res else None, stride=s, padding=pad, relu=relu).cpu()
     assert torch.equal(y32, y_ref_kernel)
     if has_res:                                        # residual handed over as planes gives the same result
-        y2 = ops.conv2d_planar(xp, pk, tuple(w.shape), bd, ops.split_planes(r.to(DEV)), stride=s, padding=pad, relu=relu, out="f32").cpu()
+        y2 = ops.conv2d_planar(xp, pkt, tuple(w.shape), bd, ops.split_planes(r.to(DEV)), stride=s, padding=pad, relu=relu,
+                               out="f32", tile_n=tile_n).cpu()
         assert torch.equal(y2, y32)
 
 
