@@ -1,0 +1,81 @@
+"""Result aggregation, SURVEY.md section 8 row f2: mirrors layers/eval_utils.py:15-106 of the reference.
+
+`bbox2result_with_id` turns one frame's tracked detections (after `output_utils.postprocess_ytbvis`) into the per-object
+dict the reference keeps per frame; `results2json_videoseg` folds the ordered per-frame dicts of one or more videos into
+YouTube-VIS records: per object the mean score over its frames (float32 mean, as `np.array(scores).mean()` of float32
+scalars gives), the majority-vote category (`np.bincount(...).argmax()`), and the per-frame RLE list with None for frames
+the object is absent from.  Host-side bookkeeping on the all-gathered detections; no device work.
+"""
+import json
+import os
+
+import numpy as np
+
+
+def bbox2result_with_id(preds, img_meta, classes):
+    """layers/eval_utils.py:15-50.  preds: dict with 'box' [n,4], 'class' [n] (or None), 'score' [n], 'segm' (list of RLE
+    dicts), 'box_ids' [n] -- tensors on any device."""
+    video_id, frame_id = img_meta["video_id"], img_meta["frame_id"]
+    results = {"video_id": video_id, "frame_id": frame_id}
+    if preds["box"].shape[0] == 0:
+        return results
+    bboxes = preds["box"].cpu().numpy()
+    labels = preds["class"].cpu().numpy() if preds["class"] is not None else None
+    scores = preds["score"].cpu().numpy()
+    segms = preds["segm"]
+    obj_ids = preds["box_ids"].cpu().numpy()
+    if labels is not None:
+        for bbox, label, score, segm, obj_id in zip(bboxes, labels, scores, segms, obj_ids):
+            if obj_id >= 0:
+                results[obj_id] = {"bbox": bbox, "label": label, "score": score, "segm": segm,
+                                   "category": classes[label - 1]}
+    else:
+        for bbox, score, segm, obj_id in zip(bboxes, scores, segms, obj_ids):
+            if obj_id >= 0:
+                results[obj_id] = {"bbox": bbox, "score": score, "segm": segm}
+    return results
+
+
+def video_records(results):
+    """The list `results2json_videoseg` (layers/eval_utils.py:53-101) dumps: `results` is the frame-ordered list of
+    bbox2result_with_id dicts of one or more videos.  RLE counts given as bytes are decoded to str, as the reference does."""
+    json_results = []
+    vid_objs = {}
+    size = len(results)
+    for idx in range(size):
+        vid_id, frame_id = results[idx]["video_id"], results[idx]["frame_id"]
+        is_last = idx == size - 1 or results[idx + 1]["video_id"] != vid_id
+        det = results[idx]
+        for obj_id in det:
+            if obj_id in ("video_id", "frame_id"):
+                continue
+            obj = det[obj_id]
+            segm = obj["segm"]
+            if obj_id not in vid_objs:
+                vid_objs[obj_id] = {"scores": [], "cats": [], "segms": {}}
+            vid_objs[obj_id]["scores"].append(obj["score"])
+            vid_objs[obj_id]["cats"].append(obj["label"])
+            if isinstance(segm["counts"], bytes):
+                segm["counts"] = segm["counts"].decode()
+            vid_objs[obj_id]["segms"][frame_id] = segm
+        if is_last:
+            for obj_id, obj in vid_objs.items():
+                data = {"video_id": vid_id,
+                        "score": np.array(obj["scores"]).mean().item(),
+                        # majority voting for the sequence category (eval_utils.py:91)
+                        "category_id": np.bincount(np.array(obj["cats"])).argmax().item()}
+                data["segmentations"] = [obj["segms"].get(fid) for fid in range(frame_id + 1)]
+                json_results.append(data)
+            vid_objs = {}
+    return json_results
+
+
+def results2json_videoseg(results, out_file):
+    """layers/eval_utils.py:53-106: write the records as JSON (mmcv.dump of a .json path is json.dump)."""
+    records = video_records(results)
+    out_dir = os.path.dirname(out_file)
+    if out_dir and not os.path.exists(out_dir):
+        os.makedirs(out_dir)
+    with open(out_file, "w") as f:
+        json.dump(records, f)
+    return records

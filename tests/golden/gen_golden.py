@@ -233,6 +233,31 @@ def gen_model(cfg_name, tag, hw=(128, 192), n_frames=3, temporal_fusion=True):
     save(f"model_{tag}.npz", **out)
 
 
+from synth_results import synth_video_results  # noqa: E402  (tests/golden/synth_results.py, shared with the test)
+
+
+def gen_results_json():
+    """Row f2: the reference's own bbox2result_with_id + results2json_videoseg (layers/eval_utils.py) on seeded inputs."""
+    import json
+    sys.modules["mmcv"].dump = lambda obj, path: json.dump(obj, open(path, "w"))
+    from layers import eval_utils
+    classes = ["c%d" % i for i in range(40)]
+    frames = synth_video_results()
+    results = [eval_utils.bbox2result_with_id(det, meta, classes) for det, meta in frames]
+    per_frame = [{str(k): (v if k in ("video_id", "frame_id") else
+                           {"bbox": v["bbox"].tolist(), "label": int(v["label"]), "score": float(v["score"]),
+                            "category": v["category"]}) for k, v in r.items()} for r in results]
+    out = os.path.join(HERE, "_tmp_results_dir", "results.json")   # the reference makedirs(out_file[:-13])
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    eval_utils.results2json_videoseg(results, out)
+    records = json.load(open(out))
+    os.remove(out)
+    os.rmdir(os.path.dirname(out))
+    with open(os.path.join(HERE, "results_json.json"), "w") as f:
+        json.dump({"per_frame": per_frame, "records": records}, f)
+    print("wrote results_json.json:", len(records), "records")
+
+
 def main():
     install_stubs()
     torch.manual_seed(0)
@@ -248,6 +273,8 @@ def main():
         gen_model("STMask_plus_resnet50_config", "r50_fca")
         gen_model("STMask_plus_resnet50_ada_config", "r50_ada")
         gen_model("STMask_plus_resnet50_ali_config", "r50_ali")
+    if "results_json" in which:
+        gen_results_json()
     if "model_extra" in which:
         # NB: the reference's non-TF path (Detect/Track, STMask.py:323-327) cannot produce a golden: Detect.__call__
         # reads result['bbox_idx'] (detection.py:93), a key its cc_fast_nms never sets -> KeyError on the first frame.
