@@ -271,6 +271,15 @@ int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const
                           const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu,
                           stm_stream_t stream);
 
+/* ---- frame pre-processing on the device (row f3) ------------------------------------------------------------------
+ * Replaces the host chain of eval.py:703-717 (evaluate_single): mmcv.imresize(im, (w, h)) [cv2.resize INTER_LINEAR on
+ * the uint8 HWC image] -> (im - MEANS) / STD [numpy float64] -> mmcv.impad_to_multiple(im, 32) -> permute(2,0,1).float().
+ * img [n, H0, W0, 3] uint8 (channel order as read), out [n, 3, Hp, Wp] fp32 (zero outside [h, w]); mean/std: 3 doubles
+ * in the image's channel order.  mode 0: no normalisation; 1: (v-mean)/std; 2: v-mean; 3: v/255
+ * (cfg.backbone.transform.{normalize, subtract_means, to_float}).  Bit-exact against oracle orc_preprocess_u8. */
+int stm_preprocess_u8_f32(const uint8_t* img, float* out, int n, int H0, int W0, int h, int w, int Hp, int Wp,
+                          const double* mean, const double* stdv, int mode, stm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -309,6 +309,22 @@ def rle_decode(counts, h, w):
     return flat.view(w, h).t().contiguous()
 
 
+# ------------------------------------------------------------------------------ pre-processing (row f3)
+def preprocess_frames(img_u8, size=(640, 360), divisor=32, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375),
+                      mode=1):
+    """eval.py:703-717: uint8 [n,H0,W0,3] -> fp32 [n,3,Hp,Wp] (cv2-style 8-bit bilinear resize to size=(w,h), numpy
+    normalisation in float64, zero pad to a multiple of `divisor`, CHW)."""
+    img = img_u8.to(torch.uint8).contiguous()
+    n, H0, W0, c = img.shape
+    assert c == 3
+    w, h = size
+    Hp, Wp = -(-h // divisor) * divisor, -(-w // divisor) * divisor
+    out = torch.empty(n, 3, Hp, Wp, dtype=torch.float32)
+    m3, s3 = (c_d * 3)(*mean), (c_d * 3)(*std)
+    lib().orc_preprocess_u8(_ptr(img), c_i(n), c_i(H0), c_i(W0), c_i(h), c_i(w), c_i(Hp), c_i(Wp), m3, s3, c_i(mode), _ptr(out))
+    return out
+
+
 # --------------------------------------------------------------- reference-import stand-ins
 class OracleDCN(nn.Module):
     """CPU stand-in for dcn_v2.DCN (backbone.py:21-26,45): same parameters and state-dict keys."""

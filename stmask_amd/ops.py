@@ -474,3 +474,20 @@ def conv2d_planar(xp, packed, weight_shape, bias=None, residual=None, stride=1, 
                                            _p(y32), _p(ypl), ctypes.byref(g), c_i(1 if relu else 0), _stream()),
           "stm_conv2d_planar_f32")
     return (y32, ypl) if out == "both" else (y32 if out == "f32" else ypl)
+
+
+def preprocess_frames(img_u8, size=(640, 360), divisor=32, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375),
+                      mode=1):
+    """eval.py:703-717 on the device: uint8 [n,H0,W0,3] -> fp32 [n,3,Hp,Wp]; size = (w, h) as mmcv.imresize takes it."""
+    _dev(img_u8)
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 4 or img_u8.shape[-1] != 3:
+        raise StmError(f"preprocess_frames: expected uint8 [n,H,W,3], got {img_u8.dtype} {tuple(img_u8.shape)}")
+    img = img_u8.contiguous()
+    n, H0, W0, _ = img.shape
+    w, h = size
+    Hp, Wp = -(-h // divisor) * divisor, -(-w // divisor) * divisor
+    out = torch.empty(n, 3, Hp, Wp, device=img.device, dtype=torch.float32)
+    m3, s3 = (ctypes.c_double * 3)(*mean), (ctypes.c_double * 3)(*std)
+    check(_lib.lib().stm_preprocess_u8_f32(_p(img), _p(out), c_i(n), c_i(H0), c_i(W0), c_i(h), c_i(w), c_i(Hp), c_i(Wp), m3, s3,
+                                           c_i(mode), _stream()), "stm_preprocess_u8_f32")
+    return out
