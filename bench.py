@@ -37,13 +37,15 @@ BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def pmc_traffic():
-    """HBM bytes per im2col launch from the committed rocprofv3 PMC passes (bench.py cannot collect PMC counters about
-    itself): profiles/r01_pmc_traffic.json, produced by `scripts/gpu_round.sh pmc` on the same command and batch."""
+def pmc_traffic(kernel=None):
+    """HBM bytes per launch (im2col by default, or the named kernel entry) from the committed rocprofv3 PMC passes
+    (bench.py cannot collect PMC counters about itself): profiles/r01_pmc_traffic.json, produced by
+    `scripts/gpu_round.sh pmc` on the same command and batch."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         with open(path) as fh:
-            return int(json.load(fh)["traffic_bytes_per_launch"])
+            d = json.load(fh)
+        return int((d[kernel] if kernel else d)["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
 
@@ -207,7 +209,9 @@ def main():
             tf = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
             res["roofline"] = {"bound": "mfma", "kernel": "conv_planar_kernel (bf16x3-plane split conv: backbone 1x1/3x3, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
                                "achieved": round(tf, 1), "peak": round(BF16_MFMA_PEAK_TF / 6.0, 1), "unit": "TFLOP/s",
-                               "frac": round(tf / (BF16_MFMA_PEAK_TF / 6.0), 4), "traffic": None,
+                               "frac": round(tf / (BF16_MFMA_PEAK_TF / 6.0), 4),
+                               "traffic": pmc_traffic("conv_planar") if (args.clips == 8 and args.config == "STMask_plus_resnet50_config") else None,
+                               "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction); average over all launches",
                                "peak_note": "fp32-equivalent: 2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 product (fp32 MFMA peak is 157)",
                                "launches": len(conv_t), "avg_launch_us": round(c_ms * 1e3 / len(conv_t), 2),
                                "ms_per_step": round(c_ms / args.steps, 3),
