@@ -241,7 +241,9 @@ typedef struct stm_conv_geom {
                              pixels [lvl_start[l], lvl_start[l+1]) = B images of lvl_h[l] x lvl_w[l]; stride 1 and
                              "same" padding only; B/H/W/Ho/Wo are then ignored */
     int lvl_start[9], lvl_h[8], lvl_w[8];
-    long long x_plane_stride, out_plane_stride, res_plane_stride; /* elements between bf16 planes; 0 = dense (pixels*ld) */
+    long long x_plane_stride, out_plane_stride, res_plane_stride; /* elements between bf16 planes; 0 = dense (slabs*np*32) */
+    int x_np, out_np, res_np; /* pixels per channel slab of the planar input / output / residual buffers (0 = exactly the
+                             pixels of this launch): lets a layer read from / write into a slice of a larger buffer */
     int tile_n;           /* output-channel tile the weights were packed for: 0 / 128 (stm_conv_pack_weights_f32) or 64
                              (stm_conv_pack_weights_tiled_f32): 128 x 64 tiles, two workgroups per CU -- narrow layers
                              (few output channels) and layers with few pixel tiles */
@@ -260,13 +262,16 @@ int stm_conv_pack_weights_tiled_f32(const float* weight, void* packed, int Cout,
 int stm_conv2d_nhwc_f32(const float* x, const void* packed_weight, const float* bias, const float* residual, float* out,
                         const stm_conv_geom* g, int relu, stm_stream_t stream);
 
-/* Planar form of the same convolution: activations travel between layers ALREADY split, as bf16 planes
- * [planes][B*H*W][ld] (plane p of element i at planes + (p * B*H*W*ld + i) * 2 bytes; fp32 value = sum of the planes,
- * exactly).  Staging a K-slab is then pure LDS-DMA -- each element is split once, by its producer's epilogue, instead of
- * kh*kw*(Cout/128) times by its consumers.  stm_split_bf16_planes_f32 enters the format from an fp32 tensor (n % 8 == 0);
+/* Planar form of the same convolution: activations travel between layers ALREADY split, as bf16 planes in
+ * channel-slab-major order [planes][C/32][pixels][32]: the 32-channel slab of one pixel is one 64-byte line and
+ * consecutive pixels are consecutive lines (a K-slab's activation tile, and its shifted re-reads by the other taps, are
+ * dense in memory and in L2); element (plane p, pixel i, channel c) sits at
+ * ((p * plane_stride) + ((c/32) * np + i) * 32 + c%32) * 2 bytes; fp32 value = sum of the planes, exactly.  Staging a K-slab is then pure LDS-DMA -- each element is split once, by its producer's epilogue, instead of
+ * kh*kw*(Cout/128) times by its consumers.  stm_split_bf16_planes_f32 enters the format from an fp32 NHWC tensor (C % 32 == 0);
  * the convolution writes fp32 NHWC (out_f32), three planes (out_planes), or both; the residual may be given in either
  * form.  g->planes selects how many input planes take part in the products (3 or 2); outputs always carry three. */
-int stm_split_bf16_planes_f32(const float* x, void* planes, int64_t n, stm_stream_t stream);
+int stm_split_bf16_planes_f32(const float* x /* [n_pixels][C] fp32 */, void* planes /* [3][C/32][n_pixels][32] */,
+                              int64_t n_pixels, int C, stm_stream_t stream);
 int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
                           const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu,
                           stm_stream_t stream);

@@ -57,9 +57,9 @@ for name, H, W, C, O, k, s in SHAPES:
     xn = xc.contiguous()
     f_nchw = lambda: F.conv2d(xn, w, b, stride=s, padding=k // 2)
     xp = ops.split_planes(x)
-    f_pl = lambda: ops.conv2d_planar(xp, pk, (O, C, k, k), b, None, stride=s, padding=k // 2, relu=True, planes=planes, out="planes")
+    f_pl = lambda: ops.conv2d_planar(xp, pk, (O, C, k, k), (B, H, W), b, None, stride=s, padding=k // 2, relu=True, planes=planes, out="planes")
     pk64 = ops.conv_pack_weights(w, planes, 64)
-    f_p64 = lambda: ops.conv2d_planar(xp, pk64, (O, C, k, k), b, None, stride=s, padding=k // 2, relu=True, planes=planes, out="planes", tile_n=64)
+    f_p64 = lambda: ops.conv2d_planar(xp, pk64, (O, C, k, k), (B, H, W), b, None, stride=s, padding=k // 2, relu=True, planes=planes, out="planes", tile_n=64)
     f_sp = lambda: ops.split_planes(x)
     to, tt, tn, tp, tsp, tp64 = timeit(f_ours), timeit(f_torch), timeit(f_nchw), timeit(f_pl), timeit(f_sp), timeit(f_p64)
     gf = 2.0 * B * out.shape[1] * out.shape[2] * O * C * k * k / 1e9

@@ -8,10 +8,10 @@ x = torch.randn(8, H, W, C, device="cuda"); w = torch.randn(O, C, k, k, device="
 pk = ops.conv_pack_weights(w)
 xp = ops.split_planes(x)
 for _ in range(3):
-    ops.conv2d_planar(xp, pk, (O, C, k, k), None, None, padding=1)
+    ops.conv2d_planar(xp, pk, (O, C, k, k), (8, H, W), None, None, padding=1)
 tr = torch.zeros(2 * 64 * 8, dtype=torch.int64, device="cuda")
 _lib.lib().stm_debug_conv_set_trace(ctypes.c_void_p(tr.data_ptr()))
-ops.conv2d_planar(xp, pk, (O, C, k, k), None, None, padding=1)
+ops.conv2d_planar(xp, pk, (O, C, k, k), (8, H, W), None, None, padding=1)
 torch.cuda.synchronize()
 _lib.lib().stm_debug_conv_set_trace(ctypes.c_void_p(0))
 t = tr.cpu().view(2, 64, 8)

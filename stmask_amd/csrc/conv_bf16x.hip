@@ -428,16 +428,17 @@ __global__ __launch_bounds__(512, 1) void conv_bf16x_pp_kernel(const ConvArgs a)
 // pipe, set their speed.  Two LDS buffers; slab s+1 streams in while the MFMAs run on slab s; one barrier per slab.
 // Workgroup = 4*MG waves as (2*MG) x 2, tile = 128*MG pixels x 128 channels.
 struct PlanarArgs {
-    const uint8_t* xp;      // [NPL][B*H*W][x_ld] bf16
+    const uint8_t* xp;      // [NPL][C/32][x_np][32] bf16 (channel-slab major: a pixel's 32-channel slab is one 64-B line)
     const uint8_t* wp;
     const float* bias;
     const float* res_f32;   // [M][res_ld] or null
-    const uint8_t* res_pl;  // [3][M][res_ld] bf16 or null
+    const uint8_t* res_pl;  // [3][Cout/32][res_np][32] bf16 or null
     float* out_f32;         // [M][out_ld] or null
-    uint8_t* out_pl;        // [3][M][out_ld] bf16 or null
+    uint8_t* out_pl;        // [3][Cout/32][out_np][32] bf16 or null
     int B, H, W, C, Ho, Wo, Cout;
     int kh, kw, sh, sw, ph, pw;
-    int x_ld, out_ld, res_ld;
+    int x_ld, out_ld, res_ld;                        // fp32 tensors only (pixels x ld)
+    int x_np, out_np, res_np;                        // pixels per channel slab of the planar buffers
     int relu;
     int M, n_tiles, m_tiles, slabs;
     unsigned plane_bytes;   // bytes of one input plane that may be addressed (buffer range)
@@ -445,6 +446,7 @@ struct PlanarArgs {
     int groups, ntpg, cout_g;                        // grouped conv: n-tiles per group, output channels per group
     int n_levels;                                    // > 0: pixels are the concatenation of n_levels images sizes
     int lvl_start[9], lvl_h[8], lvl_w[8];
+    int dbg;                // STM_CONV_DEBUG timing ablations (results wrong): 1 no DMA in the loop, 2 no barrier, 4 no MFMA
     int vec_epilogue;       // Cout, out_ld, res_ld multiples of 8 and 16-byte aligned pointers: vector epilogue
     long long* trace;
 };
@@ -501,15 +503,15 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         iy0[i] = ok ? oy * a.sh - a.ph : -(1 << 20);
         ix0[i] = ox * a.sw - a.pw;
         hl[i] = H; wl[i] = W;
-        // byte offset of (image origin, group channel base, logical chunk) within a plane
-        pbase[i] = ((first + b * H * W) * a.x_ld + grp * a.C) * 2 + ((slot ^ ((r >> 2) & 3)) << 4);
+        // byte offset of (image origin, logical chunk) within one channel slab of a plane
+        pbase[i] = (first + b * H * W) * 64 + ((slot ^ ((r >> 2) & 3)) << 4);
     }
     __amdgpu_buffer_rsrc_t xr[NPL];
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
         xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
     const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * WBUF;
-    const int taps = a.kh * a.kw, S = a.slabs;
+    const int taps = a.kh * a.kw, S = a.slabs, cslabs = a.C / CV_BK;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -517,12 +519,13 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     auto dma_x = [&](int buf) {
         uint8_t* xb = smem + buf * BUF;
         const int ky = s_tap / a.kw, kx = s_tap - ky * a.kw;
+        const int slab_off = (grp * cslabs + s_c) * (a.x_np * 64);     // uniform: this K-slab's channel slab
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int iy = iy0[i] + ky, ix = ix0[i] + kx;
             // branch-free (a select the compiler turns into an exec-masked branch would split the MFMA block)
             const unsigned oob = ((unsigned)iy >= (unsigned)hl[i]) | ((unsigned)ix >= (unsigned)wl[i]);
-            const unsigned off = (unsigned)(pbase[i] + ((iy * wl[i] + ix) * a.x_ld + s_c * CV_BK) * 2) | (oob << 31);
+            const unsigned off = (unsigned)(pbase[i] + (iy * wl[i] + ix) * 64 + slab_off) | (oob << 31);
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(xb + p * (BM * 64) + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         PL_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of slab s has landed
         PL_STAMP(1);
-        __syncthreads();                                     // ... everyone's has, and buffer (s+1)&1 is no longer read
+        if (!(a.dbg & 2)) __syncthreads();                   // ... everyone's has, and buffer (s+1)&1 is no longer read
         PL_STAMP(2);
         const uint8_t* xs = smem + (s & 1) * BUF;
         const uint8_t* ws = xs + XBUF;
@@ -583,8 +586,11 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 #pragma unroll
                 for (int p = 0; p < NPL; ++p)
                     bf[j][p] = *reinterpret_cast<const bf16x8*>(ws + p * WPL + lds_off(wn * (32 * NJ) + j * 32 + lrow, 2 * ks + lh));
-            if (ks == 0) dma_x((s + 1) & 1);
-            else dma_w(min(s + 1, S - 1), (s + 1) & 1);
+            if (!(a.dbg & 1)) {
+                if (ks == 0) dma_x((s + 1) & 1);
+                else dma_w(min(s + 1, S - 1), (s + 1) & 1);
+            }
+            if (!(a.dbg & 4))
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -618,6 +624,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     // now) and re-reads it pixel-major, 8 consecutive channels per lane, so every global access is a 16-byte vector
     // (24 stores per thread for the three planes instead of 192 two-byte ones).
     const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
+    // element index of (pixel m, channel co) in a slab-major planar buffer with np pixels per slab
+    auto pidx = [](int m, int co, int np) { return ((size_t)(co >> 5) * np + m) * 32 + (co & 31); };
     if (a.vec_epilogue) {
         __syncthreads();                                   // all fragment reads of the last slab are done
         constexpr int EP_LD = 32 * NJ + 4;                 // floats per parked pixel row (+ 4 pad)
@@ -653,7 +661,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                 v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
             }
             if (a.res_pl) {
-                const size_t ri = ((size_t)m * a.res_ld + co) * 2;
+                const size_t ri = pidx(m, co, a.res_np) * 2;
                 const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri);
                 const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 2);
                 const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 4);
@@ -673,7 +681,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                 unsigned q0[4], q1[4], q2[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
-                uint8_t* o = a.out_pl + ((size_t)m * a.out_ld + co) * 2;
+                uint8_t* o = a.out_pl + pidx(m, co, a.out_np) * 2;
                 *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
                 *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
                 *reinterpret_cast<u32x4*>(o + opl * 4) = u32x4{q2[0], q2[1], q2[2], q2[3]};
@@ -697,13 +705,13 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                     float v = (acc[i][j][r] + accl[i][j][r]) + bv;
                     if (a.res_f32) v += a.res_f32[(size_t)m * a.res_ld + co];
                     if (resp) {
-                        const size_t ri = (size_t)m * a.res_ld + co;
+                        const size_t ri = pidx(m, co, a.res_np);
                         v += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
                     }
                     if (a.relu) v = v > 0.0f ? v : 0.0f;
                     if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co] = v;
                     if (outp) {
-                        const size_t oi = (size_t)m * a.out_ld + co;
+                        const size_t oi = pidx(m, co, a.out_np);
                         const __bf16 h = (__bf16)v;
                         const float r1 = v - (float)h;
                         const __bf16 mid = (__bf16)r1;
@@ -719,31 +727,27 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 #endif
 }
 
-// fp32 -> three bf16 planes [3][n] (entry into the planar format from a foreign producer); 8 elements per thread
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint8_t* __restrict__ planes, int64_t n)
+// fp32 [n pixels][C] (NHWC) -> three bf16 planes [3][C/32][n][32] (entry into the planar format from a foreign producer);
+// thread = 8 channels of one pixel
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint8_t* __restrict__ planes, int64_t n, int C)
 {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (i >= n) return;
-    if (i + 8 <= n) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + i), a1 = *reinterpret_cast<const f32x4*>(x + i + 4);
-        unsigned q0[4], q1[4], q2[4];
-        split2(f32x2{a0.x, a0.y}, q0[0], q1[0], q2[0]);
-        split2(f32x2{a0.z, a0.w}, q0[1], q1[1], q2[1]);
-        split2(f32x2{a1.x, a1.y}, q0[2], q1[2], q2[2]);
-        split2(f32x2{a1.z, a1.w}, q0[3], q1[3], q2[3]);
-        *reinterpret_cast<u32x4*>(planes + i * 2) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-        *reinterpret_cast<u32x4*>(planes + (n + i) * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-        *reinterpret_cast<u32x4*>(planes + (2 * n + i) * 2) = u32x4{q2[0], q2[1], q2[2], q2[3]};
-    } else {
-        __bf16* pl = reinterpret_cast<__bf16*>(planes);
-        for (int64_t k = i; k < n; ++k) {
-            const float v = x[k];
-            const __bf16 h = (__bf16)v;
-            const float r1 = v - (float)h;
-            const __bf16 mid = (__bf16)r1;
-            pl[k] = h; pl[n + k] = mid; pl[2 * n + k] = (__bf16)(r1 - (float)mid);
-        }
-    }
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c8n = C >> 3;
+    if (idx >= n * c8n) return;
+    const int64_t pix = idx / c8n;
+    const int c8 = (int)(idx - pix * c8n);
+    const float* src = x + pix * C + c8 * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+    unsigned q0[4], q1[4], q2[4];
+    split2(f32x2{a0.x, a0.y}, q0[0], q1[0], q2[0]);
+    split2(f32x2{a0.z, a0.w}, q0[1], q1[1], q2[1]);
+    split2(f32x2{a1.x, a1.y}, q0[2], q1[2], q2[2]);
+    split2(f32x2{a1.z, a1.w}, q0[3], q1[3], q2[3]);
+    const size_t plane_b = (size_t)n * C * 2;
+    uint8_t* dst = planes + (((size_t)(c8 >> 2) * n + pix) * 32 + (c8 & 3) * 8) * 2;
+    *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+    *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+    *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
 }
 
 // Weights [Cout][Cin][kh][kw] fp32 -> packed [n_tile][slab][plane][row 0..127][swizzled 16-B chunk][8 bf16]; rows past
@@ -913,12 +917,14 @@ extern "C" int stm_conv2d_nhwc_f32(const float* x, const void* packed_weight, co
     return STM_OK;
 }
 
-extern "C" int stm_split_bf16_planes_f32(const float* x, void* planes, int64_t n, stm_stream_t stream)
+extern "C" int stm_split_bf16_planes_f32(const float* x, void* planes, int64_t n_pixels, int C, stm_stream_t stream)
 {
     STM_REQUIRE(x && planes, STM_ENULL, "stm_split_bf16_planes_f32: x/planes must be non-NULL");
-    STM_REQUIRE(n > 0 && n % 8 == 0, STM_EINVAL, "stm_split_bf16_planes_f32: n (%lld) must be a positive multiple of 8", (long long)n);
+    STM_REQUIRE(n_pixels > 0 && C > 0 && C % 32 == 0, STM_EINVAL, "stm_split_bf16_planes_f32: n_pixels (%lld) > 0 and C (%d) a multiple of 32",
+                (long long)n_pixels, C);
     STM_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)planes % 16 == 0, STM_EINVAL, "stm_split_bf16_planes_f32: 16-byte alignment required");
-    hipLaunchKernelGGL(split_planes_kernel, dim3(stm_cdiv(n / 8, 256)), dim3(256), 0, stm_hs(stream), x, static_cast<uint8_t*>(planes), n);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(stm_cdiv(n_pixels * (C / 8), 256)), dim3(256), 0, stm_hs(stream), x,
+                       static_cast<uint8_t*>(planes), n_pixels, C);
     STM_CHECK_LAUNCH("split_planes_kernel");
     return STM_OK;
 }
@@ -954,18 +960,23 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
         M = (int64_t)g->B * g->Ho * g->Wo;
         in_pixels = (int64_t)g->B * g->H * g->W;
     }
-    const int x_ld = g->x_ld ? g->x_ld : groups * g->C, out_ld = g->out_ld ? g->out_ld : g->Cout, res_ld = g->res_ld ? g->res_ld : g->Cout;
-    STM_REQUIRE(x_ld >= groups * g->C && x_ld % 8 == 0 && out_ld >= g->Cout && res_ld >= g->Cout, STM_EINVAL,
-                "%s: bad leading dimensions x_ld=%d out_ld=%d res_ld=%d", who, x_ld, out_ld, res_ld);
+    // fp32 tensors: [pixels][ld]; planar buffers: [plane][channel slab][np pixels][32]
+    const int out_ld = g->out_ld ? g->out_ld : g->Cout, res_ld = g->res_ld ? g->res_ld : g->Cout;
+    STM_REQUIRE(out_ld >= g->Cout && res_ld >= g->Cout, STM_EINVAL, "%s: bad leading dimensions out_ld=%d res_ld=%d", who, out_ld, res_ld);
+    const int64_t x_np = g->x_np ? g->x_np : in_pixels, out_np = g->out_np ? g->out_np : M, res_np = g->res_np ? g->res_np : M;
+    STM_REQUIRE(x_np >= in_pixels && out_np >= M && res_np >= M, STM_EINVAL, "%s: x_np / out_np / res_np smaller than the pixel count", who);
     STM_REQUIRE((uintptr_t)x_planes % 16 == 0 && (uintptr_t)packed_weight % 16 == 0, STM_EINVAL,
                 "%s: x_planes and packed_weight must be 16-byte aligned", who);
-    const int64_t plane_bytes = in_pixels * x_ld * 2;
+    const int64_t x_slabs = (int64_t)groups * (g->C / CV_BK);
+    const int64_t plane_bytes = x_slabs * x_np * 64;          // the channel slabs this launch may address, from x_planes
     STM_REQUIRE(plane_bytes < ((int64_t)1 << 31), STM_EUNSUPPORTED, "%s: plane larger than 2 GiB", who);
     STM_REQUIRE(M < ((int64_t)1 << 30), STM_EUNSUPPORTED, "%s: too many output pixels", who);
-    const int64_t xps = g->x_plane_stride ? g->x_plane_stride : in_pixels * x_ld;
-    const int64_t ops = g->out_plane_stride ? g->out_plane_stride : M * out_ld;
-    const int64_t rps = g->res_plane_stride ? g->res_plane_stride : M * res_ld;
+    const int64_t o_slabs = stm_cdiv(g->Cout, 32);
+    const int64_t xps = g->x_plane_stride ? g->x_plane_stride : x_slabs * x_np * 32;
+    const int64_t ops = g->out_plane_stride ? g->out_plane_stride : o_slabs * out_np * 32;
+    const int64_t rps = g->res_plane_stride ? g->res_plane_stride : o_slabs * res_np * 32;
     STM_REQUIRE(xps % 8 == 0, STM_EINVAL, "%s: x_plane_stride must be a multiple of 8 elements", who);
+    const int x_ld = 0;
     PlanarArgs a;
     a.xp = static_cast<const uint8_t*>(x_planes); a.wp = static_cast<const uint8_t*>(packed_weight); a.bias = bias;
     a.res_f32 = residual_f32; a.res_pl = static_cast<const uint8_t*>(residual_planes);
@@ -973,6 +984,7 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout;
     a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw;
     a.x_ld = x_ld; a.out_ld = out_ld; a.res_ld = res_ld; a.relu = relu;
+    a.x_np = (int)x_np; a.out_np = (int)out_np; a.res_np = (int)res_np;
     a.M = (int)M; a.n_tiles = stm_cdiv(g->Cout, bn); a.slabs = g->kh * g->kw * (g->C / CV_BK);
     a.plane_bytes = (unsigned)plane_bytes;
     a.x_pstride = xps * 2; a.out_pstride = ops * 2; a.res_pstride = rps * 2;
@@ -980,10 +992,11 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     a.n_levels = g->n_levels > 0 ? g->n_levels : 0;
     for (int l = 0; l < 8; ++l) { a.lvl_start[l] = g->lvl_start[l]; a.lvl_h[l] = g->lvl_h[l]; a.lvl_w[l] = g->lvl_w[l]; }
     a.lvl_start[8] = g->lvl_start[8];
-    a.vec_epilogue = (cout_g % 8 == 0) && (out_ld % 8 == 0) && (res_ld % 8 == 0) && ((uintptr_t)out_f32 % 16 == 0) &&
+    a.vec_epilogue = (cout_g % 8 == 0) && (!out_f32 || out_ld % 4 == 0) && (!residual_f32 || res_ld % 4 == 0) && ((uintptr_t)out_f32 % 16 == 0) &&
                      ((uintptr_t)out_planes % 16 == 0) && ((uintptr_t)residual_f32 % 16 == 0) && ((uintptr_t)residual_planes % 16 == 0) &&
                      (ops % 8 == 0) && (rps % 8 == 0) && !getenv("STM_CONV_SCALAR_EPILOGUE");
     a.trace = g_conv_trace;
+    { const char* dbg = getenv("STM_CONV_DEBUG"); a.dbg = dbg ? atoi(dbg) : 0; }
     if (bn == 64) {
         // 128 x 64 tiles, 72 KB of LDS: two independent workgroups per CU, each one's barrier / staging gaps filled by
         // the other's MFMAs

@@ -435,39 +435,52 @@ def conv2d_nhwc(x, packed, weight_shape, bias=None, residual=None, stride=1, pad
 
 
 def split_planes(x):
-    """fp32 tensor (any shape, numel % 8 == 0) -> [3, *shape] bf16 planes whose fp32 sum is x exactly."""
+    """fp32 NHWC tensor [..., C] (C % 32 == 0) -> bf16 planes [3, C/32, N, 32] (N = product of the leading dims) whose fp32
+    sum is x exactly; channel-slab-major: see include/stmask_hip.h."""
     _dev(x)
     x = _f32c(x)
-    planes = torch.empty((3,) + tuple(x.shape), device=x.device, dtype=torch.bfloat16)
-    check(_lib.lib().stm_split_bf16_planes_f32(_p(x), _p(planes), c_l(x.numel()), _stream()), "stm_split_bf16_planes_f32")
+    C = x.shape[-1]
+    N = x.numel() // C
+    if C % 32:
+        raise StmError(f"split_planes: channel count {C} is not a multiple of 32")
+    planes = torch.empty(3, C // 32, N, 32, device=x.device, dtype=torch.bfloat16)
+    check(_lib.lib().stm_split_bf16_planes_f32(_p(x), _p(planes), c_l(N), c_i(C), _stream()), "stm_split_bf16_planes_f32")
     return planes
 
 
-def conv2d_planar(xp, packed, weight_shape, bias=None, residual=None, stride=1, padding=0, relu=False, planes=3,
+def planes_to_f32(planes):
+    """[3, S, N, 32] bf16 planes -> fp32 [N, 32*S] (exact)."""
+    v = (planes[0].float() + planes[1].float()) + planes[2].float()
+    return v.permute(1, 0, 2).reshape(v.shape[1], -1)
+
+
+def conv2d_planar(xp, packed, weight_shape, hw, bias=None, residual=None, stride=1, padding=0, relu=False, planes=3,
                   out="planes", tile_n=128):
-    """The same convolution on the planar activation format: xp [3,B,H,W,C] bf16 (split_planes / a previous layer's
-    output).  `residual` may be fp32 [B,Ho,Wo,O] or planes [3,B,Ho,Wo,O].  out: "planes" | "f32" | "both"."""
+    """The same convolution on the planar activation format: xp [3, C/32, B*H*W, 32] bf16 (split_planes / a previous
+    layer's output), hw = (B, H, W).  `residual` may be fp32 [B*Ho*Wo, O] or planes [3, O/32, B*Ho*Wo, 32].
+    out: "planes" | "f32" | "both"; fp32 result [B*Ho*Wo, O]."""
     _dev(xp, packed, bias, residual)
-    if xp.dtype != torch.bfloat16 or xp.dim() != 5 or xp.shape[0] != 3 or not xp.is_contiguous():
-        raise StmError(f"conv2d_planar: expected contiguous bf16 planes [3,B,H,W,C], got {xp.dtype} {tuple(xp.shape)}")
+    if xp.dtype != torch.bfloat16 or xp.dim() != 4 or xp.shape[0] != 3 or xp.shape[3] != 32 or not xp.is_contiguous():
+        raise StmError(f"conv2d_planar: expected contiguous bf16 planes [3,C/32,N,32], got {xp.dtype} {tuple(xp.shape)}")
     O, C, kh, kw = weight_shape
-    _, B, H, W, Cx = xp.shape
-    if Cx != C:
-        raise StmError(f"conv2d_planar: input has {Cx} channels, weights expect {C}")
+    B, H, W = hw
+    if xp.shape[1] * 32 != C or xp.shape[2] != B * H * W:
+        raise StmError(f"conv2d_planar: planes {tuple(xp.shape)} do not match C={C}, B*H*W={B * H * W}")
     (sh, sw), (ph, pw) = _pair(stride), _pair(padding)
     Ho, Wo = conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, 1, 1)
-    y32 = torch.empty(B, Ho, Wo, O, device=xp.device, dtype=torch.float32) if out in ("f32", "both") else None
-    ypl = torch.empty(3, B, Ho, Wo, O, device=xp.device, dtype=torch.bfloat16) if out in ("planes", "both") else None
+    M = B * Ho * Wo
+    y32 = torch.empty(M, O, device=xp.device, dtype=torch.float32) if out in ("f32", "both") else None
+    ypl = torch.empty(3, -(-O // 32), M, 32, device=xp.device, dtype=torch.bfloat16) if out in ("planes", "both") else None
     r32 = rpl = None
     if residual is not None:
         if residual.dtype == torch.bfloat16:
-            if tuple(residual.shape) != (3, B, Ho, Wo, O) or not residual.is_contiguous():
-                raise StmError(f"conv2d_planar: residual planes {tuple(residual.shape)} != {(3, B, Ho, Wo, O)}")
+            if tuple(residual.shape) != (3, -(-O // 32), M, 32) or not residual.is_contiguous():
+                raise StmError(f"conv2d_planar: residual planes {tuple(residual.shape)} != {(3, -(-O // 32), M, 32)}")
             rpl = residual
         else:
             r32 = _f32c(residual)
-            if tuple(r32.shape) != (B, Ho, Wo, O):
-                raise StmError(f"conv2d_planar: residual {tuple(r32.shape)} != output {(B, Ho, Wo, O)}")
+            if r32.numel() != M * O:
+                raise StmError(f"conv2d_planar: residual has {r32.numel()} elements, output {M * O}")
     g = _lib.ConvGeom(B, H, W, C, Ho, Wo, O, kh, kw, sh, sw, ph, pw, 0, 0, 0, planes)
     g.tile_n = tile_n
     check(_lib.lib().stm_conv2d_planar_f32(_p(xp), _p(packed), _p(_f32c(bias) if bias is not None else None), _p(r32), _p(rpl),

@@ -61,17 +61,18 @@ class PlanarConv:
         return 64 if tiles128 < 400 else 128
 
     def __call__(self, xp, shape, out="planes", x_off=0, out_planes=None, out_f32=None, out_off=0, residual=None, x_ch_off=0):
-        """xp: [3, N, x_ld] bf16.  shape: ("img", B, H, W) -> pixels [x_off, x_off + B*H*W) of xp are one image batch;
-        ("levels", B, [(H, W), ...]) -> all of xp, concatenated levels.  out: "planes" | "f32" | "both" allocates dense
-        outputs unless out_planes / out_f32 ([3, N', ld] / [N', ld]) are given, then rows [out_off, ...) are written."""
-        if xp.dtype != torch.bfloat16 or xp.dim() != 3 or xp.shape[0] != 3 or not xp.is_contiguous():
-            raise StmError(f"PlanarConv: expected contiguous bf16 planes [3, N, C], got {xp.dtype} {tuple(xp.shape)}")
-        x_ld = xp.shape[2]
+        """xp: [3, S, N, 32] bf16 (channel-slab-major planes).  shape: ("img", B, H, W) -> pixels [x_off, x_off + B*H*W)
+        of xp are one image batch; ("levels", B, [(H, W), ...]) -> all of xp, concatenated levels.  The layer reads
+        groups*C channels starting at channel x_ch_off.  out: "planes" | "f32" | "both" allocates dense outputs
+        ([3, O/32, M, 32] / [M, O]) unless out_planes / out_f32 are given, then pixels [out_off, ...) are written."""
+        if xp.dtype != torch.bfloat16 or xp.dim() != 4 or xp.shape[0] != 3 or xp.shape[3] != 32 or not xp.is_contiguous():
+            raise StmError(f"PlanarConv: expected contiguous bf16 planes [3, S, N, 32], got {xp.dtype} {tuple(xp.shape)}")
+        S, N = xp.shape[1], xp.shape[2]
         g = _lib.ConvGeom()
         g.C, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw = self.C, self.O, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw
-        g.planes, g.groups, g.x_ld = self.planes, self.groups, x_ld
-        if x_ld < x_ch_off + self.groups * self.C or x_ch_off % 8:
-            raise StmError(f"PlanarConv: input has {x_ld} channels, layer reads {self.groups} x {self.C} from channel {x_ch_off}")
+        g.planes, g.groups = self.planes, self.groups
+        if S * 32 < x_ch_off + self.groups * self.C or x_ch_off % 32:
+            raise StmError(f"PlanarConv: input has {S * 32} channels, layer reads {self.groups} x {self.C} from channel {x_ch_off}")
         if shape[0] == "levels":
             _, B, sizes = shape
             g.n_levels = len(sizes)
@@ -80,21 +81,21 @@ class PlanarConv:
                 g.lvl_start[l], g.lvl_h[l], g.lvl_w[l] = start, h, w
                 start += B * h * w
             g.lvl_start[len(sizes)] = start
-            M = n_in = start
-            if x_off or xp.shape[1] != start:
+            M = start
+            if x_off or N != start:
                 raise StmError("PlanarConv: a multi-level launch covers the whole plane buffer")
         else:
             _, B, H, W = shape
             Ho, Wo = ops.conv_out_hw(H, W, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, 1, 1)
             g.B, g.H, g.W, g.Ho, g.Wo = B, H, W, Ho, Wo
-            M, n_in = B * Ho * Wo, B * H * W
-            if x_off + n_in > xp.shape[1]:
+            M = B * Ho * Wo
+            if x_off + B * H * W > N:
                 raise StmError("PlanarConv: input slice runs past the plane buffer")
-        g.x_plane_stride = xp.shape[1] * x_ld
+        g.x_np, g.x_plane_stride = N, S * N * 32
         g.tile_n = self.pick_tile(M)
         dev = xp.device
         if out in ("planes", "both") and out_planes is None:
-            out_planes, out_off_p = torch.empty(3, M, self.O, device=dev, dtype=torch.bfloat16), 0
+            out_planes, out_off_p = torch.empty(3, -(-self.O // 32), M, 32, device=dev, dtype=torch.bfloat16), 0
         else:
             out_off_p = out_off
         if out in ("f32", "both") and out_f32 is None:
@@ -105,23 +106,17 @@ class PlanarConv:
             out_f32 = None
         if out == "f32":
             out_planes = None
-        ld = None
-        for t in (out_planes, out_f32):
-            if t is not None:
-                if ld is not None and t.shape[-1] != ld:
-                    raise StmError("PlanarConv: fp32 and planar outputs must share their leading dimension")
-                ld = t.shape[-1]
-        g.out_ld = ld
         p_pl = p_f32 = 0
         if out_planes is not None:
-            g.out_plane_stride = out_planes.shape[1] * ld
-            p_pl = out_planes.data_ptr() + out_off_p * ld * 2
+            g.out_np, g.out_plane_stride = out_planes.shape[2], out_planes.shape[1] * out_planes.shape[2] * 32
+            p_pl = out_planes.data_ptr() + out_off_p * 64
         if out_f32 is not None:
-            p_f32 = out_f32.data_ptr() + out_off_f * ld * 4
+            g.out_ld = out_f32.shape[-1]
+            p_f32 = out_f32.data_ptr() + out_off_f * g.out_ld * 4
         r32 = rpl = 0
         if residual is not None:
             if residual.dtype == torch.bfloat16:
-                g.res_ld, g.res_plane_stride = residual.shape[2], residual.shape[1] * residual.shape[2]
+                g.res_np, g.res_plane_stride = residual.shape[2], residual.shape[1] * residual.shape[2] * 32
                 rpl = residual.data_ptr()
             else:
                 g.res_ld = residual.shape[-1]
@@ -130,7 +125,8 @@ class PlanarConv:
         if timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rc = _lib.lib().stm_conv2d_planar_f32(ctypes.c_void_p(xp.data_ptr() + (x_off * x_ld + x_ch_off) * 2), ops._p(self.packed(g.tile_n)),
+        x_ptr = xp.data_ptr() + ((x_ch_off // 32) * N + x_off) * 64
+        rc = _lib.lib().stm_conv2d_planar_f32(ctypes.c_void_p(x_ptr), ops._p(self.packed(g.tile_n)),
                                               ops._p(self.bias), ctypes.c_void_p(r32), ctypes.c_void_p(rpl),
                                               ctypes.c_void_p(p_f32), ctypes.c_void_p(p_pl), ctypes.byref(g),
                                               c_i(1 if self.relu else 0), ops._stream())
@@ -149,9 +145,8 @@ def _nhwc(t):
 
 
 def _split(t_nhwc):
-    """fp32 [B, H, W, C] -> planes [3, B*H*W, C]."""
-    B, H, W, C = t_nhwc.shape
-    return ops.split_planes(t_nhwc).view(3, B * H * W, C)
+    """fp32 [B, H, W, C] -> planes [3, C/32, B*H*W, 32]."""
+    return ops.split_planes(t_nhwc)
 
 
 class PlanarGraph:
@@ -244,7 +239,7 @@ class PlanarGraph:
             starts.append(starts[-1] + B * h * w)
         ntot, nf = starts[-1], self.fpn_pred[0].O
         dev = lat[0].device
-        feat = torch.empty(3, ntot, nf, device=dev, dtype=torch.bfloat16)    # P3..P7, all levels, planar
+        feat = torch.empty(3, nf // 32, ntot, 32, device=dev, dtype=torch.bfloat16)   # P3..P7, all levels, planar
         feat32 = torch.empty(ntot, nf, device=dev, dtype=torch.float32) if not self.head_planar else None
         fpn_outs = [None] * len(sizes)
         for i, conv in enumerate(self.fpn_pred):
@@ -267,8 +262,7 @@ class PlanarGraph:
         if feat32 is None and self.cor_idx is not None:
             # fp32 NCHW view of the correlation level, rebuilt from its planes (exact)
             j = self.cor_idx
-            pl = feat[:, starts[j]:starts[j + 1]].float()
-            fpn_outs[j] = ((pl[0] + pl[1]) + pl[2]).view(B, *sizes[j], nf).permute(0, 3, 1, 2)
+            fpn_outs[j] = ops.planes_to_f32(feat[:, :, starts[j]:starts[j + 1]]).view(B, *sizes[j], nf).permute(0, 3, 1, 2)
 
         toc("fpn_pred_down")
         # ---- proto-net on P3 (mask_proto_src) ------------------------------------------------------------------
@@ -373,7 +367,7 @@ class PlanarTemporalNet:
         """roi_feats [n, 633, 7, 7] fp32 -> (loc shift [n, 4], coeff shift [n, 32])."""
         n, c, h, w = roi_feats.shape
         x = F.pad(roi_feats.permute(0, 2, 3, 1), (0, self.cpad - c)).contiguous()       # NHWC, channels padded
-        xp = ops.split_planes(x).view(3, n * h * w, self.cpad)
+        xp = ops.split_planes(x)
         shape = ("img", n, h, w)
         y = self.c3(self.c2(self.c1(xp, shape), shape), shape, out="f32")                # [n*h*w, 1024]
         pooled = y.view(n, h * w, -1).mean(dim=1)                                        # AvgPool2d((7, 7)) on a 7x7 map

@@ -125,14 +125,14 @@ def test_conv_rejects_bad_arguments():
 
 
 def planes_to_f32(pl):
-    return (pl[0].float() + pl[1].float()) + pl[2].float()
+    return ops.planes_to_f32(pl)
 
 
 def test_split_planes_is_exact():
     x = rnd(3, 5, 8, 64, seed=11) * torch.logspace(-6, 6, 64)
     pl = ops.split_planes(x.to(DEV)).cpu()
-    assert pl.shape == (3, 3, 5, 8, 64) and pl.dtype == torch.bfloat16
-    assert torch.equal(planes_to_f32(pl), x)          # 8+8+8 mantissa bits: the fp32 value is recovered exactly
+    assert pl.shape == (3, 2, 3 * 5 * 8, 32) and pl.dtype == torch.bfloat16       # [plane, channel slab, pixel, 32]
+    assert torch.equal(planes_to_f32(pl), x.view(-1, 64))   # 8+8+8 significand bits: the fp32 value is recovered exactly
 
 
 @pytest.mark.parametrize("mg", ["1", "2", "n64"])
@@ -155,18 +155,19 @@ def test_conv_planar_vs_oracle(case, mg, monkeypatch):
     pkt = ops.conv_pack_weights(w.to(DEV), tile_n=tile_n)
     xp = ops.split_planes(x.to(DEV))
     bd = b.to(DEV) if has_bias else None
-    y32, ypl = ops.conv2d_planar(xp, pkt, tuple(w.shape), bd, r.to(DEV) if has_res else None, stride=s, padding=pad, relu=relu,
-                                 out="both", tile_n=tile_n)
-    y32, ypl = y32.cpu(), ypl.cpu()
+    y32, ypl = ops.conv2d_planar(xp, pkt, tuple(w.shape), (B, H, W), bd, r.to(DEV) if has_res else None, stride=s, padding=pad,
+                                 relu=relu, out="both", tile_n=tile_n)
+    y32, ypl = y32.cpu().view(ref.shape), ypl.cpu()
     assert ((y32 - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
-    assert torch.equal(planes_to_f32(ypl), y32)        # the planar output IS the fp32 output, split
+    # the planar output IS the fp32 output, split (channels past Cout in the last slab are never written)
+    assert torch.equal(planes_to_f32(ypl)[:, :O], y32.view(-1, O))
     # same inputs through the register-staged fp32-in kernel: identical products and accumulation order
     y_ref_kernel = ops.conv2d_nhwc(x.to(DEV), pk, tuple(w.shape), bd, r.to(DEV) if has_res else None, stride=s, padding=pad, relu=relu).cpu()
     assert torch.equal(y32, y_ref_kernel)
     if has_res:                                        # residual handed over as planes gives the same result
-        y2 = ops.conv2d_planar(xp, pkt, tuple(w.shape), bd, ops.split_planes(r.to(DEV)), stride=s, padding=pad, relu=relu,
-                               out="f32", tile_n=tile_n).cpu()
-        assert torch.equal(y2, y32)
+        y2 = ops.conv2d_planar(xp, pkt, tuple(w.shape), (B, H, W), bd, ops.split_planes(r.to(DEV)), stride=s, padding=pad,
+                               relu=relu, out="f32", tile_n=tile_n).cpu()
+        assert torch.equal(y2.view(ref.shape), y32)
 
 
 def test_conv_planar_chain_of_layers():
@@ -176,6 +177,7 @@ def test_conv_planar_chain_of_layers():
     b1 = rnd(64, seed=24)
     h_ref = oracle.conv2d_nhwc(x, w1, b1, None, padding=1, relu=True)
     y_ref = oracle.conv2d_nhwc(h_ref, w2, None, None)
-    h = ops.conv2d_planar(ops.split_planes(x.to(DEV)), ops.conv_pack_weights(w1.to(DEV)), (64, 64, 3, 3), b1.to(DEV), padding=1, relu=True)
-    y = ops.conv2d_planar(h, ops.conv_pack_weights(w2.to(DEV)), (96, 64, 1, 1), out="f32").cpu()
-    assert (y - y_ref).abs().max().item() < 1e-5
+    h = ops.conv2d_planar(ops.split_planes(x.to(DEV)), ops.conv_pack_weights(w1.to(DEV)), (64, 64, 3, 3), (2, 24, 40), b1.to(DEV),
+                          padding=1, relu=True)
+    y = ops.conv2d_planar(h, ops.conv_pack_weights(w2.to(DEV)), (96, 64, 1, 1), (2, 24, 40), out="f32").cpu()
+    assert (y.view(y_ref.shape) - y_ref).abs().max().item() < 1e-5
