@@ -451,6 +451,118 @@ struct PlanarArgs {
     long long* trace;
 };
 
+// Epilogue shared by the planar kernels: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes.
+template <int NJ>
+__device__ __forceinline__ void planar_epilogue(const PlanarArgs& a, f32x16 (&acc)[2][NJ], f32x16 (&accl)[2][NJ], uint8_t* smem, int wave,
+                                                int lane, int m0, int n0g, int grp, int wm, int wn)
+{
+    const int lrow = lane & 31, lh = lane >> 5;
+    // epilogue: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes of the result.
+    // Fast path (Cout, leading dimensions multiples of 8): each wave parks its 64 x 64 accumulator tile in LDS (free
+    // now) and re-reads it pixel-major, 8 consecutive channels per lane, so every global access is a 16-byte vector
+    // (24 stores per thread for the three planes instead of 192 two-byte ones).
+    const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
+    // element index of (pixel m, channel co) in a slab-major planar buffer with np pixels per slab
+    auto pidx = [](int m, int co, int np) { return ((size_t)(co >> 5) * np + m) * 32 + (co & 31); };
+    if (a.vec_epilogue) {
+        __syncthreads();                                   // all fragment reads of the last slab are done
+        constexpr int EP_LD = 32 * NJ + 4;                 // floats per parked pixel row (+ 4 pad)
+        constexpr int LPR = 4 * NJ;                        // lanes per pixel row (8 channels each)
+        float* park = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    park[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP_LD + j * 32 + lrow] = acc[i][j][r] + accl[i][j][r];
+        // same wave reads back what it wrote: no workgroup barrier needed, only the LDS counter
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int seg = lane % LPR, prow = lane / LPR;
+        const int cog = n0g + wn * (32 * NJ) + seg * 8;    // channel within the group
+        const int co = grp * a.cout_g + cog;
+        const bool co_ok = cog < a.cout_g;                 // cout_g % 8 == 0: the whole 8-channel segment is in or out
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && co_ok) ? a.bias[co + e] : 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < LPR; ++pass) {
+            const int pr = pass * (64 / LPR) + prow;
+            const int m = m0 + wm * 64 + pr;
+            if (m >= a.M || !co_ok) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
+            float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+            if (a.res_f32) {
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co);
+                const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co + 4);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            }
+            if (a.res_pl) {
+                const size_t ri = pidx(m, co, a.res_np) * 2;
+                const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri);
+                const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 2);
+                const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += ((float)p0[e] + (float)p1[e]) + (float)p2[e];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+            }
+            if (a.out_f32) {
+                float* o = a.out_f32 + (size_t)m * a.out_ld + co;
+                *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+            if (a.out_pl) {
+                unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
+                uint8_t* o = a.out_pl + pidx(m, co, a.out_np) * 2;
+                *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+                *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+                *reinterpret_cast<u32x4*>(o + opl * 4) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+            }
+        }
+    } else {
+        __bf16* outp = reinterpret_cast<__bf16*>(a.out_pl);
+        const __bf16* resp = reinterpret_cast<const __bf16*>(a.res_pl);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int cog = n0g + wn * (32 * NJ) + j * 32 + lrow;
+            if (cog >= a.cout_g) continue;
+            const int co = grp * a.cout_g + cog;
+            const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m >= a.M) continue;
+                    float v = (acc[i][j][r] + accl[i][j][r]) + bv;
+                    if (a.res_f32) v += a.res_f32[(size_t)m * a.res_ld + co];
+                    if (resp) {
+                        const size_t ri = pidx(m, co, a.res_np);
+                        v += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
+                    }
+                    if (a.relu) v = v > 0.0f ? v : 0.0f;
+                    if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co] = v;
+                    if (outp) {
+                        const size_t oi = pidx(m, co, a.out_np);
+                        const __bf16 h = (__bf16)v;
+                        const float r1 = v - (float)h;
+                        const __bf16 mid = (__bf16)r1;
+                        const float r2 = r1 - (float)mid;
+                        outp[oi] = h;
+                        outp[oi + opl] = mid;
+                        outp[oi + 2 * opl] = (__bf16)r2;
+                    }
+                }
+        }
+    }
+}
+
 template <int NPL, int MG, int NJ>
 __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 {
@@ -619,111 +731,197 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 #undef PL_STAMP
     if (tr) a.trace[(wave != 0) * 512 + 7] = clock64();
 
-    // epilogue: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes of the result.
-    // Fast path (Cout, leading dimensions multiples of 8): each wave parks its 64 x 64 accumulator tile in LDS (free
-    // now) and re-reads it pixel-major, 8 consecutive channels per lane, so every global access is a 16-byte vector
-    // (24 stores per thread for the three planes instead of 192 two-byte ones).
-    const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
-    // element index of (pixel m, channel co) in a slab-major planar buffer with np pixels per slab
-    auto pidx = [](int m, int co, int np) { return ((size_t)(co >> 5) * np + m) * 32 + (co & 31); };
-    if (a.vec_epilogue) {
-        __syncthreads();                                   // all fragment reads of the last slab are done
-        constexpr int EP_LD = 32 * NJ + 4;                 // floats per parked pixel row (+ 4 pad)
-        constexpr int LPR = 4 * NJ;                        // lanes per pixel row (8 channels each)
-        float* park = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
+    planar_epilogue<NJ>(a, acc, accl, smem, wave, lane, m0, n0g, grp, wm, wn);
+    if (tr) a.trace[(wave != 0) * 512 + 15] = clock64();
+#endif
+}
+
+// ---- kx-reuse variant for stride-1 "same" convolutions with kw >= 3 (head towers, proto-net, output layers, TemporalNet,
+// FPN prediction layers, plain bottleneck 3x3): the ablations of the kernel above show it limited by on-chip data
+// movement as much as by the matrix pipe (MFMA + fragment reads alone 464 us, LDS-DMA + fragment reads alone 382 us, both
+// 650 us on the 145-GF proto layer; 72 KB per K-slab and CU, one slab in flight).  Here the activation tile of one
+// (channel slab, ky) is staged ONCE with pw extra pixel rows either side and serves all kw taps of that kernel row: tap kx
+// of tile pixel r is LDS row r + kx (the flat pixel index moves by one per x), masked to zero where x + kx - pw leaves the
+// image row (which also covers rows that wrapped to the neighbouring image row).  Activation DMA bytes drop by kw; the
+// weight tile is staged per tap as before.  256 x 128 tiles, 8 waves; LDS: two activation buffers of (256+16) rows and two
+// weight buffers = 150 KB.
+template <int NPL>
+__global__ __launch_bounds__(512, 1) void conv_planar_kx_kernel(const PlanarArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr int NJ = 2, BM = 256, BN = 128;
+    constexpr int XROWS = BM + 16, XPL = XROWS * 64, XBUF = NPL * XPL, WBUF = NPL * CV_PLANE_B;
+    constexpr int NWAVES = 8, WDMA = 8 * NPL / NWAVES;
+    uint8_t* const wbase = smem + 2 * XBUF;
+
+    const int tiles = a.m_tiles * a.n_tiles;
+    const int per_xcd = (tiles + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= tiles) return;
+    const int nt = logical % a.n_tiles;
+    const int mt = logical / a.n_tiles;
+    const int m0 = mt * BM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % 4, wn = wave / 4;
+    const int grp = nt / a.ntpg;
+    const int n0g = (nt - grp * a.ntpg) * BN;
+
+    auto decode = [&](int m, int& iy0, int& ox, int& base, int& H, int& W) {
+        const bool ok = m >= 0 && m < a.M;
+        const int mm = ok ? m : 0;
+        H = a.H; W = a.W;
+        int first = 0;
+        if (a.n_levels > 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int l = 0; l < 8; ++l)
+                if (l < a.n_levels && mm >= a.lvl_start[l]) { first = a.lvl_start[l]; H = a.lvl_h[l]; W = a.lvl_w[l]; }
+        }
+        const int local = mm - first;
+        const int b = local / (H * W);
+        const int rem = local - b * (H * W);
+        const int oy = rem / W;
+        ox = rem - oy * W;
+        iy0 = ok ? oy - a.ph : -(1 << 20);
+        base = (first + b * H * W) * 64;
+    };
+    // activation DMA duties: lds rows of groups {wave, wave + 8} (16 rows each) and, shared, the extra group 16
+    int d_iy0[3], d_ox[3], d_base[3], d_h[3], d_w[3];
+    const int slot = lane & 3;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+    for (int t = 0; t < 3; ++t) {
+        const int g = t < 2 ? wave + 8 * t : 16;
+        const int j = g * 16 + (lane >> 2);                 // lds row; tile pixel j - pw
+        decode(m0 + j - a.pw, d_iy0[t], d_ox[t], d_base[t], d_h[t], d_w[t]);
+        d_base[t] += (slot ^ ((j >> 2) & 3)) << 4;
+    }
+    // fragment rows of this lane (tile pixels wm*64 + i*32 + lane%32): x coordinate and row width for the kx masks
+    int f_ox[2], f_w[2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    park[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP_LD + j * 32 + lrow] = acc[i][j][r] + accl[i][j][r];
-        // same wave reads back what it wrote: no workgroup barrier needed, only the LDS counter
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int seg = lane % LPR, prow = lane / LPR;
-        const int cog = n0g + wn * (32 * NJ) + seg * 8;    // channel within the group
-        const int co = grp * a.cout_g + cog;
-        const bool co_ok = cog < a.cout_g;                 // cout_g % 8 == 0: the whole 8-channel segment is in or out
-        float bv[8];
+    for (int i = 0; i < 2; ++i) {
+        int t0, t1, t2;
+        decode(m0 + wm * 64 + i * 32 + (lane & 31), t0, f_ox[i], t1, t2, f_w[i]);
+    }
+    __amdgpu_buffer_rsrc_t xr[NPL];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && co_ok) ? a.bias[co + e] : 0.0f;
+    for (int p = 0; p < NPL; ++p)
+        xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
+    const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * WBUF;
+    const int S = a.slabs, cslabs = a.C / CV_BK;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+    auto dma_x = [&](int cs, int ky, int xi) {
+        uint8_t* xb = smem + xi * XBUF;
+        const int slab_off = (grp * cslabs + cs) * (a.x_np * 64);
 #pragma unroll
-        for (int pass = 0; pass < LPR; ++pass) {
-            const int pr = pass * (64 / LPR) + prow;
-            const int m = m0 + wm * 64 + pr;
-            if (m >= a.M || !co_ok) continue;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
-            float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-            if (a.res_f32) {
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co);
-                const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co + 4);
-                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-            }
-            if (a.res_pl) {
-                const size_t ri = pidx(m, co, a.res_np) * 2;
-                const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri);
-                const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 2);
-                const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 4);
+        for (int t = 0; t < 3; ++t) {
+            const int iy = d_iy0[t] + ky;
+            const unsigned oob = (unsigned)iy >= (unsigned)d_h[t];
+            const unsigned off = (unsigned)(d_base[t] + (iy * d_w[t] + d_ox[t]) * 64 + slab_off) | (oob << 31);
+            const int g = t < 2 ? wave + 8 * t : 16;
+            if (t < 2) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += ((float)p0[e] + (float)p1[e]) + (float)p2[e];
-            }
-            if (a.relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-            }
-            if (a.out_f32) {
-                float* o = a.out_f32 + (size_t)m * a.out_ld + co;
-                *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            }
-            if (a.out_pl) {
-                unsigned q0[4], q1[4], q2[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
-                uint8_t* o = a.out_pl + pidx(m, co, a.out_np) * 2;
-                *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-                *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-                *reinterpret_cast<u32x4*>(o + opl * 4) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+                for (int p = 0; p < NPL; ++p)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(xb + p * XPL + g * 1024), 16, off, 0, 0, 0);
+            } else {
+                // the 17th row group: one plane per wave (waves 3.. repeat planes: identical writes), so every wave issues
+                // the same number of DMA instructions
+                const int p = wave % NPL;                   // wave-uniform: scalar branches
+                if (p == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[0], (lds_ptr)(xb + g * 1024), 16, off, 0, 0, 0);
+                else if (p == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[1], (lds_ptr)(xb + XPL + g * 1024), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[NPL - 1], (lds_ptr)(xb + (NPL - 1) * XPL + g * 1024), 16, off, 0, 0, 0);
             }
         }
-    } else {
-        __bf16* outp = reinterpret_cast<__bf16*>(a.out_pl);
-        const __bf16* resp = reinterpret_cast<const __bf16*>(a.res_pl);
+    };
+    auto dma_w = [&](int slab, int buf) {
+        uint8_t* wb = wbase + buf * WBUF;
+        const uint8_t* wsrc = wtile + (size_t)slab * WBUF;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int cog = n0g + wn * (32 * NJ) + j * 32 + lrow;
-            if (cog >= a.cout_g) continue;
-            const int co = grp * a.cout_g + cog;
-            const float bv = a.bias ? a.bias[co] : 0.0f;
+        for (int j = 0; j < WDMA; ++j) {
+            const int wi = wave + NWAVES * j;
+            __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + wi * 1024 + lane * 16), (lds_ptr)(wb + wi * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][NJ], accl[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    int cs = 0, ky = 0, kx = 0, xi = 0;
+    bool x_in_flight = false;
+    dma_x(0, 0, 0);
+    dma_w(0, 0);
+    for (int s = 0; s < S; ++s) {
+        // this step's weight tile must have landed; an activation tile issued AFTER it in the previous step (2*NPL+1 DMA
+        // instructions per wave, needed only at the next kx == 0) may stay in flight: the counter retires in issue order
+        if (x_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPL + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(a.dbg & 2)) __syncthreads();
+        const uint8_t* xs = smem + xi * XBUF;
+        const uint8_t* ws = wbase + (s & 1) * WBUF;
+        // the next (channel slab, ky) tile, once per kernel row: a whole row of taps (kw steps) ahead of its first use
+        int ncs = cs, nky = ky + 1;
+        if (nky == a.kh) { nky = 0; ++ncs; }
+        const bool stage_x = kx == 0 && ncs < cslabs;
+        // masks of this tap: x + kx - pw inside the image row
+        unsigned msk[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) msk[i] = ((unsigned)(f_ox[i] + kx - a.pw) < (unsigned)f_w[i]) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2][NPL], bf[NJ][NPL];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m >= a.M) continue;
-                    float v = (acc[i][j][r] + accl[i][j][r]) + bv;
-                    if (a.res_f32) v += a.res_f32[(size_t)m * a.res_ld + co];
-                    if (resp) {
-                        const size_t ri = pidx(m, co, a.res_np);
-                        v += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
-                    }
-                    if (a.relu) v = v > 0.0f ? v : 0.0f;
-                    if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co] = v;
-                    if (outp) {
-                        const size_t oi = pidx(m, co, a.out_np);
-                        const __bf16 h = (__bf16)v;
-                        const float r1 = v - (float)h;
-                        const __bf16 mid = (__bf16)r1;
-                        const float r2 = r1 - (float)mid;
-                        outp[oi] = h;
-                        outp[oi + opl] = mid;
-                        outp[oi + 2 * opl] = (__bf16)r2;
-                    }
+                for (int p = 0; p < NPL; ++p) {
+                    u32x4 v = *reinterpret_cast<const u32x4*>(xs + p * XPL + lds_off(wm * 64 + i * 32 + lrow + kx, 2 * ks + lh));
+                    v.x &= msk[i]; v.y &= msk[i]; v.z &= msk[i]; v.w &= msk[i];
+                    af[i][p] = __builtin_bit_cast(bf16x8, v);
                 }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p)
+                    bf[j][p] = *reinterpret_cast<const bf16x8*>(ws + p * CV_PLANE_B + lds_off(wn * 64 + j * 32 + lrow, 2 * ks + lh));
+            if (ks == 0) {
+                if (!(a.dbg & 8)) dma_w(min(s + 1, S - 1), (s + 1) & 1);             // weights first (see the wait above)
+                if (stage_x && !(a.dbg & 1)) dma_x(ncs, nky, xi ^ 1);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x16 c = accl[i][j];
+                    if constexpr (NPL == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                    accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+            if (ks == 0) {
+#pragma unroll
+                for (int k = 0; k < 4 * NJ * NPL; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+                    if (k % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        x_in_flight = stage_x && !(a.dbg & 1);
+        if (++kx == a.kw) { kx = 0; xi ^= 1; if (++ky == a.kh) { ky = 0; ++cs; } }
     }
-    if (tr) a.trace[(wave != 0) * 512 + 15] = clock64();
+    planar_epilogue<NJ>(a, acc, accl, smem, wave, lane, m0, n0g, grp, wm, wn);
 #endif
 }
 
@@ -796,6 +994,23 @@ int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
     }
     hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kernel");
+    return STM_OK;
+}
+
+template <int NPL>
+int launch_planar_kx(const PlanarArgs& a, int tiles, stm_stream_t stream)
+{
+    const size_t lds = (size_t)2 * NPL * (2 * CV_BM + 16) * 64 + (size_t)2 * NPL * CV_PLANE_B;   // >= the epilogue's 139 KB park (NPL 3)
+    const size_t park = (size_t)8 * 64 * 68 * sizeof(float);
+    const size_t need = lds < park ? park : lds;
+    static bool lds_reserved = false;
+    if (!lds_reserved) {
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kx_kernel<NPL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)need) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", need);
+        lds_reserved = true;
+    }
+    hipLaunchKernelGGL((conv_planar_kx_kernel<NPL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(512), need, stm_hs(stream), a);
+    STM_CHECK_LAUNCH("conv_planar_kx_kernel");
     return STM_OK;
 }
 
@@ -1006,10 +1221,20 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     }
     const char* fk = getenv("STM_CONV_MG");
     const int forced = fk ? atoi(fk) : 0;
-    const int64_t big_tiles = (int64_t)stm_cdiv(M, 2 * CV_BM) * a.n_tiles;
-    const int mg = forced ? forced : (big_tiles >= 192 ? 2 : 1);
+    // 256-pixel tiles once there are enough of them, else 128-pixel tiles.  (A cost model of rounds x tile time x measured
+    // efficiency was tried for this choice and for the 64-channel tile: 478-483 frames/s against 502-509 with these plain
+    // thresholds in the same session -- rejected.)
+    const int64_t t2 = (int64_t)stm_cdiv(M, 2 * CV_BM) * a.n_tiles;
+    const int mg = forced ? forced : (t2 >= 192 ? 2 : 1);
     a.m_tiles = stm_cdiv(M, CV_BM * mg);
     const int tiles = a.m_tiles * a.n_tiles;
+    // stride-1 "same" convolutions with a kernel row of >= 3 taps: stage each activation row tile once per kernel row
+    const char* fkx = getenv("STM_CONV_KX");
+    // (measured: no gain over the per-tap kernel -- 654 vs 670 us on the 145-GF proto layer although it moves 1.8x fewer
+    // bytes; the ablations in DESIGN.md section 6 show why -- so it is opt-in: STM_CONV_KX=1)
+    const bool kx_ok = mg == 2 && g->kw >= 3 && g->kw <= 5 && g->sh == 1 && g->sw == 1 && 2 * g->pw == g->kw - 1 &&
+                       2 * g->ph == g->kh - 1 && fkx && atoi(fkx) == 1;
+    if (kx_ok) return g->planes == 3 ? launch_planar_kx<3>(a, tiles, stream) : launch_planar_kx<2>(a, tiles, stream);
     if (g->planes == 3) return mg == 2 ? launch_planar<3, 2, 2>(a, tiles, stream) : launch_planar<3, 1, 2>(a, tiles, stream);
     return mg == 2 ? launch_planar<2, 2, 2>(a, tiles, stream) : launch_planar<2, 1, 2>(a, tiles, stream);
 }
