@@ -285,6 +285,21 @@ int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const
 int stm_preprocess_u8_f32(const uint8_t* img, float* out, int n, int H0, int W0, int h, int w, int Hp, int Wp,
                           const double* mean, const double* stdv, int mode, stm_stream_t stream);
 
+/* ---- head output assembly (row a5 / f4) -----------------------------------------------------------------------------
+ * Replaces the cat / view / tanh / F.normalize tail of PredictionModule_FC.forward (prediction_head_FC.py:168-195) for the
+ * planar head: small[k] [pixels, small_ld] holds, per kernel shape k, the conf | centerness+bbox | mask groups (group_pad
+ * channels each, real ones first), trk[k] [pixels, trk_ld] the track embedding; pixel axis = levels concatenated, level l =
+ * B images of lvl_hw[l] pixels starting at lvl_start[l].  Outputs (N = K * sum lvl_hw): conf [B,N,n_cls], loc [B,N,4],
+ * mask [B,N,mask_dim], track [B,N,embed_dim] L2-normalised, centerness [B,N,1] = tanh, the latter in the reference's
+ * (level, k, pixel) order (it concatenates centerness along H), the others in (level, pixel, k) order.  One prior per
+ * kernel shape (num_priors == 1, as every STMask config has). */
+typedef struct stm_head_layout {
+    int B, K, n_levels, n_cls, mask_dim, embed_dim, group_pad, small_ld, trk_ld;
+    int lvl_start[8], lvl_hw[8];
+} stm_head_layout;
+int stm_head_assemble_f32(const float* const* small, const float* const* trk, const stm_head_layout* layout, float* conf,
+                          float* loc, float* mask, float* track, float* centerness, stm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "stm_bias_act_f32", "stm_mask_rle_workspace_bytes", "stm_mask_resize_rle_f32",
     "stm_conv_packed_weight_bytes", "stm_conv_pack_weights_f32", "stm_conv2d_nhwc_f32",
     "stm_split_bf16_planes_f32", "stm_conv2d_planar_f32", "stm_conv_packed_weight_bytes_tiled",
-    "stm_conv_pack_weights_tiled_f32", "stm_preprocess_u8_f32",
+    "stm_conv_pack_weights_tiled_f32", "stm_preprocess_u8_f32", "stm_head_assemble_f32",
 ]
 
 
@@ -39,6 +39,11 @@ class ConvGeom(ctypes.Structure):
                                     "out_ld", "res_ld", "planes", "groups", "n_levels")] +
                 [("lvl_start", c_i * 9), ("lvl_h", c_i * 8), ("lvl_w", c_i * 8),
                  ("x_plane_stride", c_l), ("out_plane_stride", c_l), ("res_plane_stride", c_l), ("x_np", c_i), ("out_np", c_i), ("res_np", c_i), ("tile_n", c_i)])
+
+
+class HeadLayout(ctypes.Structure):
+    _fields_ = ([(n, c_i) for n in ("B", "K", "n_levels", "n_cls", "mask_dim", "embed_dim", "group_pad", "small_ld", "trk_ld")] +
+                [("lvl_start", c_i * 8), ("lvl_hw", c_i * 8)])
 
 
 def build(force=False):

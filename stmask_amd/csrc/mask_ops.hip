@@ -221,3 +221,87 @@ extern "C" int stm_bias_act_f32(float* y, const float* bias, const float* residu
     STM_CHECK_LAUNCH("bias_act_kernel");
     return STM_OK;
 }
+
+
+// ---- head output assembly (prediction_head_FC.py:168-195) -----------------------------------------------------------
+// The planar head (stmask_amd/planar.py) leaves, per kernel shape k, one fp32 matrix [pixels, 3*64] (conf | centerness+bbox
+// | mask groups, zero-padded to 64 channels each) and one [pixels, embed] track matrix, pixel axis = the FPN levels
+// concatenated (level l: B images of hw_l pixels).  The reference concatenates the per-level, per-k tensors into
+// conf [B, N, n_cls], loc [B, N, 4], mask_coeff [B, N, mask_dim], track [B, N, embed] (L2-normalised) with prior index
+// n = off_l + p*K + k, and centerness [B, N, 1] = tanh(.) concatenated along H, i.e. prior index off_l + k*hw_l + p
+// (prediction_head_FC.py:189 concatenates on dim 1).  One wave per (image, prior): ~60 torch launches become one.
+namespace {
+
+struct HeadArgs {
+    const float* small[4];
+    const float* trk[4];
+    float *conf, *loc, *mask, *track, *cen;
+    int B, K, n_levels, n_cls, mask_dim, embed, gpad, small_ld, trk_ld, N;
+    int lvl_start[9], lvl_hw[8], lvl_off[8];
+};
+
+__global__ __launch_bounds__(256) void head_assemble_kernel(const HeadArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, n)
+    if (row >= (int64_t)a.B * a.N) return;
+    const int b = (int)(row / a.N), n = (int)(row - (int64_t)b * a.N);
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < a.n_levels && n >= a.lvl_off[i]) l = i;
+    const int r = n - a.lvl_off[l];
+    const int p = r / a.K, k = r - p * a.K;
+    const int hw = a.lvl_hw[l];
+    const int64_t src = (int64_t)a.lvl_start[l] + (int64_t)b * hw + p;
+    const float* sm = a.small[k] + src * a.small_ld;
+    const float* tk = a.trk[k] + src * a.trk_ld;
+    const int64_t o = (int64_t)b * a.N + n;
+    for (int c = lane; c < a.n_cls; c += 64) a.conf[o * a.n_cls + c] = sm[c];
+    if (lane < 4) a.loc[o * 4 + lane] = sm[a.gpad + 1 + lane];
+    for (int c = lane; c < a.mask_dim; c += 64) a.mask[o * a.mask_dim + c] = sm[2 * a.gpad + c];
+    if (lane == 0) a.cen[(int64_t)b * a.N + a.lvl_off[l] + (int64_t)k * hw + p] = tanhf(sm[a.gpad]);
+    // track: x / max(||x||_2, 1e-12) (F.normalize, prediction_head_FC.py:177)
+    float ss = 0.0f;
+    for (int c = lane; c < a.embed; c += 64) { const float v = tk[c]; ss = fmaf(v, v, ss); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int c = lane; c < a.embed; c += 64) a.track[o * a.embed + c] = tk[c] * inv;
+}
+
+}  // namespace
+
+extern "C" int stm_head_assemble_f32(const float* const* small, const float* const* trk, const stm_head_layout* L, float* conf,
+                                     float* loc, float* mask, float* track, float* centerness, stm_stream_t stream)
+{
+    STM_REQUIRE(small && trk && L && conf && loc && mask && track && centerness, STM_ENULL, "stm_head_assemble_f32: NULL argument");
+    STM_REQUIRE(L->B > 0 && L->K > 0 && L->K <= 4 && L->n_levels > 0 && L->n_levels <= 8 && L->n_cls > 0 && L->n_cls <= L->group_pad &&
+                L->mask_dim > 0 && L->mask_dim <= L->group_pad && L->embed_dim > 0 && L->group_pad >= 5 &&
+                L->small_ld >= 3 * L->group_pad && L->trk_ld >= L->embed_dim, STM_EINVAL, "stm_head_assemble_f32: bad layout");
+    HeadArgs a;
+    for (int k = 0; k < 4; ++k) {
+        a.small[k] = k < L->K ? small[k] : nullptr;
+        a.trk[k] = k < L->K ? trk[k] : nullptr;
+        STM_REQUIRE(k >= L->K || (a.small[k] && a.trk[k]), STM_ENULL, "stm_head_assemble_f32: input %d is NULL", k);
+    }
+    a.conf = conf; a.loc = loc; a.mask = mask; a.track = track; a.cen = centerness;
+    a.B = L->B; a.K = L->K; a.n_levels = L->n_levels; a.n_cls = L->n_cls; a.mask_dim = L->mask_dim; a.embed = L->embed_dim;
+    a.gpad = L->group_pad; a.small_ld = L->small_ld; a.trk_ld = L->trk_ld;
+    int off = 0;
+    for (int l = 0; l < 8; ++l) {
+        a.lvl_start[l] = l < L->n_levels ? L->lvl_start[l] : 0;
+        a.lvl_hw[l] = l < L->n_levels ? L->lvl_hw[l] : 1;
+        a.lvl_off[l] = off;
+        if (l < L->n_levels) {
+            STM_REQUIRE(L->lvl_hw[l] > 0, STM_EINVAL, "stm_head_assemble_f32: level %d has no pixels", l);
+            off += L->lvl_hw[l] * L->K;
+        }
+    }
+    a.lvl_start[8] = 0;
+    a.N = off;
+    const int64_t rows = (int64_t)a.B * a.N;
+    hipLaunchKernelGGL(head_assemble_kernel, dim3(stm_cdiv(rows, 4)), dim3(256), 0, stm_hs(stream), a);
+    STM_CHECK_LAUNCH("head_assemble_kernel");
+    return STM_OK;
+}

@@ -504,3 +504,33 @@ def preprocess_frames(img_u8, size=(640, 360), divisor=32, mean=(123.675, 116.28
     check(_lib.lib().stm_preprocess_u8_f32(_p(img), _p(out), c_i(n), c_i(H0), c_i(W0), c_i(h), c_i(w), c_i(Hp), c_i(Wp), m3, s3,
                                            c_i(mode), _stream()), "stm_preprocess_u8_f32")
     return out
+
+
+def head_assemble(small, trk, B, sizes, n_cls, mask_dim, embed_dim, group_pad):
+    """prediction_head_FC.py:168-195 for the planar head: small / trk = per-kernel-shape lists of [pixels, 3*group_pad] /
+    [pixels, embed] fp32 matrices over the concatenated levels `sizes` = [(H, W), ...] with B images each.
+    -> conf [B,N,n_cls], loc [B,N,4], mask [B,N,mask_dim], track [B,N,embed] (normalised), centerness [B,N,1] (tanh)."""
+    _dev(*small, *trk)
+    K = len(small)
+    L = _lib.HeadLayout()
+    L.B, L.K, L.n_levels, L.n_cls, L.mask_dim, L.embed_dim, L.group_pad = B, K, len(sizes), n_cls, mask_dim, embed_dim, group_pad
+    L.small_ld, L.trk_ld = small[0].shape[-1], trk[0].shape[-1]
+    start = 0
+    for l, (h, w) in enumerate(sizes):
+        L.lvl_start[l], L.lvl_hw[l] = start, h * w
+        start += B * h * w
+    N = K * sum(h * w for h, w in sizes)
+    for t in list(small) + list(trk):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape[0] != start:
+            raise StmError("head_assemble: inputs must be contiguous fp32 matrices over all level pixels")
+    dev = small[0].device
+    conf = torch.empty(B, N, n_cls, device=dev)
+    loc = torch.empty(B, N, 4, device=dev)
+    mask = torch.empty(B, N, mask_dim, device=dev)
+    track = torch.empty(B, N, embed_dim, device=dev)
+    cen = torch.empty(B, N, 1, device=dev)
+    sp = (ctypes.c_void_p * 4)(*([t.data_ptr() for t in small] + [0] * (4 - K)))
+    tp = (ctypes.c_void_p * 4)(*([t.data_ptr() for t in trk] + [0] * (4 - K)))
+    check(_lib.lib().stm_head_assemble_f32(sp, tp, ctypes.byref(L), _p(conf), _p(loc), _p(mask), _p(track), _p(cen), _stream()),
+          "stm_head_assemble_f32")
+    return conf, loc, mask, track, cen

@@ -318,29 +318,35 @@ class PlanarGraph:
         P = self.GROUP_PAD
         ncls, nbox, nmask, ntrk = self.dims
         npri = head.num_priors
-        conf, loc, mask, track, cen, t2s = [], [], [], [], [], []
-        for l, (hh, ww) in enumerate(sizes):
-            sl = slice(starts[l], starts[l + 1])
-            per_k = [o[0][sl].view(B, hh * ww, 3 * P) for o in outs]
-            cat = torch.stack(per_k, dim=2)                                           # [B, HW, K, 3P]
-            conf.append(cat[..., 0:ncls].reshape(B, -1, head.num_classes))
-            # group 1 = centerness (1 per prior) then bbox (4 per prior)
-            loc.append(cat[..., P + npri:P + npri + nbox].reshape(B, -1, 4))
-            mask.append(cat[..., 2 * P:2 * P + nmask].reshape(B, -1, head.mask_dim))
-            track.append(torch.stack([o[1][sl].view(B, hh * ww, ntrk) for o in outs], dim=2).reshape(B, -1, head.embed_dim))
-            # the reference concatenates centerness along H (prediction_head_FC.py:189): order (k, y, x)
-            cen.append(torch.stack([pk[..., P:P + npri] for pk in per_k], dim=1).reshape(B, -1, 1))
+        t2s = [None] * len(sizes)
+        if up32 is not None:
+            l = self.cor_idx
+            t2s[l] = up32[starts[l]:starts[l + 1]].view(B, *sizes[l], -1).permute(0, 3, 1, 2)
+        for hh, ww in sizes:
             pred["priors"].append(head.make_priors(hh, ww, dev))
-            if up32 is not None and l == self.cor_idx:
-                t2s.append(up32[sl].view(B, hh, ww, -1).permute(0, 3, 1, 2))
-            else:
-                t2s.append(None)
-        pred["conf"] = torch.cat(conf, 1)
-        pred["loc"] = torch.cat(loc, 1)
-        pred["mask_coeff"] = torch.cat(mask, 1)
-        pred["track"] = F.normalize(torch.cat(track, 1), dim=-1)
-        pred["centerness"] = torch.tanh(torch.cat(cen, 1))
         pred["priors"] = torch.cat(pred["priors"], 1)
+        if npri == 1:
+            # one kernel for the reference's cat / view / tanh / normalize tail over all levels and kernel shapes
+            conf, loc, mask, track, cen = ops.head_assemble([o[0] for o in outs], [o[1] for o in outs], B, sizes,
+                                                            head.num_classes, head.mask_dim, head.embed_dim, P)
+            pred["conf"], pred["loc"], pred["mask_coeff"], pred["track"], pred["centerness"] = conf, loc, mask, track, cen
+        else:
+            conf, loc, mask, track, cen = [], [], [], [], []
+            for l, (hh, ww) in enumerate(sizes):
+                sl = slice(starts[l], starts[l + 1])
+                per_k = [o[0][sl].view(B, hh * ww, 3 * P) for o in outs]
+                cat = torch.stack(per_k, dim=2)                                           # [B, HW, K, 3P]
+                conf.append(cat[..., 0:ncls].reshape(B, -1, head.num_classes))
+                loc.append(cat[..., P + npri:P + npri + nbox].reshape(B, -1, 4))
+                mask.append(cat[..., 2 * P:2 * P + nmask].reshape(B, -1, head.mask_dim))
+                track.append(torch.stack([o[1][sl].view(B, hh * ww, ntrk) for o in outs], dim=2).reshape(B, -1, head.embed_dim))
+                # the reference concatenates centerness along H (prediction_head_FC.py:189): order (k, y, x)
+                cen.append(torch.stack([pk[..., P:P + npri] for pk in per_k], dim=1).reshape(B, -1, 1))
+            pred["conf"] = torch.cat(conf, 1)
+            pred["loc"] = torch.cat(loc, 1)
+            pred["mask_coeff"] = torch.cat(mask, 1)
+            pred["track"] = F.normalize(torch.cat(track, 1), dim=-1)
+            pred["centerness"] = torch.tanh(torch.cat(cen, 1))
         pred["T2S_feat"] = t2s
         pred["proto"] = proto
         toc("head_assemble")
