@@ -60,7 +60,8 @@ class PlanarConv:
         tiles128 = -(-M // 128) * -(-self.O // 128)
         return 64 if tiles128 < 400 else 128
 
-    def __call__(self, xp, shape, out="planes", x_off=0, out_planes=None, out_f32=None, out_off=0, residual=None, x_ch_off=0):
+    def __call__(self, xp, shape, out="planes", x_off=0, out_planes=None, out_f32=None, out_off=0, residual=None, x_ch_off=0,
+                 out_ch_off=0):
         """xp: [3, S, N, 32] bf16 (channel-slab-major planes).  shape: ("img", B, H, W) -> pixels [x_off, x_off + B*H*W)
         of xp are one image batch; ("levels", B, [(H, W), ...]) -> all of xp, concatenated levels.  The layer reads
         groups*C channels starting at channel x_ch_off.  out: "planes" | "f32" | "both" allocates dense outputs
@@ -112,7 +113,7 @@ class PlanarConv:
             p_pl = out_planes.data_ptr() + out_off_p * 64
         if out_f32 is not None:
             g.out_ld = out_f32.shape[-1]
-            p_f32 = out_f32.data_ptr() + out_off_f * g.out_ld * 4
+            p_f32 = out_f32.data_ptr() + (out_off_f * g.out_ld + out_ch_off) * 4   # fp32 output may start at a column
         r32 = rpl = 0
         if residual is not None:
             if residual.dtype == torch.bfloat16:
@@ -171,7 +172,10 @@ class PlanarGraph:
         self.cor_idx = net.correlation_selected_layer if cfg.temporal_fusion_module else None
         self.timer = None      # a pipeline._StageTimer (STM_PIPE_TIMING=1 diagnosis runs only)
         head = net.prediction_layers[0]
-        self.head_planar = not (cfg.use_dcn_class or cfg.use_dcn_track or cfg.use_dcn_mask) and cfg.share_prediction_module
+        # FCB on the class branch (FCB-ada / FCB-ali configs) is handled below; FCB on the track / mask branches is not
+        # used by any STMask config (config.py:698-701, 793-807) and keeps the module path
+        self.head_planar = not (cfg.use_dcn_track or cfg.use_dcn_mask) and cfg.share_prediction_module
+        self.fcb = bool(cfg.use_dcn_class)
         if not self.head_planar:
             return
         convs = lambda seq: [m for m in seq.children() if isinstance(m, torch.nn.Conv2d)]
@@ -194,7 +198,9 @@ class PlanarGraph:
         self.dims = (head.num_priors * head.num_classes, head.num_priors * 4, head.num_priors * head.mask_dim,
                      head.num_priors * head.embed_dim)
         for k in range(len(cfg.head_layer_params)):
-            mods = [[head.conf_layer[k]], [head.centerness_layer[k], head.bbox_layer[k]], [head.mask_layer[k]]]
+            mods = [[head.centerness_layer[k], head.bbox_layer[k]], [head.mask_layer[k]]]
+            if not self.fcb:
+                mods = [[head.conf_layer[k]]] + mods
             ws, bs = [], []
             for grp in mods:
                 w = torch.cat([m.weight for m in grp], 0)
@@ -204,10 +210,17 @@ class PlanarGraph:
                 bs.append(F.pad(b, (0, P - b.shape[0])))
             m0 = mods[0][0]
             real = sum(m.weight.shape[0] for grp in mods for m in grp)
-            small = PlanarConv(torch.cat(ws, 0), torch.cat(bs, 0), 1, m0.padding, relu=False, groups=3,
-                               algo_frac=real / (3.0 * P), tile_n=64)
+            small = PlanarConv(torch.cat(ws, 0), torch.cat(bs, 0), 1, m0.padding, relu=False, groups=len(mods),
+                               algo_frac=real / (len(mods) * float(P)), tile_n=64)
             tr = head.track_layer[k]
-            self.finals.append((small, PlanarConv(tr.weight, tr.bias, 1, tr.padding, relu=False)))
+            entry = [small, PlanarConv(tr.weight, tr.bias, 1, tr.padding, relu=False)]
+            if self.fcb:
+                # FeatureAlign (Featurealign.py:6-74): offsets from the box regression, DeformConv2d + ReLU on the existing
+                # deformable kernels (NCHW fp32), then its trailing conv on the planar kernel over all levels at once
+                fa = head.conf_layer[k]
+                entry.append(fa)
+                entry.append(PlanarConv(fa.conv.weight, fa.conv.bias, 1, fa.conv.padding, relu=False, tile_n=64))
+            self.finals.append(tuple(entry))
         self.head = head
 
     # ------------------------------------------------------------------------------------------------------------
@@ -310,10 +323,36 @@ class PlanarGraph:
         else:
             up32, up = None, self.up(feat, lv, out="planes")
         t1 = self.tower1(up, lv, out="planes")
-        t2 = self.tower2(t1, lv, out="planes")
-        toc("head_towers")
         cw = self.tower2.O // 4                                       # channels per branch in t2 (conf, bbox, mask, track)
-        outs = [(small(t2, lv, out="f32"), trk(t2, lv, out="f32", x_ch_off=3 * cw)) for small, trk in self.finals]
+        P = self.GROUP_PAD
+        if not self.fcb:
+            t2 = self.tower2(t1, lv, out="planes")
+            toc("head_towers")
+            outs = [(small(t2, lv, out="f32"), trk(t2, lv, out="f32", x_ch_off=3 * cw)) for small, trk in self.finals]
+        else:
+            t2_32, t2 = self.tower2(t1, lv, out="both")               # the class branch also leaves as fp32 for the sampler
+            toc("head_towers")
+            # conf_x per level as NCHW fp32 (shared by the three kernel shapes)
+            conf_x = [t2_32[starts[l]:starts[l + 1], 0:cw].reshape(B, hh, ww, cw).permute(0, 3, 1, 2).contiguous()
+                      for l, (hh, ww) in enumerate(sizes)]
+            outs = []
+            for small, trk, fa, fconv in self.finals:
+                buf = torch.empty(ntot, 3 * P, device=dev, dtype=torch.float32)   # [conf | centerness+bbox | mask] groups
+                small(t2, lv, out="f32", out_f32=buf, x_ch_off=cw, out_ch_off=P)
+                feat_k = torch.empty(ntot, cw, device=dev, dtype=torch.float32)
+                npri = head.num_priors
+                for l, (hh, ww) in enumerate(sizes):
+                    sl = slice(starts[l], starts[l + 1])
+                    bbox_cur = buf[sl, P + npri:P + npri + 4 * npri].reshape(B, hh, ww, 4 * npri).permute(0, 3, 1, 2).contiguous()
+                    if fa.use_pred_offset:
+                        offset = fa.conv_offset(bbox_cur)
+                    else:
+                        offset = ops.fcb_ali_offsets(bbox_cur, fa.kernel_size[0], fa.kernel_size[1])
+                    y = ops.deform_conv(conf_x[l], offset, None, fa.conv_adaption.weight, None, 1, fa.padding, 1,
+                                        fa.conv_adaption.deform_groups, relu=True)
+                    feat_k[sl] = y.permute(0, 2, 3, 1).reshape(-1, cw)
+                fconv(ops.split_planes(feat_k), lv, out="f32", out_f32=buf)        # conf logits into columns [0, n_cls)
+                outs.append((buf, trk(t2, lv, out="f32", x_ch_off=3 * cw)))
         toc("head_finals")
         P = self.GROUP_PAD
         ncls, nbox, nmask, ntrk = self.dims

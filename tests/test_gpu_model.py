@@ -150,7 +150,7 @@ def test_planar_graph_matches_module_path_and_reference(name, tag):
     optimize_for_inference(opt_net, planar=True)
     opt_net = opt_net.to(memory_format=torch.channels_last)
     opt_net.TemporalNet = opt_net.TemporalNet.to(memory_format=torch.contiguous_format)
-    assert opt_net._planar.head_planar == (tag == "r50_fca")
+    assert opt_net._planar.head_planar and opt_net._planar.fcb == (tag != "r50_fca")
     frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0)
     x = frames[:2].cuda()
     with torch.no_grad():
