@@ -181,3 +181,45 @@ def test_conv_planar_chain_of_layers():
                           padding=1, relu=True)
     y = ops.conv2d_planar(h, ops.conv_pack_weights(w2.to(DEV)), (96, 64, 1, 1), (2, 24, 40), out="f32").cpu()
     assert (y.view(y_ref.shape) - y_ref).abs().max().item() < 1e-5
+
+
+def test_conv_planar_levels_groups_and_slices():
+    """Launch-descriptor features of stm_conv2d_planar_f32 against the oracle: pixel axis = concatenated levels (one launch
+    over several image sizes), grouped convolution, reading a channel range of a wider buffer, writing fp32 output at a
+    column offset of a wider matrix, and writing planes into a pixel slice of a larger buffer."""
+    from stmask_amd.planar import PlanarConv
+    B, sizes, C = 2, [(12, 20), (6, 10), (3, 5)], 64
+    G, Og = 2, 64
+    xs = [rnd(B, h, w, G * C + 32, seed=10 + i) for i, (h, w) in enumerate(sizes)]       # 32 leading channels are skipped
+    wts = rnd(G * Og, C, 3, 5, seed=20, scale=0.03)
+    bias = rnd(G * Og, seed=21)
+    starts = [0]
+    for h, w in sizes:
+        starts.append(starts[-1] + B * h * w)
+    ntot = starts[-1]
+    flat = torch.cat([x.reshape(-1, x.shape[-1]) for x in xs], 0)                     # [ntot, 160] fp32, levels concatenated
+    xp = ops.split_planes(flat.to(DEV))                                                # [3, 5, ntot, 32]
+    conv = PlanarConv(wts.to(DEV), bias.to(DEV), 1, (1, 2), relu=True, groups=G, tile_n=64)
+    buf = torch.zeros(ntot, 3 * G * Og, device=DEV)
+    y32, ypl = conv(xp, ("levels", B, sizes), out="both", out_f32=buf, x_ch_off=32, out_ch_off=G * Og)
+    assert y32 is buf and torch.count_nonzero(buf[:, :G * Og]) == 0 and torch.count_nonzero(buf[:, 2 * G * Og:]) == 0
+    got = buf[:, G * Og:2 * G * Og].cpu()
+    for l, (h, w) in enumerate(sizes):
+        for g in range(G):
+            xg = xs[l][..., 32 + g * C:32 + (g + 1) * C].contiguous()
+            ref = oracle.conv2d_nhwc(xg, wts[g * Og:(g + 1) * Og], bias[g * Og:(g + 1) * Og], None, padding=(1, 2), relu=True)
+            mag = oracle.conv2d_nhwc(xg.abs(), wts[g * Og:(g + 1) * Og].abs(), bias[g * Og:(g + 1) * Og].abs(), None, padding=(1, 2))
+            out = got[starts[l]:starts[l + 1], g * Og:(g + 1) * Og].view(B, h, w, Og)
+            assert ((out - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6, (l, g)
+    assert torch.equal(planes_to_f32(ypl.cpu()), got)
+    # one level as an image batch read from / written into pixel slices of larger plane buffers
+    l = 1
+    h, w = sizes[l]
+    w1 = rnd(32, 32, 3, 3, seed=30, scale=0.05)
+    c1 = PlanarConv(w1.to(DEV), None, 1, 1, relu=False)
+    dst = torch.zeros(3, 1, ntot, 32, device=DEV, dtype=torch.bfloat16)
+    c1(xp, ("img", B, h, w), out="planes", x_off=starts[l], out_planes=dst, out_off=starts[l], x_ch_off=0)
+    ref = oracle.conv2d_nhwc(xs[l][..., :32].contiguous(), w1, None, None, padding=1)
+    full = planes_to_f32(dst.cpu())
+    assert (full[starts[l]:starts[l + 1]].view(B, h, w, 32) - ref).abs().max().item() < 1e-5
+    assert torch.count_nonzero(full[:starts[l]]) == 0 and torch.count_nonzero(full[starts[l + 1]:]) == 0
