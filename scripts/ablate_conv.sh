@@ -1,7 +1,6 @@
 #!/bin/bash
-# timing ablations of the planar kernels (results are WRONG under a debug mask; timing only)
-# bits: 1 no activation DMA in the loop, 2 no barrier, 4 no MFMA (planar kernel only), 8 no weight DMA (kx kernel)
+# A/B of the MFMA shape in the planar kernel (both give valid results)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-for d in 0 1 8 9 11; do
-  echo "== STM_CONV_DEBUG=$d (kx kernel)"; STM_CONV_DEBUG=$d timeout 200 python scripts/bench_conv.py 8 3 2>&1 | grep -E "P3|proto 3x3" | cut -c1-75
+for m in 32 16 32 16; do
+  echo "== STM_CONV_MFMA=$m"; STM_CONV_MFMA=$m timeout 200 python scripts/bench_conv.py 8 3 2>&1 | grep -E "P3|proto 3x3|layer1 3x3|layer2 1x1 128|TOTAL" | cut -c1-118
 done

@@ -57,7 +57,12 @@ struct ConvArgs {
     int dbg;      // STM_CONV_DEBUG ablation bits (timing experiments only): 1 no MFMA, 2 no global loads, 4 no split, 8 no LDS writes
 };
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// 16-B chunk swizzle of the 64-B LDS rows: chunk ^ f((row >> 2) & 3) with f = (0, 2, 3, 1).  f being a permutation keeps the
+// row-major fragment reads of the 32x32x16 MFMA operands conflict-free (16-lane groups of ds_read_b128 see four row
+// blocks with four different f), and this particular f does the same for the 16x16x32 operands, whose 16-lane groups mix
+// two chunk indices (chunk c of rows 0-3 / 12-15 with chunk c^1 of rows 4-11).
+__device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ swz(row)) << 4); }
 
 // two fp32 -> three packed bf16 pairs (round-to-nearest of the running residual; the subtractions are exact)
 __device__ __forceinline__ void split2(f32x2 v, unsigned& p0, unsigned& p1, unsigned& p2)
@@ -452,47 +457,74 @@ struct PlanarArgs {
 };
 
 // Epilogue shared by the planar kernels: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes.
+// Each wave first parks its 64 x (32*NJ) accumulator tile in LDS (free now) -- park32 / park16 know the C/D register layout
+// of the MFMA shape used -- and the tail re-reads it pixel-major, 8 consecutive channels per lane, so that (Cout and the
+// leading dimensions multiples of 8) every global access is a 16-byte vector: 24 stores per thread for the three planes
+// instead of 192 two-byte ones.  Otherwise the same 8-channel segments are written element by element, guarded.
 template <int NJ>
-__device__ __forceinline__ void planar_epilogue(const PlanarArgs& a, f32x16 (&acc)[2][NJ], f32x16 (&accl)[2][NJ], uint8_t* smem, int wave,
-                                                int lane, int m0, int n0g, int grp, int wm, int wn)
+__device__ __forceinline__ float* park_base(uint8_t* smem, int wave) { return reinterpret_cast<float*>(smem) + wave * (64 * (32 * NJ + 4)); }
+
+template <int NJ>   // v_mfma_f32_32x32x16: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ void park32(f32x16 (&acc)[2][NJ], f32x16 (&accl)[2][NJ], uint8_t* smem, int wave, int lane)
 {
+    constexpr int EP_LD = 32 * NJ + 4;
+    float* park = park_base<NJ>(smem, wave);
     const int lrow = lane & 31, lh = lane >> 5;
-    // epilogue: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes of the result.
-    // Fast path (Cout, leading dimensions multiples of 8): each wave parks its 64 x 64 accumulator tile in LDS (free
-    // now) and re-reads it pixel-major, 8 consecutive channels per lane, so every global access is a 16-byte vector
-    // (24 stores per thread for the three planes instead of 192 two-byte ones).
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                park[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP_LD + j * 32 + lrow] = acc[i][j][r] + accl[i][j][r];
+}
+
+template <int NJ>   // v_mfma_f32_16x16x32: col = lane & 15, row = 4 (lane >> 4) + r
+__device__ __forceinline__ void park16(f32x4 (&acc)[4][2 * NJ], f32x4 (&accl)[4][2 * NJ], uint8_t* smem, int wave, int lane)
+{
+    constexpr int EP_LD = 32 * NJ + 4;
+    float* park = park_base<NJ>(smem, wave);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                park[(i * 16 + 4 * (lane >> 4) + r) * EP_LD + j * 16 + (lane & 15)] = acc[i][j][r] + accl[i][j][r];
+}
+
+template <int NJ>
+__device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_t* smem, int wave, int lane, int m0, int n0g, int grp,
+                                                     int wm, int wn)
+{
+    constexpr int EP_LD = 32 * NJ + 4;                 // floats per parked pixel row (+ 4 pad)
+    constexpr int LPR = 4 * NJ;                        // lanes per pixel row (8 channels each)
     const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
     // element index of (pixel m, channel co) in a slab-major planar buffer with np pixels per slab
     auto pidx = [](int m, int co, int np) { return ((size_t)(co >> 5) * np + m) * 32 + (co & 31); };
-    if (a.vec_epilogue) {
-        __syncthreads();                                   // all fragment reads of the last slab are done
-        constexpr int EP_LD = 32 * NJ + 4;                 // floats per parked pixel row (+ 4 pad)
-        constexpr int LPR = 4 * NJ;                        // lanes per pixel row (8 channels each)
-        float* park = reinterpret_cast<float*>(smem) + wave * (64 * EP_LD);
+    const float* park = park_base<NJ>(smem, wave);
+    // same wave reads back what it wrote: no workgroup barrier needed, only the LDS counter
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int seg = lane % LPR, prow = lane / LPR;
+    const int cog = n0g + wn * (32 * NJ) + seg * 8;    // channel within the group
+    const int co = grp * a.cout_g + cog;
+    const int nvalid = min(8, a.cout_g - cog);         // channels of this segment that exist (<= 0: none)
+    if (nvalid <= 0) return;
+    float bv[8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int e = 0; e < 8; ++e) bv[e] = (a.bias && e < nvalid) ? a.bias[co + e] : 0.0f;
+    const bool vec = a.vec_epilogue != 0;              // implies nvalid == 8
+    __bf16* outp = reinterpret_cast<__bf16*>(a.out_pl);
+    const __bf16* resp = reinterpret_cast<const __bf16*>(a.res_pl);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    park[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP_LD + j * 32 + lrow] = acc[i][j][r] + accl[i][j][r];
-        // same wave reads back what it wrote: no workgroup barrier needed, only the LDS counter
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int seg = lane % LPR, prow = lane / LPR;
-        const int cog = n0g + wn * (32 * NJ) + seg * 8;    // channel within the group
-        const int co = grp * a.cout_g + cog;
-        const bool co_ok = cog < a.cout_g;                 // cout_g % 8 == 0: the whole 8-channel segment is in or out
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && co_ok) ? a.bias[co + e] : 0.0f;
-#pragma unroll
-        for (int pass = 0; pass < LPR; ++pass) {
-            const int pr = pass * (64 / LPR) + prow;
-            const int m = m0 + wm * 64 + pr;
-            if (m >= a.M || !co_ok) continue;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
-            float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+    for (int pass = 0; pass < LPR; ++pass) {
+        const int pr = pass * (64 / LPR) + prow;
+        const int m = m0 + wm * 64 + pr;
+        if (m >= a.M) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
+        float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+        if (vec) {
             if (a.res_f32) {
                 const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co);
                 const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co + 4);
@@ -524,46 +556,42 @@ __device__ __forceinline__ void planar_epilogue(const PlanarArgs& a, f32x16 (&ac
                 *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
                 *reinterpret_cast<u32x4*>(o + opl * 4) = u32x4{q2[0], q2[1], q2[2], q2[3]};
             }
-        }
-    } else {
-        __bf16* outp = reinterpret_cast<__bf16*>(a.out_pl);
-        const __bf16* resp = reinterpret_cast<const __bf16*>(a.res_pl);
+        } else {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int cog = n0g + wn * (32 * NJ) + j * 32 + lrow;
-            if (cog >= a.cout_g) continue;
-            const int co = grp * a.cout_g + cog;
-            const float bv = a.bias ? a.bias[co] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m >= a.M) continue;
-                    float v = (acc[i][j][r] + accl[i][j][r]) + bv;
-                    if (a.res_f32) v += a.res_f32[(size_t)m * a.res_ld + co];
-                    if (resp) {
-                        const size_t ri = pidx(m, co, a.res_np);
-                        v += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
-                    }
-                    if (a.relu) v = v > 0.0f ? v : 0.0f;
-                    if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co] = v;
-                    if (outp) {
-                        const size_t oi = pidx(m, co, a.out_np);
-                        const __bf16 h = (__bf16)v;
-                        const float r1 = v - (float)h;
-                        const __bf16 mid = (__bf16)r1;
-                        const float r2 = r1 - (float)mid;
-                        outp[oi] = h;
-                        outp[oi + opl] = mid;
-                        outp[oi + 2 * opl] = (__bf16)r2;
-                    }
+            for (int e = 0; e < 8; ++e) {
+                if (e >= nvalid) break;
+                float x = v[e];
+                if (a.res_f32) x += a.res_f32[(size_t)m * a.res_ld + co + e];
+                if (resp) {
+                    const size_t ri = pidx(m, co + e, a.res_np);
+                    x += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
                 }
+                if (a.relu) x = x > 0.0f ? x : 0.0f;
+                if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co + e] = x;
+                if (outp) {
+                    const size_t oi = pidx(m, co + e, a.out_np);
+                    const __bf16 h = (__bf16)x;
+                    const float r1 = x - (float)h;
+                    const __bf16 mid = (__bf16)r1;
+                    outp[oi] = h;
+                    outp[oi + opl] = mid;
+                    outp[oi + 2 * opl] = (__bf16)(r1 - (float)mid);
+                }
+            }
         }
     }
 }
 
-template <int NPL, int MG, int NJ>
+template <int NJ>
+__device__ __forceinline__ void planar_epilogue(const PlanarArgs& a, f32x16 (&acc)[2][NJ], f32x16 (&accl)[2][NJ], uint8_t* smem, int wave,
+                                                int lane, int m0, int n0g, int grp, int wm, int wn)
+{
+    __syncthreads();                                   // all fragment reads of the last slab are done
+    park32<NJ>(acc, accl, smem, wave, lane);
+    planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
+}
+
+template <int NPL, int MG, int NJ, int MF>   // MF = 1: v_mfma_f32_16x16x32_bf16 (less energy per flop; the chip is power-limited here), 0: 32x32x16
 __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
@@ -616,7 +644,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         ix0[i] = ox * a.sw - a.pw;
         hl[i] = H; wl[i] = W;
         // byte offset of (image origin, logical chunk) within one channel slab of a plane
-        pbase[i] = (first + b * H * W) * 64 + ((slot ^ ((r >> 2) & 3)) << 4);
+        pbase[i] = (first + b * H * W) * 64 + ((slot ^ swz(r)) << 4);
     }
     __amdgpu_buffer_rsrc_t xr[NPL];
 #pragma unroll
@@ -654,13 +682,20 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         }
     };
 
-    f32x16 acc[2][NJ], accl[2][NJ];
+    f32x16 acc[2][NJ], accl[2][NJ];            // MF == 0
+    f32x4 acc16[4][2 * NJ], accl16[4][2 * NJ];   // MF == 1 (the unused set is dead code)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc16[i][j][r] = 0.0f; accl16[i][j][r] = 0.0f; }
 
     const int lrow = lane & 31, lh = lane >> 5;
 #ifdef STM_CONV_TRACE
@@ -685,6 +720,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         // schedule directives deal the DMA's address arithmetic and issue out between that half's MFMAs.  Issued as one
         // block ahead of the MFMAs the same ~60 instructions took 850-2800 cycles: the SIMD's other wave is issuing
         // MFMAs then and takes the issue slots.  Past the last slab the DMA re-reads it into the idle buffer (no branch).
+        if constexpr (MF == 0) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[2][NPL], bf[NJ][NPL];
@@ -726,12 +762,63 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        } else {
+            // 16x16x32: one instruction covers the slab's 32 channels; lane (l & 15, l >> 4) holds row l & 15, chunk l >> 4
+            const int r16 = lane & 15, kc = lane >> 4;
+            bf16x8 bf[2 * NJ][NPL];
+#pragma unroll
+            for (int j = 0; j < 2 * NJ; ++j)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p)
+                    bf[j][p] = *reinterpret_cast<const bf16x8*>(ws + p * WPL + lds_off(wn * (32 * NJ) + j * 16 + r16, kc));
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                bf16x8 af[2][NPL];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p)
+                        af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + (2 * hf + i) * 16 + r16, kc));
+                if (!(a.dbg & 1)) {
+                    if (hf == 0) dma_x((s + 1) & 1);
+                    else dma_w(min(s + 1, S - 1), (s + 1) & 1);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2 * NJ; ++j) {
+                        f32x4 c = accl16[2 * hf + i][j];
+                        if constexpr (NPL == 3) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                        }
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                        accl16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                        acc16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc16[2 * hf + i][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int k = 0; k < 8 * NJ * NPL; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA (16 cycles)
+                    if (hf == 0 && (k & 1)) __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+                    else if (k % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
+                    if (k % 6 == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // a DMA
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         PL_STAMP(4);
     }
 #undef PL_STAMP
     if (tr) a.trace[(wave != 0) * 512 + 7] = clock64();
 
-    planar_epilogue<NJ>(a, acc, accl, smem, wave, lane, m0, n0g, grp, wm, wn);
+    if constexpr (MF == 0) {
+        planar_epilogue<NJ>(a, acc, accl, smem, wave, lane, m0, n0g, grp, wm, wn);
+    } else {
+        __syncthreads();                               // all fragment reads of the last slab are done
+        park16<NJ>(acc16, accl16, smem, wave, lane);
+        planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
+    }
     if (tr) a.trace[(wave != 0) * 512 + 15] = clock64();
 #endif
 }
@@ -794,7 +881,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx_kernel(const PlanarArgs
         const int g = t < 2 ? wave + 8 * t : 16;
         const int j = g * 16 + (lane >> 2);                 // lds row; tile pixel j - pw
         decode(m0 + j - a.pw, d_iy0[t], d_ox[t], d_base[t], d_h[t], d_w[t]);
-        d_base[t] += (slot ^ ((j >> 2) & 3)) << 4;
+        d_base[t] += (slot ^ swz(j)) << 4;
     }
     // fragment rows of this lane (tile pixels wm*64 + i*32 + lane%32): x coordinate and row width for the kx masks
     int f_ox[2], f_w[2];
@@ -980,7 +1067,7 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
     }
 }
 
-template <int NPL, int MG, int NJ>
+template <int NPL, int MG, int NJ, int MF>
 int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
 {
     size_t lds = (size_t)2 * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
@@ -988,11 +1075,11 @@ int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
     if (lds < park) lds = park;
     static bool lds_reserved = false;   // per instantiation; the attribute is sticky, setting it again each launch only costs host time
     if (!lds_reserved) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, MF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
         lds_reserved = true;
     }
-    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
+    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, MF>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kernel");
     return STM_OK;
 }
@@ -1212,12 +1299,18 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
                      (ops % 8 == 0) && (rps % 8 == 0) && !getenv("STM_CONV_SCALAR_EPILOGUE");
     a.trace = g_conv_trace;
     { const char* dbg = getenv("STM_CONV_DEBUG"); a.dbg = dbg ? atoi(dbg) : 0; }
+    // MFMA shape: v_mfma_f32_16x16x32_bf16 by default -- same flops per cycle as 32x32x16 on paper, but this kernel runs
+    // the board into its power limit (rocm-smi: 1378 W, 2.0 GHz; the MFMA-only ablation 1244 W at 2.34 GHz) and the 16x16x32
+    // form spends less energy per flop: 593 vs 656 us on the 145-GF proto layer.  STM_CONV_MFMA=32 selects the other form.
+    const char* fm = getenv("STM_CONV_MFMA");
+    const bool mf16 = fm ? atoi(fm) != 32 : true;
     if (bn == 64) {
         // 128 x 64 tiles, 72 KB of LDS: two independent workgroups per CU, each one's barrier / staging gaps filled by
         // the other's MFMAs
         a.m_tiles = stm_cdiv(M, CV_BM);
         const int tiles = a.m_tiles * a.n_tiles;
-        return g->planes == 3 ? launch_planar<3, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1>(a, tiles, stream);
+        if (mf16) return g->planes == 3 ? launch_planar<3, 1, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
+        return g->planes == 3 ? launch_planar<3, 1, 1, 0>(a, tiles, stream) : launch_planar<2, 1, 1, 0>(a, tiles, stream);
     }
     const char* fk = getenv("STM_CONV_MG");
     const int forced = fk ? atoi(fk) : 0;
@@ -1235,6 +1328,10 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     const bool kx_ok = mg == 2 && g->kw >= 3 && g->kw <= 5 && g->sh == 1 && g->sw == 1 && 2 * g->pw == g->kw - 1 &&
                        2 * g->ph == g->kh - 1 && fkx && atoi(fkx) == 1;
     if (kx_ok) return g->planes == 3 ? launch_planar_kx<3>(a, tiles, stream) : launch_planar_kx<2>(a, tiles, stream);
-    if (g->planes == 3) return mg == 2 ? launch_planar<3, 2, 2>(a, tiles, stream) : launch_planar<3, 1, 2>(a, tiles, stream);
-    return mg == 2 ? launch_planar<2, 2, 2>(a, tiles, stream) : launch_planar<2, 1, 2>(a, tiles, stream);
+    if (mf16) {
+        if (g->planes == 3) return mg == 2 ? launch_planar<3, 2, 2, 1>(a, tiles, stream) : launch_planar<3, 1, 2, 1>(a, tiles, stream);
+        return mg == 2 ? launch_planar<2, 2, 2, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1>(a, tiles, stream);
+    }
+    if (g->planes == 3) return mg == 2 ? launch_planar<3, 2, 2, 0>(a, tiles, stream) : launch_planar<3, 1, 2, 0>(a, tiles, stream);
+    return mg == 2 ? launch_planar<2, 2, 2, 0>(a, tiles, stream) : launch_planar<2, 1, 2, 0>(a, tiles, stream);
 }
