@@ -244,6 +244,8 @@ typedef struct stm_conv_geom {
     long long x_plane_stride, out_plane_stride, res_plane_stride; /* elements between bf16 planes; 0 = dense (slabs*np*32) */
     int x_np, out_np, res_np; /* pixels per channel slab of the planar input / output / residual buffers (0 = exactly the
                              pixels of this launch): lets a layer read from / write into a slice of a larger buffer */
+    int group_cout[8];    /* grouped layers whose groups are zero-padded to a common width: real output channels of group i
+                             (0 = all Cout/groups); the matrix-core tiles that would only multiply padding are skipped */
     int tile_n;           /* output-channel tile the weights were packed for: 0 / 128 (stm_conv_pack_weights_f32) or 64
                              (stm_conv_pack_weights_tiled_f32): 128 x 64 tiles, two workgroups per CU -- narrow layers
                              (few output channels) and layers with few pixel tiles */

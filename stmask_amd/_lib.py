@@ -38,7 +38,7 @@ class ConvGeom(ctypes.Structure):
     _fields_ = ([(n, c_i) for n in ("B", "H", "W", "C", "Ho", "Wo", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "x_ld",
                                     "out_ld", "res_ld", "planes", "groups", "n_levels")] +
                 [("lvl_start", c_i * 9), ("lvl_h", c_i * 8), ("lvl_w", c_i * 8),
-                 ("x_plane_stride", c_l), ("out_plane_stride", c_l), ("res_plane_stride", c_l), ("x_np", c_i), ("out_np", c_i), ("res_np", c_i), ("tile_n", c_i)])
+                 ("x_plane_stride", c_l), ("out_plane_stride", c_l), ("res_plane_stride", c_l), ("x_np", c_i), ("out_np", c_i), ("res_np", c_i), ("group_cout", c_i * 8), ("tile_n", c_i)])
 
 
 class HeadLayout(ctypes.Structure):

@@ -449,6 +449,7 @@ struct PlanarArgs {
     unsigned plane_bytes;   // bytes of one input plane that may be addressed (buffer range)
     long long x_pstride, out_pstride, res_pstride;   // bytes between planes
     int groups, ntpg, cout_g;                        // grouped conv: n-tiles per group, output channels per group
+    int group_real[8];                               // output channels per group that are not zero padding (MFMA tiles past them are skipped)
     int n_levels;                                    // > 0: pixels are the concatenation of n_levels images sizes
     int lvl_start[9], lvl_h[8], lvl_w[8];
     int dbg;                // STM_CONV_DEBUG timing ablations (results wrong): 1 no DMA in the loop, 2 no barrier, 4 no MFMA
@@ -619,6 +620,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     // grouped convolution: n-tile -> group; the group reads its own C input channels and writes its own cout_g outputs
     const int grp = nt / a.ntpg;
     const int n0g = (nt - grp * a.ntpg) * BN;           // first output channel of this tile within its group
+    const int creal = a.group_real[grp & 7];            // real (not zero-padding) output channels of the group
     // DMA duties of this lane: activation row groups 2*wave and 2*wave+1 (16 rows x 64 B each, all planes)
     int iy0[2], ix0[2], pbase[2], hl[2], wl[2];
     const int slot = lane & 3;
@@ -765,48 +767,92 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         } else {
             // 16x16x32: one instruction covers the slab's 32 channels; lane (l & 15, l >> 4) holds row l & 15, chunk l >> 4
             const int r16 = lane & 15, kc = lane >> 4;
+            // 16-column tiles of this wave that hold real output channels (wave-uniform): narrow layers and zero-padded
+            // groups skip the MFMAs of the others
+            const int jn = min(2 * NJ, (creal - (n0g + wn * (32 * NJ)) + 15) >> 4);
             bf16x8 bf[2 * NJ][NPL];
 #pragma unroll
             for (int j = 0; j < 2 * NJ; ++j)
 #pragma unroll
                 for (int p = 0; p < NPL; ++p)
                     bf[j][p] = *reinterpret_cast<const bf16x8*>(ws + p * WPL + lds_off(wn * (32 * NJ) + j * 16 + r16, kc));
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                bf16x8 af[2][NPL];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int p = 0; p < NPL; ++p)
-                        af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + (2 * hf + i) * 16 + r16, kc));
-                if (!(a.dbg & 1)) {
-                    if (hf == 0) dma_x((s + 1) & 1);
-                    else dma_w(min(s + 1, S - 1), (s + 1) & 1);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2 * NJ; ++j) {
-                        f32x4 c = accl16[2 * hf + i][j];
-                        if constexpr (NPL == 3) {
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-                        }
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-                        accl16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-                        acc16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc16[2 * hf + i][j], 0, 0, 0);
+            if (NJ == 2 || jn == 2 * NJ) {   // every column tile is real (always, for the 128-wide tiles): one branch-free
+                                             // block -- the schedule directives need one, and a second copy of the
+                                             // 128-wide body spills registers
+    #pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    bf16x8 af[2][NPL];
+    #pragma unroll
+                    for (int i = 0; i < 2; ++i)
+    #pragma unroll
+                        for (int p = 0; p < NPL; ++p)
+                            af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + (2 * hf + i) * 16 + r16, kc));
+                    if (!(a.dbg & 1)) {
+                        if (hf == 0) dma_x((s + 1) & 1);
+                        else dma_w(min(s + 1, S - 1), (s + 1) & 1);
                     }
-#pragma unroll
-                for (int k = 0; k < 8 * NJ * NPL; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA (16 cycles)
-                    if (hf == 0 && (k & 1)) __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
-                    else if (k % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
-                    if (k % 6 == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // a DMA
+    #pragma unroll
+                    for (int i = 0; i < 2; ++i)
+    #pragma unroll
+                        for (int j = 0; j < 2 * NJ; ++j) {
+                            f32x4 c = accl16[2 * hf + i][j];
+                            if constexpr (NPL == 3) {
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                            }
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                            accl16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                            acc16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc16[2 * hf + i][j], 0, 0, 0);
+                        }
+    #pragma unroll
+                    for (int k = 0; k < 8 * NJ * NPL; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA (16 cycles)
+                        if (hf == 0 && (k & 1)) __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+                        else if (k % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
+                        if (k % 6 == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // a DMA
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (NJ == 1) {  // narrow layer / zero-padded group (64-wide tiles): guarded column tiles
+    #pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    bf16x8 af[2][NPL];
+    #pragma unroll
+                    for (int i = 0; i < 2; ++i)
+    #pragma unroll
+                        for (int p = 0; p < NPL; ++p)
+                            af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + (2 * hf + i) * 16 + r16, kc));
+                    if (!(a.dbg & 1)) {
+                        if (hf == 0) dma_x((s + 1) & 1);
+                        else dma_w(min(s + 1, S - 1), (s + 1) & 1);
+                    }
+    #pragma unroll
+                    for (int i = 0; i < 2; ++i)
+    #pragma unroll
+                        for (int j = 0; j < 2 * NJ; ++j) {
+                            if (j >= jn) continue;
+                            f32x4 c = accl16[2 * hf + i][j];
+                            if constexpr (NPL == 3) {
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                            }
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+                            accl16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+                            acc16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc16[2 * hf + i][j], 0, 0, 0);
+                        }
+    #pragma unroll
+                    for (int k = 0; k < 8 * NJ * NPL; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA (16 cycles)
+                        if (hf == 0 && (k & 1)) __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
+                        else if (k % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
+                        if (k % 6 == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // a DMA
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        }
+}
         PL_STAMP(4);
     }
 #undef PL_STAMP
@@ -1291,6 +1337,7 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     a.plane_bytes = (unsigned)plane_bytes;
     a.x_pstride = xps * 2; a.out_pstride = ops * 2; a.res_pstride = rps * 2;
     a.groups = groups; a.cout_g = cout_g; a.ntpg = stm_cdiv(cout_g, bn);
+    for (int i = 0; i < 8; ++i) a.group_real[i] = (i < groups && g->group_cout[i] > 0 && g->group_cout[i] < cout_g) ? g->group_cout[i] : cout_g;
     a.n_levels = g->n_levels > 0 ? g->n_levels : 0;
     for (int l = 0; l < 8; ++l) { a.lvl_start[l] = g->lvl_start[l]; a.lvl_h[l] = g->lvl_h[l]; a.lvl_w[l] = g->lvl_w[l]; }
     a.lvl_start[8] = g->lvl_start[8];

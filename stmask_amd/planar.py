@@ -29,12 +29,14 @@ class PlanarConv:
     """One packed convolution layer.  x / outputs are described by raw (tensor, pixel offset) pairs so that a layer can
     read from and write into slices of larger plane buffers."""
 
-    def __init__(self, weight, bias, stride=1, padding=0, relu=False, groups=1, planes=3, algo_frac=1.0, tile_n=None):
+    def __init__(self, weight, bias, stride=1, padding=0, relu=False, groups=1, planes=3, algo_frac=1.0, tile_n=None,
+                 group_cout=None):
         """algo_frac: share of the packed layer that is the reference's own arithmetic (zero-padded channels excluded);
         only used for the flop count of the live roofline measurement.  tile_n: 64 / 128 forces the output-channel tile,
         None picks per call from the problem size (weights are packed once per tile width used)."""
         self.weight = weight.detach().float().contiguous()
         self.algo_frac = algo_frac
+        self.group_cout = list(group_cout) if group_cout else None   # real channels of zero-padded groups
         self.O, self.C, self.kh, self.kw = self.weight.shape
         (self.sh, self.sw), (self.ph, self.pw) = _pair(stride), _pair(padding)
         self.relu, self.groups, self.planes, self.tile_n = relu, groups, planes, tile_n
@@ -72,6 +74,9 @@ class PlanarConv:
         g = _lib.ConvGeom()
         g.C, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw = self.C, self.O, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw
         g.planes, g.groups = self.planes, self.groups
+        if self.group_cout:
+            for i, c in enumerate(self.group_cout):
+                g.group_cout[i] = c
         if S * 32 < x_ch_off + self.groups * self.C or x_ch_off % 32:
             raise StmError(f"PlanarConv: input has {S * 32} channels, layer reads {self.groups} x {self.C} from channel {x_ch_off}")
         if shape[0] == "levels":
@@ -211,7 +216,8 @@ class PlanarGraph:
             m0 = mods[0][0]
             real = sum(m.weight.shape[0] for grp in mods for m in grp)
             small = PlanarConv(torch.cat(ws, 0), torch.cat(bs, 0), 1, m0.padding, relu=False, groups=len(mods),
-                               algo_frac=real / (len(mods) * float(P)), tile_n=64)
+                               algo_frac=real / (len(mods) * float(P)), tile_n=64,
+                               group_cout=[sum(m.weight.shape[0] for m in grp) for grp in mods])
             tr = head.track_layer[k]
             entry = [small, PlanarConv(tr.weight, tr.bias, 1, tr.padding, relu=False)]
             if self.fcb:

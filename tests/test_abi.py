@@ -69,3 +69,25 @@ def test_product_path_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle", src, flags=re.M), f"{f} imports the oracle"
                 assert "libstm_oracle" not in src, f"{f} references the oracle library"
+
+
+def test_planar_conv_kernels_do_not_spill():
+    """hipcc's resource report for csrc/conv_bf16x.hip: no instantiation of the planar convolution kernels may use scratch
+    (a register spill in the MFMA loop costs 2x: seen once when the 128-wide body was duplicated)."""
+    import re
+    import subprocess
+    src = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc", "conv_bf16x.hip")
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize",
+           "--cuda-device-only", "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600).stderr
+    blocks = re.split(r"remark: [^\n]*Function Name: ", out)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "conv_planar_kernel" not in name and "conv_planar_kx_kernel" not in name:
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        vgprs = int(re.search(r" VGPRs: (\d+)", b).group(1))
+        assert scratch == 0 and vgprs <= 256, (name, scratch, vgprs)
+    assert seen >= 8
