@@ -6,5 +6,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_I
   i=$((i+1)); rm -rf $OUT/pmc_conv/p$i
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_conv/p$i -o p -- python3 $R/scripts/prof_conv.py 2 > $OUT/pmc_conv_$i.log 2>&1; echo "pass $i exit $?"; tail -1 $OUT/pmc_conv_$i.log | cut -c1-200
 done
-cd $R; python3 scripts/summarize_pmc_kernel.py $OUT/pmc_conv conv_bf16x | cut -c1-600
+cd $R; python3 scripts/summarize_pmc_kernel.py $OUT/pmc_conv conv_planar | cut -c1-600
 find $OUT/pmc_conv -name '*.csv' -size +5M -delete

@@ -11,6 +11,6 @@ for H, W, C, O, k in [(48, 80, 256, 256, 3), (96, 160, 256, 256, 3), (48, 80, 12
     b = torch.randn(O, device="cuda")
     pk = ops.conv_pack_weights(w, planes)
     for _ in range(REPS):
-        ops.conv2d_nhwc(x, pk, (O, C, k, k), b, None, padding=k // 2, relu=True, planes=planes)
+        ops.conv2d_planar(ops.split_planes(x), pk, (O, C, k, k), (8, H, W), b, None, padding=k // 2, relu=True, planes=planes)
 torch.cuda.synchronize()
 print("done")

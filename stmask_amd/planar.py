@@ -431,6 +431,8 @@ class PlanarBackbone:
     conv3's epilogue.  The stem (7x7, 3 input channels) stays on the dense-conv library; the deformable 3x3 layers stay on
     deform im2col + fp32 MFMA GEMM (they take / return NCHW fp32: one layout change either side)."""
 
+    OM_PLANAR_MIN_PIXELS = 16384    # offset / mask conv of a DCN layer on the planar kernel from this many output pixels
+
     def __init__(self, bb):
         from .dcn_v2 import DCN
         self.bb = bb
@@ -471,8 +473,15 @@ class PlanarBackbone:
                     # conv1 -> fp32 (NCHW copy for the deformable sampler) and planes (offset / mask convolution);
                     # the sampler reads the raw conv_offset_mask output (sigmoid folded in), GEMM adds bias + ReLU
                     d = e["dcn"]
-                    t32, tpl = e["c1"](xp, shape, out="both")
-                    om = e["om"](tpl, shape, out="f32").view(B, Ho, Wo, -1).permute(0, 3, 1, 2).contiguous()
+                    if B * Ho * Wo >= self.OM_PLANAR_MIN_PIXELS:
+                        t32, tpl = e["c1"](xp, shape, out="both")
+                        om = e["om"](tpl, shape, out="f32").view(B, Ho, Wo, -1).permute(0, 3, 1, 2).contiguous()
+                    else:
+                        # few output pixels and 27 output channels: 8-64 tiles of 72-144 K-slabs each would leave most CUs
+                        # idle for 80-150 us (no split-K in the planar kernel yet); the dense-conv library's small-tile
+                        # kernel takes ~35 us here
+                        t32 = e["c1"](xp, shape, out="f32")
+                        om = d.conv_offset_mask(t32.view(B, H, W, -1).permute(0, 3, 1, 2)).contiguous()
                     xin = t32.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
                     t = ops.deform_conv(xin, None, None, d.weight, d.bias, d.stride, d.padding, d.dilation,
                                         d.deformable_groups, relu=True, fused_om=om)
