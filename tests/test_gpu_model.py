@@ -192,6 +192,31 @@ def test_planar_temporalnet_matches_module():
         assert (ca - cb).abs().max().item() < 2e-5 * max(1.0, ca.abs().max().item())
 
 
+def test_video_demo_end_to_end_flow():
+    """uint8 frames -> device pre-processing (f3) -> hot path -> postprocess + RLE (f1) -> YouTube-VIS records (f2): the
+    stages compose, every record is well-formed and its RLEs decode to masks of the original frame size."""
+    import importlib.util
+    import os
+    import oracle
+    spec = importlib.util.spec_from_file_location("run_video_demo", os.path.join(os.path.dirname(__file__), "..", "scripts",
+                                                                                 "run_video_demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    recs = demo.run(n_clips=2, n_frames=3)
+    assert len(recs) > 0 and {r["video_id"] for r in recs} <= {0, 1}
+    n_seg = 0
+    for r in recs:
+        assert 0.0 < r["score"] <= 1.0 and 1 <= r["category_id"] <= 40 and len(r["segmentations"]) == 3
+        for sgm in r["segmentations"]:
+            if sgm is None:
+                continue
+            assert sgm["size"] == [720, 1280] and isinstance(sgm["counts"], str)
+            counts = oracle.rle_from_string(sgm["counts"].encode())
+            assert int(counts.sum()) == 720 * 1280
+            n_seg += 1
+    assert n_seg > 0
+
+
 def test_fp16_backbone_option_config5():
     """BASELINE config 5 flavour: fp16 autocast ResNet trunk (DCN, FPN, heads fp32).  fp16 trunk activations carry ~1e-3
     relative error, so only closeness of the prototypes / box regression to the fp32 run is asserted."""
