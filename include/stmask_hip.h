@@ -277,6 +277,13 @@ int stm_split_bf16_planes_f32(const float* x /* [n_pixels][C] fp32 */, void* pla
 int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
                           const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu,
                           stm_stream_t stream);
+/* the same with a scratch buffer: launches whose grid would leave most CUs idle over a long K (few pixels, many input
+ * channels) are split along K, the parts' fp32 partial sums go through `workspace` and a finishing kernel adds them and
+ * runs the epilogue; splitk * pixels * ceil(Cout / tile_n) * tile_n * 4 bytes are needed, otherwise (or with NULL) the
+ * launch is not split */
+int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
+                             const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu,
+                             void* workspace, size_t workspace_bytes, stm_stream_t stream);
 
 /* ---- frame pre-processing on the device (row f3) ------------------------------------------------------------------
  * Replaces the host chain of eval.py:703-717 (evaluate_single): mmcv.imresize(im, (w, h)) [cv2.resize INTER_LINEAR on

@@ -20,6 +20,7 @@
 // ds_read_b128 fragment reads of both operands conflict-free without padding.  48 KB LDS and < 256 VGPRs per thread:
 // two workgroups per CU, so one workgroup's split/stage phase runs under the other's MFMA phase.
 #include "stm_common.h"
+#include <algorithm>
 
 static long long* g_conv_trace = nullptr;   // see stm_debug_conv_set_trace
 
@@ -452,6 +453,8 @@ struct PlanarArgs {
     int group_real[8];                               // output channels per group that are not zero padding (MFMA tiles past them are skipped)
     int n_levels;                                    // > 0: pixels are the concatenation of n_levels images sizes
     int lvl_start[9], lvl_h[8], lvl_w[8];
+    int splitk, kslabs, ldp;  // split-K: K-slabs per split, fp32 partial sums [splitk][M][ldp] in `partial`
+    float* partial;
     int dbg;                // STM_CONV_DEBUG timing ablations (results wrong): 1 no DMA in the loop, 2 no barrier, 4 no MFMA
     int vec_epilogue;       // Cout, out_ld, res_ld multiples of 8 and 16-byte aligned pointers: vector epilogue
     long long* trace;
@@ -494,15 +497,79 @@ __device__ __forceinline__ void park16(f32x4 (&acc)[4][2 * NJ], f32x4 (&accl)[4]
                 park[(i * 16 + 4 * (lane >> 4) + r) * EP_LD + j * 16 + (lane & 15)] = acc[i][j][r] + accl[i][j][r];
 }
 
+// bias + residual + ReLU + stores of one 8-channel segment (pixel m, channels co .. co+7, nvalid of them real); v = raw sums
+__device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int co, int nvalid, float (&v)[8])
+{
+    const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
+    // element index of (pixel m, channel co) in a slab-major planar buffer with np pixels per slab
+    auto pidx = [](int m_, int co_, int np) { return ((size_t)(co_ >> 5) * np + m_) * 32 + (co_ & 31); };
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (a.bias && e < nvalid) ? a.bias[co + e] : 0.0f;
+    if (a.vec_epilogue) {                              // implies nvalid == 8
+        if (a.res_f32) {
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co);
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        }
+        if (a.res_pl) {
+            const size_t ri = pidx(m, co, a.res_np) * 2;
+            const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri);
+            const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 2);
+            const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += ((float)p0[e] + (float)p1[e]) + (float)p2[e];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+        }
+        if (a.out_f32) {
+            float* o = a.out_f32 + (size_t)m * a.out_ld + co;
+            *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        if (a.out_pl) {
+            unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
+            uint8_t* o = a.out_pl + pidx(m, co, a.out_np) * 2;
+            *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+            *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+            *reinterpret_cast<u32x4*>(o + opl * 4) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+        }
+        return;
+    }
+    __bf16* outp = reinterpret_cast<__bf16*>(a.out_pl);
+    const __bf16* resp = reinterpret_cast<const __bf16*>(a.res_pl);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (e >= nvalid) break;
+        float x = v[e];
+        if (a.res_f32) x += a.res_f32[(size_t)m * a.res_ld + co + e];
+        if (resp) {
+            const size_t ri = pidx(m, co + e, a.res_np);
+            x += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
+        }
+        if (a.relu) x = x > 0.0f ? x : 0.0f;
+        if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co + e] = x;
+        if (outp) {
+            const size_t oi = pidx(m, co + e, a.out_np);
+            const __bf16 h = (__bf16)x;
+            const float r1 = x - (float)h;
+            const __bf16 mid = (__bf16)r1;
+            outp[oi] = h;
+            outp[oi + opl] = mid;
+            outp[oi + 2 * opl] = (__bf16)(r1 - (float)mid);
+        }
+    }
+}
+
 template <int NJ>
 __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_t* smem, int wave, int lane, int m0, int n0g, int grp,
                                                      int wm, int wn)
 {
     constexpr int EP_LD = 32 * NJ + 4;                 // floats per parked pixel row (+ 4 pad)
     constexpr int LPR = 4 * NJ;                        // lanes per pixel row (8 channels each)
-    const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
-    // element index of (pixel m, channel co) in a slab-major planar buffer with np pixels per slab
-    auto pidx = [](int m, int co, int np) { return ((size_t)(co >> 5) * np + m) * 32 + (co & 31); };
     const float* park = park_base<NJ>(smem, wave);
     // same wave reads back what it wrote: no workgroup barrier needed, only the LDS counter
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -511,12 +578,6 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
     const int co = grp * a.cout_g + cog;
     const int nvalid = min(8, a.cout_g - cog);         // channels of this segment that exist (<= 0: none)
     if (nvalid <= 0) return;
-    float bv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (a.bias && e < nvalid) ? a.bias[co + e] : 0.0f;
-    const bool vec = a.vec_epilogue != 0;              // implies nvalid == 8
-    __bf16* outp = reinterpret_cast<__bf16*>(a.out_pl);
-    const __bf16* resp = reinterpret_cast<const __bf16*>(a.res_pl);
 #pragma unroll
     for (int pass = 0; pass < LPR; ++pass) {
         const int pr = pass * (64 / LPR) + prow;
@@ -524,63 +585,29 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
         if (m >= a.M) continue;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
-        float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-        if (vec) {
-            if (a.res_f32) {
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co);
-                const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co + 4);
-                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-            }
-            if (a.res_pl) {
-                const size_t ri = pidx(m, co, a.res_np) * 2;
-                const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri);
-                const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 2);
-                const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 4);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += ((float)p0[e] + (float)p1[e]) + (float)p2[e];
-            }
-            if (a.relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-            }
-            if (a.out_f32) {
-                float* o = a.out_f32 + (size_t)m * a.out_ld + co;
-                *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            }
-            if (a.out_pl) {
-                unsigned q0[4], q1[4], q2[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
-                uint8_t* o = a.out_pl + pidx(m, co, a.out_np) * 2;
-                *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-                *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-                *reinterpret_cast<u32x4*>(o + opl * 4) = u32x4{q2[0], q2[1], q2[2], q2[3]};
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (e >= nvalid) break;
-                float x = v[e];
-                if (a.res_f32) x += a.res_f32[(size_t)m * a.res_ld + co + e];
-                if (resp) {
-                    const size_t ri = pidx(m, co + e, a.res_np);
-                    x += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
-                }
-                if (a.relu) x = x > 0.0f ? x : 0.0f;
-                if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co + e] = x;
-                if (outp) {
-                    const size_t oi = pidx(m, co + e, a.out_np);
-                    const __bf16 h = (__bf16)x;
-                    const float r1 = x - (float)h;
-                    const __bf16 mid = (__bf16)r1;
-                    outp[oi] = h;
-                    outp[oi + opl] = mid;
-                    outp[oi + 2 * opl] = (__bf16)(r1 - (float)mid);
-                }
-            }
-        }
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        epilogue_store8(a, m, co, nvalid, v);
     }
+}
+
+// split-K: add the partial sums of one (pixel, 8-channel segment) and run the epilogue; thread per segment
+__global__ __launch_bounds__(256) void planar_splitk_finish_kernel(const PlanarArgs a, int bn)
+{
+    const int segs_g = (a.cout_g + 7) >> 3;                            // segments per group
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)a.M * a.groups * segs_g;
+    if (idx >= total) return;
+    const int sg = (int)(idx % (a.groups * segs_g));
+    const int m = (int)(idx / (a.groups * segs_g));
+    const int grp = sg / segs_g, cog = (sg - grp * segs_g) * 8;
+    const int col = grp * a.ntpg * bn + cog;                           // column in the tile-padded partial matrix
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < a.splitk; ++k) {
+        const float* p = a.partial + ((size_t)k * a.M + m) * a.ldp + col;
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(p), p1 = *reinterpret_cast<const f32x4*>(p + 4);
+        v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+    }
+    epilogue_store8(a, m, grp * a.cout_g + cog, min(8, a.cout_g - cog), v);
 }
 
 template <int NJ>
@@ -605,13 +632,16 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     constexpr int WDMA = (BN / 16) * NPL / NWAVES;   // weight DMA instructions (1 KB each) per wave per slab
     static_assert((BN / 16) * NPL % NWAVES == 0, "weight tile must split evenly over the waves");
 
-    const int tiles = a.m_tiles * a.n_tiles;
+    const int tiles = a.m_tiles * a.n_tiles * a.splitk;
     const int per_xcd = (tiles + 7) >> 3;
     const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (logical >= tiles) return;
-    const int nt = logical % a.n_tiles;
-    const int mt = logical / a.n_tiles;
+    const int ksp = logical % a.splitk;                  // split-K part (the parts of one tile sit on one XCD)
+    const int tile = logical / a.splitk;
+    const int nt = tile % a.n_tiles;
+    const int mt = tile / a.n_tiles;
     const int m0 = mt * BM;
+    const int s_begin = ksp * a.kslabs, s_end = min(a.slabs, s_begin + a.kslabs);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -653,11 +683,11 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     for (int p = 0; p < NPL; ++p)
         xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
     const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * WBUF;
-    const int taps = a.kh * a.kw, S = a.slabs, cslabs = a.C / CV_BK;
+    const int taps = a.kh * a.kw, cslabs = a.C / CV_BK;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
 
-    int s_tap = 0, s_c = 0;
+    int s_tap = s_begin % (a.kh * a.kw), s_c = s_begin / (a.kh * a.kw);
     auto dma_x = [&](int buf) {
         uint8_t* xb = smem + buf * BUF;
         const int ky = s_tap / a.kw, kx = s_tap - ky * a.kw;
@@ -707,9 +737,9 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     const bool tr = false;
 #define PL_STAMP(k)
 #endif
-    dma_x(0);
-    dma_w(0, 0);
-    for (int s = 0; s < S; ++s) {
+    dma_x(s_begin & 1);
+    dma_w(s_begin, s_begin & 1);
+    for (int s = s_begin; s < s_end; ++s) {
         PL_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of slab s has landed
         PL_STAMP(1);
@@ -738,7 +768,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                     bf[j][p] = *reinterpret_cast<const bf16x8*>(ws + p * WPL + lds_off(wn * (32 * NJ) + j * 32 + lrow, 2 * ks + lh));
             if (!(a.dbg & 1)) {
                 if (ks == 0) dma_x((s + 1) & 1);
-                else dma_w(min(s + 1, S - 1), (s + 1) & 1);
+                else dma_w(min(s + 1, s_end - 1), (s + 1) & 1);
             }
             if (!(a.dbg & 4))
 #pragma unroll
@@ -789,7 +819,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                             af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + (2 * hf + i) * 16 + r16, kc));
                     if (!(a.dbg & 1)) {
                         if (hf == 0) dma_x((s + 1) & 1);
-                        else dma_w(min(s + 1, S - 1), (s + 1) & 1);
+                        else dma_w(min(s + 1, s_end - 1), (s + 1) & 1);
                     }
     #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -825,7 +855,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                             af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + (2 * hf + i) * 16 + r16, kc));
                     if (!(a.dbg & 1)) {
                         if (hf == 0) dma_x((s + 1) & 1);
-                        else dma_w(min(s + 1, S - 1), (s + 1) & 1);
+                        else dma_w(min(s + 1, s_end - 1), (s + 1) & 1);
                     }
     #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -858,11 +888,26 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 #undef PL_STAMP
     if (tr) a.trace[(wave != 0) * 512 + 7] = clock64();
 
-    if constexpr (MF == 0) {
-        planar_epilogue<NJ>(a, acc, accl, smem, wave, lane, m0, n0g, grp, wm, wn);
+    __syncthreads();                                   // all fragment reads of the last slab are done
+    if constexpr (MF == 0) park32<NJ>(acc, accl, smem, wave, lane);
+    else park16<NJ>(acc16, accl16, smem, wave, lane);
+    if (a.splitk > 1) {
+        // raw fp32 partial sums of this K range; planar_splitk_finish_kernel adds the parts and runs the epilogue
+        constexpr int EP_LD = 32 * NJ + 4, LPR = 4 * NJ;
+        const float* park = park_base<NJ>(smem, wave);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int seg = lane % LPR, prow = lane / LPR;
+        const int col = nt * BN + wn * (32 * NJ) + seg * 8;          // column in the tile-padded space
+#pragma unroll
+        for (int pass = 0; pass < LPR; ++pass) {
+            const int pr = pass * (64 / LPR) + prow;
+            const int m = m0 + wm * 64 + pr;
+            if (m >= a.M) continue;
+            float* o = a.partial + ((size_t)ksp * a.M + m) * a.ldp + col;
+            *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
+            *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
+        }
     } else {
-        __syncthreads();                               // all fragment reads of the last slab are done
-        park16<NJ>(acc16, accl16, smem, wave, lane);
         planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
     }
     if (tr) a.trace[(wave != 0) * 512 + 15] = clock64();
@@ -1277,9 +1322,9 @@ extern "C" int stm_split_bf16_planes_f32(const float* x, void* planes, int64_t n
     return STM_OK;
 }
 
-extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
-                                     const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
-                                     int relu, stm_stream_t stream)
+extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
+                                        const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
+                                        int relu, void* workspace, size_t workspace_bytes, stm_stream_t stream)
 {
     const char* who = "stm_conv2d_planar_f32";
     STM_REQUIRE(x_planes && packed_weight && (out_f32 || out_planes), STM_ENULL,
@@ -1351,13 +1396,39 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     // form spends less energy per flop: 593 vs 656 us on the 145-GF proto layer.  STM_CONV_MFMA=32 selects the other form.
     const char* fm = getenv("STM_CONV_MFMA");
     const bool mf16 = fm ? atoi(fm) != 32 : true;
+    a.splitk = 1; a.kslabs = a.slabs; a.partial = nullptr; a.ldp = a.n_tiles * bn;
+    // split-K for grids that would leave most CUs idle over a long K (small feature maps: ResNet stages 3/4, P5-P7):
+    // parts write fp32 partial sums into the caller's workspace, planar_splitk_finish_kernel adds them and runs the epilogue
+    auto plan_splitk = [&](int tiles) {
+        const char* fs = getenv("STM_CONV_SPLITK");
+        int sk = fs ? atoi(fs) : 0;
+        if (sk <= 0) {
+            sk = 1;
+            if (tiles < 128 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, 256 / tiles), a.slabs / 12);
+        }
+        if (sk < 2) return;
+        const int per = stm_cdiv(a.slabs, sk);
+        sk = stm_cdiv(a.slabs, per);
+        if (sk < 2 || !workspace || (size_t)sk * M * a.ldp * sizeof(float) > workspace_bytes || ((uintptr_t)workspace % 16)) return;
+        a.splitk = sk; a.kslabs = per; a.partial = static_cast<float*>(workspace);
+    };
+    auto finish_splitk = [&]() -> int {
+        if (a.splitk < 2) return STM_OK;
+        const int64_t total = M * groups * ((cout_g + 7) / 8);
+        hipLaunchKernelGGL(planar_splitk_finish_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), a, bn);
+        STM_CHECK_LAUNCH("planar_splitk_finish_kernel");
+        return STM_OK;
+    };
     if (bn == 64) {
         // 128 x 64 tiles, 72 KB of LDS: two independent workgroups per CU, each one's barrier / staging gaps filled by
         // the other's MFMAs
         a.m_tiles = stm_cdiv(M, CV_BM);
-        const int tiles = a.m_tiles * a.n_tiles;
-        if (mf16) return g->planes == 3 ? launch_planar<3, 1, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
-        return g->planes == 3 ? launch_planar<3, 1, 1, 0>(a, tiles, stream) : launch_planar<2, 1, 1, 0>(a, tiles, stream);
+        plan_splitk(a.m_tiles * a.n_tiles);
+        const int tiles = a.m_tiles * a.n_tiles * a.splitk;
+        int rc64;
+        if (mf16) rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
+        else rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 0>(a, tiles, stream) : launch_planar<2, 1, 1, 0>(a, tiles, stream);
+        return rc64 != STM_OK ? rc64 : finish_splitk();
     }
     const char* fk = getenv("STM_CONV_MG");
     const int forced = fk ? atoi(fk) : 0;
@@ -1367,18 +1438,28 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     const int64_t t2 = (int64_t)stm_cdiv(M, 2 * CV_BM) * a.n_tiles;
     const int mg = forced ? forced : (t2 >= 192 ? 2 : 1);
     a.m_tiles = stm_cdiv(M, CV_BM * mg);
-    const int tiles = a.m_tiles * a.n_tiles;
     // stride-1 "same" convolutions with a kernel row of >= 3 taps: stage each activation row tile once per kernel row
     const char* fkx = getenv("STM_CONV_KX");
     // (measured: no gain over the per-tap kernel -- 654 vs 670 us on the 145-GF proto layer although it moves 1.8x fewer
     // bytes; the ablations in DESIGN.md section 6 show why -- so it is opt-in: STM_CONV_KX=1)
     const bool kx_ok = mg == 2 && g->kw >= 3 && g->kw <= 5 && g->sh == 1 && g->sw == 1 && 2 * g->pw == g->kw - 1 &&
                        2 * g->ph == g->kh - 1 && fkx && atoi(fkx) == 1;
-    if (kx_ok) return g->planes == 3 ? launch_planar_kx<3>(a, tiles, stream) : launch_planar_kx<2>(a, tiles, stream);
+    if (kx_ok) return g->planes == 3 ? launch_planar_kx<3>(a, a.m_tiles * a.n_tiles, stream) : launch_planar_kx<2>(a, a.m_tiles * a.n_tiles, stream);
+    plan_splitk(a.m_tiles * a.n_tiles);
+    const int tiles = a.m_tiles * a.n_tiles * a.splitk;
+    int rc;
     if (mf16) {
-        if (g->planes == 3) return mg == 2 ? launch_planar<3, 2, 2, 1>(a, tiles, stream) : launch_planar<3, 1, 2, 1>(a, tiles, stream);
-        return mg == 2 ? launch_planar<2, 2, 2, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1>(a, tiles, stream);
-    }
-    if (g->planes == 3) return mg == 2 ? launch_planar<3, 2, 2, 0>(a, tiles, stream) : launch_planar<3, 1, 2, 0>(a, tiles, stream);
-    return mg == 2 ? launch_planar<2, 2, 2, 0>(a, tiles, stream) : launch_planar<2, 1, 2, 0>(a, tiles, stream);
+        if (g->planes == 3) rc = mg == 2 ? launch_planar<3, 2, 2, 1>(a, tiles, stream) : launch_planar<3, 1, 2, 1>(a, tiles, stream);
+        else rc = mg == 2 ? launch_planar<2, 2, 2, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1>(a, tiles, stream);
+    } else if (g->planes == 3) rc = mg == 2 ? launch_planar<3, 2, 2, 0>(a, tiles, stream) : launch_planar<3, 1, 2, 0>(a, tiles, stream);
+    else rc = mg == 2 ? launch_planar<2, 2, 2, 0>(a, tiles, stream) : launch_planar<2, 1, 2, 0>(a, tiles, stream);
+    return rc != STM_OK ? rc : finish_splitk();
+}
+
+extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
+                                     const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
+                                     int relu, stm_stream_t stream)
+{
+    return stm_conv2d_planar_ws_f32(x_planes, packed_weight, bias, residual_f32, residual_planes, out_f32, out_planes, g, relu, nullptr,
+                                    0, stream);
 }

@@ -29,6 +29,8 @@ class PlanarConv:
     """One packed convolution layer.  x / outputs are described by raw (tensor, pixel offset) pairs so that a layer can
     read from and write into slices of larger plane buffers."""
 
+    SPLITK_WS_BYTES = 64 << 20   # scratch for split-K partial sums (small feature maps with long K)
+
     def __init__(self, weight, bias, stride=1, padding=0, relu=False, groups=1, planes=3, algo_frac=1.0, tile_n=None,
                  group_cout=None):
         """algo_frac: share of the packed layer that is the reference's own arithmetic (zero-padded channels excluded);
@@ -132,10 +134,12 @@ class PlanarConv:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         x_ptr = xp.data_ptr() + ((x_ch_off // 32) * N + x_off) * 64
-        rc = _lib.lib().stm_conv2d_planar_f32(ctypes.c_void_p(x_ptr), ops._p(self.packed(g.tile_n)),
-                                              ops._p(self.bias), ctypes.c_void_p(r32), ctypes.c_void_p(rpl),
-                                              ctypes.c_void_p(p_f32), ctypes.c_void_p(p_pl), ctypes.byref(g),
-                                              c_i(1 if self.relu else 0), ops._stream())
+        ws = ops._workspace(self.SPLITK_WS_BYTES, dev, "conv_splitk")     # grow-only, shared: split-K partial sums
+        rc = _lib.lib().stm_conv2d_planar_ws_f32(ctypes.c_void_p(x_ptr), ops._p(self.packed(g.tile_n)),
+                                                 ops._p(self.bias), ctypes.c_void_p(r32), ctypes.c_void_p(rpl),
+                                                 ctypes.c_void_p(p_f32), ctypes.c_void_p(p_pl), ctypes.byref(g),
+                                                 c_i(1 if self.relu else 0), ops._p(ws), ctypes.c_size_t(ws.numel()),
+                                                 ops._stream())
         check(rc, "stm_conv2d_planar_f32")
         if timing is not None:
             e1.record()
@@ -431,7 +435,8 @@ class PlanarBackbone:
     conv3's epilogue.  The stem (7x7, 3 input channels) stays on the dense-conv library; the deformable 3x3 layers stay on
     deform im2col + fp32 MFMA GEMM (they take / return NCHW fp32: one layout change either side)."""
 
-    OM_PLANAR_MIN_PIXELS = 16384    # offset / mask conv of a DCN layer on the planar kernel from this many output pixels
+    import os as _os
+    OM_PLANAR_MIN_PIXELS = int(_os.environ.get("STM_OM_PLANAR_MIN", 16384))   # offset / mask conv of a DCN layer on the planar kernel from this many output pixels
 
     def __init__(self, bb):
         from .dcn_v2 import DCN

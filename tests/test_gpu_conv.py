@@ -230,3 +230,29 @@ def test_conv_planar_levels_groups_and_slices():
     full = planes_to_f32(dst.cpu())
     assert (full[starts[l]:starts[l + 1]].view(B, h, w, 32) - ref).abs().max().item() < 1e-5
     assert torch.count_nonzero(full[:starts[l]]) == 0 and torch.count_nonzero(full[starts[l + 1]:]) == 0
+
+
+@pytest.mark.parametrize("splitk", ["2", "5"])
+@pytest.mark.parametrize("tile_n", [64, 128])
+def test_conv_planar_splitk(splitk, tile_n, monkeypatch):
+    """Split-K (partial sums through a workspace + finishing kernel, taken for grids that would idle most CUs) against the
+    oracle and the unsplit launch, with residual, ReLU, both output forms, Cout not a multiple of 8 (scalar finish)."""
+    from stmask_amd.planar import PlanarConv
+    for (B, H, W, C, O, k, has_res) in [(2, 6, 10, 256, 128, 3, True), (1, 5, 7, 512, 41, 1, False)]:
+        x = rnd(B, H, W, C, seed=3)
+        w = rnd(O, C, k, k, seed=4, scale=(C * k * k) ** -0.5)
+        b = rnd(O, seed=5)
+        r = rnd(B * H * W, O, seed=6) if has_res else None
+        ref = oracle.conv2d_nhwc(x, w, b, r.view(B, H, W, O) if has_res else None, padding=k // 2, relu=True)
+        mag = oracle.conv2d_nhwc(x.abs(), w.abs(), b.abs(), r.abs().view(B, H, W, O) if has_res else None, padding=k // 2)
+        conv = PlanarConv(w.to(DEV), b.to(DEV), 1, k // 2, relu=True, tile_n=tile_n)
+        xp = ops.split_planes(x.to(DEV))
+        monkeypatch.setenv("STM_CONV_SPLITK", "1")
+        y1 = conv(xp, ("img", B, H, W), out="f32", residual=r.to(DEV) if has_res else None).cpu()
+        monkeypatch.setenv("STM_CONV_SPLITK", splitk)
+        y32, ypl = conv(xp, ("img", B, H, W), out="both", residual=r.to(DEV) if has_res else None)
+        monkeypatch.delenv("STM_CONV_SPLITK")
+        y32, ypl = y32.cpu(), ypl.cpu()
+        assert ((y32.view(ref.shape) - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
+        assert ((y32 - y1).abs() / mag.view(-1, O).clamp_min(1e-6)).max().item() < 1e-6      # only the summation order differs
+        assert torch.equal(planes_to_f32(ypl)[:, :O], y32)
