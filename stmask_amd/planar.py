@@ -435,8 +435,8 @@ class PlanarBackbone:
     conv3's epilogue.  The stem (7x7, 3 input channels) stays on the dense-conv library; the deformable 3x3 layers stay on
     deform im2col + fp32 MFMA GEMM (they take / return NCHW fp32: one layout change either side)."""
 
-    import os as _os
-    OM_PLANAR_MIN_PIXELS = int(_os.environ.get("STM_OM_PLANAR_MIN", 16384))   # offset / mask conv of a DCN layer on the planar kernel from this many output pixels
+    OM_PLANAR_MIN_PIXELS = 0    # offset / mask conv of a DCN layer on the planar kernel from this many output pixels (with
+                                # split-K the small stages are fine there too: 547-549 vs 538-539 frames/s with the library)
 
     def __init__(self, bb):
         from .dcn_v2 import DCN
@@ -482,9 +482,7 @@ class PlanarBackbone:
                         t32, tpl = e["c1"](xp, shape, out="both")
                         om = e["om"](tpl, shape, out="f32").view(B, Ho, Wo, -1).permute(0, 3, 1, 2).contiguous()
                     else:
-                        # few output pixels and 27 output channels: 8-64 tiles of 72-144 K-slabs each would leave most CUs
-                        # idle for 80-150 us (no split-K in the planar kernel yet); the dense-conv library's small-tile
-                        # kernel takes ~35 us here
+                        # alternative for tiny maps: the dense-conv library's small-tile kernel (not taken by default)
                         t32 = e["c1"](xp, shape, out="f32")
                         om = d.conv_offset_mask(t32.view(B, H, W, -1).permute(0, 3, 1, 2)).contiguous()
                     xin = t32.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
