@@ -309,6 +309,16 @@ typedef struct stm_head_layout {
 int stm_head_assemble_f32(const float* const* small, const float* const* trk, const stm_head_layout* layout, float* conf,
                           float* loc, float* mask, float* track, float* centerness, stm_stream_t stream);
 
+/* ---- deformable sampling into the planar format (row a1, inference graph) ------------------------------------------
+ * The im2col half of dcn_v2.DCN (backbone.py:20-26,45) for activations that already live in the planar graph: x is fp32
+ * NHWC [B,H,W,C] (C = 128 / 256 / 512), offset_mask the raw conv_offset_mask output pixel-major [B*Ho*Wo, om_ld] (18
+ * offsets dy,dx per tap, then 9 mask logits; sigmoid applied here), the columns are written as bf16 planes
+ * [3][9C/32][out_np][32] with K index = tap*C + channel, i.e. the input of stm_conv2d_planar_f32 as a 1x1 convolution over
+ * 9C channels with the DCN weight reordered to [O][tap][C].  Sampling arithmetic and border rule are those of
+ * stm_deform_im2col_f32, value for value. */
+int stm_dcn_sample_planar_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
+                              long long out_plane_stride, const stm_deform_geom* g, stm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -713,3 +713,118 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
 }
 
 extern "C" int stm_validate_deform_geom(const stm_deform_geom* g) { return validate_geom(g, "stm_deform_geom"); }
+
+
+// ---- planar variant for the inference graph (stmask_amd/planar.py): the same sampling arithmetic, but NHWC fp32 in (what the
+// planar 1x1 convolution in front of it writes), the raw conv_offset_mask output pixel-major [pixels][3K] (what the planar
+// offset convolution writes), and the columns out in the planar activation format -- three bf16 planes, channel-slab major,
+// K index = tap * C + channel -- so that the deformable convolution's GEMM is a planar 1x1 convolution over 9C channels on
+// the bf16 matrix cores (csrc/conv_bf16x.hip) instead of the fp32 GEMM, and no layout change is left either side.
+// One wave per output pixel: the 27 offset / mask values are read once and broadcast, every corner read is C contiguous
+// floats (the whole wave reads one 128-B..2-KB line run), coefficients are computed once per (pixel, tap) for all channels.
+// Values are bit-identical to the NCHW kernels above (same expression order), then split exactly.
+namespace {
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
+struct SampleArgs {
+    const float* x;      // [B, H, W, C]
+    const float* om;     // [B*Ho*Wo, om_ld]: 2K offsets (dy, dx per tap) then K mask logits
+    uint8_t* out;        // planes [3][K*C/32][out_np][32] bf16
+    int B, H, W, C, Ho, Wo, sh, sw, ph, pw, dh, dw;
+    int om_ld, out_np, M;
+    long long out_pstride;   // bytes
+};
+
+__device__ __forceinline__ void split2_planes(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2)
+{
+    const f32x2v v = {a, b};
+    const bf16x2v h = __builtin_convertvector(v, bf16x2v);
+    const f32x2v r1 = v - __builtin_convertvector(h, f32x2v);
+    const bf16x2v m = __builtin_convertvector(r1, bf16x2v);
+    const f32x2v r2 = r1 - __builtin_convertvector(m, f32x2v);
+    const bf16x2v l = __builtin_convertvector(r2, bf16x2v);
+    p0 = __builtin_bit_cast(unsigned, h);
+    p1 = __builtin_bit_cast(unsigned, m);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+
+template <int CPL>   // channels per lane: C = 64 * CPL (2, 4 or 8)
+__global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs a)
+{
+    constexpr int K = 9;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int b = m / (a.Ho * a.Wo);
+    const int rem = m - b * (a.Ho * a.Wo);
+    const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    const float omv = lane < 3 * K ? a.om[(size_t)m * a.om_ld + lane] : 0.0f;
+    const float* xb = a.x + (size_t)b * a.H * a.W * a.C + lane * CPL;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = k / 3, j = k - 3 * i;
+        const float dy = __shfl(omv, 2 * k), dx = __shfl(omv, 2 * k + 1);
+        const float mk = sigmoidf_dev(__shfl(omv, 2 * K + k));
+        const float fy = (float)(ho * a.sh - a.ph + i * a.dh) + dy;
+        const float fx = (float)(wo * a.sw - a.pw + j * a.dw) + dx;
+        float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+        int a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        if (fy > -1.0f && fx > -1.0f && fy < (float)a.H && fx < (float)a.W) {
+            const float fl_y = floorf(fy), fl_x = floorf(fx);
+            const int h_low = (int)fl_y, w_low = (int)fl_x, h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = fy - fl_y, lw = fx - fl_x, hh = 1.0f - lh, hw = 1.0f - lw;
+            const bool t = h_low >= 0, l = w_low >= 0, bt = h_high <= a.H - 1, r = w_high <= a.W - 1;
+            const int hl = max(h_low, 0), wl = max(w_low, 0), hh_i = min(h_high, a.H - 1), wh_i = min(w_high, a.W - 1);
+            w1 = (t && l) ? hh * hw * mk : 0.f;
+            w2 = (t && r) ? hh * lw * mk : 0.f;
+            w3 = (bt && l) ? lh * hw * mk : 0.f;
+            w4 = (bt && r) ? lh * lw * mk : 0.f;
+            a1 = (hl * a.W + wl) * a.C;
+            a2 = (hl * a.W + wh_i) * a.C;
+            a3 = (hh_i * a.W + wl) * a.C;
+            a4 = (hh_i * a.W + wh_i) * a.C;
+        }
+        float v[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) v[e] = bilerp(w1, w2, w3, w4, xb[a1 + e], xb[a2 + e], xb[a3 + e], xb[a4 + e]);
+        unsigned p0[CPL / 2], p1[CPL / 2], p2[CPL / 2];
+#pragma unroll
+        for (int e = 0; e < CPL / 2; ++e) split2_planes(v[2 * e], v[2 * e + 1], p0[e], p1[e], p2[e]);
+        const int kc = k * a.C + lane * CPL;                 // K index of the lane's first channel
+        uint8_t* o = a.out + (((size_t)(kc >> 5) * a.out_np + m) * 32 + (kc & 31)) * 2;
+#pragma unroll
+        for (int e = 0; e < CPL / 2; ++e) {
+            reinterpret_cast<unsigned*>(o)[e] = p0[e];
+            reinterpret_cast<unsigned*>(o + a.out_pstride)[e] = p1[e];
+            reinterpret_cast<unsigned*>(o + 2 * a.out_pstride)[e] = p2[e];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int stm_dcn_sample_planar_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
+                                         long long out_plane_stride, const stm_deform_geom* g, stm_stream_t stream)
+{
+    STM_REQUIRE(x && offset_mask && planes && g, STM_ENULL, "stm_dcn_sample_planar_f32: NULL argument");
+    STM_REQUIRE(g->kh == 3 && g->kw == 3 && g->dg == 1, STM_EUNSUPPORTED, "stm_dcn_sample_planar_f32: 3x3 kernels, one deformable group");
+    STM_REQUIRE(g->C == 128 || g->C == 256 || g->C == 512, STM_EUNSUPPORTED, "stm_dcn_sample_planar_f32: C must be 128, 256 or 512 (got %d)", g->C);
+    STM_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->Ho > 0 && g->Wo > 0 && om_ld >= 27, STM_EINVAL, "stm_dcn_sample_planar_f32: bad geometry");
+    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
+    STM_REQUIRE(M < ((int64_t)1 << 30) && (int64_t)g->B * g->H * g->W * g->C < ((int64_t)1 << 31), STM_EUNSUPPORTED,
+                "stm_dcn_sample_planar_f32: tensor too large for 32-bit indexing");
+    SampleArgs a;
+    a.x = x; a.om = offset_mask; a.out = static_cast<uint8_t*>(planes);
+    a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.Ho = g->Ho; a.Wo = g->Wo;
+    a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw; a.dh = g->dh; a.dw = g->dw;
+    a.om_ld = om_ld; a.M = (int)M; a.out_np = out_np > 0 ? out_np : (int)M;
+    a.out_pstride = (out_plane_stride > 0 ? out_plane_stride : (long long)(9 * g->C / 32) * a.out_np * 32) * 2;
+    const dim3 grid(stm_cdiv(M, 4));
+    if (g->C == 128) hipLaunchKernelGGL(dcn_sample_planar_kernel<2>, grid, dim3(256), 0, stm_hs(stream), a);
+    else if (g->C == 256) hipLaunchKernelGGL(dcn_sample_planar_kernel<4>, grid, dim3(256), 0, stm_hs(stream), a);
+    else hipLaunchKernelGGL(dcn_sample_planar_kernel<8>, grid, dim3(256), 0, stm_hs(stream), a);
+    STM_CHECK_LAUNCH("dcn_sample_planar_kernel");
+    return STM_OK;
+}

@@ -534,3 +534,30 @@ def head_assemble(small, trk, B, sizes, n_cls, mask_dim, embed_dim, group_pad):
     check(_lib.lib().stm_head_assemble_f32(sp, tp, ctypes.byref(L), _p(conf), _p(loc), _p(mask), _p(track), _p(cen), _stream()),
           "stm_head_assemble_f32")
     return conf, loc, mask, track, cen
+
+
+def dcn_sample_planar(x_nhwc, om, stride=1, padding=1, dilation=1):
+    """Deformable 3x3 sampling for the planar graph: x fp32 [B,H,W,C], om fp32 [B*Ho*Wo, >=27] (raw conv_offset_mask output,
+    pixel-major) -> bf16 planes [3, 9C/32, B*Ho*Wo, 32] with K index = tap*C + channel."""
+    _dev(x_nhwc, om)
+    x = _f32c(x_nhwc)
+    om = _f32c(om)
+    B, H, W, C = x.shape
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    Ho, Wo = conv_out_hw(H, W, 3, 3, sh, sw, ph, pw, dh, dw)
+    M = B * Ho * Wo
+    if om.shape[0] != M or om.shape[1] < 27:
+        raise StmError(f"dcn_sample_planar: offset/mask matrix {tuple(om.shape)} does not match {M} output pixels x 27")
+    g = DeformGeom(B, C, H, W, 3, 3, sh, sw, ph, pw, dh, dw, 1, Ho, Wo)
+    out = torch.empty(3, 9 * C // 32, M, 32, device=x.device, dtype=torch.bfloat16)
+    timing = _im2col_timing
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.lib().stm_dcn_sample_planar_f32(_p(x), _p(om), c_i(om.shape[1]), _p(out), c_i(M), c_l(0), ctypes.byref(g),
+                                               _stream()), "stm_dcn_sample_planar_f32")
+    if timing is not None:
+        e1.record()
+        # algorithmic bytes: input once, 27 offset/mask values per output pixel, columns as three bf16 planes (6 B / element)
+        timing.append((e0, e1, 4 * B * C * H * W + 4 * 27 * M + 6 * 9 * C * M))
+    return out

@@ -452,6 +452,12 @@ class PlanarBackbone:
                     e["dcn"] = c2
                     om = c2.conv_offset_mask
                     e["om"] = PlanarConv(om.weight, om.bias, om.stride, om.padding, relu=False)
+                    # the deformable conv's GEMM as a planar 1x1 convolution over the sampled columns [pixel][tap*C + c]
+                    O, Cin = c2.weight.shape[:2]
+                    e["dcn_planar"] = (c2.kernel_size == (3, 3) and c2.deformable_groups == 1 and Cin in (128, 256, 512))
+                    if e["dcn_planar"]:
+                        wk = c2.weight.detach().permute(0, 2, 3, 1).reshape(O, 9 * Cin, 1, 1)
+                        e["dcn_conv"] = PlanarConv(wk, c2.bias, 1, 0, relu=True)
                 else:
                     e["c2"] = PlanarConv(c2.weight, c2.bias, c2.stride, c2.padding, relu=True)
                 if blk.downsample is not None:
@@ -478,17 +484,25 @@ class PlanarBackbone:
                     # conv1 -> fp32 (NCHW copy for the deformable sampler) and planes (offset / mask convolution);
                     # the sampler reads the raw conv_offset_mask output (sigmoid folded in), GEMM adds bias + ReLU
                     d = e["dcn"]
-                    if B * Ho * Wo >= self.OM_PLANAR_MIN_PIXELS:
+                    if e["dcn_planar"]:
+                        # all planar: conv1 -> fp32 NHWC (sampler input) + planes (offset conv input); offset conv -> fp32
+                        # [pixels, 27]; sampler -> planar columns; GEMM + bias + ReLU as a planar 1x1 convolution
+                        t32, tpl = e["c1"](xp, shape, out="both")
+                        om = e["om"](tpl, shape, out="f32")
+                        cols = ops.dcn_sample_planar(t32.view(B, H, W, -1), om, d.stride, d.padding, d.dilation)
+                        mid = e["dcn_conv"](cols, ("img", B, Ho, Wo))
+                    elif B * Ho * Wo >= self.OM_PLANAR_MIN_PIXELS:
                         t32, tpl = e["c1"](xp, shape, out="both")
                         om = e["om"](tpl, shape, out="f32").view(B, Ho, Wo, -1).permute(0, 3, 1, 2).contiguous()
                     else:
                         # alternative for tiny maps: the dense-conv library's small-tile kernel (not taken by default)
                         t32 = e["c1"](xp, shape, out="f32")
                         om = d.conv_offset_mask(t32.view(B, H, W, -1).permute(0, 3, 1, 2)).contiguous()
-                    xin = t32.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
-                    t = ops.deform_conv(xin, None, None, d.weight, d.bias, d.stride, d.padding, d.dilation,
-                                        d.deformable_groups, relu=True, fused_om=om)
-                    mid = _split(_nhwc(t))
+                    if not e["dcn_planar"]:
+                        xin = t32.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+                        t = ops.deform_conv(xin, None, None, d.weight, d.bias, d.stride, d.padding, d.dilation,
+                                            d.deformable_groups, relu=True, fused_om=om)
+                        mid = _split(_nhwc(t))
                 else:
                     mid = e["c2"](e["c1"](xp, shape), shape)
                 res = e["ds"](xp, shape) if "ds" in e else xp

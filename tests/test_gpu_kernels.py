@@ -506,3 +506,20 @@ def test_bad_arguments_raise():
         ops.corr_patch(x, x, 4)                                                         # even patch size
     with pytest.raises(StmError):
         ops.cc_fast_nms(torch.zeros(4, 41, device=DEV), torch.zeros(4, 4, device=DEV), None, 0.5, 4096)
+
+
+@pytest.mark.parametrize("B,C,H,W,stride", [(2, 128, 12, 20, 1), (1, 256, 9, 13, 2), (2, 512, 6, 10, 1), (8, 128, 48, 80, 1)])
+def test_dcn_sample_planar_equals_im2col(B, C, H, W, stride):
+    """The planar deformable sampler (NHWC in, pixel-major offsets, bf16-plane columns with K = tap*C + channel) holds
+    exactly the values of stm_deform_im2col_f32 on the same inputs, and through them the oracle's."""
+    x = rnd(B, C, H, W, seed=C)
+    Ho, Wo = ops.conv_out_hw(H, W, 3, 3, stride, stride, 1, 1, 1, 1)
+    om = rnd(B, 27, Ho, Wo, seed=C + 1, scale=1.5)                   # raw conv_offset_mask output (mask logits last)
+    cols = ops.deform_im2col(x.to(DEV), None, None, 3, stride, 1, 1, 1, fused_om=om.to(DEV))       # [B, C*9, Ho*Wo], row c*9 + k
+    ref = cols.view(B, C, 9, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, 9 * C)           # -> [pixel, k*C + c]
+    pl = ops.dcn_sample_planar(x.permute(0, 2, 3, 1).contiguous().to(DEV), om.permute(0, 2, 3, 1).reshape(-1, 27).to(DEV), stride, 1, 1)
+    assert pl.shape == (3, 9 * C // 32, B * Ho * Wo, 32)
+    assert torch.equal(ops.planes_to_f32(pl), ref)
+    if B * H * W <= 1000:
+        o_cols = oracle.deform_im2col(x, om[:, 0:18].contiguous(), torch.sigmoid(om[:, 18:27]), (3, 3), stride, 1, 1, 1)
+        assert (cols.cpu() - o_cols).abs().max().item() < 2e-5
