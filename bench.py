@@ -193,10 +193,13 @@ def main():
                                      else "fp32",
                        "memory_format": "channels_last" if args.channels_last else "nchw"},
         }
-        im2col_roof = {"bound": "hbm", "kernel": "deform_im2col_lds (7 DCN layers, all launches of the timed region)",
+        planar_dcn = args.fuse and args.planar and args.channels_last
+        im2col_roof = {"bound": "hbm", "kernel": ("dcn_sample_planar_kernel (deformable im2col of the 7 DCN layers, NHWC in, bf16-plane columns out)"
+                                                   if planar_dcn else "deform_im2col_lds (7 DCN layers)") + ", all launches of the timed region",
                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(achieved / HBM_PEAK_GBS, 4),
-                       "traffic": pmc_traffic() if (args.clips == 8 and args.config == "STMask_plus_resnet50_config") else None,
+                       "traffic": pmc_traffic("dcn_sample_planar" if planar_dcn else None)
+                                  if (args.clips == 8 and args.config == "STMask_plus_resnet50_config") else None,
                        "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)",
                        "launches": len(timing), "avg_launch_us": round(ker_ms * 1e3 / n_launch, 2),
                        "algorithmic_bytes_per_launch": int(ker_bytes / n_launch)}

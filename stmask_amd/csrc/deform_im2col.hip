@@ -720,8 +720,8 @@ extern "C" int stm_validate_deform_geom(const stm_deform_geom* g) { return valid
 // offset convolution writes), and the columns out in the planar activation format -- three bf16 planes, channel-slab major,
 // K index = tap * C + channel -- so that the deformable convolution's GEMM is a planar 1x1 convolution over 9C channels on
 // the bf16 matrix cores (csrc/conv_bf16x.hip) instead of the fp32 GEMM, and no layout change is left either side.
-// One wave per output pixel: the 27 offset / mask values are read once and broadcast, every corner read is C contiguous
-// floats (the whole wave reads one 128-B..2-KB line run), coefficients are computed once per (pixel, tap) for all channels.
+// C/8 lanes per output pixel, 8 channels per lane: every corner read is a run of C contiguous floats, every store 16 bytes,
+// the coefficients of a (pixel, tap) are computed by one lane and broadcast inside the pixel's lane group.
 // Values are bit-identical to the NCHW kernels above (same expression order), then split exactly.
 namespace {
 
@@ -750,55 +750,72 @@ __device__ __forceinline__ void split2_planes(float a, float b, unsigned& p0, un
     p2 = __builtin_bit_cast(unsigned, l);
 }
 
-template <int CPL>   // channels per lane: C = 64 * CPL (2, 4 or 8)
+template <int LPP>   // lanes per pixel: C = 8 * LPP (16, 32 or 64 lanes -> 4, 2 or 1 pixels per wave), 8 channels per lane
 __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs a)
 {
-    constexpr int K = 9;
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= a.M) return;
-    const int b = m / (a.Ho * a.Wo);
-    const int rem = m - b * (a.Ho * a.Wo);
+    constexpr int K = 9, PPW = 64 / LPP;
+    const int lane = threadIdx.x & 63, sl = lane % LPP;
+    const int m = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LPP;
+    const bool live = m < a.M;
+    const int mm = live ? m : a.M - 1;                       // dead pixel groups shadow the last pixel, stores masked
+    const int b = mm / (a.Ho * a.Wo);
+    const int rem = mm - b * (a.Ho * a.Wo);
     const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-    const float omv = lane < 3 * K ? a.om[(size_t)m * a.om_ld + lane] : 0.0f;
-    const float* xb = a.x + (size_t)b * a.H * a.W * a.C + lane * CPL;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int i = k / 3, j = k - 3 * i;
-        const float dy = __shfl(omv, 2 * k), dx = __shfl(omv, 2 * k + 1);
-        const float mk = sigmoidf_dev(__shfl(omv, 2 * K + k));
+    const float* xb = a.x + (size_t)b * a.H * a.W * a.C + sl * 8;
+    // sub-lane k (< 9) of each pixel group prepares tap k: corner weights with the mask folded in and clamped corner
+    // offsets; the tap loop broadcasts them inside the group, so the per-tap work is 8 vector loads, 32 FMAs, the split and
+    // three 16-byte stores per lane -- not LPP copies of the coefficient arithmetic
+    float cw1 = 0.f, cw2 = 0.f, cw3 = 0.f, cw4 = 0.f;
+    int ca1 = 0, ca2 = 0, ca3 = 0, ca4 = 0;
+    if (sl < K) {
+        const int i = sl / 3, j = sl - 3 * i;
+        const float* omp = a.om + (size_t)mm * a.om_ld;
+        const float dy = omp[2 * sl], dx = omp[2 * sl + 1];
+        const float mk = sigmoidf_dev(omp[2 * K + sl]);
         const float fy = (float)(ho * a.sh - a.ph + i * a.dh) + dy;
         const float fx = (float)(wo * a.sw - a.pw + j * a.dw) + dx;
-        float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
-        int a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         if (fy > -1.0f && fx > -1.0f && fy < (float)a.H && fx < (float)a.W) {
             const float fl_y = floorf(fy), fl_x = floorf(fx);
             const int h_low = (int)fl_y, w_low = (int)fl_x, h_high = h_low + 1, w_high = w_low + 1;
             const float lh = fy - fl_y, lw = fx - fl_x, hh = 1.0f - lh, hw = 1.0f - lw;
             const bool t = h_low >= 0, l = w_low >= 0, bt = h_high <= a.H - 1, r = w_high <= a.W - 1;
             const int hl = max(h_low, 0), wl = max(w_low, 0), hh_i = min(h_high, a.H - 1), wh_i = min(w_high, a.W - 1);
-            w1 = (t && l) ? hh * hw * mk : 0.f;
-            w2 = (t && r) ? hh * lw * mk : 0.f;
-            w3 = (bt && l) ? lh * hw * mk : 0.f;
-            w4 = (bt && r) ? lh * lw * mk : 0.f;
-            a1 = (hl * a.W + wl) * a.C;
-            a2 = (hl * a.W + wh_i) * a.C;
-            a3 = (hh_i * a.W + wl) * a.C;
-            a4 = (hh_i * a.W + wh_i) * a.C;
+            cw1 = (t && l) ? hh * hw * mk : 0.f;
+            cw2 = (t && r) ? hh * lw * mk : 0.f;
+            cw3 = (bt && l) ? lh * hw * mk : 0.f;
+            cw4 = (bt && r) ? lh * lw * mk : 0.f;
+            ca1 = (hl * a.W + wl) * a.C;
+            ca2 = (hl * a.W + wh_i) * a.C;
+            ca3 = (hh_i * a.W + wl) * a.C;
+            ca4 = (hh_i * a.W + wh_i) * a.C;
         }
-        float v[CPL];
+    }
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int e = 0; e < CPL; ++e) v[e] = bilerp(w1, w2, w3, w4, xb[a1 + e], xb[a2 + e], xb[a3 + e], xb[a4 + e]);
-        unsigned p0[CPL / 2], p1[CPL / 2], p2[CPL / 2];
+    for (int k = 0; k < K; ++k) {
+        const float w1 = __shfl(cw1, k, LPP), w2 = __shfl(cw2, k, LPP), w3 = __shfl(cw3, k, LPP), w4 = __shfl(cw4, k, LPP);
+        const int a1 = __shfl(ca1, k, LPP), a2 = __shfl(ca2, k, LPP), a3 = __shfl(ca3, k, LPP), a4 = __shfl(ca4, k, LPP);
+        float x1[8], x2[8], x3[8], x4[8], v[8];
 #pragma unroll
-        for (int e = 0; e < CPL / 2; ++e) split2_planes(v[2 * e], v[2 * e + 1], p0[e], p1[e], p2[e]);
-        const int kc = k * a.C + lane * CPL;                 // K index of the lane's first channel
-        uint8_t* o = a.out + (((size_t)(kc >> 5) * a.out_np + m) * 32 + (kc & 31)) * 2;
+        for (int h = 0; h < 2; ++h) {
+            const f32x4v q1 = *reinterpret_cast<const f32x4v*>(xb + a1 + 4 * h), q2 = *reinterpret_cast<const f32x4v*>(xb + a2 + 4 * h);
+            const f32x4v q3 = *reinterpret_cast<const f32x4v*>(xb + a3 + 4 * h), q4 = *reinterpret_cast<const f32x4v*>(xb + a4 + 4 * h);
 #pragma unroll
-        for (int e = 0; e < CPL / 2; ++e) {
-            reinterpret_cast<unsigned*>(o)[e] = p0[e];
-            reinterpret_cast<unsigned*>(o + a.out_pstride)[e] = p1[e];
-            reinterpret_cast<unsigned*>(o + 2 * a.out_pstride)[e] = p2[e];
+            for (int e = 0; e < 4; ++e) { x1[4 * h + e] = q1[e]; x2[4 * h + e] = q2[e]; x3[4 * h + e] = q3[e]; x4[4 * h + e] = q4[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bilerp(w1, w2, w3, w4, x1[e], x2[e], x3[e], x4[e]);
+        unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2_planes(v[2 * e], v[2 * e + 1], q0[e], q1[e], q2[e]);
+        const u32x4v p0 = {q0[0], q0[1], q0[2], q0[3]}, p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]};
+        const int kc = k * a.C + sl * 8;                     // K index of the lane's first channel (8 | kc: inside one slab)
+        uint8_t* o = a.out + (((size_t)(kc >> 5) * a.out_np + mm) * 32 + (kc & 31)) * 2;
+        if (live) {
+            *reinterpret_cast<u32x4v*>(o) = p0;
+            *reinterpret_cast<u32x4v*>(o + a.out_pstride) = p1;
+            *reinterpret_cast<u32x4v*>(o + 2 * a.out_pstride) = p2;
         }
     }
 }
@@ -821,10 +838,11 @@ extern "C" int stm_dcn_sample_planar_f32(const float* x, const float* offset_mas
     a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw; a.dh = g->dh; a.dw = g->dw;
     a.om_ld = om_ld; a.M = (int)M; a.out_np = out_np > 0 ? out_np : (int)M;
     a.out_pstride = (out_plane_stride > 0 ? out_plane_stride : (long long)(9 * g->C / 32) * a.out_np * 32) * 2;
-    const dim3 grid(stm_cdiv(M, 4));
-    if (g->C == 128) hipLaunchKernelGGL(dcn_sample_planar_kernel<2>, grid, dim3(256), 0, stm_hs(stream), a);
-    else if (g->C == 256) hipLaunchKernelGGL(dcn_sample_planar_kernel<4>, grid, dim3(256), 0, stm_hs(stream), a);
-    else hipLaunchKernelGGL(dcn_sample_planar_kernel<8>, grid, dim3(256), 0, stm_hs(stream), a);
+    const int ppw = 512 / g->C;                                  // pixels per wave
+    const dim3 grid(stm_cdiv(M, 4 * ppw));
+    if (g->C == 128) hipLaunchKernelGGL(dcn_sample_planar_kernel<16>, grid, dim3(256), 0, stm_hs(stream), a);
+    else if (g->C == 256) hipLaunchKernelGGL(dcn_sample_planar_kernel<32>, grid, dim3(256), 0, stm_hs(stream), a);
+    else hipLaunchKernelGGL(dcn_sample_planar_kernel<64>, grid, dim3(256), 0, stm_hs(stream), a);
     STM_CHECK_LAUNCH("dcn_sample_planar_kernel");
     return STM_OK;
 }
