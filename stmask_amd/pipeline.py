@@ -91,6 +91,8 @@ class BatchedClipPipeline:
         self.has_prev = [False] * n_clips
         self.tracked = [[] for _ in range(n_clips)]  # host-side "frames since last match" counters
         self.timer = _StageTimer()
+        self._pending = None        # (frames, (fpn_outs, pred), event): trunk of the NEXT frame, running on the side stream
+        self._side = None
 
     # -- stage helpers ------------------------------------------------------------------------------------------------
     def _shift_prev(self, P4, T2S, proto, dev):
@@ -135,10 +137,28 @@ class BatchedClipPipeline:
         for b in range(self.B):
             self.tracked[b] = [v + 1 for v in self.tracked[b]]
 
+    def _prefetch_trunk(self, next_frames):
+        """Enqueue the trunk of the next frame on a second stream.  The trunk does not depend on the tracker, and the rest
+        of this step is ~200 tiny launches around two host reads (latency-bound: the GPU idles 10-17 % of the step without
+        this).  Called after the temporal-fusion convolutions of this step are enqueued, so the two big kernel groups do
+        not share the GPU; the side stream waits for everything enqueued on the main stream so far."""
+        if next_frames is None or self.timer.on:
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=next_frames.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            out = self.net.forward_single(next_frames)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pending = (next_frames, out, ev)
+
     @torch.no_grad()
-    def step(self, frames, is_first=None):
+    def step(self, frames, is_first=None, next_frames=None):
         """frames [B,3,H,W] -> packed detections [B, top_k, 40] (stmask_amd.dist layout) without a final sync, plus the
-        per-clip tracked-instance counts (host ints)."""
+        per-clip tracked-instance counts (host ints).  next_frames (optional): the frames the NEXT call will be given;
+        their trunk is started on a second stream while this step's tracker logic runs."""
         net, cfg, B = self.net, self.cfg, self.B
         dev = frames.device
         first = (self.t == 0) if is_first is None else is_first
@@ -149,7 +169,20 @@ class BatchedClipPipeline:
         tmr.tic()
         if getattr(net, "_planar", None) is not None and tmr.on:
             net._planar.timer = tmr      # finer stages inside the trunk
-        fpn_outs, pred = net.forward_single(frames)
+        pend, self._pending = self._pending, None
+        if pend is not None and pend[0] is frames:
+            fpn_outs, pred = pend[1]
+            torch.cuda.current_stream().wait_event(pend[2])
+            for t_ in list(pred.values()) + list(fpn_outs):      # allocated on the side stream, consumed on this one
+                if torch.is_tensor(t_):
+                    t_.record_stream(torch.cuda.current_stream())
+            t2s_ = pred["T2S_feat"][net.correlation_selected_layer]
+            if torch.is_tensor(t2s_):
+                t2s_.record_stream(torch.cuda.current_stream())
+        else:
+            if pend is not None:
+                torch.cuda.current_stream().wait_event(pend[2])   # a trunk nobody asked for: let it finish, drop it
+            fpn_outs, pred = net.forward_single(frames)
         tmr.toc("trunk")
         conf = F.softmax(pred["conf"], -1)
         P4 = fpn_outs[net.correlation_selected_layer]
@@ -185,10 +218,12 @@ class BatchedClipPipeline:
             self.prev = det
             self.prev_n = list(counts)
             self.tracked = [[0] * k for k in counts]
+            self._prefetch_trunk(next_frames)
         else:
             Pn = sum(self.prev_n)
             if Pn:
                 self._shift_prev(P4, T2S, proto, dev)
+            self._prefetch_trunk(next_frames)
             prev = self.prev
             if D and Pn:
                 # matching scores for all clips at once; pairs from different clips can never match

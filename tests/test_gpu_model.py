@@ -217,6 +217,34 @@ def test_video_demo_end_to_end_flow():
     assert n_seg > 0
 
 
+def test_batched_pipeline_trunk_overlap_is_transparent():
+    """step(..., next_frames=) runs the next frame's trunk on a second stream during the tracker stage; the packed
+    detections of every step equal the serial schedule's to the run-to-run noise of the pipeline itself (two serial runs
+    differ by ~2e-6: the dense-conv library's lateral 1x1 convolutions use a split-K kernel with atomic adds)."""
+    from stmask_amd.pipeline import BatchedClipPipeline
+    from stmask_amd.fuse import optimize_for_inference
+    net = build("STMask_plus_resnet50_config")
+    optimize_for_inference(net, planar=True)
+    net = net.to(memory_format=torch.channels_last)
+    net.TemporalNet = net.TemporalNet.to(memory_format=torch.contiguous_format)
+    T = 5
+    clips = torch.stack([synthetic.synthetic_clip(T, 128, 192, seed=s) for s in (0, 5, 9)]).cuda()
+    frames = [clips[:, t].contiguous(memory_format=torch.channels_last) for t in range(T)]
+    a, b = BatchedClipPipeline(net, 3), BatchedClipPipeline(net, 3)
+    for t in range(T):
+        ya = a.step(frames[t], is_first=(t == 0)).clone()
+        yb = b.step(frames[t], is_first=(t == 0), next_frames=frames[t + 1] if t + 1 < T else None).clone()
+        torch.cuda.synchronize()
+        assert ya.shape == yb.shape and (ya - yb).abs().max().item() < 1e-4, t
+    # a caller that changes its mind about the next frame still gets the right answer
+    c = BatchedClipPipeline(net, 3)
+    y0 = c.step(frames[0], is_first=True, next_frames=frames[3])
+    y1 = c.step(frames[1], is_first=False)
+    d = BatchedClipPipeline(net, 3)
+    d.step(frames[0], is_first=True)
+    assert (y1 - d.step(frames[1], is_first=False)).abs().max().item() < 1e-4
+
+
 def test_fp16_backbone_option_config5():
     """BASELINE config 5 flavour: fp16 autocast ResNet trunk (DCN, FPN, heads fp32).  fp16 trunk activations carry ~1e-3
     relative error, so only closeness of the prototypes / box regression to the fp32 run is asserted."""
