@@ -93,6 +93,7 @@ class BatchedClipPipeline:
         self.timer = _StageTimer()
         self._pending = None        # (frames, (fpn_outs, pred), event): trunk of the NEXT frame, running on the side stream
         self._side = None
+        self.prefetch_early = False  # True: start the next trunk at the beginning of step() instead of after the TF convolutions
 
     # -- stage helpers ------------------------------------------------------------------------------------------------
     def _shift_prev(self, P4, T2S, proto, dev):
@@ -184,6 +185,11 @@ class BatchedClipPipeline:
                 torch.cuda.current_stream().wait_event(pend[2])   # a trunk nobody asked for: let it finish, drop it
             fpn_outs, pred = net.forward_single(frames)
         tmr.toc("trunk")
+        if self.prefetch_early:
+            # start the next trunk right away: it then also shares the GPU with this step's temporal-fusion convolutions
+            # (more throughput, but kernels of the two streams stretch each other: per-kernel timings stop being clean)
+            self._prefetch_trunk(next_frames)
+            next_frames = None
         conf = F.softmax(pred["conf"], -1)
         P4 = fpn_outs[net.correlation_selected_layer]
         T2S = pred["T2S_feat"][net.correlation_selected_layer]
