@@ -190,10 +190,18 @@ class BatchedClipPipeline:
             # (more throughput, but kernels of the two streams stretch each other: per-kernel timings stop being clean)
             self._prefetch_trunk(next_frames)
             next_frames = None
-        conf = F.softmax(pred["conf"], -1)
         P4 = fpn_outs[net.correlation_selected_layer]
         T2S = pred["T2S_feat"][net.correlation_selected_layer]
         proto = pred["proto"]
+        # CandidateShift of the tracked set needs this frame's features but not its detections: enqueue it first, then
+        # start the next frame's trunk on the second stream -- everything that follows in this step (detection, two host
+        # reads, matching, tracker update: ~200 tiny launches) then runs beside that trunk, while the two big kernel groups
+        # (temporal-fusion convolutions, trunk) never share the GPU
+        Pn = sum(self.prev_n) if self.prev is not None else 0
+        if Pn:
+            self._shift_prev(P4, T2S, proto, dev)
+        self._prefetch_trunk(next_frames)
+        conf = F.softmax(pred["conf"], -1)
         N = conf.shape[1]
         priors = pred["priors"].squeeze(0)
         idx, cls, score, box, cnt = ops.detect_cc(pred["loc"], priors, conf, pred["centerness"], cfg.eval_conf_thresh,
@@ -224,12 +232,7 @@ class BatchedClipPipeline:
             self.prev = det
             self.prev_n = list(counts)
             self.tracked = [[0] * k for k in counts]
-            self._prefetch_trunk(next_frames)
         else:
-            Pn = sum(self.prev_n)
-            if Pn:
-                self._shift_prev(P4, T2S, proto, dev)
-            self._prefetch_trunk(next_frames)
             prev = self.prev
             if D and Pn:
                 # matching scores for all clips at once; pairs from different clips can never match
