@@ -246,6 +246,11 @@ typedef struct stm_conv_geom {
                              pixels of this launch): lets a layer read from / write into a slice of a larger buffer */
     int group_cout[8];    /* grouped layers whose groups are zero-padded to a common width: real output channels of group i
                              (0 = all Cout/groups); the matrix-core tiles that would only multiply padding are skipped */
+    int fmt;              /* plane format: 0 = three bf16 planes (six MFMA products per fp32 product; any fp32 range),
+                             1 = two fp16 planes (three products: half the matrix work, same fp32-level error, but the
+                             activations must stay below fp16's 65504 -- beyond it results are non-finite, not wrong);
+                             planes must then be 2 and the weights packed with stm_conv_pack_weights_fmt_f32 */
+    float out_scale;      /* fmt 1: 1 / wscale of the packed weights (0 = 1) */
     int tile_n;           /* output-channel tile the weights were packed for: 0 / 128 (stm_conv_pack_weights_f32) or 64
                              (stm_conv_pack_weights_tiled_f32): 128 x 64 tiles, two workgroups per CU -- narrow layers
                              (few output channels) and layers with few pixel tiles */
@@ -260,6 +265,11 @@ int stm_conv_pack_weights_f32(const float* weight, void* packed, int Cout, int C
 size_t stm_conv_packed_weight_bytes_tiled(int Cout, int Cin, int kh, int kw, int planes, int tile_n);
 int stm_conv_pack_weights_tiled_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int planes,
                                     int tile_n, stm_stream_t stream);
+/* plane-format aware forms: fmt 0 = bf16 x 3 (as above), fmt 1 = fp16 x 2 with the weights multiplied by the power of two
+ * `wscale` (bring max |w| to ~2^10; pass 1 / wscale as stm_conv_geom.out_scale) */
+int stm_conv_pack_weights_fmt_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int tile_n, int fmt,
+                                  float wscale, stm_stream_t stream);
+int stm_split_planes_fmt_f32(const float* x, void* planes, int64_t n_pixels, int C, int fmt, stm_stream_t stream);
 /* out = act(conv(x, weight) + bias + residual); bias [Cout] or NULL, residual NHWC or NULL, relu 0/1 */
 int stm_conv2d_nhwc_f32(const float* x, const void* packed_weight, const float* bias, const float* residual, float* out,
                         const stm_conv_geom* g, int relu, stm_stream_t stream);

@@ -60,12 +60,18 @@ for name, H, W, C, O, k, s in SHAPES:
     f_pl = lambda: ops.conv2d_planar(xp, pk, (O, C, k, k), (B, H, W), b, None, stride=s, padding=k // 2, relu=True, planes=planes, out="planes")
     pk64 = ops.conv_pack_weights(w, planes, 64)
     f_p64 = lambda: ops.conv2d_planar(xp, pk64, (O, C, k, k), (B, H, W), b, None, stride=s, padding=k // 2, relu=True, planes=planes, out="planes", tile_n=64)
+    pk16, osc = ops.conv_pack_weights(w, tile_n=128, fmt=1)
+    xp16 = ops.split_planes(x, fmt=1)
+    f_h16 = lambda: ops.conv2d_planar(xp16, pk16, (O, C, k, k), (B, H, W), b, None, stride=s, padding=k // 2, relu=True, out="planes", fmt=1, out_scale=osc)
+    pk16n, _ = ops.conv_pack_weights(w, tile_n=64, fmt=1)
+    f_h16n = lambda: ops.conv2d_planar(xp16, pk16n, (O, C, k, k), (B, H, W), b, None, stride=s, padding=k // 2, relu=True, out="planes", fmt=1, out_scale=osc, tile_n=64)
     f_sp = lambda: ops.split_planes(x)
     to, tt, tn, tp, tsp, tp64 = timeit(f_ours), timeit(f_torch), timeit(f_nchw), timeit(f_pl), timeit(f_sp), timeit(f_p64)
+    th16, th16n = timeit(f_h16), timeit(f_h16n)
     gf = 2.0 * B * out.shape[1] * out.shape[2] * O * C * k * k / 1e9
     err = (f_ours().permute(0, 3, 1, 2) - torch.relu(f_torch())).abs().max().item()
     tot_o += tp
     tot_t += min(tt, tn)
-    print(f"{name:26s} {gf:7.1f} GF | planar {tp:8.1f} us {gf / tp * 1e3:7.1f} TF | n64 {tp64:8.1f} us {gf / tp64 * 1e3:7.1f} TF (split {tsp:6.1f} us) | f32-in {to:8.1f} us {gf / to * 1e3:7.1f} TF | MIOpen NHWC {tt:8.1f} us {gf / tt * 1e3:6.1f} TF | "
+    print(f"{name:26s} {gf:7.1f} GF | fp16x2 {th16:7.1f} us {gf / th16 * 1e3:6.1f} TF n64 {th16n:7.1f} us {gf / th16n * 1e3:6.1f} TF | planar {tp:8.1f} us {gf / tp * 1e3:7.1f} TF | n64 {tp64:8.1f} us {gf / tp64 * 1e3:7.1f} TF (split {tsp:6.1f} us) | f32-in {to:8.1f} us {gf / to * 1e3:7.1f} TF | MIOpen NHWC {tt:8.1f} us {gf / tt * 1e3:6.1f} TF | "
           f"NCHW {tn:8.1f} us {gf / tn * 1e3:6.1f} TF | maxdiff {err:.2e}")
 print(f"TOTAL ours {tot_o:.1f} us  best-MIOpen {tot_t:.1f} us")

@@ -78,6 +78,22 @@ __device__ __forceinline__ void split2(f32x2 v, unsigned& p0, unsigned& p1, unsi
     p2 = __builtin_bit_cast(unsigned, l);
 }
 
+// fp16 form of the split: x = h0 + h1 (11 + 11 significand bits, round to nearest).  With the products h0 g0 + h0 g1 + h1 g0
+// the error is ~2^-21 |x g| -- at the level of fp32's own accumulation error for K in the hundreds -- for HALF the MFMAs of
+// the bf16 three-plane form.  The price is fp16's range: |x| must stay below 65504 (beyond it the high plane becomes inf
+// and the result is non-finite, never silently wrong); weights are brought to ~2^10 by a power-of-two scale per layer that
+// the epilogue takes out again, small activations keep an absolute error of 2^-25.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2_f16(f32x2 v, unsigned& p0, unsigned& p1)
+{
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r1, f16x2);
+    p0 = __builtin_bit_cast(unsigned, h);
+    p1 = __builtin_bit_cast(unsigned, l);
+}
+
 template <int NPL>
 __global__ __launch_bounds__(256, 2) void conv_bf16x_kernel(const ConvArgs a)
 {
@@ -453,6 +469,8 @@ struct PlanarArgs {
     int group_real[8];                               // output channels per group that are not zero padding (MFMA tiles past them are skipped)
     int n_levels;                                    // > 0: pixels are the concatenation of n_levels images sizes
     int lvl_start[9], lvl_h[8], lvl_w[8];
+    int fmt;                  // 0: three bf16 planes (six products), 1: two fp16 planes (three products)
+    float out_scale;          // 1 / (power-of-two weight scale of the packed image)
     int splitk, kslabs, ldp;  // split-K: K-slabs per split, fp32 partial sums [splitk][M][ldp] in `partial`
     float* partial;
     int dbg;                // STM_CONV_DEBUG timing ablations (results wrong): 1 no DMA in the loop, 2 no barrier, 4 no MFMA
@@ -504,7 +522,7 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
     // element index of (pixel m, channel co) in a slab-major planar buffer with np pixels per slab
     auto pidx = [](int m_, int co_, int np) { return ((size_t)(co_ >> 5) * np + m_) * 32 + (co_ & 31); };
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += (a.bias && e < nvalid) ? a.bias[co + e] : 0.0f;
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * a.out_scale + ((a.bias && e < nvalid) ? a.bias[co + e] : 0.0f);
     if (a.vec_epilogue) {                              // implies nvalid == 8
         if (a.res_f32) {
             const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co);
@@ -513,11 +531,18 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         }
         if (a.res_pl) {
             const size_t ri = pidx(m, co, a.res_np) * 2;
-            const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri);
-            const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 2);
-            const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 4);
+            if (a.fmt == 1) {
+                const f16x8 p0 = *reinterpret_cast<const f16x8*>(a.res_pl + ri);
+                const f16x8 p1 = *reinterpret_cast<const f16x8*>(a.res_pl + ri + rpl * 2);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += ((float)p0[e] + (float)p1[e]) + (float)p2[e];
+                for (int e = 0; e < 8; ++e) v[e] += (float)p0[e] + (float)p1[e];
+            } else {
+                const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri);
+                const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 2);
+                const bf16x8 p2 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += ((float)p0[e] + (float)p1[e]) + (float)p2[e];
+            }
         }
         if (a.relu) {
 #pragma unroll
@@ -530,12 +555,19 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         }
         if (a.out_pl) {
             unsigned q0[4], q1[4], q2[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
             uint8_t* o = a.out_pl + pidx(m, co, a.out_np) * 2;
-            *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-            *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-            *reinterpret_cast<u32x4*>(o + opl * 4) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+            if (a.fmt == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
+                *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+                *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
+                *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+                *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+                *reinterpret_cast<u32x4*>(o + opl * 4) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+            }
         }
         return;
     }
@@ -548,18 +580,30 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         if (a.res_f32) x += a.res_f32[(size_t)m * a.res_ld + co + e];
         if (resp) {
             const size_t ri = pidx(m, co + e, a.res_np);
-            x += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
+            if (a.fmt == 1) {
+                const _Float16* rh = reinterpret_cast<const _Float16*>(a.res_pl);
+                x += (float)rh[ri] + (float)rh[ri + rpl];
+            } else {
+                x += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
+            }
         }
         if (a.relu) x = x > 0.0f ? x : 0.0f;
         if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co + e] = x;
         if (outp) {
             const size_t oi = pidx(m, co + e, a.out_np);
-            const __bf16 h = (__bf16)x;
-            const float r1 = x - (float)h;
-            const __bf16 mid = (__bf16)r1;
-            outp[oi] = h;
-            outp[oi + opl] = mid;
-            outp[oi + 2 * opl] = (__bf16)(r1 - (float)mid);
+            if (a.fmt == 1) {
+                _Float16* oh = reinterpret_cast<_Float16*>(a.out_pl);
+                const _Float16 h = (_Float16)x;
+                oh[oi] = h;
+                oh[oi + opl] = (_Float16)(x - (float)h);
+            } else {
+                const __bf16 h = (__bf16)x;
+                const float r1 = x - (float)h;
+                const __bf16 mid = (__bf16)r1;
+                outp[oi] = h;
+                outp[oi + opl] = mid;
+                outp[oi + 2 * opl] = (__bf16)(r1 - (float)mid);
+            }
         }
     }
 }
@@ -619,7 +663,7 @@ __device__ __forceinline__ void planar_epilogue(const PlanarArgs& a, f32x16 (&ac
     planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
 }
 
-template <int NPL, int MG, int NJ, int MF>   // MF = 1: v_mfma_f32_16x16x32_bf16 (less energy per flop; the chip is power-limited here), 0: 32x32x16
+template <int NPL, int MG, int NJ, int MF, int DT = 0>   // DT = 1: fp16 planes / v_mfma_f32_16x16x32_f16 (NPL 2, MF 1 only); MF = 1: v_mfma_f32_16x16x32_bf16 (less energy per flop; the chip is power-limited here), 0: 32x32x16
 __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
@@ -796,6 +840,9 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         }
         } else {
             // 16x16x32: one instruction covers the slab's 32 channels; lane (l & 15, l >> 4) holds row l & 15, chunk l >> 4
+#define MFMA16(x_, y_, c_, i0_, i1_, i2_) \
+    (DT == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x_), __builtin_bit_cast(f16x8, y_), c_, 0, 0, 0) \
+             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_, y_, c_, 0, 0, 0))
             const int r16 = lane & 15, kc = lane >> 4;
             // 16-column tiles of this wave that hold real output channels (wave-uniform): narrow layers and zero-padded
             // groups skip the MFMAs of the others
@@ -827,13 +874,13 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                         for (int j = 0; j < 2 * NJ; ++j) {
                             f32x4 c = accl16[2 * hf + i][j];
                             if constexpr (NPL == 3) {
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                                c = MFMA16(af[i][2], bf[j][0], c, 0, 0, 0);
+                                c = MFMA16(af[i][0], bf[j][2], c, 0, 0, 0);
+                                c = MFMA16(af[i][1], bf[j][1], c, 0, 0, 0);
                             }
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-                            accl16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-                            acc16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc16[2 * hf + i][j], 0, 0, 0);
+                            c = MFMA16(af[i][1], bf[j][0], c, 0, 0, 0);
+                            accl16[2 * hf + i][j] = MFMA16(af[i][0], bf[j][1], c, 0, 0, 0);
+                            acc16[2 * hf + i][j] = MFMA16(af[i][0], bf[j][0], acc16[2 * hf + i][j], 0, 0, 0);
                         }
     #pragma unroll
                     for (int k = 0; k < 8 * NJ * NPL; ++k) {
@@ -864,13 +911,13 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                             if (j >= jn) continue;
                             f32x4 c = accl16[2 * hf + i][j];
                             if constexpr (NPL == 3) {
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                                c = MFMA16(af[i][2], bf[j][0], c, 0, 0, 0);
+                                c = MFMA16(af[i][0], bf[j][2], c, 0, 0, 0);
+                                c = MFMA16(af[i][1], bf[j][1], c, 0, 0, 0);
                             }
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-                            accl16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-                            acc16[2 * hf + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], acc16[2 * hf + i][j], 0, 0, 0);
+                            c = MFMA16(af[i][1], bf[j][0], c, 0, 0, 0);
+                            accl16[2 * hf + i][j] = MFMA16(af[i][0], bf[j][1], c, 0, 0, 0);
+                            acc16[2 * hf + i][j] = MFMA16(af[i][0], bf[j][0], acc16[2 * hf + i][j], 0, 0, 0);
                         }
     #pragma unroll
                     for (int k = 0; k < 8 * NJ * NPL; ++k) {
@@ -885,6 +932,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 }
         PL_STAMP(4);
     }
+#undef MFMA16
 #undef PL_STAMP
     if (tr) a.trace[(wave != 0) * 512 + 7] = clock64();
 
@@ -1105,7 +1153,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx_kernel(const PlanarArgs
 
 // fp32 [n pixels][C] (NHWC) -> three bf16 planes [3][C/32][n][32] (entry into the planar format from a foreign producer);
 // thread = 8 channels of one pixel
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint8_t* __restrict__ planes, int64_t n, int C)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint8_t* __restrict__ planes, int64_t n, int C,
+                                                           int fmt)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int c8n = C >> 3;
@@ -1115,12 +1164,21 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     const float* src = x + pix * C + c8 * 8;
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
     unsigned q0[4], q1[4], q2[4];
+    const size_t plane_b = (size_t)n * C * 2;
+    uint8_t* dst = planes + (((size_t)(c8 >> 2) * n + pix) * 32 + (c8 & 3) * 8) * 2;
+    if (fmt == 1) {
+        split2_f16(f32x2{a0.x, a0.y}, q0[0], q1[0]);
+        split2_f16(f32x2{a0.z, a0.w}, q0[1], q1[1]);
+        split2_f16(f32x2{a1.x, a1.y}, q0[2], q1[2]);
+        split2_f16(f32x2{a1.z, a1.w}, q0[3], q1[3]);
+        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        return;
+    }
     split2(f32x2{a0.x, a0.y}, q0[0], q1[0], q2[0]);
     split2(f32x2{a0.z, a0.w}, q0[1], q1[1], q2[1]);
     split2(f32x2{a1.x, a1.y}, q0[2], q1[2], q2[2]);
     split2(f32x2{a1.z, a1.w}, q0[3], q1[3], q2[3]);
-    const size_t plane_b = (size_t)n * C * 2;
-    uint8_t* dst = planes + (((size_t)(c8 >> 2) * n + pix) * 32 + (c8 & 3) * 8) * 2;
     *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
     *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
     *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
@@ -1129,7 +1187,8 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 // Weights [Cout][Cin][kh][kw] fp32 -> packed [n_tile][slab][plane][row 0..127][swizzled 16-B chunk][8 bf16]; rows past
 // Cout are zero.  One thread per (n_tile, slab, row, chunk).
 __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp, int Cout,
-                                                                int C, int kh, int kw, int slabs, int n_tiles, int npl, int bn)
+                                                                int C, int kh, int kw, int slabs, int n_tiles, int npl, int bn, int fmt,
+                                                                float wscale)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int per_tile = bn * 4;                       // (row, chunk) pairs of one slab tile
@@ -1148,7 +1207,8 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
             v.x = w[((size_t)co * C + c0 + 2 * e) * (kh * kw) + tap];
             v.y = w[((size_t)co * C + c0 + 2 * e + 1) * (kh * kw) + tap];
         }
-        split2(v, pl[0][e], pl[1][e], pl[2][e]);
+        if (fmt == 1) { pl[2][e] = 0; split2_f16(v * wscale, pl[0][e], pl[1][e]); }
+        else split2(v, pl[0][e], pl[1][e], pl[2][e]);
     }
     const int wpl = bn * 64;
     uint8_t* dst = wp + ((size_t)nt * slabs + slab) * (npl * wpl) + lds_off(row, chunk);
@@ -1158,7 +1218,7 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
     }
 }
 
-template <int NPL, int MG, int NJ, int MF>
+template <int NPL, int MG, int NJ, int MF, int DT = 0>
 int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
 {
     size_t lds = (size_t)2 * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
@@ -1166,11 +1226,11 @@ int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
     if (lds < park) lds = park;
     static bool lds_reserved = false;   // per instantiation; the attribute is sticky, setting it again each launch only costs host time
     if (!lds_reserved) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, MF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, MF, DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
         lds_reserved = true;
     }
-    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, MF>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
+    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, MF, DT>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kernel");
     return STM_OK;
 }
@@ -1226,9 +1286,13 @@ extern "C" size_t stm_conv_packed_weight_bytes(int Cout, int Cin, int kh, int kw
     return stm_conv_packed_weight_bytes_tiled(Cout, Cin, kh, kw, planes, CV_BN);
 }
 
+extern "C" int stm_conv_pack_weights_fmt_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int tile_n, int fmt,
+                                             float wscale, stm_stream_t stream);
+
 extern "C" int stm_conv_pack_weights_tiled_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int planes,
                                                int tile_n, stm_stream_t stream)
 {
+    if (planes == 3) return stm_conv_pack_weights_fmt_f32(weight, packed, Cout, Cin, kh, kw, tile_n, 0, 1.0f, stream);
     STM_REQUIRE(weight && packed, STM_ENULL, "stm_conv_pack_weights_f32: weight/packed must be non-NULL");
     STM_REQUIRE(stm_conv_packed_weight_bytes_tiled(Cout, Cin, kh, kw, planes, tile_n) > 0, STM_EINVAL,
                 "stm_conv_pack_weights_f32: bad sizes Cout=%d Cin=%d (multiple of 32) k=%dx%d planes=%d tile_n=%d (64 or 128)", Cout,
@@ -1237,7 +1301,26 @@ extern "C" int stm_conv_pack_weights_tiled_f32(const float* weight, void* packed
     const int slabs = kh * kw * (Cin / CV_BK), n_tiles = stm_cdiv(Cout, tile_n);
     const int64_t total = (int64_t)n_tiles * slabs * tile_n * 4;
     hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), weight,
-                       static_cast<uint8_t*>(packed), Cout, Cin, kh, kw, slabs, n_tiles, planes, tile_n);
+                       static_cast<uint8_t*>(packed), Cout, Cin, kh, kw, slabs, n_tiles, planes, tile_n, 0, 1.0f);
+    STM_CHECK_LAUNCH("conv_pack_weights_kernel");
+    return STM_OK;
+}
+
+extern "C" int stm_conv_pack_weights_fmt_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int tile_n, int fmt,
+                                             float wscale, stm_stream_t stream)
+{
+    STM_REQUIRE(weight && packed, STM_ENULL, "stm_conv_pack_weights_fmt_f32: weight/packed must be non-NULL");
+    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_conv_pack_weights_fmt_f32: fmt must be 0 (bf16 x 3) or 1 (fp16 x 2)");
+    const int planes = fmt == 1 ? 2 : 3;
+    STM_REQUIRE(stm_conv_packed_weight_bytes_tiled(Cout, Cin, kh, kw, planes, tile_n) > 0, STM_EINVAL,
+                "stm_conv_pack_weights_fmt_f32: bad sizes Cout=%d Cin=%d (multiple of 32) k=%dx%d tile_n=%d (64 or 128)", Cout, Cin, kh, kw,
+                tile_n);
+    STM_REQUIRE((uintptr_t)packed % 16 == 0, STM_EINVAL, "stm_conv_pack_weights_fmt_f32: packed buffer must be 16-byte aligned");
+    STM_REQUIRE(fmt == 0 || (wscale > 0.0f && wscale < 3.0e38f), STM_EINVAL, "stm_conv_pack_weights_fmt_f32: bad weight scale");
+    const int slabs = kh * kw * (Cin / CV_BK), n_tiles = stm_cdiv(Cout, tile_n);
+    const int64_t total = (int64_t)n_tiles * slabs * tile_n * 4;
+    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), weight,
+                       static_cast<uint8_t*>(packed), Cout, Cin, kh, kw, slabs, n_tiles, planes, tile_n, fmt, fmt == 1 ? wscale : 1.0f);
     STM_CHECK_LAUNCH("conv_pack_weights_kernel");
     return STM_OK;
 }
@@ -1310,14 +1393,21 @@ extern "C" int stm_conv2d_nhwc_f32(const float* x, const void* packed_weight, co
     return STM_OK;
 }
 
+extern "C" int stm_split_planes_fmt_f32(const float* x, void* planes, int64_t n_pixels, int C, int fmt, stm_stream_t stream);
 extern "C" int stm_split_bf16_planes_f32(const float* x, void* planes, int64_t n_pixels, int C, stm_stream_t stream)
 {
+    return stm_split_planes_fmt_f32(x, planes, n_pixels, C, 0, stream);
+}
+
+extern "C" int stm_split_planes_fmt_f32(const float* x, void* planes, int64_t n_pixels, int C, int fmt, stm_stream_t stream)
+{
+    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_split_planes_fmt_f32: fmt must be 0 or 1");
     STM_REQUIRE(x && planes, STM_ENULL, "stm_split_bf16_planes_f32: x/planes must be non-NULL");
     STM_REQUIRE(n_pixels > 0 && C > 0 && C % 32 == 0, STM_EINVAL, "stm_split_bf16_planes_f32: n_pixels (%lld) > 0 and C (%d) a multiple of 32",
                 (long long)n_pixels, C);
     STM_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)planes % 16 == 0, STM_EINVAL, "stm_split_bf16_planes_f32: 16-byte alignment required");
     hipLaunchKernelGGL(split_planes_kernel, dim3(stm_cdiv(n_pixels * (C / 8), 256)), dim3(256), 0, stm_hs(stream), x,
-                       static_cast<uint8_t*>(planes), n_pixels, C);
+                       static_cast<uint8_t*>(planes), n_pixels, C, fmt);
     STM_CHECK_LAUNCH("split_planes_kernel");
     return STM_OK;
 }
@@ -1396,6 +1486,9 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     // form spends less energy per flop: 593 vs 656 us on the 145-GF proto layer.  STM_CONV_MFMA=32 selects the other form.
     const char* fm = getenv("STM_CONV_MFMA");
     const bool mf16 = fm ? atoi(fm) != 32 : true;
+    a.fmt = g->fmt == 1 ? 1 : 0;
+    a.out_scale = (g->fmt == 1 && g->out_scale > 0.0f) ? g->out_scale : 1.0f;
+    STM_REQUIRE(a.fmt == 0 || g->planes == 2, STM_EINVAL, "%s: the fp16 format has two planes", who);
     a.splitk = 1; a.kslabs = a.slabs; a.partial = nullptr; a.ldp = a.n_tiles * bn;
     // split-K for grids that would leave most CUs idle over a long K (small feature maps: ResNet stages 3/4, P5-P7):
     // parts write fp32 partial sums into the caller's workspace, planar_splitk_finish_kernel adds them and runs the epilogue
@@ -1426,7 +1519,8 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         plan_splitk(a.m_tiles * a.n_tiles);
         const int tiles = a.m_tiles * a.n_tiles * a.splitk;
         int rc64;
-        if (mf16) rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
+        if (a.fmt == 1) rc64 = launch_planar<2, 1, 1, 1, 1>(a, tiles, stream);
+        else if (mf16) rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
         else rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 0>(a, tiles, stream) : launch_planar<2, 1, 1, 0>(a, tiles, stream);
         return rc64 != STM_OK ? rc64 : finish_splitk();
     }
@@ -1442,13 +1536,14 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     const char* fkx = getenv("STM_CONV_KX");
     // (measured: no gain over the per-tap kernel -- 654 vs 670 us on the 145-GF proto layer although it moves 1.8x fewer
     // bytes; the ablations in DESIGN.md section 6 show why -- so it is opt-in: STM_CONV_KX=1)
-    const bool kx_ok = mg == 2 && g->kw >= 3 && g->kw <= 5 && g->sh == 1 && g->sw == 1 && 2 * g->pw == g->kw - 1 &&
+    const bool kx_ok = a.fmt == 0 && mg == 2 && g->kw >= 3 && g->kw <= 5 && g->sh == 1 && g->sw == 1 && 2 * g->pw == g->kw - 1 &&
                        2 * g->ph == g->kh - 1 && fkx && atoi(fkx) == 1;
     if (kx_ok) return g->planes == 3 ? launch_planar_kx<3>(a, a.m_tiles * a.n_tiles, stream) : launch_planar_kx<2>(a, a.m_tiles * a.n_tiles, stream);
     plan_splitk(a.m_tiles * a.n_tiles);
     const int tiles = a.m_tiles * a.n_tiles * a.splitk;
     int rc;
-    if (mf16) {
+    if (a.fmt == 1) rc = mg == 2 ? launch_planar<2, 2, 2, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 1>(a, tiles, stream);
+    else if (mf16) {
         if (g->planes == 3) rc = mg == 2 ? launch_planar<3, 2, 2, 1>(a, tiles, stream) : launch_planar<3, 1, 2, 1>(a, tiles, stream);
         else rc = mg == 2 ? launch_planar<2, 2, 2, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1>(a, tiles, stream);
     } else if (g->planes == 3) rc = mg == 2 ? launch_planar<3, 2, 2, 0>(a, tiles, stream) : launch_planar<3, 1, 2, 0>(a, tiles, stream);

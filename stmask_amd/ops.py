@@ -396,16 +396,26 @@ def mask_resize_rle(masks, crop_h, crop_w, out_h, out_w, thr=0.5, max_runs=4096)
     return counts, n_runs
 
 
-def conv_pack_weights(weight, planes=3, tile_n=128):
-    """OIHW fp32 weights -> the pre-split, pre-tiled bf16 image the convolution kernels stream (done once per layer).
-    tile_n = 64 packs for the 128 x 64-tile planar kernel (stm_conv_geom.tile_n must say so too)."""
+def conv_pack_weights(weight, planes=3, tile_n=128, fmt=0):
+    """OIHW fp32 weights -> the pre-split, pre-tiled image the convolution kernels stream (done once per layer).
+    tile_n = 64 packs for the 128 x 64-tile planar kernel (stm_conv_geom.tile_n must say so too).
+    fmt = 1: two fp16 planes of weight * wscale (power of two bringing max |w| to ~2^10) -> returns (packed, 1 / wscale)."""
     _dev(weight)
     weight = _f32c(weight)
     O, C, kh, kw = weight.shape
+    if fmt == 1:
+        planes = 2
     nbytes = _lib.lib().stm_conv_packed_weight_bytes_tiled(c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes), c_i(tile_n))
     if nbytes == 0:
         raise StmError(f"conv_pack_weights: unsupported weight shape {tuple(weight.shape)} (Cin must be a multiple of 32)")
     packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
+    if fmt == 1:
+        import math
+        wmax = float(weight.abs().max())
+        wscale = 2.0 ** (10 - math.floor(math.log2(wmax))) if wmax > 0 else 1.0
+        check(_lib.lib().stm_conv_pack_weights_fmt_f32(_p(weight), _p(packed), c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(tile_n), c_i(1),
+                                                       c_f(wscale), _stream()), "stm_conv_pack_weights_fmt_f32")
+        return packed, 1.0 / wscale
     check(_lib.lib().stm_conv_pack_weights_tiled_f32(_p(weight), _p(packed), c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes),
                                                      c_i(tile_n), _stream()), "stm_conv_pack_weights_tiled_f32")
     return packed
@@ -434,34 +444,41 @@ def conv2d_nhwc(x, packed, weight_shape, bias=None, residual=None, stride=1, pad
     return out
 
 
-def split_planes(x):
-    """fp32 NHWC tensor [..., C] (C % 32 == 0) -> bf16 planes [3, C/32, N, 32] (N = product of the leading dims) whose fp32
-    sum is x exactly; channel-slab-major: see include/stmask_hip.h."""
+def split_planes(x, fmt=0):
+    """fp32 NHWC tensor [..., C] (C % 32 == 0) -> planes [P, C/32, N, 32] (N = product of the leading dims) whose fp32 sum is
+    x: fmt 0 = three bf16 planes (exact), fmt 1 = two fp16 planes (22 bits; |x| < 65504).  Channel-slab-major: see
+    include/stmask_hip.h."""
     _dev(x)
     x = _f32c(x)
     C = x.shape[-1]
     N = x.numel() // C
     if C % 32:
         raise StmError(f"split_planes: channel count {C} is not a multiple of 32")
-    planes = torch.empty(3, C // 32, N, 32, device=x.device, dtype=torch.bfloat16)
-    check(_lib.lib().stm_split_bf16_planes_f32(_p(x), _p(planes), c_l(N), c_i(C), _stream()), "stm_split_bf16_planes_f32")
+    planes = torch.empty(2 if fmt == 1 else 3, C // 32, N, 32, device=x.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    check(_lib.lib().stm_split_planes_fmt_f32(_p(x), _p(planes), c_l(N), c_i(C), c_i(fmt), _stream()), "stm_split_planes_fmt_f32")
     return planes
 
 
 def planes_to_f32(planes):
-    """[3, S, N, 32] bf16 planes -> fp32 [N, 32*S] (exact)."""
-    v = (planes[0].float() + planes[1].float()) + planes[2].float()
+    """[P, S, N, 32] planes -> fp32 [N, 32*S]."""
+    v = planes[0].float()
+    for p in range(1, planes.shape[0]):
+        v = v + planes[p].float()
     return v.permute(1, 0, 2).reshape(v.shape[1], -1)
 
 
 def conv2d_planar(xp, packed, weight_shape, hw, bias=None, residual=None, stride=1, padding=0, relu=False, planes=3,
-                  out="planes", tile_n=128):
-    """The same convolution on the planar activation format: xp [3, C/32, B*H*W, 32] bf16 (split_planes / a previous
-    layer's output), hw = (B, H, W).  `residual` may be fp32 [B*Ho*Wo, O] or planes [3, O/32, B*Ho*Wo, 32].
-    out: "planes" | "f32" | "both"; fp32 result [B*Ho*Wo, O]."""
+                  out="planes", tile_n=128, fmt=0, out_scale=1.0):
+    """The same convolution on the planar activation format: xp [P, C/32, B*H*W, 32] (split_planes / a previous layer's
+    output), hw = (B, H, W).  `residual` may be fp32 [B*Ho*Wo, O] or planes [P, O/32, B*Ho*Wo, 32].
+    out: "planes" | "f32" | "both"; fp32 result [B*Ho*Wo, O].  fmt 1: fp16 planes, `packed` / `out_scale` from
+    conv_pack_weights(..., fmt=1)."""
     _dev(xp, packed, bias, residual)
-    if xp.dtype != torch.bfloat16 or xp.dim() != 4 or xp.shape[0] != 3 or xp.shape[3] != 32 or not xp.is_contiguous():
-        raise StmError(f"conv2d_planar: expected contiguous bf16 planes [3,C/32,N,32], got {xp.dtype} {tuple(xp.shape)}")
+    P, dt = (2, torch.float16) if fmt == 1 else (3, torch.bfloat16)
+    if fmt == 1:
+        planes = 2
+    if xp.dtype != dt or xp.dim() != 4 or xp.shape[0] != P or xp.shape[3] != 32 or not xp.is_contiguous():
+        raise StmError(f"conv2d_planar: expected contiguous {dt} planes [{P},C/32,N,32], got {xp.dtype} {tuple(xp.shape)}")
     O, C, kh, kw = weight_shape
     B, H, W = hw
     if xp.shape[1] * 32 != C or xp.shape[2] != B * H * W:
@@ -470,19 +487,19 @@ def conv2d_planar(xp, packed, weight_shape, hw, bias=None, residual=None, stride
     Ho, Wo = conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, 1, 1)
     M = B * Ho * Wo
     y32 = torch.empty(M, O, device=xp.device, dtype=torch.float32) if out in ("f32", "both") else None
-    ypl = torch.empty(3, -(-O // 32), M, 32, device=xp.device, dtype=torch.bfloat16) if out in ("planes", "both") else None
+    ypl = torch.empty(P, -(-O // 32), M, 32, device=xp.device, dtype=dt) if out in ("planes", "both") else None
     r32 = rpl = None
     if residual is not None:
-        if residual.dtype == torch.bfloat16:
-            if tuple(residual.shape) != (3, -(-O // 32), M, 32) or not residual.is_contiguous():
-                raise StmError(f"conv2d_planar: residual planes {tuple(residual.shape)} != {(3, -(-O // 32), M, 32)}")
+        if residual.dtype == dt:
+            if tuple(residual.shape) != (P, -(-O // 32), M, 32) or not residual.is_contiguous():
+                raise StmError(f"conv2d_planar: residual planes {tuple(residual.shape)} != {(P, -(-O // 32), M, 32)}")
             rpl = residual
         else:
             r32 = _f32c(residual)
             if r32.numel() != M * O:
                 raise StmError(f"conv2d_planar: residual has {r32.numel()} elements, output {M * O}")
     g = _lib.ConvGeom(B, H, W, C, Ho, Wo, O, kh, kw, sh, sw, ph, pw, 0, 0, 0, planes)
-    g.tile_n = tile_n
+    g.tile_n, g.fmt, g.out_scale = tile_n, fmt, out_scale
     check(_lib.lib().stm_conv2d_planar_f32(_p(xp), _p(packed), _p(_f32c(bias) if bias is not None else None), _p(r32), _p(rpl),
                                            _p(y32), _p(ypl), ctypes.byref(g), c_i(1 if relu else 0), _stream()),
           "stm_conv2d_planar_f32")

@@ -256,3 +256,32 @@ def test_conv_planar_splitk(splitk, tile_n, monkeypatch):
         assert ((y32.view(ref.shape) - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
         assert ((y32 - y1).abs() / mag.view(-1, O).clamp_min(1e-6)).max().item() < 1e-6      # only the summation order differs
         assert torch.equal(planes_to_f32(ypl)[:, :O], y32)
+
+
+@pytest.mark.parametrize("tile_n", [64, 128])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_planar_fp16_two_plane_format(case, tile_n):
+    """fmt 1: two fp16 planes, three MFMA products (h0 g0 + h0 g1 + h1 g0), weights scaled by a power of two.  Same stated
+    tolerance as the bf16 three-plane form: |y - y_fp64| <= 2e-6 * sum|x w| (observed ~4e-7); planar output = fp32 output
+    to 2^-21 relative (22 significand bits)."""
+    B, H, W, C, O, kh, kw, s, pad, has_bias, has_res, relu = case
+    x = rnd(B, H, W, C, seed=0)
+    w = rnd(O, C, kh, kw, seed=1, scale=(C * kh * kw) ** -0.5)
+    b = rnd(O, seed=2) if has_bias else None
+    Ho, Wo = ops.conv_out_hw(H, W, kh, kw, s, s, pad[0], pad[1], 1, 1)
+    r = rnd(B, Ho, Wo, O, seed=3) if has_res else None
+    ref = oracle.conv2d_nhwc(x, w, b, r, stride=s, padding=pad, relu=relu)
+    mag = oracle.conv2d_nhwc(x.abs(), w.abs(), b.abs() if has_bias else None, r.abs() if has_res else None, stride=s, padding=pad)
+    pk, osc = ops.conv_pack_weights(w.to(DEV), tile_n=tile_n, fmt=1)
+    xp = ops.split_planes(x.to(DEV), fmt=1)
+    assert xp.dtype == torch.float16 and xp.shape[0] == 2
+    assert (planes_to_f32(xp.cpu()) - x.view(-1, C)).abs().max().item() <= 2.0 ** -21 * x.abs().max().item()
+    y32, ypl = ops.conv2d_planar(xp, pk, tuple(w.shape), (B, H, W), b.to(DEV) if has_bias else None, r.to(DEV) if has_res else None,
+                                 stride=s, padding=pad, relu=relu, out="both", tile_n=tile_n, fmt=1, out_scale=osc)
+    y32, ypl = y32.cpu().view(ref.shape), ypl.cpu()
+    assert ((y32 - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
+    assert (planes_to_f32(ypl)[:, :O] - y32.view(-1, O)).abs().max().item() <= 2.0 ** -21 * max(1.0, y32.abs().max().item())
+    if has_res:
+        y2 = ops.conv2d_planar(xp, pk, tuple(w.shape), (B, H, W), b.to(DEV) if has_bias else None, ops.split_planes(r.to(DEV), fmt=1),
+                               stride=s, padding=pad, relu=relu, out="f32", tile_n=tile_n, fmt=1, out_scale=osc).cpu()
+        assert (y2.view(ref.shape) - y32).abs().max().item() < 2e-6 * max(1.0, y32.abs().max().item())
