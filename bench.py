@@ -95,6 +95,9 @@ def main():
                          "enqueued (default: big kernels never share the GPU, per-kernel timings stay clean), 'early' = at the "
                          "start of the step (about +10 %% frames/s, but kernels of the two streams stretch each other), 'off'")
     ap.add_argument("--no-overlap", dest="overlap", action="store_const", const="off", help="same as --overlap off")
+    ap.add_argument("--planes", choices=["fp16x2", "bf16x3"], default="fp16x2",
+                    help="operand split of the planar MFMA convolutions: two fp16 planes / 3 products (default) or three bf16 "
+                         "planes / 6 products (no fp16 range limit); both are fp32-equivalent to 2e-6 of sum|x w|")
     ap.add_argument("--no-planar", dest="planar", action="store_false",
                     help="FPN / proto-net / head convolutions through MIOpen instead of the bf16-split matrix-core kernel")
     ap.add_argument("--fp16-backbone", action="store_true",
@@ -127,7 +130,7 @@ def main():
         from stmask_amd.fuse import optimize_for_inference
         # BN folded into conv / DCN weights, bias (+residual) + ReLU as one epilogue pass; FPN / proto-net / shared head
         # on stm_conv2d_planar_f32 (fp32-equivalent bf16-split MFMA convolution, all FPN levels per launch)
-        optimize_for_inference(net, planar=args.planar and args.channels_last)
+        optimize_for_inference(net, planar=args.planar and args.channels_last, planes=args.planes)
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)  # dense convs NHWC (17.0 vs 20.6 ms trunk at batch 8)
         # ... except TemporalNet: on 7x7 RoI tiles MIOpen is 1.5x faster in NCHW (scripts/bench_temporalnet.py)
@@ -198,15 +201,16 @@ def main():
                        "clips_per_gpu": args.clips, "frames_per_step": world * args.clips,
                        "detections_last_step": n_det, "parallelism": f"clip-dp{world}",
                        "pipeline": args.pipeline + (f"+next-trunk-overlap-{args.overlap}" if (args.pipeline == "batched" and args.overlap != "off") else ""),
-                       "inference_graph": ("bn-folded+fused-epilogues" + ("+planar-bf16x6-convs" if (args.planar and args.channels_last) else ""))
+                       "inference_graph": ("bn-folded+fused-epilogues" + ("+planar-%s-convs" % args.planes if (args.planar and args.channels_last) else ""))
                                           if args.fuse else "reference-ops",
-                       "arithmetic": "fp32 in / fp32 out / fp32 accumulate; dense convs as 3 bf16 planes x 6 MFMA products "
-                                     "(max error 2e-6 of sum|x w| vs fp64, tests/test_gpu_conv.py)" if (args.fuse and args.planar and args.channels_last)
+                       "arithmetic": ("fp32 in / fp32 out / fp32 accumulate; dense convs as "
+                                      + ("2 fp16 planes x 3 MFMA products" if args.planes == "fp16x2" else "3 bf16 planes x 6 MFMA products")
+                                      + " (max error 2e-6 of sum|x w| vs fp64, tests/test_gpu_conv.py)") if (args.fuse and args.planar and args.channels_last)
                                      else "fp32",
                        "memory_format": "channels_last" if args.channels_last else "nchw"},
         }
         planar_dcn = args.fuse and args.planar and args.channels_last
-        im2col_roof = {"bound": "hbm", "kernel": ("dcn_sample_planar_kernel (deformable im2col of the 7 DCN layers, NHWC in, bf16-plane columns out)"
+        im2col_roof = {"bound": "hbm", "kernel": ("dcn_sample_planar_kernel (deformable im2col of the 7 DCN layers, NHWC in, plane columns out)"
                                                    if planar_dcn else "deform_im2col_lds (7 DCN layers)") + ", all launches of the timed region",
                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -217,17 +221,19 @@ def main():
                        "algorithmic_bytes_per_launch": int(ker_bytes / n_launch)}
         if conv_t:
             # dominant kernel of the step: the bf16-split convolution.  achieved = fp32-equivalent algorithmic flops
-            # (2*M*Cout*Cin*kh*kw of the reference layers, zero-padded channels excluded) / launch time; peak = dense bf16
-            # MFMA peak / 6, because each fp32 product is carried by six bf16 MFMA products.
+            # (2*M*Cout*Cin*kh*kw of the reference layers, zero-padded channels excluded) / launch time; peak = dense 16-bit
+            # MFMA peak / n_prod, because each fp32 product is carried by n_prod MFMA products (3 fp16 or 6 bf16).
+            n_prod = 3 if args.planes == "fp16x2" else 6
+            split = "fp16x2-plane" if args.planes == "fp16x2" else "bf16x3-plane"
             c_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in conv_t)
             c_fl = sum(f for _, _, f in conv_t)
             tf = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
-            res["roofline"] = {"bound": "mfma", "kernel": "conv_planar_kernel (bf16x3-plane split conv: backbone 1x1/3x3, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
-                               "achieved": round(tf, 1), "peak": round(BF16_MFMA_PEAK_TF / 6.0, 1), "unit": "TFLOP/s",
-                               "frac": round(tf / (BF16_MFMA_PEAK_TF / 6.0), 4),
+            res["roofline"] = {"bound": "mfma", "kernel": f"conv_planar_kernel ({split} split conv: backbone 1x1/3x3, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
+                               "achieved": round(tf, 1), "peak": round(BF16_MFMA_PEAK_TF / n_prod, 1), "unit": "TFLOP/s",
+                               "frac": round(tf / (BF16_MFMA_PEAK_TF / n_prod), 4),
                                "traffic": pmc_traffic("conv_planar") if (args.clips == 8 and args.config == "STMask_plus_resnet50_config") else None,
                                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction); average over all launches",
-                               "peak_note": "fp32-equivalent: 2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 product (fp32 MFMA peak is 157)",
+                               "peak_note": f"fp32-equivalent: 2500 TFLOP/s dense 16-bit MFMA / {n_prod} products per fp32 product (fp32 MFMA peak is 157)",
                                "launches": len(conv_t), "avg_launch_us": round(c_ms * 1e3 / len(conv_t), 2),
                                "ms_per_step": round(c_ms / args.steps, 3),
                                "algorithmic_gflop_per_launch": round(c_fl / len(conv_t) / 1e9, 2)}

@@ -247,8 +247,10 @@ typedef struct stm_conv_geom {
     int group_cout[8];    /* grouped layers whose groups are zero-padded to a common width: real output channels of group i
                              (0 = all Cout/groups); the matrix-core tiles that would only multiply padding are skipped */
     int fmt;              /* plane format: 0 = three bf16 planes (six MFMA products per fp32 product; any fp32 range),
-                             1 = two fp16 planes (three products: half the matrix work, same fp32-level error, but the
-                             activations must stay below fp16's 65504 -- beyond it results are non-finite, not wrong);
+                             1 = two fp16 planes, x = h + l / 2048 with the low plane stored scaled so that it keeps its
+                             11 bits (three products: half the matrix work, same fp32-level error; 22 bits of x for
+                             6.1e-5 <= |x| <= 65504, absolute error < 1.5e-11 below.  Beyond 65504 a value has no
+                             representation: see stm_planar_set_range_flag);
                              planes must then be 2 and the weights packed with stm_conv_pack_weights_fmt_f32 */
     float out_scale;      /* fmt 1: 1 / wscale of the packed weights (0 = 1) */
     int tile_n;           /* output-channel tile the weights were packed for: 0 / 128 (stm_conv_pack_weights_f32) or 64
@@ -328,6 +330,17 @@ int stm_head_assemble_f32(const float* const* small, const float* const* trk, co
  * stm_deform_im2col_f32, value for value. */
 int stm_dcn_sample_planar_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
                               long long out_plane_stride, const stm_deform_geom* g, stm_stream_t stream);
+/* fp16 plane format (fmt 1) range guard.  A value with |x| > 65504 (or inf / nan) has no fp16 plane representation and
+ * would poison the following layers silently (inf - inf = nan, and a ReLU epilogue maps nan to 0).  Every producer of
+ * fp16 planes (stm_split_planes_fmt_f32, the stm_conv2d_planar_* epilogues, stm_dcn_sample_planar_fmt_f32) therefore
+ * writes 1 to *device_flag when it meets one.  The flag is sticky: the caller zeroes it, reads it with whatever
+ * device-to-host read it does anyway, and must discard the results if it is set.  NULL (the initial state) disables
+ * the guard.  One registration per process (one process per GPU). */
+int stm_planar_set_range_flag(int* device_flag);
+
+/* plane-format aware form (fmt as in stm_conv_geom: 0 = bf16 x 3, 1 = fp16 x 2) */
+int stm_dcn_sample_planar_fmt_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
+                                  long long out_plane_stride, const stm_deform_geom* g, int fmt, stm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -85,14 +85,32 @@ __device__ __forceinline__ void split2(f32x2 v, unsigned& p0, unsigned& p1, unsi
 // the epilogue takes out again, small activations keep an absolute error of 2^-25.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// fp16 two-plane format: x = h + l / 2048 with h = RN16(x), l = RN16((x - h) * 2048).  The residual of a normal h is below
+// 2^-11 |x|, so the scaled low plane has the magnitude of x itself and keeps its 11 bits wherever h is normal: 22 bits of
+// x for 6.1e-5 <= |x| <= 65504, an absolute error below 1.5e-11 under that.  Both operands scale their low plane, the
+// kernel keeps h*h in one accumulator and h*l + l*h in the other and adds them as acc + accl / 2048.
+#define STM_F16_LOW_SCALE 2048.0f
 __device__ __forceinline__ void split2_f16(f32x2 v, unsigned& p0, unsigned& p1)
 {
     const f16x2 h = __builtin_convertvector(v, f16x2);
-    const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+    const f32x2 r1 = (v - __builtin_convertvector(h, f32x2)) * STM_F16_LOW_SCALE;
     const f16x2 l = __builtin_convertvector(r1, f16x2);
     p0 = __builtin_bit_cast(unsigned, h);
     p1 = __builtin_bit_cast(unsigned, l);
 }
+
+// |x| > 65504, inf or nan in any of 8 values (the magnitude bits of those are the largest as integers): such a value has
+// no fp16 plane representation.  A producer that meets one raises the caller's sticky flag (stm_planar_set_range_flag),
+// because downstream the damage is silent: inf * w + (-inf) * w = nan, and a ReLU epilogue turns nan into 0.
+__device__ __forceinline__ void f16_range_check8(const float (&v)[8], int* flag)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = max(m, __builtin_bit_cast(unsigned, v[e]) & 0x7fffffffu);
+    if (m > 0x477fe000u && flag) *reinterpret_cast<volatile int*>(flag) = 1;
+}
+
+static int* g_range_flag = nullptr;
 
 template <int NPL>
 __global__ __launch_bounds__(256, 2) void conv_bf16x_kernel(const ConvArgs a)
@@ -471,6 +489,7 @@ struct PlanarArgs {
     int lvl_start[9], lvl_h[8], lvl_w[8];
     int fmt;                  // 0: three bf16 planes (six products), 1: two fp16 planes (three products)
     float out_scale;          // 1 / (power-of-two weight scale of the packed image)
+    int* range_flag;          // fmt 1: set to 1 when an output has no fp16 representation (see f16_range_check8); may be null
     int splitk, kslabs, ldp;  // split-K: K-slabs per split, fp32 partial sums [splitk][M][ldp] in `partial`
     float* partial;
     int dbg;                // STM_CONV_DEBUG timing ablations (results wrong): 1 no DMA in the loop, 2 no barrier, 4 no MFMA
@@ -487,7 +506,7 @@ template <int NJ>
 __device__ __forceinline__ float* park_base(uint8_t* smem, int wave) { return reinterpret_cast<float*>(smem) + wave * (64 * (32 * NJ + 4)); }
 
 template <int NJ>   // v_mfma_f32_32x32x16: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-__device__ __forceinline__ void park32(f32x16 (&acc)[2][NJ], f32x16 (&accl)[2][NJ], uint8_t* smem, int wave, int lane)
+__device__ __forceinline__ void park32(f32x16 (&acc)[2][NJ], f32x16 (&accl)[2][NJ], uint8_t* smem, int wave, int lane, float ls = 1.0f)
 {
     constexpr int EP_LD = 32 * NJ + 4;
     float* park = park_base<NJ>(smem, wave);
@@ -498,11 +517,11 @@ __device__ __forceinline__ void park32(f32x16 (&acc)[2][NJ], f32x16 (&accl)[2][N
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                park[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP_LD + j * 32 + lrow] = acc[i][j][r] + accl[i][j][r];
+                park[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP_LD + j * 32 + lrow] = acc[i][j][r] + accl[i][j][r] * ls;
 }
 
 template <int NJ>   // v_mfma_f32_16x16x32: col = lane & 15, row = 4 (lane >> 4) + r
-__device__ __forceinline__ void park16(f32x4 (&acc)[4][2 * NJ], f32x4 (&accl)[4][2 * NJ], uint8_t* smem, int wave, int lane)
+__device__ __forceinline__ void park16(f32x4 (&acc)[4][2 * NJ], f32x4 (&accl)[4][2 * NJ], uint8_t* smem, int wave, int lane, float ls = 1.0f)
 {
     constexpr int EP_LD = 32 * NJ + 4;
     float* park = park_base<NJ>(smem, wave);
@@ -512,7 +531,7 @@ __device__ __forceinline__ void park16(f32x4 (&acc)[4][2 * NJ], f32x4 (&accl)[4]
         for (int j = 0; j < 2 * NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                park[(i * 16 + 4 * (lane >> 4) + r) * EP_LD + j * 16 + (lane & 15)] = acc[i][j][r] + accl[i][j][r];
+                park[(i * 16 + 4 * (lane >> 4) + r) * EP_LD + j * 16 + (lane & 15)] = acc[i][j][r] + accl[i][j][r] * ls;
 }
 
 // bias + residual + ReLU + stores of one 8-channel segment (pixel m, channels co .. co+7, nvalid of them real); v = raw sums
@@ -535,7 +554,7 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
                 const f16x8 p0 = *reinterpret_cast<const f16x8*>(a.res_pl + ri);
                 const f16x8 p1 = *reinterpret_cast<const f16x8*>(a.res_pl + ri + rpl * 2);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)p0[e] + (float)p1[e];
+                for (int e = 0; e < 8; ++e) v[e] += (float)p0[e] + (float)p1[e] * (1.0f / STM_F16_LOW_SCALE);
             } else {
                 const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri);
                 const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 2);
@@ -557,6 +576,7 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
             unsigned q0[4], q1[4], q2[4];
             uint8_t* o = a.out_pl + pidx(m, co, a.out_np) * 2;
             if (a.fmt == 1) {
+                f16_range_check8(v, a.range_flag);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
                 *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
@@ -582,7 +602,7 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
             const size_t ri = pidx(m, co + e, a.res_np);
             if (a.fmt == 1) {
                 const _Float16* rh = reinterpret_cast<const _Float16*>(a.res_pl);
-                x += (float)rh[ri] + (float)rh[ri + rpl];
+                x += (float)rh[ri] + (float)rh[ri + rpl] * (1.0f / STM_F16_LOW_SCALE);
             } else {
                 x += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
             }
@@ -595,7 +615,8 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
                 _Float16* oh = reinterpret_cast<_Float16*>(a.out_pl);
                 const _Float16 h = (_Float16)x;
                 oh[oi] = h;
-                oh[oi + opl] = (_Float16)(x - (float)h);
+                oh[oi + opl] = (_Float16)((x - (float)h) * STM_F16_LOW_SCALE);
+                if (!(fabsf(x) <= 65504.0f) && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
             } else {
                 const __bf16 h = (__bf16)x;
                 const float r1 = x - (float)h;
@@ -937,8 +958,9 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     if (tr) a.trace[(wave != 0) * 512 + 7] = clock64();
 
     __syncthreads();                                   // all fragment reads of the last slab are done
-    if constexpr (MF == 0) park32<NJ>(acc, accl, smem, wave, lane);
-    else park16<NJ>(acc16, accl16, smem, wave, lane);
+    constexpr float LS = DT == 1 ? 1.0f / STM_F16_LOW_SCALE : 1.0f;   // fp16 planes: the corrections carry the low-plane scale
+    if constexpr (MF == 0) park32<NJ>(acc, accl, smem, wave, lane, LS);
+    else park16<NJ>(acc16, accl16, smem, wave, lane, LS);
     if (a.splitk > 1) {
         // raw fp32 partial sums of this K range; planar_splitk_finish_kernel adds the parts and runs the epilogue
         constexpr int EP_LD = 32 * NJ + 4, LPR = 4 * NJ;
@@ -1154,7 +1176,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx_kernel(const PlanarArgs
 // fp32 [n pixels][C] (NHWC) -> three bf16 planes [3][C/32][n][32] (entry into the planar format from a foreign producer);
 // thread = 8 channels of one pixel
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint8_t* __restrict__ planes, int64_t n, int C,
-                                                           int fmt)
+                                                           int fmt, int* range_flag)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int c8n = C >> 3;
@@ -1167,6 +1189,8 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     const size_t plane_b = (size_t)n * C * 2;
     uint8_t* dst = planes + (((size_t)(c8 >> 2) * n + pix) * 32 + (c8 & 3) * 8) * 2;
     if (fmt == 1) {
+        const float v8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        f16_range_check8(v8, range_flag);
         split2_f16(f32x2{a0.x, a0.y}, q0[0], q1[0]);
         split2_f16(f32x2{a0.z, a0.w}, q0[1], q1[1]);
         split2_f16(f32x2{a1.x, a1.y}, q0[2], q1[2]);
@@ -1270,6 +1294,13 @@ bool geom_ok(const stm_conv_geom* g, const char* who)
 }
 
 }  // namespace
+
+int* stm_internal_range_flag() { return g_range_flag; }
+extern "C" int stm_planar_set_range_flag(int* device_flag)
+{
+    g_range_flag = device_flag;
+    return STM_OK;
+}
 
 // debugging aid (not part of include/stmask_hip.h): device buffer of 2*64*8 int64 receiving workgroup 0's per-phase clocks
 extern "C" void stm_debug_conv_set_trace(void* dev_buf) { g_conv_trace = static_cast<long long*>(dev_buf); }
@@ -1407,7 +1438,7 @@ extern "C" int stm_split_planes_fmt_f32(const float* x, void* planes, int64_t n_
                 (long long)n_pixels, C);
     STM_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)planes % 16 == 0, STM_EINVAL, "stm_split_bf16_planes_f32: 16-byte alignment required");
     hipLaunchKernelGGL(split_planes_kernel, dim3(stm_cdiv(n_pixels * (C / 8), 256)), dim3(256), 0, stm_hs(stream), x,
-                       static_cast<uint8_t*>(planes), n_pixels, C, fmt);
+                       static_cast<uint8_t*>(planes), n_pixels, C, fmt, g_range_flag);
     STM_CHECK_LAUNCH("split_planes_kernel");
     return STM_OK;
 }
@@ -1488,6 +1519,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     const bool mf16 = fm ? atoi(fm) != 32 : true;
     a.fmt = g->fmt == 1 ? 1 : 0;
     a.out_scale = (g->fmt == 1 && g->out_scale > 0.0f) ? g->out_scale : 1.0f;
+    a.range_flag = g_range_flag;
     STM_REQUIRE(a.fmt == 0 || g->planes == 2, STM_EINVAL, "%s: the fp16 format has two planes", who);
     a.splitk = 1; a.kslabs = a.slabs; a.partial = nullptr; a.ldp = a.n_tiles * bn;
     // split-K for grids that would leave most CUs idle over a long K (small feature maps: ResNet stages 3/4, P5-P7):

@@ -733,9 +733,21 @@ struct SampleArgs {
     const float* om;     // [B*Ho*Wo, om_ld]: 2K offsets (dy, dx per tap) then K mask logits
     uint8_t* out;        // planes [3][K*C/32][out_np][32] bf16
     int B, H, W, C, Ho, Wo, sh, sw, ph, pw, dh, dw;
-    int om_ld, out_np, M;
+    int om_ld, out_np, M, fmt;   // fmt 0: three bf16 planes, 1: two fp16 planes
+    int* range_flag;             // fmt 1: raised when a sampled value has no fp16 representation (may be null)
     long long out_pstride;   // bytes
 };
+
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_planes_f16(float a, float b, unsigned& p0, unsigned& p1)
+{
+    const f32x2v v = {a, b};
+    const f16x2v h = __builtin_convertvector(v, f16x2v);
+    const f32x2v r1 = (v - __builtin_convertvector(h, f32x2v)) * 2048.0f;   // STM_F16_LOW_SCALE of conv_bf16x.hip
+    const f16x2v l = __builtin_convertvector(r1, f16x2v);
+    p0 = __builtin_bit_cast(unsigned, h);
+    p1 = __builtin_bit_cast(unsigned, l);
+}
 
 __device__ __forceinline__ void split2_planes(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2)
 {
@@ -806,25 +818,43 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = bilerp(w1, w2, w3, w4, x1[e], x2[e], x3[e], x4[e]);
-        unsigned q0[4], q1[4], q2[4];
+        unsigned q0[4], q1[4], q2[4] = {0, 0, 0, 0};
+        if (a.fmt == 1) {
+            unsigned mag = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split2_planes(v[2 * e], v[2 * e + 1], q0[e], q1[e], q2[e]);
+            for (int e = 0; e < 8; ++e) mag = max(mag, __builtin_bit_cast(unsigned, v[e]) & 0x7fffffffu);
+            if (mag > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;   // > 65504, inf, nan
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2_planes_f16(v[2 * e], v[2 * e + 1], q0[e], q1[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2_planes(v[2 * e], v[2 * e + 1], q0[e], q1[e], q2[e]);
+        }
         const u32x4v p0 = {q0[0], q0[1], q0[2], q0[3]}, p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]};
         const int kc = k * a.C + sl * 8;                     // K index of the lane's first channel (8 | kc: inside one slab)
         uint8_t* o = a.out + (((size_t)(kc >> 5) * a.out_np + mm) * 32 + (kc & 31)) * 2;
         if (live) {
             *reinterpret_cast<u32x4v*>(o) = p0;
             *reinterpret_cast<u32x4v*>(o + a.out_pstride) = p1;
-            *reinterpret_cast<u32x4v*>(o + 2 * a.out_pstride) = p2;
+            if (a.fmt == 0) *reinterpret_cast<u32x4v*>(o + 2 * a.out_pstride) = p2;
         }
     }
 }
 
 }  // namespace
 
+extern "C" int stm_dcn_sample_planar_fmt_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
+                                             long long out_plane_stride, const stm_deform_geom* g, int fmt, stm_stream_t stream);
 extern "C" int stm_dcn_sample_planar_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
                                          long long out_plane_stride, const stm_deform_geom* g, stm_stream_t stream)
 {
+    return stm_dcn_sample_planar_fmt_f32(x, offset_mask, om_ld, planes, out_np, out_plane_stride, g, 0, stream);
+}
+
+extern "C" int stm_dcn_sample_planar_fmt_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
+                                             long long out_plane_stride, const stm_deform_geom* g, int fmt, stm_stream_t stream)
+{
+    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_dcn_sample_planar_f32: fmt must be 0 or 1");
     STM_REQUIRE(x && offset_mask && planes && g, STM_ENULL, "stm_dcn_sample_planar_f32: NULL argument");
     STM_REQUIRE(g->kh == 3 && g->kw == 3 && g->dg == 1, STM_EUNSUPPORTED, "stm_dcn_sample_planar_f32: 3x3 kernels, one deformable group");
     STM_REQUIRE(g->C == 128 || g->C == 256 || g->C == 512, STM_EUNSUPPORTED, "stm_dcn_sample_planar_f32: C must be 128, 256 or 512 (got %d)", g->C);
@@ -836,7 +866,7 @@ extern "C" int stm_dcn_sample_planar_f32(const float* x, const float* offset_mas
     a.x = x; a.om = offset_mask; a.out = static_cast<uint8_t*>(planes);
     a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.Ho = g->Ho; a.Wo = g->Wo;
     a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw; a.dh = g->dh; a.dw = g->dw;
-    a.om_ld = om_ld; a.M = (int)M; a.out_np = out_np > 0 ? out_np : (int)M;
+    a.om_ld = om_ld; a.M = (int)M; a.out_np = out_np > 0 ? out_np : (int)M; a.fmt = fmt; a.range_flag = stm_internal_range_flag();
     a.out_pstride = (out_plane_stride > 0 ? out_plane_stride : (long long)(9 * g->C / 32) * a.out_np * 32) * 2;
     const int ppw = 512 / g->C;                                  // pixels per wave
     const dim3 grid(stm_cdiv(M, 4 * ppw));

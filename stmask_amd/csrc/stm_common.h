@@ -28,6 +28,8 @@ void stm_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+int* stm_internal_range_flag();   // conv_bf16x.hip: the device flag registered with stm_planar_set_range_flag (or null)
+
 static inline hipStream_t stm_hs(stm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int stm_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -91,11 +91,13 @@ class _FusedBottleneck(Bottleneck):
         return _epilogue(out, self.bias3, res, True)
 
 
-def optimize_for_inference(net, planar=False):
+def optimize_for_inference(net, planar=False, planes="fp16x2"):
     """fold_batchnorm + fused conv epilogues on the backbone, FPN prediction layers, proto-net and the head towers.
     In place, eval mode only; call after the weights are loaded and the model is on its device.
     planar=True (GPU only) additionally routes FPN prediction/downsample layers, proto-net and the shared head through
-    the bf16-split matrix-core convolution (stmask_amd/planar.py)."""
+    the split-operand matrix-core convolution (stmask_amd/planar.py); planes = "fp16x2" (two fp16 planes, three MFMA
+    products per fp32 product; activations must stay inside fp16's range, the pipeline checks) or "bf16x3" (three bf16
+    planes, six products; any range).  Both carry fp32-level error (tests/test_gpu_conv.py)."""
     n_bn = fold_batchnorm(net)
     n_fused = 0
     bb = net.backbone
@@ -132,7 +134,11 @@ def optimize_for_inference(net, planar=False):
         n_fused += 1
     net.fpn.pred_relu_fused = True
     if planar:
+        from . import planar as _planar
         from .planar import PlanarBackbone, PlanarGraph, PlanarTemporalNet
+        if planes not in ("fp16x2", "bf16x3"):
+            raise ValueError("planes must be 'fp16x2' or 'bf16x3'")
+        _planar.set_format(1 if planes == "fp16x2" else 0)
         net._planar = PlanarGraph(net)
         net._planar_backbone = PlanarBackbone(net.backbone)
         if getattr(net, "TemporalNet", None) is not None:

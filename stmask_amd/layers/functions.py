@@ -33,7 +33,7 @@ def generate_candidate(predictions, cfg=None):
     loc, conf = predictions["loc"], predictions["conf"]
     priors = predictions["priors"].squeeze(0)
     keep_idx, cand_box, count = ops.generate_candidates(loc, priors, conf, cfg.eval_conf_thresh)
-    counts = count.tolist()
+    counts = ops.counts_to_host(count)   # + the fp16 range flag of a fp16x2 planar graph
     out = []
     for i, k in enumerate(counts):
         idx = keep_idx[i, :k]

@@ -459,11 +459,56 @@ def split_planes(x, fmt=0):
     return planes
 
 
+F16_LOW_SCALE = 2048.0   # fp16 plane format: x = h + l / 2048 (include/stmask_hip.h, stm_conv_geom.fmt)
+
+_range_flags = {}
+
+
+def planar_range_flag():
+    """The sticky fp16-range flag of this device (stm_planar_set_range_flag): an int32 tensor of one element that every
+    producer of fp16 planes sets to 1 when it meets |x| > 65504, inf or nan.  Registered with the library on first use."""
+    dev = torch.cuda.current_device()
+    flag = _range_flags.get(dev)
+    if flag is None:
+        flag = torch.zeros(1, device=f"cuda:{dev}", dtype=torch.int32)
+        check(_lib.lib().stm_planar_set_range_flag(_p(flag)), "stm_planar_set_range_flag")
+        _range_flags[dev] = flag
+    return flag
+
+
+RANGE_MESSAGE = ("an activation left the range of the fp16x2 planar format (|x| > 65504, inf or nan): results of this step are "
+                 "invalid; build the graph with optimize_for_inference(net, planar=True, planes='bf16x3')")
+
+
+def check_planar_range():
+    """Synchronising check of the flag (callers with a host read of their own fold the flag into it instead)."""
+    flag = _range_flags.get(torch.cuda.current_device())
+    if flag is not None and int(flag.item()):
+        flag.zero_()
+        raise StmError(RANGE_MESSAGE)
+
+
+def counts_to_host(cnt):
+    """cnt.tolist() for an integer device tensor -- the host read every detection step does -- with the fp16 range flag
+    of the device (if a fp16x2 graph registered one) riding in the same copy.  Raises StmError when the flag is set."""
+    flag = _range_flags.get(cnt.device.index) if cnt.is_cuda else None
+    if flag is None:
+        return cnt.tolist()
+    host = torch.cat([cnt.reshape(-1), flag.to(cnt.dtype)]).tolist()
+    if host[-1]:
+        flag.zero_()
+        raise StmError(RANGE_MESSAGE)
+    return host[:-1]
+
+
 def planes_to_f32(planes):
     """[P, S, N, 32] planes -> fp32 [N, 32*S]."""
     v = planes[0].float()
-    for p in range(1, planes.shape[0]):
-        v = v + planes[p].float()
+    if planes.dtype == torch.float16:
+        v = v + planes[1].float() / F16_LOW_SCALE
+    else:
+        for p in range(1, planes.shape[0]):
+            v = v + planes[p].float()
     return v.permute(1, 0, 2).reshape(v.shape[1], -1)
 
 
@@ -553,7 +598,7 @@ def head_assemble(small, trk, B, sizes, n_cls, mask_dim, embed_dim, group_pad):
     return conf, loc, mask, track, cen
 
 
-def dcn_sample_planar(x_nhwc, om, stride=1, padding=1, dilation=1):
+def dcn_sample_planar(x_nhwc, om, stride=1, padding=1, dilation=1, fmt=0):
     """Deformable 3x3 sampling for the planar graph: x fp32 [B,H,W,C], om fp32 [B*Ho*Wo, >=27] (raw conv_offset_mask output,
     pixel-major) -> bf16 planes [3, 9C/32, B*Ho*Wo, 32] with K index = tap*C + channel."""
     _dev(x_nhwc, om)
@@ -566,15 +611,15 @@ def dcn_sample_planar(x_nhwc, om, stride=1, padding=1, dilation=1):
     if om.shape[0] != M or om.shape[1] < 27:
         raise StmError(f"dcn_sample_planar: offset/mask matrix {tuple(om.shape)} does not match {M} output pixels x 27")
     g = DeformGeom(B, C, H, W, 3, 3, sh, sw, ph, pw, dh, dw, 1, Ho, Wo)
-    out = torch.empty(3, 9 * C // 32, M, 32, device=x.device, dtype=torch.bfloat16)
+    out = torch.empty(2 if fmt == 1 else 3, 9 * C // 32, M, 32, device=x.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
     timing = _im2col_timing
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.lib().stm_dcn_sample_planar_f32(_p(x), _p(om), c_i(om.shape[1]), _p(out), c_i(M), c_l(0), ctypes.byref(g),
-                                               _stream()), "stm_dcn_sample_planar_f32")
+    check(_lib.lib().stm_dcn_sample_planar_fmt_f32(_p(x), _p(om), c_i(om.shape[1]), _p(out), c_i(M), c_l(0), ctypes.byref(g),
+                                                   c_i(fmt), _stream()), "stm_dcn_sample_planar_fmt_f32")
     if timing is not None:
         e1.record()
-        # algorithmic bytes: input once, 27 offset/mask values per output pixel, columns as three bf16 planes (6 B / element)
-        timing.append((e0, e1, 4 * B * C * H * W + 4 * 27 * M + 6 * 9 * C * M))
+        # algorithmic bytes: input once, 27 offset/mask values per output pixel, columns as planes (6 or 4 B / element)
+        timing.append((e0, e1, 4 * B * C * H * W + 4 * 27 * M + (4 if fmt == 1 else 6) * 9 * C * M))
     return out

@@ -206,7 +206,7 @@ class BatchedClipPipeline:
         priors = pred["priors"].squeeze(0)
         idx, cls, score, box, cnt = ops.detect_cc(pred["loc"], priors, conf, pred["centerness"], cfg.eval_conf_thresh,
                                                   cfg.nms_thresh, cfg.nms_top_k)
-        counts = cnt.tolist()  # host read 1 (B ints)
+        counts = ops.counts_to_host(cnt)  # host read 1 (B ints, + the fp16 range flag of a fp16x2 graph)
         tmr.toc("detect")
         D = sum(counts)
         top_k = cfg.nms_top_k

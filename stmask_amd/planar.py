@@ -25,6 +25,23 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+# Plane format of the graphs built next (fuse.optimize_for_inference sets it): 0 = three bf16 planes, six MFMA products per
+# fp32 product, any fp32 range; 1 = two fp16 planes, three products -- half the matrix work at the same fp32-level error,
+# activations limited to fp16's range (|x| < 65504; beyond it the outputs are non-finite and the pipeline raises).
+FMT = 0
+
+
+def set_format(fmt):
+    global FMT
+    if fmt not in (0, 1):
+        raise StmError("planar format must be 0 (bf16 x 3) or 1 (fp16 x 2)")
+    FMT = fmt
+
+
+def _planes_dtype(fmt):
+    return (2, torch.float16) if fmt == 1 else (3, torch.bfloat16)
+
+
 class PlanarConv:
     """One packed convolution layer.  x / outputs are described by raw (tensor, pixel offset) pairs so that a layer can
     read from and write into slices of larger plane buffers."""
@@ -37,17 +54,23 @@ class PlanarConv:
         only used for the flop count of the live roofline measurement.  tile_n: 64 / 128 forces the output-channel tile,
         None picks per call from the problem size (weights are packed once per tile width used)."""
         self.weight = weight.detach().float().contiguous()
+        self.fmt = FMT
         self.algo_frac = algo_frac
         self.group_cout = list(group_cout) if group_cout else None   # real channels of zero-padded groups
         self.O, self.C, self.kh, self.kw = self.weight.shape
         (self.sh, self.sw), (self.ph, self.pw) = _pair(stride), _pair(padding)
-        self.relu, self.groups, self.planes, self.tile_n = relu, groups, planes, tile_n
+        self.relu, self.groups, self.planes, self.tile_n = relu, groups, (2 if self.fmt == 1 else planes), tile_n
         self._packed = {}
+        self.out_scale = 1.0
         self.bias = bias.detach().float().contiguous() if bias is not None else None
 
     def packed(self, tile_n):
         if tile_n not in self._packed:
-            self._packed[tile_n] = ops.conv_pack_weights(self.weight, self.planes, tile_n)
+            if self.fmt == 1:
+                ops.planar_range_flag()     # the producers of fp16 planes report |x| > 65504 through it
+                self._packed[tile_n], self.out_scale = ops.conv_pack_weights(self.weight, tile_n=tile_n, fmt=1)
+            else:
+                self._packed[tile_n] = ops.conv_pack_weights(self.weight, self.planes, tile_n)
         return self._packed[tile_n]
 
     def pick_tile(self, M):
@@ -70,8 +93,9 @@ class PlanarConv:
         of xp are one image batch; ("levels", B, [(H, W), ...]) -> all of xp, concatenated levels.  The layer reads
         groups*C channels starting at channel x_ch_off.  out: "planes" | "f32" | "both" allocates dense outputs
         ([3, O/32, M, 32] / [M, O]) unless out_planes / out_f32 are given, then pixels [out_off, ...) are written."""
-        if xp.dtype != torch.bfloat16 or xp.dim() != 4 or xp.shape[0] != 3 or xp.shape[3] != 32 or not xp.is_contiguous():
-            raise StmError(f"PlanarConv: expected contiguous bf16 planes [3, S, N, 32], got {xp.dtype} {tuple(xp.shape)}")
+        NP, dt = _planes_dtype(self.fmt)
+        if xp.dtype != dt or xp.dim() != 4 or xp.shape[0] != NP or xp.shape[3] != 32 or not xp.is_contiguous():
+            raise StmError(f"PlanarConv: expected contiguous {dt} planes [{NP}, S, N, 32], got {xp.dtype} {tuple(xp.shape)}")
         S, N = xp.shape[1], xp.shape[2]
         g = _lib.ConvGeom()
         g.C, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw = self.C, self.O, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw
@@ -103,7 +127,7 @@ class PlanarConv:
         g.tile_n = self.pick_tile(M)
         dev = xp.device
         if out in ("planes", "both") and out_planes is None:
-            out_planes, out_off_p = torch.empty(3, -(-self.O // 32), M, 32, device=dev, dtype=torch.bfloat16), 0
+            out_planes, out_off_p = torch.empty(NP, -(-self.O // 32), M, 32, device=dev, dtype=dt), 0
         else:
             out_off_p = out_off
         if out in ("f32", "both") and out_f32 is None:
@@ -123,7 +147,7 @@ class PlanarConv:
             p_f32 = out_f32.data_ptr() + (out_off_f * g.out_ld + out_ch_off) * 4   # fp32 output may start at a column
         r32 = rpl = 0
         if residual is not None:
-            if residual.dtype == torch.bfloat16:
+            if residual.dtype == dt:
                 g.res_np, g.res_plane_stride = residual.shape[2], residual.shape[1] * residual.shape[2] * 32
                 rpl = residual.data_ptr()
             else:
@@ -134,8 +158,10 @@ class PlanarConv:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         x_ptr = xp.data_ptr() + ((x_ch_off // 32) * N + x_off) * 64
+        packed = self.packed(g.tile_n)                     # (sets self.out_scale for the fp16 format)
+        g.fmt, g.out_scale = self.fmt, self.out_scale
         ws = ops._workspace(self.SPLITK_WS_BYTES, dev, "conv_splitk")     # grow-only, shared: split-K partial sums
-        rc = _lib.lib().stm_conv2d_planar_ws_f32(ctypes.c_void_p(x_ptr), ops._p(self.packed(g.tile_n)),
+        rc = _lib.lib().stm_conv2d_planar_ws_f32(ctypes.c_void_p(x_ptr), ops._p(packed),
                                                  ops._p(self.bias), ctypes.c_void_p(r32), ctypes.c_void_p(rpl),
                                                  ctypes.c_void_p(p_f32), ctypes.c_void_p(p_pl), ctypes.byref(g),
                                                  c_i(1 if self.relu else 0), ops._p(ws), ctypes.c_size_t(ws.numel()),
@@ -154,9 +180,9 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
-def _split(t_nhwc):
-    """fp32 [B, H, W, C] -> planes [3, C/32, B*H*W, 32]."""
-    return ops.split_planes(t_nhwc)
+def _split(t_nhwc, fmt=None):
+    """fp32 [B, H, W, C] -> planes [P, C/32, B*H*W, 32] in the current (or given) plane format."""
+    return ops.split_planes(t_nhwc, FMT if fmt is None else fmt)
 
 
 class PlanarGraph:
@@ -165,6 +191,7 @@ class PlanarGraph:
     def __init__(self, net):
         cfg = net.cfg
         self.net = net
+        self.fmt = FMT
         fpn = net.fpn
         self.n_lat = len(fpn.lat_layers)
         # FPN prediction convs always end in ReLU (FPN.py:96-100); downsample convs do not
@@ -262,13 +289,14 @@ class PlanarGraph:
             starts.append(starts[-1] + B * h * w)
         ntot, nf = starts[-1], self.fpn_pred[0].O
         dev = lat[0].device
-        feat = torch.empty(3, nf // 32, ntot, 32, device=dev, dtype=torch.bfloat16)   # P3..P7, all levels, planar
+        NP, pdt = _planes_dtype(self.fmt)
+        feat = torch.empty(NP, nf // 32, ntot, 32, device=dev, dtype=pdt)   # P3..P7, all levels, planar
         feat32 = torch.empty(ntot, nf, device=dev, dtype=torch.float32) if not self.head_planar else None
         fpn_outs = [None] * len(sizes)
         for i, conv in enumerate(self.fpn_pred):
             j = n - 1 - i
             h, w = sizes[j]
-            xp = _split(_nhwc(lat[j]))
+            xp = _split(_nhwc(lat[j]), self.fmt)
             if feat32 is not None:     # module-path head: it wants every level in fp32 as well
                 conv(xp, ("img", B, h, w), out="both", out_planes=feat, out_f32=feat32, out_off=starts[j])
                 fpn_outs[j] = feat32[starts[j]:starts[j + 1]].view(B, h, w, nf).permute(0, 3, 1, 2)
@@ -298,7 +326,7 @@ class PlanarGraph:
             if isinstance(layer, PlanarConv):
                 nxt_is_interp = (not last) and not isinstance(self.proto[li + 1], PlanarConv)
                 if cur is not None:            # fp32 NHWC tensor pending a split
-                    xp, x_off = _split(cur), 0
+                    xp, x_off = _split(cur, self.fmt), 0
                     cur = None
                 if last or nxt_is_interp:
                     y = layer(xp, ("img", B, h, w), out="f32", x_off=x_off)
@@ -361,7 +389,7 @@ class PlanarGraph:
                     y = ops.deform_conv(conf_x[l], offset, None, fa.conv_adaption.weight, None, 1, fa.padding, 1,
                                         fa.conv_adaption.deform_groups, relu=True)
                     feat_k[sl] = y.permute(0, 2, 3, 1).reshape(-1, cw)
-                fconv(ops.split_planes(feat_k), lv, out="f32", out_f32=buf)        # conf logits into columns [0, n_cls)
+                fconv(ops.split_planes(feat_k, self.fmt), lv, out="f32", out_f32=buf)        # conf logits into columns [0, n_cls)
                 outs.append((buf, trk(t2, lv, out="f32", x_ch_off=3 * cw)))
         toc("head_finals")
         P = self.GROUP_PAD
@@ -417,12 +445,13 @@ class PlanarTemporalNet:
         self.c2 = PlanarConv(tn.conv2.weight, tn.conv2.bias, 1, tn.conv2.padding, relu=True)
         self.c3 = PlanarConv(tn.conv3.weight, tn.conv3.bias, 1, tn.conv3.padding, relu=True)
         self.fc, self.fc_coeff = tn.fc, tn.fc_coeff
+        self.fmt = FMT
 
     def __call__(self, roi_feats):
         """roi_feats [n, 633, 7, 7] fp32 -> (loc shift [n, 4], coeff shift [n, 32])."""
         n, c, h, w = roi_feats.shape
         x = F.pad(roi_feats.permute(0, 2, 3, 1), (0, self.cpad - c)).contiguous()       # NHWC, channels padded
-        xp = ops.split_planes(x)
+        xp = ops.split_planes(x, self.fmt)
         shape = ("img", n, h, w)
         y = self.c3(self.c2(self.c1(xp, shape), shape), shape, out="f32")                # [n*h*w, 1024]
         pooled = y.view(n, h * w, -1).mean(dim=1)                                        # AvgPool2d((7, 7)) on a 7x7 map
@@ -441,6 +470,7 @@ class PlanarBackbone:
     def __init__(self, bb):
         from .dcn_v2 import DCN
         self.bb = bb
+        self.fmt = FMT
         self.blocks = []
         for layer in bb.layers:
             blks = []
@@ -471,7 +501,7 @@ class PlanarBackbone:
         bb = self.bb
         x = bb.maxpool(bb.relu(bb.bn1(bb.conv1(x))))        # conv1 carries the folded BN + ReLU after fuse
         B, C, H, W = x.shape
-        xp = _split(_nhwc(x))
+        xp = _split(_nhwc(x), self.fmt)
         outs = []
         for blks in self.blocks:
             y32 = None
@@ -489,7 +519,7 @@ class PlanarBackbone:
                         # [pixels, 27]; sampler -> planar columns; GEMM + bias + ReLU as a planar 1x1 convolution
                         t32, tpl = e["c1"](xp, shape, out="both")
                         om = e["om"](tpl, shape, out="f32")
-                        cols = ops.dcn_sample_planar(t32.view(B, H, W, -1), om, d.stride, d.padding, d.dilation)
+                        cols = ops.dcn_sample_planar(t32.view(B, H, W, -1), om, d.stride, d.padding, d.dilation, fmt=self.fmt)
                         mid = e["dcn_conv"](cols, ("img", B, Ho, Wo))
                     elif B * Ho * Wo >= self.OM_PLANAR_MIN_PIXELS:
                         t32, tpl = e["c1"](xp, shape, out="both")
@@ -502,7 +532,7 @@ class PlanarBackbone:
                         xin = t32.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
                         t = ops.deform_conv(xin, None, None, d.weight, d.bias, d.stride, d.padding, d.dilation,
                                             d.deformable_groups, relu=True, fused_om=om)
-                        mid = _split(_nhwc(t))
+                        mid = _split(_nhwc(t), self.fmt)
                 else:
                     mid = e["c2"](e["c1"](xp, shape), shape)
                 res = e["ds"](xp, shape) if "ds" in e else xp

@@ -285,3 +285,85 @@ def test_conv_planar_fp16_two_plane_format(case, tile_n):
         y2 = ops.conv2d_planar(xp, pk, tuple(w.shape), (B, H, W), b.to(DEV) if has_bias else None, ops.split_planes(r.to(DEV), fmt=1),
                                stride=s, padding=pad, relu=relu, out="f32", tile_n=tile_n, fmt=1, out_scale=osc).cpu()
         assert (y2.view(ref.shape) - y32).abs().max().item() < 2e-6 * max(1.0, y32.abs().max().item())
+
+
+def test_fp16_planes_keep_22_bits_across_magnitudes():
+    """x = h + l / 2048 with the low plane stored scaled: every element keeps 22 significand bits from 6.1e-5 to 65504 and
+    an absolute error below 1.5e-11 under that (an unscaled low plane would lose bits from |x| < 0.12 down)."""
+    g = torch.Generator().manual_seed(11)
+    mant = 1.0 + torch.rand(4096, 32, generator=g)
+    expo = torch.randint(-30, 16, (4096, 32), generator=g).float()
+    sign = torch.where(torch.rand(4096, 32, generator=g) < 0.5, -1.0, 1.0)
+    x = (sign * mant * 2.0 ** expo).clamp(-65504.0, 65504.0)
+    xp = ops.split_planes(x.to(DEV), fmt=1)
+    back = planes_to_f32(xp.cpu())
+    err = (back.double() - x.double()).abs()
+    assert (err <= torch.maximum(2.0 ** -22 * x.double().abs(), torch.tensor(1.5e-11, dtype=torch.float64))).all()
+    torch.cuda.synchronize()
+    assert int(ops.planar_range_flag().item()) == 0
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1e-6, 3e3])
+def test_conv_planar_fp16_format_small_and_large_activations(scale):
+    """The stated bound (2e-6 of sum|x w|) holds for activations far from 1: 1e-3 (low-plane scaling) and 3e3 (outputs
+    near the top of the fp16 range); at 1e-6, under fp16's normal range, the documented absolute floor takes over."""
+    B, H, W, C, O = 2, 9, 12, 64, 96
+    x = rnd(B, H, W, C, seed=20) * scale
+    w = rnd(O, C, 3, 3, seed=21, scale=(C * 9) ** -0.5)
+    ref = oracle.conv2d_nhwc(x, w, None, None, padding=1)
+    mag = oracle.conv2d_nhwc(x.abs(), w.abs(), None, None, padding=1)
+    pk, osc = ops.conv_pack_weights(w.to(DEV), fmt=1)
+    y32, ypl = ops.conv2d_planar(ops.split_planes(x.to(DEV), fmt=1), pk, tuple(w.shape), (B, H, W), padding=1, out="both", fmt=1,
+                                 out_scale=osc)
+    y32 = y32.cpu().view(ref.shape)
+    # elements under fp16's normal range (6.1e-5) carry an absolute error of up to 1.5e-11 instead of a relative one
+    wsum = oracle.conv2d_nhwc(torch.ones_like(x), w.abs(), None, None, padding=1)
+    assert ((y32 - ref).abs() <= 2e-6 * mag + 1.5e-11 * wsum).all()
+    if scale >= 1e-3:
+        assert ((y32 - ref).abs() / mag.clamp_min(1e-30)).max().item() < 2e-6
+    yb = planes_to_f32(ypl.cpu())[:, :O]
+    assert ((yb - y32.view(-1, O)).abs() <= 2.0 ** -21 * y32.view(-1, O).abs() + 1.5e-11).all()
+    assert int(ops.planar_range_flag().item()) == 0
+
+
+def test_fp16_range_flag_is_raised_by_every_plane_producer():
+    """|x| > 65504 has no fp16 plane representation: stm_split_planes_fmt_f32, the planar conv epilogue (vector and scalar
+    forms) and the planar deformable sampler raise the registered sticky flag; in-range runs leave it alone; a fp32-only
+    output does not raise it."""
+    flag = ops.planar_range_flag()
+    flag.zero_()
+
+    def raised():
+        torch.cuda.synchronize()
+        v = int(flag.item())
+        flag.zero_()
+        return v
+
+    x = rnd(1, 4, 4, 32, seed=1)
+    ops.split_planes(x.to(DEV), fmt=1)
+    assert raised() == 0
+    for bad in (7e4, -1e9, float("inf"), float("nan")):
+        xb = x.clone()
+        xb[0, 2, 1, 5] = bad
+        ops.split_planes(xb.to(DEV), fmt=1)
+        assert raised() == 1, bad
+    ops.split_planes(xb.to(DEV), fmt=0)                  # the bf16 format has fp32's range
+    assert raised() == 0
+    # conv epilogue: inputs in range, outputs beyond it
+    for O in (64, 41):                                   # vector / scalar epilogue
+        w = torch.full((O, 32, 1, 1), 1.0)
+        xin = torch.full((1, 4, 4, 32), 3000.0)          # y = 96000
+        pk, osc = ops.conv_pack_weights(w.to(DEV), fmt=1)
+        xp = ops.split_planes(xin.to(DEV), fmt=1)
+        y = ops.conv2d_planar(xp, pk, tuple(w.shape), (1, 4, 4), out="f32", fmt=1, out_scale=osc)
+        assert raised() == 0 and torch.equal(y.cpu(), torch.full((16, O), 96000.0))
+        ops.conv2d_planar(xp, pk, tuple(w.shape), (1, 4, 4), out="both", fmt=1, out_scale=osc)
+        assert raised() == 1
+    # sampler
+    xs = torch.full((1, 6, 6, 32), 1e5)
+    om = torch.zeros(36, 27)
+    om[:, 18:] = 10.0                                    # mask ~ 1
+    ops.dcn_sample_planar(xs.to(DEV), om.to(DEV), 1, 1, 1, fmt=1)
+    assert raised() == 1
+    ops.dcn_sample_planar((xs * 1e-3).to(DEV), om.to(DEV), 1, 1, 1, fmt=1)
+    assert raised() == 0

@@ -520,6 +520,11 @@ def test_dcn_sample_planar_equals_im2col(B, C, H, W, stride):
     pl = ops.dcn_sample_planar(x.permute(0, 2, 3, 1).contiguous().to(DEV), om.permute(0, 2, 3, 1).reshape(-1, 27).to(DEV), stride, 1, 1)
     assert pl.shape == (3, 9 * C // 32, B * Ho * Wo, 32)
     assert torch.equal(ops.planes_to_f32(pl), ref)
+    # fp16 two-plane output: the same planes stm_split_planes_fmt_f32 makes of those values
+    ph = ops.dcn_sample_planar(x.permute(0, 2, 3, 1).contiguous().to(DEV), om.permute(0, 2, 3, 1).reshape(-1, 27).to(DEV), stride, 1, 1,
+                               fmt=1)
+    assert ph.shape == (2, 9 * C // 32, B * Ho * Wo, 32) and ph.dtype == torch.float16
+    assert torch.equal(ph, ops.split_planes(ref.contiguous(), fmt=1).view_as(ph))
     if B * H * W <= 1000:
         o_cols = oracle.deform_im2col(x, om[:, 0:18].contiguous(), torch.sigmoid(om[:, 18:27]), (3, 3), stride, 1, 1, 1)
         assert (cols.cpu() - o_cols).abs().max().item() < 2e-5

@@ -136,8 +136,9 @@ def test_optimized_inference_graph_on_gpu(channels_last):
         assert (a[k] - b[k]).abs().max().item() < 2e-4 * scale, k
 
 
+@pytest.mark.parametrize("planes", ["fp16x2", "bf16x3"])
 @pytest.mark.parametrize("name,tag", CASES[:3])
-def test_planar_graph_matches_module_path_and_reference(name, tag):
+def test_planar_graph_matches_module_path_and_reference(name, tag, planes):
     """fuse.optimize_for_inference(planar=True): FPN pred/downsample layers, proto-net and (FCA-only configs) the whole
     shared head on the bf16-split matrix-core convolution, all five levels per launch.  Same tensors as the module
     path to fp32 rounding (5e-5 relative, the convolutions themselves are at 2e-6), the reference goldens to the
@@ -147,9 +148,10 @@ def test_planar_graph_matches_module_path_and_reference(name, tag):
     h, w = [int(v) for v in g["frames_hw"]]
     ref_net = build(name)
     opt_net = build(name)
-    optimize_for_inference(opt_net, planar=True)
+    optimize_for_inference(opt_net, planar=True, planes=planes)
     opt_net = opt_net.to(memory_format=torch.channels_last)
     opt_net.TemporalNet = opt_net.TemporalNet.to(memory_format=torch.contiguous_format)
+    assert opt_net._planar.fmt == (1 if planes == "fp16x2" else 0)
     assert opt_net._planar.head_planar and opt_net._planar.fcb == (tag != "r50_fca")
     frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0)
     x = frames[:2].cuda()
@@ -178,10 +180,13 @@ def test_planar_graph_matches_module_path_and_reference(name, tag):
             assert d.pow(2).mean(dim=(1, 2)).sqrt().median() < 1e-4
 
 
-def test_planar_temporalnet_matches_module():
+@pytest.mark.parametrize("fmt", [1, 0])
+def test_planar_temporalnet_matches_module(fmt):
     """PlanarTemporalNet (633 -> 640 zero-padded channels, any RoI count per launch) == the nn.Module TemporalNet."""
+    from stmask_amd import planar
     from stmask_amd.planar import PlanarTemporalNet
     net = build("STMask_plus_resnet50_config")
+    planar.set_format(fmt)
     ptn = PlanarTemporalNet(net.TemporalNet)
     for n in (1, 37, 200):
         x = torch.relu(torch.randn(n, 633, 7, 7, generator=torch.Generator().manual_seed(n))).cuda()
@@ -243,6 +248,27 @@ def test_batched_pipeline_trunk_overlap_is_transparent():
     d = BatchedClipPipeline(net, 3)
     d.step(frames[0], is_first=True)
     assert (y1 - d.step(frames[1], is_first=False)).abs().max().item() < 1e-4
+
+
+def test_fp16_plane_graph_fails_loudly_out_of_range():
+    """The fp16x2 graph cannot carry |activation| > 65504: such an input must raise, never return detections computed
+    from inf / nan -- which a ReLU epilogue would turn into zeros, i.e. into plausible-looking wrong results (the bf16x3
+    graph has fp32's range and runs the same input)."""
+    from stmask_amd.pipeline import BatchedClipPipeline
+    from stmask_amd.fuse import optimize_for_inference
+    from stmask_amd.ops import StmError
+    frames = (synthetic.synthetic_clip(1, 128, 192, seed=2) * 1e5).cuda().contiguous(memory_format=torch.channels_last)
+    for planes in ("fp16x2", "bf16x3"):
+        net = build("STMask_plus_resnet50_config")
+        optimize_for_inference(net, planar=True, planes=planes)
+        net = net.to(memory_format=torch.channels_last)
+        net.TemporalNet = net.TemporalNet.to(memory_format=torch.contiguous_format)
+        pipe = BatchedClipPipeline(net, 1)
+        if planes == "fp16x2":
+            with pytest.raises(StmError, match="range of the fp16x2 planar format"):
+                pipe.step(frames, is_first=True)
+        else:
+            pipe.step(frames, is_first=True)
 
 
 def test_fp16_backbone_option_config5():
