@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--planes", choices=["fp16x2", "bf16x3"], default="fp16x2",
                     help="operand split of the planar MFMA convolutions: two fp16 planes / 3 products (default) or three bf16 "
                          "planes / 6 products (no fp16 range limit); both are fp32-equivalent to 2e-6 of sum|x w|")
+    ap.add_argument("--layer-table", action="store_true", help="per-layer-shape timing table of the planar convolution on stderr")
     ap.add_argument("--no-planar", dest="planar", action="store_false",
                     help="FPN / proto-net / head convolutions through MIOpen instead of the bf16-split matrix-core kernel")
     ap.add_argument("--fp16-backbone", action="store_true",
@@ -225,8 +226,8 @@ def main():
             # MFMA peak / n_prod, because each fp32 product is carried by n_prod MFMA products (3 fp16 or 6 bf16).
             n_prod = 3 if args.planes == "fp16x2" else 6
             split = "fp16x2-plane" if args.planes == "fp16x2" else "bf16x3-plane"
-            c_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in conv_t)
-            c_fl = sum(f for _, _, f in conv_t)
+            c_ms = sum(t[0].elapsed_time(t[1]) for t in conv_t)
+            c_fl = sum(t[2] for t in conv_t)
             tf = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
             res["roofline"] = {"bound": "mfma", "kernel": f"conv_planar_kernel ({split} split conv: backbone 1x1/3x3, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
                                "achieved": round(tf, 1), "peak": round(BF16_MFMA_PEAK_TF / n_prod, 1), "unit": "TFLOP/s",
@@ -238,6 +239,16 @@ def main():
                                "ms_per_step": round(c_ms / args.steps, 3),
                                "algorithmic_gflop_per_launch": round(c_fl / len(conv_t) / 1e9, 2)}
             res["roofline_im2col"] = im2col_roof
+            if args.layer_table:
+                # per-layer-shape table of the dominant kernel (stderr; the JSON line stays alone on stdout)
+                agg = {}
+                for t in conv_t:
+                    a = agg.setdefault(t[3], [0, 0.0, 0.0])
+                    a[0] += 1; a[1] += t[0].elapsed_time(t[1]); a[2] += t[2]
+                print("%9s %5s %5s %2s %2s %2s %4s %6s %9s %8s %7s" % ("M", "C", "O", "k", "s", "g", "tile", "calls", "us/call", "TF", "ms/step"), file=sys.stderr)
+                for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    print("%9d %5d %5d %2d %2d %2d %4d %6d %9.1f %8.1f %7.3f" % (*key, n, ms * 1e3 / n, fl / (ms * 1e-3) / 1e12, ms / args.steps),
+                          file=sys.stderr)
         else:
             res["roofline"] = im2col_roof
         if world == 1 and not args.no_cpu_baseline:

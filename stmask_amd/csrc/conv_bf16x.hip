@@ -1529,7 +1529,12 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         int sk = fs ? atoi(fs) : 0;
         if (sk <= 0) {
             sk = 1;
-            if (tiles < 128 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, 256 / tiles), a.slabs / 12);
+            if (bn == 64) {
+                // 128 x 64 tiles run two workgroups per CU; a grid of at most one workgroup per CU spends its time in
+                // the staging latency of each K-slab, so split K until ~3 workgroups per CU are resident or queued
+                static const int target = getenv("STM_CONV_SK_TARGET") ? atoi(getenv("STM_CONV_SK_TARGET")) : 768;
+                if (tiles <= 256 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, target / tiles), a.slabs / 10);
+            } else if (tiles < 128 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, 256 / tiles), a.slabs / 12);
         }
         if (sk < 2) return;
         const int per = stm_cdiv(a.slabs, sk);

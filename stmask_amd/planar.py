@@ -169,7 +169,8 @@ class PlanarConv:
         check(rc, "stm_conv2d_planar_f32")
         if timing is not None:
             e1.record()
-            timing.append((e0, e1, 2.0 * M * self.O * self.C * self.kh * self.kw * self.algo_frac))
+            timing.append((e0, e1, 2.0 * M * self.O * self.C * self.kh * self.kw * self.algo_frac,
+                           (M, self.C, self.O, self.kh, self.sh, self.groups, g.tile_n)))
         if out == "both":
             return out_f32, out_planes
         return out_f32 if out == "f32" else out_planes

@@ -360,7 +360,7 @@ def test_fp16_range_flag_is_raised_by_every_plane_producer():
         ops.conv2d_planar(xp, pk, tuple(w.shape), (1, 4, 4), out="both", fmt=1, out_scale=osc)
         assert raised() == 1
     # sampler
-    xs = torch.full((1, 6, 6, 32), 1e5)
+    xs = torch.full((1, 6, 6, 128), 1e5)
     om = torch.zeros(36, 27)
     om[:, 18:] = 10.0                                    # mask ~ 1
     ops.dcn_sample_planar(xs.to(DEV), om.to(DEV), 1, 1, 1, fmt=1)
