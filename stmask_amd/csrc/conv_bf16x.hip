@@ -677,14 +677,14 @@ __global__ __launch_bounds__(256) void planar_splitk_finish_kernel(const PlanarA
 
 template <int NJ>
 __device__ __forceinline__ void planar_epilogue(const PlanarArgs& a, f32x16 (&acc)[2][NJ], f32x16 (&accl)[2][NJ], uint8_t* smem, int wave,
-                                                int lane, int m0, int n0g, int grp, int wm, int wn)
+                                                int lane, int m0, int n0g, int grp, int wm, int wn, float ls = 1.0f)
 {
     __syncthreads();                                   // all fragment reads of the last slab are done
-    park32<NJ>(acc, accl, smem, wave, lane);
+    park32<NJ>(acc, accl, smem, wave, lane, ls);
     planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
 }
 
-template <int NPL, int MG, int NJ, int MF, int DT = 0>   // DT = 1: fp16 planes / v_mfma_f32_16x16x32_f16 (NPL 2, MF 1 only); MF = 1: v_mfma_f32_16x16x32_bf16 (less energy per flop; the chip is power-limited here), 0: 32x32x16
+template <int NPL, int MG, int NJ, int MF, int DT = 0, int ST = 2, int ABL = 0>   // ABL: timing ablations of the ring loop (results wrong): 1 no DMA, 2 no barrier, 4 no fragment reads; ST = 3: three-buffer LDS ring with fragment prefetch (fp16 format); DT = 1: fp16 planes / v_mfma_f32_16x16x32_f16 (NPL 2, MF 1 only); MF = 1: v_mfma_f32_16x16x32_bf16 (less energy per flop; the chip is power-limited here), 0: 32x32x16
 __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
@@ -696,6 +696,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     constexpr int NWAVES = 4 * MG;
     constexpr int WDMA = (BN / 16) * NPL / NWAVES;   // weight DMA instructions (1 KB each) per wave per slab
     static_assert((BN / 16) * NPL % NWAVES == 0, "weight tile must split evenly over the waves");
+    static_assert(ST == 2 || (ST == 3 && MF == 1 && DT == 1 && NPL == 2), "the three-buffer ring is built for the fp16 format");
 
     const int tiles = a.m_tiles * a.n_tiles * a.splitk;
     const int per_xcd = (tiles + 7) >> 3;
@@ -802,6 +803,123 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     const bool tr = false;
 #define PL_STAMP(k)
 #endif
+    if constexpr (ST == 3) {
+        // ---- three-buffer ring (fp16 format) ------------------------------------------------------------------------
+        // With two buffers every K-slab opens with a barrier followed by a burst of fragment reads (12 ds_read_b128 per
+        // wave, 8 waves) that the matrix pipe waits for: the PMC passes show it busy 48 % of the kernel's cycles, 57 % with
+        // the DMA removed, bank conflicts ~0.  Here slab s+2 is in flight while slab s is multiplied, so slab s+1 is
+        // already resident during the second half of slab s and its fragments are read then, between the MFMAs that still
+        // work on slab s: the activation fragments of its first half into the registers the first half of slab s just
+        // freed, each weight fragment as soon as the last MFMA of slab s that uses its predecessor has issued (the MFMAs
+        // run column-tile-major for that).  One barrier per slab as before, placed mid-slab.
+        constexpr int NDMA = 2 * NPL + WDMA;             // DMA instructions per wave and slab
+        constexpr int NM = 12 * NJ;                      // MFMAs per half
+#define MM16(x_, y_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x_), __builtin_bit_cast(f16x8, y_), c_, 0, 0, 0)
+        const int r16 = lane & 15, kc = lane >> 4;
+        int xoff[4], woff[2 * NJ];                       // fragment byte offsets within a buffer (plane 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xoff[i] = lds_off(wm * 64 + i * 16 + r16, kc);
+#pragma unroll
+        for (int j = 0; j < 2 * NJ; ++j) woff[j] = XBUF + lds_off(wn * (32 * NJ) + j * 16 + r16, kc);
+        dma_x(0);
+        dma_w(s_begin, 0);
+        dma_x(1);
+        dma_w(min(s_begin + 1, s_end - 1), 1);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+        bf16x8 bf[2 * NJ][NPL], af0[2][NPL], af1[2][NPL];
+#pragma unroll
+        for (int j = 0; j < 2 * NJ; ++j)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(smem + woff[j] + p * WPL);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + xoff[i] + p * (BM * 64));
+        int cur = 0, nxt = 1, dmb = 2;                   // ring positions of slab s, slab s+1 and of the DMA target (slab s+2)
+        // first half of a slab: row tiles 0, 1 (fragments already in registers); reads the second half's activation
+        // fragments and starts slab S_+2 on its way in
+#define RING_HALF0(S_, DMA_)                                                                                                        \
+        {                                                                                                                       \
+            const uint8_t* xs = smem + cur * BUF;                                                                               \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                       \
+                _Pragma("unroll") for (int p = 0; p < NPL; ++p)                                                                 \
+                    if (!(ABL & 4)) af1[i][p] = *reinterpret_cast<const bf16x8*>(xs + xoff[2 + i] + p * (BM * 64));            \
+            if (DMA_ && !(ABL & 1)) {                                                                                           \
+                dma_x(dmb);                                                                                                     \
+                dma_w(min((S_) + 2, s_end - 1), dmb);                                                                           \
+            }                                                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < 2 * NJ; ++j)                                                                  \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
+                    f32x4 c = MM16(af0[i][1], bf[j][0], accl16[i][j]);                                                          \
+                    accl16[i][j] = MM16(af0[i][0], bf[j][1], c);                                                                \
+                    acc16[i][j] = MM16(af0[i][0], bf[j][0], acc16[i][j]);                                                       \
+                }                                                                                                               \
+            _Pragma("unroll") for (int k = 0; k < NM; ++k) {                                                                    \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    /* one MFMA (16 cycles) */                \
+                if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         /* second half's activation fragments */  \
+                if (DMA_) {                                                                                                     \
+                    __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                /* VALU / SALU of the DMA addresses */    \
+                    if (k % (NM / NDMA) == NM / NDMA - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* a DMA */      \
+                }                                                                                                               \
+            }                                                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        }
+        // second half: row tiles 2, 3; with PRE_ the fragments of the next slab (buffer nxt) replace this slab's as they
+        // retire (the MFMAs run column-tile-major for that)
+#define RING_HALF1(PRE_, S_, DMA_)                                                                                                      \
+        {                                                                                                                       \
+            const uint8_t* xn = smem + nxt * BUF;                                                                               \
+            if (DMA_ && !(ABL & 1)) {                                                                                           \
+                dma_x(dmb);                                                                                                     \
+                dma_w(min((S_) + 2, s_end - 1), dmb);                                                                           \
+            }                                                                                                                   \
+            if (PRE_ && !(ABL & 4)) {                                                                                           \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                   \
+                    _Pragma("unroll") for (int p = 0; p < NPL; ++p)                                                             \
+                        af0[i][p] = *reinterpret_cast<const bf16x8*>(xn + xoff[i] + p * (BM * 64));                             \
+            }                                                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < 2 * NJ; ++j) {                                                                \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
+                    f32x4 c = MM16(af1[i][1], bf[j][0], accl16[2 + i][j]);                                                      \
+                    accl16[2 + i][j] = MM16(af1[i][0], bf[j][1], c);                                                            \
+                    acc16[2 + i][j] = MM16(af1[i][0], bf[j][0], acc16[2 + i][j]);                                               \
+                }                                                                                                               \
+                if (PRE_ && !(ABL & 4)) {                                                                                       \
+                    _Pragma("unroll") for (int p = 0; p < NPL; ++p)                                                             \
+                        bf[j][p] = *reinterpret_cast<const bf16x8*>(xn + woff[j] + p * WPL);                                    \
+                }                                                                                                               \
+            }                                                                                                                   \
+            if (PRE_) {                                                                                                         \
+                _Pragma("unroll") for (int k = 0; k < NM; ++k) {                                                                \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                          \
+                    if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+                    else if (k >= 6 && ((k - 6) % 6) < NPL) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  \
+                    if (DMA_) {                                                                                                 \
+                        __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                                                      \
+                        if (k % (NM / NDMA) == NM / NDMA - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
+                    }                                                                                                           \
+                }                                                                                                               \
+                __builtin_amdgcn_sched_barrier(0);                                                                              \
+            }                                                                                                                   \
+        }
+        // (Tried: the two waves that share a SIMD issuing their DMAs in different halves -- early waves in the first half with
+        // the DMAs left in flight over the barrier, late waves right after it -- so that one of the pair always feeds the
+        // matrix pipe while the other sits in a DMA's issue.  445 vs 429 us on the 145-GF layer, and 256 VGPRs: rejected.)
+        RING_HALF0(s_begin, true);
+        for (int s = s_begin; s < s_end - 1; ++s) {
+            // slab s+1 (issued one slab ago) has landed for this wave, then for every wave; slab s+2's DMAs stay in flight
+            if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+            RING_HALF1(true, s, false);
+            cur = nxt; nxt = dmb; dmb = dmb == 2 ? 0 : dmb + 1;
+            RING_HALF0(s + 1, true);
+        }
+        RING_HALF1(false, 0, false);
+#undef RING_HALF0
+#undef RING_HALF1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (unused) slabs must land before the epilogue reuses the LDS
+#undef MM16
+    } else {
     dma_x(s_begin & 1);
     dma_w(s_begin, s_begin & 1);
     for (int s = s_begin; s < s_end; ++s) {
@@ -953,6 +1071,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 }
         PL_STAMP(4);
     }
+    }
 #undef MFMA16
 #undef PL_STAMP
     if (tr) a.trace[(wave != 0) * 512 + 7] = clock64();
@@ -993,7 +1112,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 // image row (which also covers rows that wrapped to the neighbouring image row).  Activation DMA bytes drop by kw; the
 // weight tile is staged per tap as before.  256 x 128 tiles, 8 waves; LDS: two activation buffers of (256+16) rows and two
 // weight buffers = 150 KB.
-template <int NPL>
+template <int NPL, int DT = 0>
 __global__ __launch_bounds__(512, 1) void conv_planar_kx_kernel(const PlanarArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1093,6 +1212,9 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx_kernel(const PlanarArgs
         }
     };
 
+#define KX_MFMA(x_, y_, c_, i0_, i1_, i2_) \
+    (DT == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x_), __builtin_bit_cast(f16x8, y_), c_, 0, 0, 0) \
+             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, y_, c_, 0, 0, 0))
     f32x16 acc[2][NJ], accl[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1148,13 +1270,13 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx_kernel(const PlanarArgs
                 for (int j = 0; j < NJ; ++j) {
                     f32x16 c = accl[i][j];
                     if constexpr (NPL == 3) {
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+                        c = KX_MFMA(af[i][2], bf[j][0], c, 0, 0, 0);
+                        c = KX_MFMA(af[i][0], bf[j][2], c, 0, 0, 0);
+                        c = KX_MFMA(af[i][1], bf[j][1], c, 0, 0, 0);
                     }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-                    accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    c = KX_MFMA(af[i][1], bf[j][0], c, 0, 0, 0);
+                    accl[i][j] = KX_MFMA(af[i][0], bf[j][1], c, 0, 0, 0);
+                    acc[i][j] = KX_MFMA(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                 }
             if (ks == 0) {
 #pragma unroll
@@ -1169,7 +1291,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx_kernel(const PlanarArgs
         x_in_flight = stage_x && !(a.dbg & 1);
         if (++kx == a.kw) { kx = 0; xi ^= 1; if (++ky == a.kh) { ky = 0; ++cs; } }
     }
-    planar_epilogue<NJ>(a, acc, accl, smem, wave, lane, m0, n0g, grp, wm, wn);
+    #undef KX_MFMA
+    planar_epilogue<NJ>(a, acc, accl, smem, wave, lane, m0, n0g, grp, wm, wn, DT == 1 ? 1.0f / STM_F16_LOW_SCALE : 1.0f);
 #endif
 }
 
@@ -1242,24 +1365,24 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
     }
 }
 
-template <int NPL, int MG, int NJ, int MF, int DT = 0>
+template <int NPL, int MG, int NJ, int MF, int DT = 0, int ST = 2, int ABL = 0>
 int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
 {
-    size_t lds = (size_t)2 * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
+    size_t lds = (size_t)ST * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
     const size_t park = (size_t)4 * MG * 64 * (32 * NJ + 4) * sizeof(float);   // the epilogue parks one 64 x 32NJ tile per wave
     if (lds < park) lds = park;
     static bool lds_reserved = false;   // per instantiation; the attribute is sticky, setting it again each launch only costs host time
     if (!lds_reserved) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, MF, DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, MF, DT, ST, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
         lds_reserved = true;
     }
-    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, MF, DT>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
+    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, MF, DT, ST, ABL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kernel");
     return STM_OK;
 }
 
-template <int NPL>
+template <int NPL, int DT = 0>
 int launch_planar_kx(const PlanarArgs& a, int tiles, stm_stream_t stream)
 {
     const size_t lds = (size_t)2 * NPL * (2 * CV_BM + 16) * 64 + (size_t)2 * NPL * CV_PLANE_B;   // >= the epilogue's 139 KB park (NPL 3)
@@ -1267,11 +1390,11 @@ int launch_planar_kx(const PlanarArgs& a, int tiles, stm_stream_t stream)
     const size_t need = lds < park ? park : lds;
     static bool lds_reserved = false;
     if (!lds_reserved) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kx_kernel<NPL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kx_kernel<NPL, DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)need) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", need);
         lds_reserved = true;
     }
-    hipLaunchKernelGGL((conv_planar_kx_kernel<NPL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(512), need, stm_hs(stream), a);
+    hipLaunchKernelGGL((conv_planar_kx_kernel<NPL, DT>), dim3(8 * stm_cdiv(tiles, 8)), dim3(512), need, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kx_kernel");
     return STM_OK;
 }
@@ -1556,7 +1679,16 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         plan_splitk(a.m_tiles * a.n_tiles);
         const int tiles = a.m_tiles * a.n_tiles * a.splitk;
         int rc64;
-        if (a.fmt == 1) rc64 = launch_planar<2, 1, 1, 1, 1>(a, tiles, stream);
+        // the three-buffer ring (72 KB: still two workgroups per CU) has no skip of zero-padded column tiles: layers whose
+        // every group fills its 64-channel tile take it, the narrow ones keep the guarded two-buffer loop
+        bool full = cout_g % 64 == 0;
+        for (int gi = 0; gi < groups && gi < 8; ++gi) full = full && a.group_real[gi] == cout_g;
+        static const int ring64 = getenv("STM_CONV_RING64") ? atoi(getenv("STM_CONV_RING64")) : 3;
+        // measured in the graph (bench.py --layer-table): the ring wins on the short K loops (<= 36 slabs: 35 -> 30 us,
+        // 46 -> 36 us, 45 -> 37 us), where its two-slab head start hides the first DMA latency, and loses on the long and
+        // the split-K ones (100 -> 114 us at 72 slabs), where two resident two-buffer workgroups already cover each other
+        if (a.fmt == 1 && full && (ring64 == 3 ? (a.splitk == 1 && a.slabs <= 40) : ring64 == 4)) rc64 = launch_planar<2, 1, 1, 1, 1, 3>(a, tiles, stream);
+        else if (a.fmt == 1) rc64 = launch_planar<2, 1, 1, 1, 1>(a, tiles, stream);
         else if (mf16) rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
         else rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 0>(a, tiles, stream) : launch_planar<2, 1, 1, 0>(a, tiles, stream);
         return rc64 != STM_OK ? rc64 : finish_splitk();
@@ -1573,13 +1705,21 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     const char* fkx = getenv("STM_CONV_KX");
     // (measured: no gain over the per-tap kernel -- 654 vs 670 us on the 145-GF proto layer although it moves 1.8x fewer
     // bytes; the ablations in DESIGN.md section 6 show why -- so it is opt-in: STM_CONV_KX=1)
-    const bool kx_ok = a.fmt == 0 && mg == 2 && g->kw >= 3 && g->kw <= 5 && g->sh == 1 && g->sw == 1 && 2 * g->pw == g->kw - 1 &&
+    const bool kx_ok = mg == 2 && g->kw >= 3 && g->kw <= 5 && g->sh == 1 && g->sw == 1 && 2 * g->pw == g->kw - 1 &&
                        2 * g->ph == g->kh - 1 && fkx && atoi(fkx) == 1;
+    if (kx_ok && a.fmt == 1) return launch_planar_kx<2, 1>(a, a.m_tiles * a.n_tiles, stream);
     if (kx_ok) return g->planes == 3 ? launch_planar_kx<3>(a, a.m_tiles * a.n_tiles, stream) : launch_planar_kx<2>(a, a.m_tiles * a.n_tiles, stream);
     plan_splitk(a.m_tiles * a.n_tiles);
     const int tiles = a.m_tiles * a.n_tiles * a.splitk;
     int rc;
-    if (a.fmt == 1) rc = mg == 2 ? launch_planar<2, 2, 2, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 1>(a, tiles, stream);
+    static const int ring = getenv("STM_CONV_RING") ? atoi(getenv("STM_CONV_RING")) : 3;   // 2: the two-buffer loop (A/B runs)
+    static const int abl = getenv("STM_CONV_ABL") ? atoi(getenv("STM_CONV_ABL")) : 0;   // timing ablations (wrong results)
+    if (a.fmt == 1 && ring == 3 && mg == 2 && abl)
+        rc = abl == 1 ? launch_planar<2, 2, 2, 1, 1, 3, 1>(a, tiles, stream) : abl == 2 ? launch_planar<2, 2, 2, 1, 1, 3, 2>(a, tiles, stream)
+           : abl == 3 ? launch_planar<2, 2, 2, 1, 1, 3, 3>(a, tiles, stream) : abl == 5 ? launch_planar<2, 2, 2, 1, 1, 3, 5>(a, tiles, stream)
+                      : launch_planar<2, 2, 2, 1, 1, 3, 7>(a, tiles, stream);
+    else if (a.fmt == 1 && ring == 3) rc = mg == 2 ? launch_planar<2, 2, 2, 1, 1, 3>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 1, 3>(a, tiles, stream);
+    else if (a.fmt == 1) rc = mg == 2 ? launch_planar<2, 2, 2, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 1>(a, tiles, stream);
     else if (mf16) {
         if (g->planes == 3) rc = mg == 2 ? launch_planar<3, 2, 2, 1>(a, tiles, stream) : launch_planar<3, 1, 2, 1>(a, tiles, stream);
         else rc = mg == 2 ? launch_planar<2, 2, 2, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1>(a, tiles, stream);
