@@ -141,6 +141,7 @@ def optimize_for_inference(net, planar=False, planes="fp16x2"):
         _planar.set_format(1 if planes == "fp16x2" else 0)
         net._planar = PlanarGraph(net)
         net._planar_backbone = PlanarBackbone(net.backbone)
+        net._planar_backbone.planes_only = True     # the planar FPN laterals read the stage outputs as planes
         if getattr(net, "TemporalNet", None) is not None:
             net._planar_temporal = PlanarTemporalNet(net.TemporalNet)
     return n_bn, n_fused

@@ -66,16 +66,18 @@ class STMask(nn.Module):
 
     # -- trunk + heads (reference STMask.py:205-282) ----------------------------------------------------------------
     def forward_single(self, x):
+        planes = None      # planar form of the selected backbone outputs (PlanarBackbone only)
         if self.backbone_fp16 and x.is_cuda:
             with torch.autocast("cuda", dtype=torch.float16):
                 bb_outs = self.backbone(x)
             bb_outs = tuple(o.float() for o in bb_outs)
         elif getattr(self, "_planar_backbone", None) is not None:
             bb_outs = self._planar_backbone(x)
+            planes = [self._planar_backbone.out_planes[i] for i in self.backbone_selected]
         else:
             bb_outs = self.backbone(x)
         if getattr(self, "_planar", None) is not None:     # fuse.optimize_for_inference(net, planar=True)
-            return self._planar.run([bb_outs[i] for i in self.backbone_selected])
+            return self._planar.run([bb_outs[i] for i in self.backbone_selected], planes=planes)
         fpn_outs = self.fpn([bb_outs[i] for i in self.backbone_selected])
         proto = F.relu(self.proto_net(fpn_outs[self.proto_src]))
         proto = proto.permute(0, 2, 3, 1).contiguous()

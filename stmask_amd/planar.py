@@ -198,6 +198,9 @@ class PlanarGraph:
         # FPN prediction convs always end in ReLU (FPN.py:96-100); downsample convs do not
         self.fpn_pred = [PlanarConv(m.weight, m.bias, m.stride, m.padding, relu=True) for m in fpn.pred_layers]
         self.fpn_down = [PlanarConv(m.weight, m.bias, m.stride, m.padding, relu=False) for m in fpn.downsample_layers]
+        # lateral 1x1 convs (FPN.py:84-93), used when the backbone hands over its outputs as planes (PlanarBackbone): the
+        # upsampled coarser level enters as the fp32 residual of the epilogue, the sum leaves as planes for the prediction conv
+        self.fpn_lat = [PlanarConv(m.weight, m.bias, 1, 0, relu=False) for m in fpn.lat_layers]
         # proto-net: Conv2d / ReLU / InterpolateModule sequence, then F.relu in STMask.forward_single
         self.proto = []
         mods = [m for m in net.proto_net.children() if not isinstance(m, (torch.nn.ReLU, torch.nn.Identity))]
@@ -262,26 +265,45 @@ class PlanarGraph:
         self.head = head
 
     # ------------------------------------------------------------------------------------------------------------
-    def run(self, bb_outs):
-        """bb_outs: the selected backbone outputs (C3, C4, C5).  Returns (fpn_outs, pred) as STMask.forward_single."""
+    def run(self, bb_outs, planes=None):
+        """bb_outs: the selected backbone outputs (C3, C4, C5) as fp32 NCHW tensors, or -- planes given -- their planar
+        form [(planes, B, H, W), ...] from PlanarBackbone (bb_outs may then hold None).  Returns (fpn_outs, pred) as
+        STMask.forward_single."""
         net, fpn = self.net, self.net.fpn
         n = self.n_lat
-        B = bb_outs[0].shape[0]
         toc = self.timer.toc if self.timer is not None else (lambda name: None)
         toc("backbone")
-        # laterals + top-down pathway in fp32 (1x1 convs on the widest tensors: left to the GEMM library)
-        lat, x = [None] * n, None
-        for i, layer in enumerate(fpn.lat_layers):
-            j = n - 1 - i
-            lateral = layer(bb_outs[j])
-            if x is None:
-                x = lateral
-            else:
-                h, w = bb_outs[j].shape[2:]
-                x = F.interpolate(x, size=(h, w), mode=fpn.interpolation_mode, align_corners=False) + lateral
-            lat[j] = x
+        lat, latp, x = [None] * n, [None] * n, None
+        if planes is not None:
+            # laterals + top-down pathway on the planar kernel: lat_j = conv1x1(C_j) + upsample(lat_{j+1}) in one epilogue
+            B = planes[0][1]
+            sizes = [(h, w) for (_, _, h, w) in planes]
+            for i, conv in enumerate(self.fpn_lat):
+                j = n - 1 - i
+                h, w = sizes[j]
+                res = None
+                if x is not None:
+                    up = F.interpolate(x, size=(h, w), mode=fpn.interpolation_mode, align_corners=False)
+                    res = _nhwc(up).view(-1, conv.O)
+                if j > 0:                                  # a finer level follows: it upsamples this one in fp32
+                    y32, latp[j] = conv(planes[j][0], ("img", B, h, w), out="both", residual=res)
+                    x = y32.view(B, h, w, conv.O).permute(0, 3, 1, 2)
+                else:
+                    latp[j] = conv(planes[j][0], ("img", B, h, w), out="planes", residual=res)
+        else:
+            # fp32 NCHW inputs (module backbone): laterals + top-down pathway left to the GEMM library
+            B = bb_outs[0].shape[0]
+            for i, layer in enumerate(fpn.lat_layers):
+                j = n - 1 - i
+                lateral = layer(bb_outs[j])
+                if x is None:
+                    x = lateral
+                else:
+                    h, w = bb_outs[j].shape[2:]
+                    x = F.interpolate(x, size=(h, w), mode=fpn.interpolation_mode, align_corners=False) + lateral
+                lat[j] = x
+            sizes = [tuple(t.shape[2:]) for t in lat]
         toc("fpn_lateral")
-        sizes = [tuple(t.shape[2:]) for t in lat]
         for d in self.fpn_down:
             h, w = sizes[-1]
             sizes.append(ops.conv_out_hw(h, w, d.kh, d.kw, d.sh, d.sw, d.ph, d.pw, 1, 1))
@@ -289,7 +311,7 @@ class PlanarGraph:
         for h, w in sizes:
             starts.append(starts[-1] + B * h * w)
         ntot, nf = starts[-1], self.fpn_pred[0].O
-        dev = lat[0].device
+        dev = (latp[0] if latp[0] is not None else lat[0]).device
         NP, pdt = _planes_dtype(self.fmt)
         feat = torch.empty(NP, nf // 32, ntot, 32, device=dev, dtype=pdt)   # P3..P7, all levels, planar
         feat32 = torch.empty(ntot, nf, device=dev, dtype=torch.float32) if not self.head_planar else None
@@ -297,7 +319,7 @@ class PlanarGraph:
         for i, conv in enumerate(self.fpn_pred):
             j = n - 1 - i
             h, w = sizes[j]
-            xp = _split(_nhwc(lat[j]), self.fmt)
+            xp = latp[j] if latp[j] is not None else _split(_nhwc(lat[j]), self.fmt)
             if feat32 is not None:     # module-path head: it wants every level in fp32 as well
                 conv(xp, ("img", B, h, w), out="both", out_planes=feat, out_f32=feat32, out_off=starts[j])
                 fpn_outs[j] = feat32[starts[j]:starts[j + 1]].view(B, h, w, nf).permute(0, 3, 1, 2)
@@ -472,6 +494,8 @@ class PlanarBackbone:
         from .dcn_v2 import DCN
         self.bb = bb
         self.fmt = FMT
+        self.planes_only = False    # fuse: the planar FPN takes the stage outputs as planes; their fp32 copies are not made
+        self.out_planes = None      # [(planes, B, H, W)] of the last call, one entry per stage
         self.blocks = []
         for layer in bb.layers:
             blks = []
@@ -503,7 +527,7 @@ class PlanarBackbone:
         x = bb.maxpool(bb.relu(bb.bn1(bb.conv1(x))))        # conv1 carries the folded BN + ReLU after fuse
         B, C, H, W = x.shape
         xp = _split(_nhwc(x), self.fmt)
-        outs = []
+        outs, self.out_planes = [], []
         for blks in self.blocks:
             y32 = None
             for bi, e in enumerate(blks):
@@ -538,9 +562,10 @@ class PlanarBackbone:
                     mid = e["c2"](e["c1"](xp, shape), shape)
                 res = e["ds"](xp, shape) if "ds" in e else xp
                 H, W = Ho, Wo
-                if last:
+                if last and not self.planes_only:
                     y32, xp = e["c3"](mid, ("img", B, H, W), out="both", residual=res)
                 else:
                     xp = e["c3"](mid, ("img", B, H, W), residual=res)
-            outs.append(y32.view(B, H, W, -1).permute(0, 3, 1, 2))                       # channels_last NCHW view
+            self.out_planes.append((xp, B, H, W))
+            outs.append(y32.view(B, H, W, -1).permute(0, 3, 1, 2) if y32 is not None else None)   # channels_last NCHW view
         return tuple(outs)
