@@ -21,6 +21,8 @@
 // two workgroups per CU, so one workgroup's split/stage phase runs under the other's MFMA phase.
 #include "stm_common.h"
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 
 static long long* g_conv_trace = nullptr;   // see stm_debug_conv_set_trace
 
@@ -492,6 +494,8 @@ struct PlanarArgs {
     int* range_flag;          // fmt 1: set to 1 when an output has no fp16 representation (see f16_range_check8); may be null
     int splitk, kslabs, ldp;  // split-K: K-slabs per split, fp32 partial sums [splitk][M][ldp] in `partial`
     float* partial;
+    int* tickets;           // split-K: one counter per output tile (zero between launches); the part that draws the last
+                            // ticket adds the parts and runs the epilogue.  Null: planar_splitk_finish_kernel does it
     int dbg;                // STM_CONV_DEBUG timing ablations (results wrong): 1 no DMA in the loop, 2 no barrier, 4 no MFMA
     int vec_epilogue;       // Cout, out_ld, res_ld multiples of 8 and 16-byte aligned pointers: vector epilogue
     long long* trace;
@@ -1096,6 +1100,35 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
             *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
             *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
         }
+        if (a.tickets) {
+            // fused reduction: every part publishes its sums (device-scope release), then draws a ticket of its tile; the part
+            // that draws the last one knows all others are published, adds the parts in part order (the order the separate
+            // finishing kernel uses: same bits) and runs the epilogue.  It leaves the counter at zero for the next launch.
+            __threadfence();
+            __syncthreads();
+            int* sh = reinterpret_cast<int*>(smem);
+            if (tid == 0) sh[0] = atomicAdd(a.tickets + tile, 1);
+            __syncthreads();
+            if (sh[0] == a.splitk - 1) {
+                __threadfence();
+                constexpr int SEGS = BN / 8;
+                for (int sg = tid; sg < BM * SEGS; sg += 256 * MG) {
+                    const int pr = sg / SEGS, cs8 = (sg - pr * SEGS) * 8;
+                    const int m = m0 + pr;
+                    const int cog = n0g + cs8;
+                    const int nvalid = min(8, a.cout_g - cog);
+                    if (m >= a.M || nvalid <= 0) continue;
+                    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int k = 0; k < a.splitk; ++k) {
+                        const float* p = a.partial + ((size_t)k * a.M + m) * a.ldp + nt * BN + cs8;
+                        const f32x4 p0 = *reinterpret_cast<const f32x4*>(p), p1 = *reinterpret_cast<const f32x4*>(p + 4);
+                        v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+                    }
+                    epilogue_store8(a, m, grp * a.cout_g + cog, nvalid, v);
+                }
+                if (tid == 0) a.tickets[tile] = 0;
+            }
+        }
     } else {
         planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
     }
@@ -1416,6 +1449,22 @@ bool geom_ok(const stm_conv_geom* g, const char* who)
     return true;
 }
 
+// split-K tile tickets: one zeroed 16 KB block per stream, owned by the library (the kernels leave it zeroed)
+constexpr int SPLITK_MAX_TILES = 4096;
+int* splitk_tickets(hipStream_t stream)
+{
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, int*> blocks;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = blocks.find(stream);
+    if (it != blocks.end()) return it->second;
+    int* p = nullptr;
+    if (hipMalloc(&p, SPLITK_MAX_TILES * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, SPLITK_MAX_TILES * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }   // synchronous: done before any launch
+    blocks[stream] = p;
+    return p;
+}
+
 }  // namespace
 
 int* stm_internal_range_flag() { return g_range_flag; }
@@ -1644,7 +1693,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     a.out_scale = (g->fmt == 1 && g->out_scale > 0.0f) ? g->out_scale : 1.0f;
     a.range_flag = g_range_flag;
     STM_REQUIRE(a.fmt == 0 || g->planes == 2, STM_EINVAL, "%s: the fp16 format has two planes", who);
-    a.splitk = 1; a.kslabs = a.slabs; a.partial = nullptr; a.ldp = a.n_tiles * bn;
+    a.splitk = 1; a.kslabs = a.slabs; a.partial = nullptr; a.tickets = nullptr; a.ldp = a.n_tiles * bn;
     // split-K for grids that would leave most CUs idle over a long K (small feature maps: ResNet stages 3/4, P5-P7):
     // parts write fp32 partial sums into the caller's workspace, planar_splitk_finish_kernel adds them and runs the epilogue
     auto plan_splitk = [&](int tiles) {
@@ -1655,7 +1704,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
             if (bn == 64) {
                 // 128 x 64 tiles run two workgroups per CU; a grid of at most one workgroup per CU spends its time in
                 // the staging latency of each K-slab, so split K until ~3 workgroups per CU are resident or queued
-                static const int target = getenv("STM_CONV_SK_TARGET") ? atoi(getenv("STM_CONV_SK_TARGET")) : 768;
+                const int target = getenv("STM_CONV_SK_TARGET") ? atoi(getenv("STM_CONV_SK_TARGET")) : 768;
                 if (tiles <= 256 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, target / tiles), a.slabs / 10);
             } else if (tiles < 128 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, 256 / tiles), a.slabs / 12);
         }
@@ -1664,9 +1713,14 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         sk = stm_cdiv(a.slabs, per);
         if (sk < 2 || !workspace || (size_t)sk * M * a.ldp * sizeof(float) > workspace_bytes || ((uintptr_t)workspace % 16)) return;
         a.splitk = sk; a.kslabs = per; a.partial = static_cast<float*>(workspace);
+        // The fused reduction (last ticket of a tile adds the parts) saves the finishing launch but needs device-scope
+        // release / acquire fences around the ticket, i.e. an L2 write-back and invalidate per workgroup on this part:
+        // 665 frames/s against 919 with the separate finishing kernel.  Opt-in (STM_CONV_SPLITK_FUSED=1), kept for the record.
+        const char* ff = getenv("STM_CONV_SPLITK_FUSED");
+        if (tiles <= SPLITK_MAX_TILES && ff && atoi(ff) == 1) a.tickets = splitk_tickets(stm_hs(stream));
     };
     auto finish_splitk = [&]() -> int {
-        if (a.splitk < 2) return STM_OK;
+        if (a.splitk < 2 || a.tickets) return STM_OK;
         const int64_t total = M * groups * ((cout_g + 7) / 8);
         hipLaunchKernelGGL(planar_splitk_finish_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), a, bn);
         STM_CHECK_LAUNCH("planar_splitk_finish_kernel");
@@ -1683,7 +1737,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         // every group fills its 64-channel tile take it, the narrow ones keep the guarded two-buffer loop
         bool full = cout_g % 64 == 0;
         for (int gi = 0; gi < groups && gi < 8; ++gi) full = full && a.group_real[gi] == cout_g;
-        static const int ring64 = getenv("STM_CONV_RING64") ? atoi(getenv("STM_CONV_RING64")) : 3;
+        const int ring64 = getenv("STM_CONV_RING64") ? atoi(getenv("STM_CONV_RING64")) : 3;
         // measured in the graph (bench.py --layer-table): the ring wins on the short K loops (<= 36 slabs: 35 -> 30 us,
         // 46 -> 36 us, 45 -> 37 us), where its two-slab head start hides the first DMA latency, and loses on the long and
         // the split-K ones (100 -> 114 us at 72 slabs), where two resident two-buffer workgroups already cover each other
@@ -1712,8 +1766,8 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     plan_splitk(a.m_tiles * a.n_tiles);
     const int tiles = a.m_tiles * a.n_tiles * a.splitk;
     int rc;
-    static const int ring = getenv("STM_CONV_RING") ? atoi(getenv("STM_CONV_RING")) : 3;   // 2: the two-buffer loop (A/B runs)
-    static const int abl = getenv("STM_CONV_ABL") ? atoi(getenv("STM_CONV_ABL")) : 0;   // timing ablations (wrong results)
+    const int ring = getenv("STM_CONV_RING") ? atoi(getenv("STM_CONV_RING")) : 3;   // 2: the two-buffer loop (A/B runs)
+    const int abl = getenv("STM_CONV_ABL") ? atoi(getenv("STM_CONV_ABL")) : 0;   // timing ablations (wrong results)
     if (a.fmt == 1 && ring == 3 && mg == 2 && abl)
         rc = abl == 1 ? launch_planar<2, 2, 2, 1, 1, 3, 1>(a, tiles, stream) : abl == 2 ? launch_planar<2, 2, 2, 1, 1, 3, 2>(a, tiles, stream)
            : abl == 3 ? launch_planar<2, 2, 2, 1, 1, 3, 3>(a, tiles, stream) : abl == 5 ? launch_planar<2, 2, 2, 1, 1, 3, 5>(a, tiles, stream)

@@ -367,3 +367,48 @@ def test_fp16_range_flag_is_raised_by_every_plane_producer():
     assert raised() == 1
     ops.dcn_sample_planar((xs * 1e-3).to(DEV), om.to(DEV), 1, 1, 1, fmt=1)
     assert raised() == 0
+
+
+@pytest.mark.parametrize("tile_n", [64, 128])
+def test_conv_planar_fp16_loop_variants_agree_bitwise(tile_n, monkeypatch):
+    """The K-loop variants of the fp16-format kernel -- three-buffer ring with fragment prefetch (default on the 128-wide
+    tiles and the short loops of the 64-wide ones), the two-buffer loop, the kx-reuse kernel -- and the two split-K
+    reductions (separate finishing kernel, opt-in fused last-ticket reduction) add the same products in the same order: same bits."""
+    from stmask_amd.planar import PlanarConv, set_format
+    set_format(1)
+    try:
+        for (B, H, W, C, O, k) in [(2, 24, 40, 64, 128, 3), (8, 48, 80, 128, 256, 3), (1, 12, 20, 512, 64, 1), (2, 6, 10, 1024, 128, 3)]:
+            x = rnd(B, H, W, C, seed=C + k)
+            w = rnd(O, C, k, k, seed=O, scale=(C * k * k) ** -0.5)
+            b = rnd(O, seed=7)
+            conv = PlanarConv(w.to(DEV), b.to(DEV), 1, k // 2, relu=True, tile_n=tile_n)
+            xp = ops.split_planes(x.to(DEV), fmt=1)
+            outs = {}
+            for name, env in [("ring", {}), ("two-buffer", {"STM_CONV_RING": "2", "STM_CONV_RING64": "2"}), ("ring64", {"STM_CONV_RING64": "4"}),
+                              ("kx", {"STM_CONV_KX": "1"}), ("splitk-fused", {"STM_CONV_SPLITK": "3", "STM_CONV_SPLITK_FUSED": "1"}),
+                              ("splitk-finish", {"STM_CONV_SPLITK": "3"})]:
+                for kk, vv in env.items():
+                    monkeypatch.setenv(kk, vv)
+                y32, ypl = conv(xp, ("img", B, H, W), out="both")
+                outs[name] = (y32.cpu(), ypl.cpu())
+                for kk in env:
+                    monkeypatch.delenv(kk)
+            ref = oracle.conv2d_nhwc(x, w, b, None, padding=k // 2, relu=True)
+            mag = oracle.conv2d_nhwc(x.abs(), w.abs(), b.abs(), None, padding=k // 2)
+            assert ((outs["ring"][0].view(ref.shape) - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
+            for name in ("two-buffer", "ring64"):
+                assert torch.equal(outs[name][0], outs["ring"][0]) and torch.equal(outs[name][1], outs["ring"][1]), (name, C, k)
+            # the kx-reuse kernel multiplies with the 32x32x16 instruction (16 channels per accumulation step instead of 32)
+            assert ((outs["kx"][0] - outs["ring"][0]).abs() / mag.view(-1, O).clamp_min(1e-6)).max().item() < 1e-6
+            assert torch.equal(outs["splitk-fused"][0], outs["splitk-finish"][0]) and torch.equal(outs["splitk-fused"][1], outs["splitk-finish"][1])
+            assert ((outs["splitk-fused"][0] - outs["ring"][0]).abs() / mag.view(-1, O).clamp_min(1e-6)).max().item() < 1e-6
+        # the fused reduction leaves its tickets at zero: a second launch gives the same result
+        monkeypatch.setenv("STM_CONV_SPLITK", "4")
+        monkeypatch.setenv("STM_CONV_SPLITK_FUSED", "1")
+        y1 = conv(xp, ("img", B, H, W), out="f32").cpu()
+        y2 = conv(xp, ("img", B, H, W), out="f32").cpu()
+        monkeypatch.delenv("STM_CONV_SPLITK")
+        monkeypatch.delenv("STM_CONV_SPLITK_FUSED")
+        assert torch.equal(y1, y2)
+    finally:
+        set_format(1)
