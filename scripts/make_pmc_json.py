@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""profiles/r01_pmc_traffic.json from the two PMC passes of `scripts/gpu_round.sh pmc` (gpurun_out/pmc_fetch, pmc_write).
+Keeps the top-level deform_im2col_lds entry of the existing file (it comes from an earlier --no-planar pass).
+usage: python scripts/make_pmc_json.py gpurun_out profiles/r01_pmc_traffic.json"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from summarize_pmc import load  # noqa: E402
+
+
+def main():
+    out, dst = sys.argv[1], sys.argv[2]
+    fetch = load(os.path.join(out, "pmc_fetch"), "FETCH_SIZE")
+    write = load(os.path.join(out, "pmc_write"), "WRITE_SIZE")
+    try:
+        doc = json.load(open(dst))
+    except (OSError, ValueError):
+        doc = {}
+    keep = {k: doc[k] for k in ("kernel", "fetch_bytes_per_launch", "write_bytes_per_launch", "traffic_bytes_per_launch") if k in doc}
+
+    def group(prefix):
+        fb = sum(v[0] for k, v in fetch.items() if prefix in k) * 1024 * 2     # KiB -> bytes, gfx950 x2 correction
+        nf = sum(v[1] for k, v in fetch.items() if prefix in k)
+        wb = sum(v[0] for k, v in write.items() if prefix in k) * 1024
+        nw = sum(v[1] for k, v in write.items() if prefix in k)
+        if not nf or not nw:
+            return None
+        return {"launches": nf, "fetch_bytes_per_launch": fb / nf, "write_bytes_per_launch": wb / nw, "traffic_bytes_per_launch": fb / nf + wb / nw}
+
+    doc = dict(keep)
+    g = group("dcn_sample_planar_kernel")
+    if g:
+        doc["dcn_sample_planar"] = {"kernel": "dcn_sample_planar_kernel (7 DCN layers of R50 at batch 8)", **g}
+    g = group("conv_planar_kernel")
+    if g:
+        doc["conv_planar"] = {"kernel": "conv_planar_kernel<*> (all launches of bench.py at batch 8, fp16x2 plane format)", **g}
+    doc["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 4 --warmup 2` (scripts/gpu_round.sh pmc); "
+                     "counters are KiB; FETCH_SIZE doubled per the gfx950 correction (MI355X guide, HBM section); WRITE_SIZE exact for 16-byte streaming stores")
+    per = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not any(t in k for t in ("anonymous namespace", "stm_", "conv_planar", "dcn_", "corr_", "lincomb", "nms", "head_assemble", "roi_align", "mask_")):
+            continue
+        nf, nw = max(fetch[k][1], 1), max(write[k][1], 1)
+        name = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        per[name] = {"launches": fetch[k][1], "fetch_mb": round(fetch[k][0] / nf * 2048 / 1e6, 2), "write_mb": round(write[k][0] / nw * 1024 / 1e6, 2)}
+    doc["per_kernel"] = per
+    json.dump(doc, open(dst, "w"), indent=1)
+    print(json.dumps({k: v for k, v in doc.items() if k != "per_kernel"}, indent=1)[:1500])
+
+
+if __name__ == "__main__":
+    main()

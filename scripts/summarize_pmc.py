@@ -18,7 +18,7 @@ def load(dirname, counter):
             for row in csv.DictReader(fh):
                 if row.get("Counter_Name") != counter:
                     continue
-                k = row["Kernel_Name"].split("(")[0][:70]
+                k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
                 acc[k][0] += float(row["Counter_Value"])
                 acc[k][1] += 1
     return acc

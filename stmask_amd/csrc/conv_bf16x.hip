@@ -688,7 +688,7 @@ __device__ __forceinline__ void planar_epilogue(const PlanarArgs& a, f32x16 (&ac
     planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
 }
 
-template <int NPL, int MG, int NJ, int MF, int DT = 0, int ST = 2, int ABL = 0>   // ABL: timing ablations of the ring loop (results wrong): 1 no DMA, 2 no barrier, 4 no fragment reads; ST = 3: three-buffer LDS ring with fragment prefetch (fp16 format); DT = 1: fp16 planes / v_mfma_f32_16x16x32_f16 (NPL 2, MF 1 only); MF = 1: v_mfma_f32_16x16x32_bf16 (less energy per flop; the chip is power-limited here), 0: 32x32x16
+template <int NPL, int MG, int NJ, int MF, int DT = 0, int ST = 2, int ABL = 0>   // ABL: timing ablations of the ring loop (results wrong): 1 no DMA, 2 no barrier, 4 no fragment reads, 8 no wait for the DMAs; ST = 3: three-buffer LDS ring with fragment prefetch (fp16 format); DT = 1: fp16 planes / v_mfma_f32_16x16x32_f16 (NPL 2, MF 1 only); MF = 1: v_mfma_f32_16x16x32_bf16 (less energy per flop; the chip is power-limited here), 0: 32x32x16
 __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
@@ -912,7 +912,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         RING_HALF0(s_begin, true);
         for (int s = s_begin; s < s_end - 1; ++s) {
             // slab s+1 (issued one slab ago) has landed for this wave, then for every wave; slab s+2's DMAs stay in flight
-            if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+            if constexpr (ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // no wait for the DMAs to land
+            else if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
             RING_HALF1(true, s, false);
             cur = nxt; nxt = dmb; dmb = dmb == 2 ? 0 : dmb + 1;
@@ -1771,6 +1772,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     if (a.fmt == 1 && ring == 3 && mg == 2 && abl)
         rc = abl == 1 ? launch_planar<2, 2, 2, 1, 1, 3, 1>(a, tiles, stream) : abl == 2 ? launch_planar<2, 2, 2, 1, 1, 3, 2>(a, tiles, stream)
            : abl == 3 ? launch_planar<2, 2, 2, 1, 1, 3, 3>(a, tiles, stream) : abl == 5 ? launch_planar<2, 2, 2, 1, 1, 3, 5>(a, tiles, stream)
+           : abl == 8 ? launch_planar<2, 2, 2, 1, 1, 3, 8>(a, tiles, stream)
                       : launch_planar<2, 2, 2, 1, 1, 3, 7>(a, tiles, stream);
     else if (a.fmt == 1 && ring == 3) rc = mg == 2 ? launch_planar<2, 2, 2, 1, 1, 3>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 1, 3>(a, tiles, stream);
     else if (a.fmt == 1) rc = mg == 2 ? launch_planar<2, 2, 2, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 1>(a, tiles, stream);
