@@ -37,6 +37,9 @@ BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+DEFAULT_CLIPS = 32   # the PMC passes behind profiles/r01_pmc_traffic.json are taken at this batch
+
+
 def pmc_traffic(kernel=None):
     """HBM bytes per launch (im2col by default, or the named kernel entry) from the committed rocprofv3 PMC passes
     (bench.py cannot collect PMC counters about itself): profiles/r01_pmc_traffic.json, produced by
@@ -83,7 +86,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--clips", type=int, default=8, help="clips per GPU (frames per step per GPU)")
+    ap.add_argument("--clips", type=int, default=DEFAULT_CLIPS,
+                    help="clips per GPU = frames per step per GPU (throughput: 919 frames/s at 8, 1060 at 16, 1100-1120 from 32 up; "
+                         "32 clips step in 29 ms, i.e. 32 live 30-fps streams per GPU)")
     ap.add_argument("--config", default="STMask_plus_resnet50_config")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=640)
@@ -216,7 +221,7 @@ def main():
                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(achieved / HBM_PEAK_GBS, 4),
                        "traffic": pmc_traffic("dcn_sample_planar" if planar_dcn else None)
-                                  if (args.clips == 8 and args.config == "STMask_plus_resnet50_config") else None,
+                                  if (args.clips == DEFAULT_CLIPS and args.config == "STMask_plus_resnet50_config") else None,
                        "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)",
                        "launches": len(timing), "avg_launch_us": round(ker_ms * 1e3 / n_launch, 2),
                        "algorithmic_bytes_per_launch": int(ker_bytes / n_launch)}
@@ -232,7 +237,7 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": f"conv_planar_kernel ({split} split conv: backbone 1x1/3x3, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
                                "achieved": round(tf, 1), "peak": round(BF16_MFMA_PEAK_TF / n_prod, 1), "unit": "TFLOP/s",
                                "frac": round(tf / (BF16_MFMA_PEAK_TF / n_prod), 4),
-                               "traffic": pmc_traffic("conv_planar") if (args.clips == 8 and args.config == "STMask_plus_resnet50_config") else None,
+                               "traffic": pmc_traffic("conv_planar") if (args.clips == DEFAULT_CLIPS and args.config == "STMask_plus_resnet50_config") else None,
                                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction); average over all launches",
                                "peak_note": f"fp32-equivalent: 2500 TFLOP/s dense 16-bit MFMA / {n_prod} products per fp32 product (fp32 MFMA peak is 157)",
                                "launches": len(conv_t), "avg_launch_us": round(c_ms * 1e3 / len(conv_t), 2),
