@@ -852,12 +852,15 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                 dma_x(dmb);                                                                                                     \
                 dma_w(min((S_) + 2, s_end - 1), dmb);                                                                           \
             }                                                                                                                   \
-            _Pragma("unroll") for (int j = 0; j < 2 * NJ; ++j)                                                                  \
-                _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
-                    f32x4 c = MM16(af0[i][1], bf[j][0], accl16[i][j]);                                                          \
-                    accl16[i][j] = MM16(af0[i][0], bf[j][1], c);                                                                \
-                    acc16[i][j] = MM16(af0[i][0], bf[j][0], acc16[i][j]);                                                       \
-                }                                                                                                               \
+            _Pragma("unroll") for (int j = 0; j < 2 * NJ; ++j) {                                                                \
+                /* the two MFMAs of a correction accumulator are kept two instructions apart */                                 \
+                const f32x4 c0 = MM16(af0[0][1], bf[j][0], accl16[0][j]);                                                       \
+                const f32x4 c1 = MM16(af0[1][1], bf[j][0], accl16[1][j]);                                                       \
+                acc16[0][j] = MM16(af0[0][0], bf[j][0], acc16[0][j]);                                                           \
+                accl16[0][j] = MM16(af0[0][0], bf[j][1], c0);                                                                   \
+                acc16[1][j] = MM16(af0[1][0], bf[j][0], acc16[1][j]);                                                           \
+                accl16[1][j] = MM16(af0[1][0], bf[j][1], c1);                                                                   \
+            }                                                                                                                   \
             _Pragma("unroll") for (int k = 0; k < NM; ++k) {                                                                    \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    /* one MFMA (16 cycles) */                \
                 if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         /* second half's activation fragments */  \
@@ -883,10 +886,13 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                         af0[i][p] = *reinterpret_cast<const bf16x8*>(xn + xoff[i] + p * (BM * 64));                             \
             }                                                                                                                   \
             _Pragma("unroll") for (int j = 0; j < 2 * NJ; ++j) {                                                                \
-                _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                 \
-                    f32x4 c = MM16(af1[i][1], bf[j][0], accl16[2 + i][j]);                                                      \
-                    accl16[2 + i][j] = MM16(af1[i][0], bf[j][1], c);                                                            \
-                    acc16[2 + i][j] = MM16(af1[i][0], bf[j][0], acc16[2 + i][j]);                                               \
+                {                                                                                                               \
+                    const f32x4 c0 = MM16(af1[0][1], bf[j][0], accl16[2][j]);                                                   \
+                    const f32x4 c1 = MM16(af1[1][1], bf[j][0], accl16[3][j]);                                                   \
+                    acc16[2][j] = MM16(af1[0][0], bf[j][0], acc16[2][j]);                                                       \
+                    accl16[2][j] = MM16(af1[0][0], bf[j][1], c0);                                                               \
+                    acc16[3][j] = MM16(af1[1][0], bf[j][0], acc16[3][j]);                                                       \
+                    accl16[3][j] = MM16(af1[1][0], bf[j][1], c1);                                                               \
                 }                                                                                                               \
                 if (PRE_ && !(ABL & 4)) {                                                                                       \
                     _Pragma("unroll") for (int p = 0; p < NPL; ++p)                                                             \

@@ -323,6 +323,10 @@ class PlanarGraph:
             if feat32 is not None:     # module-path head: it wants every level in fp32 as well
                 conv(xp, ("img", B, h, w), out="both", out_planes=feat, out_f32=feat32, out_off=starts[j])
                 fpn_outs[j] = feat32[starts[j]:starts[j + 1]].view(B, h, w, nf).permute(0, 3, 1, 2)
+            elif j == self.cor_idx:
+                # the correlation level is also wanted in fp32 (temporal fusion): second output of the same epilogue
+                y32, _ = conv(xp, ("img", B, h, w), out="both", out_planes=feat, out_off=starts[j])
+                fpn_outs[j] = y32.view(B, h, w, nf).permute(0, 3, 1, 2)
             else:
                 conv(xp, ("img", B, h, w), out="planes", out_planes=feat, out_off=starts[j])
         for i, conv in enumerate(self.fpn_down):
@@ -333,7 +337,7 @@ class PlanarGraph:
                 fpn_outs[j] = feat32[starts[j]:starts[j + 1]].view(B, *sizes[j], nf).permute(0, 3, 1, 2)
             else:
                 conv(feat, ("img", B, h, w), out="planes", x_off=starts[j - 1], out_planes=feat, out_off=starts[j])
-        if feat32 is None and self.cor_idx is not None:
+        if feat32 is None and self.cor_idx is not None and fpn_outs[self.cor_idx] is None:
             # fp32 NCHW view of the correlation level, rebuilt from its planes (exact)
             j = self.cor_idx
             fpn_outs[j] = ops.planes_to_f32(feat[:, :, starts[j]:starts[j + 1]]).view(B, *sizes[j], nf).permute(0, 3, 1, 2)
