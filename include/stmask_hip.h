@@ -330,6 +330,12 @@ int stm_head_assemble_f32(const float* const* small, const float* const* trk, co
  * stm_deform_im2col_f32, value for value. */
 int stm_dcn_sample_planar_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
                               long long out_plane_stride, const stm_deform_geom* g, stm_stream_t stream);
+/* F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False) of an fp32 NHWC tensor x [B][H][W][C], written
+ * directly as planes [P][C/32][B*Ho*Wo][32] (fmt as in stm_conv_geom) for the next planar convolution: the proto-net's
+ * InterpolateModule (make_net.py:31-40, yolact's x2 upsample between its convolutions).  C % 32 == 0. */
+int stm_resize_bilinear_planes_f32(const float* x, void* planes, int B, int H, int W, int C, int Ho, int Wo, int fmt,
+                                   stm_stream_t stream);
+
 /* fp16 plane format (fmt 1) range guard.  A value with |x| > 65504 (or inf / nan) has no fp16 plane representation and
  * would poison the following layers silently (inf - inf = nan, and a ReLU epilogue maps nan to 0).  Every producer of
  * fp16 planes (stm_split_planes_fmt_f32, the stm_conv2d_planar_* epilogues, stm_dcn_sample_planar_fmt_f32) therefore

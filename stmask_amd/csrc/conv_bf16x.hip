@@ -1371,6 +1371,56 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
 }
 
+// Bilinear resize (F.interpolate(mode="bilinear", align_corners=False): make_net.py's InterpolateModule between the proto-net
+// convolutions) of an fp32 NHWC tensor straight into planes: thread = 8 channels of one output pixel; the fp32 upsampled
+// tensor (4x the input for the proto-net's x2) is never written or re-read.  Same expression order as the ATen kernel.
+__global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float* __restrict__ x, uint8_t* __restrict__ planes, int B, int H,
+                                                                    int W, int C, int Ho, int Wo, float sy, float sx, int fmt,
+                                                                    int* range_flag)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c8n = C >> 3;
+    const int64_t n = (int64_t)B * Ho * Wo;
+    if (idx >= n * c8n) return;
+    const int64_t pix = idx / c8n;
+    const int c8 = (int)(idx - pix * c8n);
+    const int b = (int)(pix / ((int64_t)Ho * Wo));
+    const int rem = (int)(pix - (int64_t)b * Ho * Wo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    // area_pixel_compute_source_index(scale, dst, align_corners=false, cubic=false): max(0, scale * (dst + 0.5) - 0.5)
+    const float fy = fmaxf(sy * ((float)oy + 0.5f) - 0.5f, 0.0f), fx = fmaxf(sx * ((float)ox + 0.5f) - 0.5f, 0.0f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    const float* base = x + (size_t)b * H * W * C + c8 * 8;
+    float v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * C + 4 * h);
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * C + 4 * h);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * C + 4 * h);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * C + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * h + e] = ly0 * (lx0 * a[e] + lx1 * bq[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
+    }
+    unsigned q0[4], q1[4], q2[4];
+    const size_t plane_b = (size_t)n * C * 2;
+    uint8_t* dst = planes + (((size_t)(c8 >> 2) * n + pix) * 32 + (c8 & 3) * 8) * 2;
+    if (fmt == 1) {
+        f16_range_check8(v, range_flag);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
+        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
+    *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+    *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+    *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+}
+
 // Weights [Cout][Cin][kh][kw] fp32 -> packed [n_tile][slab][plane][row 0..127][swizzled 16-B chunk][8 bf16]; rows past
 // Cout are zero.  One thread per (n_tile, slab, row, chunk).
 __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp, int Cout,
@@ -1619,6 +1669,23 @@ extern "C" int stm_split_planes_fmt_f32(const float* x, void* planes, int64_t n_
     hipLaunchKernelGGL(split_planes_kernel, dim3(stm_cdiv(n_pixels * (C / 8), 256)), dim3(256), 0, stm_hs(stream), x,
                        static_cast<uint8_t*>(planes), n_pixels, C, fmt, g_range_flag);
     STM_CHECK_LAUNCH("split_planes_kernel");
+    return STM_OK;
+}
+
+extern "C" int stm_resize_bilinear_planes_f32(const float* x, void* planes, int B, int H, int W, int C, int Ho, int Wo, int fmt,
+                                              stm_stream_t stream)
+{
+    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_resize_bilinear_planes_f32: fmt must be 0 or 1");
+    STM_REQUIRE(x && planes, STM_ENULL, "stm_resize_bilinear_planes_f32: x/planes must be non-NULL");
+    STM_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 32 == 0, STM_EINVAL,
+                "stm_resize_bilinear_planes_f32: sizes must be positive and C (%d) a multiple of 32", C);
+    STM_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)planes % 16 == 0, STM_EINVAL, "stm_resize_bilinear_planes_f32: 16-byte alignment required");
+    const int64_t n = (int64_t)B * Ho * Wo;
+    // scale as ATen computes it for align_corners=false without an explicit scale factor: input size / output size
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    hipLaunchKernelGGL(resize_bilinear_planes_kernel, dim3(stm_cdiv(n * (C / 8), 256)), dim3(256), 0, stm_hs(stream), x,
+                       static_cast<uint8_t*>(planes), B, H, W, C, Ho, Wo, sy, sx, fmt, g_range_flag);
+    STM_CHECK_LAUNCH("resize_bilinear_planes_kernel");
     return STM_OK;
 }
 

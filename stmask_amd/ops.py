@@ -501,6 +501,21 @@ def counts_to_host(cnt):
     return host[:-1]
 
 
+def resize_bilinear_planes(x_nhwc, size, fmt=0):
+    """F.interpolate(x, size=size, mode="bilinear", align_corners=False) of an fp32 NHWC tensor [B,H,W,C], returned as planes
+    [P, C/32, B*Ho*Wo, 32] (split_planes' format) without the fp32 intermediate."""
+    _dev(x_nhwc)
+    x = _f32c(x_nhwc)
+    B, H, W, C = x.shape
+    Ho, Wo = size
+    if C % 32:
+        raise StmError(f"resize_bilinear_planes: channel count {C} is not a multiple of 32")
+    planes = torch.empty(2 if fmt == 1 else 3, C // 32, B * Ho * Wo, 32, device=x.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    check(_lib.lib().stm_resize_bilinear_planes_f32(_p(x), _p(planes), c_i(B), c_i(H), c_i(W), c_i(C), c_i(Ho), c_i(Wo), c_i(fmt), _stream()),
+          "stm_resize_bilinear_planes_f32")
+    return planes
+
+
 def planes_to_f32(planes):
     """[P, S, N, 32] planes -> fp32 [N, 32*S]."""
     v = planes[0].float()

@@ -360,10 +360,19 @@ class PlanarGraph:
                     cur = y.view(B, h, w, layer.O)
                 else:
                     xp, x_off = layer(xp, ("img", B, h, w), out="planes", x_off=x_off), 0
-            else:                              # bilinear upsample, fp32
-                t = layer(cur.permute(0, 3, 1, 2))
-                h, w = t.shape[2:]
-                cur = _nhwc(t)
+            else:                              # bilinear upsample
+                kw = layer.kwargs
+                sf = kw.get("scale_factor")
+                nxt_conv = (not last) and isinstance(self.proto[li + 1], PlanarConv)
+                if (nxt_conv and not layer.args and kw.get("mode") == "bilinear" and not kw.get("align_corners", False)
+                        and isinstance(sf, (int, float)) and float(sf).is_integer() and set(kw) <= {"scale_factor", "mode", "align_corners"}):
+                    # ... straight into the next convolution's planes (no fp32 upsampled tensor)
+                    h, w = h * int(sf), w * int(sf)
+                    xp, x_off, cur = ops.resize_bilinear_planes(cur, (h, w), self.fmt), 0, None
+                else:
+                    t = layer(cur.permute(0, 3, 1, 2))
+                    h, w = t.shape[2:]
+                    cur = _nhwc(t)
         proto = cur                            # [B, 2h, 2w, 32], ReLU applied by the last layer (STMask.py:227)
         toc("proto_net")
 

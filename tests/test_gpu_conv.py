@@ -412,3 +412,20 @@ def test_conv_planar_fp16_loop_variants_agree_bitwise(tile_n, monkeypatch):
         assert torch.equal(y1, y2)
     finally:
         set_format(1)
+
+
+@pytest.mark.parametrize("fmt", [1, 0])
+@pytest.mark.parametrize("case", [(2, 12, 20, 64, 24, 40), (1, 9, 7, 32, 18, 14), (2, 5, 6, 96, 13, 11), (1, 8, 8, 32, 8, 8)])
+def test_resize_bilinear_planes_equals_interpolate_then_split(case, fmt):
+    """stm_resize_bilinear_planes_f32 == F.interpolate(mode="bilinear", align_corners=False) followed by
+    stm_split_planes_fmt_f32: the same expression in the same order, so at most an ulp of fp32 apart before the split."""
+    import torch.nn.functional as F
+    B, H, W, C, Ho, Wo = case
+    x = rnd(B, H, W, C, seed=H * W)
+    got = planes_to_f32(ops.resize_bilinear_planes(x.to(DEV), (Ho, Wo), fmt=fmt).cpu())
+    ref = F.interpolate(x.permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).reshape(-1, C)
+    # (non-integer scales: the source coordinate itself may differ by an ulp from ATen's, hence 4e-7 and not 2^-23)
+    tol = 2.0 ** -21 if fmt == 1 else 4e-7
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()) + 1e-7
+    on_gpu = F.interpolate(x.to(DEV).permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).contiguous()
+    assert (planes_to_f32(ops.split_planes(on_gpu, fmt=fmt).cpu()) - got).abs().max().item() <= 4e-7 * max(1.0, ref.abs().max().item())
