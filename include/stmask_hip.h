@@ -336,6 +336,12 @@ int stm_dcn_sample_planar_f32(const float* x, const float* offset_mask, int om_l
 int stm_resize_bilinear_planes_f32(const float* x, void* planes, int B, int H, int W, int C, int Ho, int Wo, int fmt,
                                    stm_stream_t stream);
 
+/* ResNet stem tail, backbone.py:73 `maxpool(relu(bn1(conv1(x))))` after BN folding: x = the raw convolution output, fp32 NHWC
+ * [B][H][W][C]; planes [P][C/32][B*Ho*Wo][32] = relu(maxpool3x3/s2/p1(x) + bias[c]) (exactly relu-bias-then-pool: both are
+ * monotone per channel), Ho = (H-1)/2+1, Wo = (W-1)/2+1.  bias may be NULL.  C % 32 == 0. */
+int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bias, void* planes, int B, int H, int W, int C, int fmt,
+                                     stm_stream_t stream);
+
 /* fp16 plane format (fmt 1) range guard.  A value with |x| > 65504 (or inf / nan) has no fp16 plane representation and
  * would poison the following layers silently (inf - inf = nan, and a ReLU epilogue maps nan to 0).  Every producer of
  * fp16 planes (stm_split_planes_fmt_f32, the stm_conv2d_planar_* epilogues, stm_dcn_sample_planar_fmt_f32) therefore

@@ -1421,6 +1421,63 @@ __global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float
     *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
 }
 
+// ResNet stem tail (backbone.py:73: relu(bn1(conv1)) -> MaxPool2d(3, 2, 1)) on the raw fp32 NHWC convolution output, written as
+// planes for layer1: y = relu(max over the 3x3 window (stride 2, pad 1) + folded-BN bias).  The bias add and the ReLU are
+// monotone and the bias is per channel, so they commute with the max exactly.  thread = 8 channels of one output pixel.
+__global__ __launch_bounds__(256) void bias_relu_maxpool_planes_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                                      uint8_t* __restrict__ planes, int B, int H, int W, int C, int Ho, int Wo,
+                                                                      int fmt, int* range_flag)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c8n = C >> 3;
+    const int64_t n = (int64_t)B * Ho * Wo;
+    if (idx >= n * c8n) return;
+    const int64_t pix = idx / c8n;
+    const int c8 = (int)(idx - pix * c8n);
+    const int b = (int)(pix / ((int64_t)Ho * Wo));
+    const int rem = (int)(pix - (int64_t)b * Ho * Wo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const float* base = x + (size_t)b * H * W * C + c8 * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = -__builtin_inff();
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = 2 * oy - 1 + dy;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = 2 * ox - 1 + dx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(base + ((size_t)iy * W + ix) * C);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(base + ((size_t)iy * W + ix) * C + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = fmaxf(v[e], a[e]); v[4 + e] = fmaxf(v[4 + e], c[e]); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float t = v[e] + (bias ? bias[c8 * 8 + e] : 0.0f);
+        v[e] = t > 0.0f ? t : 0.0f;
+    }
+    unsigned q0[4], q1[4], q2[4];
+    const size_t plane_b = (size_t)n * C * 2;
+    uint8_t* dst = planes + (((size_t)(c8 >> 2) * n + pix) * 32 + (c8 & 3) * 8) * 2;
+    if (fmt == 1) {
+        f16_range_check8(v, range_flag);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
+        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
+    *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+    *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+    *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+}
+
 // Weights [Cout][Cin][kh][kw] fp32 -> packed [n_tile][slab][plane][row 0..127][swizzled 16-B chunk][8 bf16]; rows past
 // Cout are zero.  One thread per (n_tile, slab, row, chunk).
 __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp, int Cout,
@@ -1686,6 +1743,22 @@ extern "C" int stm_resize_bilinear_planes_f32(const float* x, void* planes, int 
     hipLaunchKernelGGL(resize_bilinear_planes_kernel, dim3(stm_cdiv(n * (C / 8), 256)), dim3(256), 0, stm_hs(stream), x,
                        static_cast<uint8_t*>(planes), B, H, W, C, Ho, Wo, sy, sx, fmt, g_range_flag);
     STM_CHECK_LAUNCH("resize_bilinear_planes_kernel");
+    return STM_OK;
+}
+
+extern "C" int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bias, void* planes, int B, int H, int W, int C, int fmt,
+                                                stm_stream_t stream)
+{
+    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_bias_relu_maxpool_planes_f32: fmt must be 0 or 1");
+    STM_REQUIRE(x && planes, STM_ENULL, "stm_bias_relu_maxpool_planes_f32: x/planes must be non-NULL");
+    STM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0, STM_EINVAL,
+                "stm_bias_relu_maxpool_planes_f32: sizes must be positive and C (%d) a multiple of 32", C);
+    STM_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)planes % 16 == 0, STM_EINVAL, "stm_bias_relu_maxpool_planes_f32: 16-byte alignment required");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;     // MaxPool2d(kernel 3, stride 2, padding 1), floor mode
+    const int64_t n = (int64_t)B * Ho * Wo;
+    hipLaunchKernelGGL(bias_relu_maxpool_planes_kernel, dim3(stm_cdiv(n * (C / 8), 256)), dim3(256), 0, stm_hs(stream), x, bias,
+                       static_cast<uint8_t*>(planes), B, H, W, C, Ho, Wo, fmt, g_range_flag);
+    STM_CHECK_LAUNCH("bias_relu_maxpool_planes_kernel");
     return STM_OK;
 }
 

@@ -516,6 +516,21 @@ def resize_bilinear_planes(x_nhwc, size, fmt=0):
     return planes
 
 
+def bias_relu_maxpool_planes(x_nhwc, bias, fmt=0):
+    """relu(max_pool2d(x, 3, 2, 1) + bias) of an fp32 NHWC tensor [B,H,W,C] (the ResNet stem's convolution output), returned as
+    planes [P, C/32, B*Ho*Wo, 32] plus (Ho, Wo)."""
+    _dev(x_nhwc, bias)
+    x = _f32c(x_nhwc)
+    B, H, W, C = x.shape
+    if C % 32:
+        raise StmError(f"bias_relu_maxpool_planes: channel count {C} is not a multiple of 32")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    planes = torch.empty(2 if fmt == 1 else 3, C // 32, B * Ho * Wo, 32, device=x.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    check(_lib.lib().stm_bias_relu_maxpool_planes_f32(_p(x), _p(_f32c(bias)) if bias is not None else c_p(0), _p(planes), c_i(B), c_i(H), c_i(W),
+                                                      c_i(C), c_i(fmt), _stream()), "stm_bias_relu_maxpool_planes_f32")
+    return planes, (Ho, Wo)
+
+
 def planes_to_f32(planes):
     """[P, S, N, 32] planes -> fp32 [N, 32*S]."""
     v = planes[0].float()

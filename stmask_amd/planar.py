@@ -537,9 +537,17 @@ class PlanarBackbone:
 
     def __call__(self, x):
         bb = self.bb
-        x = bb.maxpool(bb.relu(bb.bn1(bb.conv1(x))))        # conv1 carries the folded BN + ReLU after fuse
-        B, C, H, W = x.shape
-        xp = _split(_nhwc(x), self.fmt)
+        c1, mp = bb.conv1, bb.maxpool
+        if (isinstance(bb.bn1, torch.nn.Identity) and c1.out_channels % 32 == 0 and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1
+                and not mp.ceil_mode and mp.dilation == 1):
+            # stem tail in one pass: folded-BN bias + ReLU + 3x3/2 max-pool of the raw 7x7 convolution output, straight to planes
+            y = F.conv2d(x, c1.weight, None, c1.stride, c1.padding, c1.dilation, c1.groups)
+            B, C = y.shape[:2]
+            xp, (H, W) = ops.bias_relu_maxpool_planes(_nhwc(y), c1.bias, self.fmt)
+        else:
+            x = bb.maxpool(bb.relu(bb.bn1(bb.conv1(x))))        # conv1 carries the folded BN + ReLU after fuse
+            B, C, H, W = x.shape
+            xp = _split(_nhwc(x), self.fmt)
         outs, self.out_planes = [], []
         for blks in self.blocks:
             y32 = None

@@ -429,3 +429,21 @@ def test_resize_bilinear_planes_equals_interpolate_then_split(case, fmt):
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()) + 1e-7
     on_gpu = F.interpolate(x.to(DEV).permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).contiguous()
     assert (planes_to_f32(ops.split_planes(on_gpu, fmt=fmt).cpu()) - got).abs().max().item() <= 4e-7 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("fmt", [1, 0])
+@pytest.mark.parametrize("case", [(2, 12, 20, 64), (1, 9, 7, 32), (2, 5, 6, 96), (1, 1, 1, 32)])
+def test_bias_relu_maxpool_planes_equals_torch_chain(case, fmt):
+    """stm_bias_relu_maxpool_planes_f32 == split(max_pool2d(relu(x + bias), 3, 2, 1)): bias add and ReLU are monotone per
+    channel, so pooling first changes nothing -- equal bit for bit (odd sizes, 1x1 input, borders included)."""
+    import torch.nn.functional as F
+    B, H, W, C = case
+    x = rnd(B, H, W, C, seed=H + W)
+    bias = rnd(C, seed=3)
+    pl, (Ho, Wo) = ops.bias_relu_maxpool_planes(x.to(DEV), bias.to(DEV), fmt=fmt)
+    ref = F.max_pool2d(torch.relu(x + bias).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+    assert (Ho, Wo) == tuple(ref.shape[1:3])
+    assert torch.equal(pl.cpu(), ops.split_planes(ref.to(DEV), fmt=fmt).cpu())
+    pl0, _ = ops.bias_relu_maxpool_planes(x.to(DEV), None, fmt=fmt)
+    ref0 = F.max_pool2d(torch.relu(x).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(pl0.cpu(), ops.split_planes(ref0.to(DEV), fmt=fmt).cpu())
