@@ -492,6 +492,7 @@ struct PlanarArgs {
     int fmt;                  // 0: three bf16 planes (six products), 1: two fp16 planes (three products)
     float out_scale;          // 1 / (power-of-two weight scale of the packed image)
     int* range_flag;          // fmt 1: set to 1 when an output has no fp16 representation (see f16_range_check8); may be null
+    int nt_out;               // fmt 1: nontemporal plane stores (outputs far larger than L2)
     int splitk, kslabs, ldp;  // split-K: K-slabs per split, fp32 partial sums [splitk][M][ldp] in `partial`
     float* partial;
     int* tickets;           // split-K: one counter per output tile (zero between launches); the part that draws the last
@@ -583,8 +584,13 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
                 f16_range_check8(v, a.range_flag);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
-                *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-                *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+                if (a.nt_out) {
+                    __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(o));
+                    __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(o + opl * 2));
+                } else {
+                    *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+                    *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
@@ -1839,6 +1845,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     a.fmt = g->fmt == 1 ? 1 : 0;
     a.out_scale = (g->fmt == 1 && g->out_scale > 0.0f) ? g->out_scale : 1.0f;
     a.range_flag = g_range_flag;
+    { const char* e = getenv("STM_CONV_NT"); const int64_t thr = e ? atoll(e) : 0; a.nt_out = thr > 0 && M * (int64_t)g->Cout * 4 >= thr * 1000000; }
     STM_REQUIRE(a.fmt == 0 || g->planes == 2, STM_EINVAL, "%s: the fp16 format has two planes", who);
     a.splitk = 1; a.kslabs = a.slabs; a.partial = nullptr; a.tickets = nullptr; a.ldp = a.n_tiles * bn;
     // split-K for grids that would leave most CUs idle over a long K (small feature maps: ResNet stages 3/4, P5-P7):

@@ -735,6 +735,7 @@ struct SampleArgs {
     int B, H, W, C, Ho, Wo, sh, sw, ph, pw, dh, dw;
     int om_ld, out_np, M, fmt;   // fmt 0: three bf16 planes, 1: two fp16 planes
     int* range_flag;             // fmt 1: raised when a sampled value has no fp16 representation (may be null)
+    int xcd, per_xcd, nt;        // XCD-contiguous workgroup order (workgroups per XCD); nontemporal column stores
     long long out_pstride;   // bytes
 };
 
@@ -767,7 +768,15 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
 {
     constexpr int K = 9, PPW = 64 / LPP;
     const int lane = threadIdx.x & 63, sl = lane % LPP;
-    const int m = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LPP;
+    // workgroup ids are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of pixels, so that an input row is
+    // gathered through one L2 instead of all eight
+    int bid = blockIdx.x;
+    if (a.xcd) {
+        bid = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= a.per_xcd) return;
+    }
+    const int m = (bid * 4 + (threadIdx.x >> 6)) * PPW + lane / LPP;
+    if (bid * 4 * PPW >= a.M) return;
     const bool live = m < a.M;
     const int mm = live ? m : a.M - 1;                       // dead pixel groups shadow the last pixel, stores masked
     const int b = mm / (a.Ho * a.Wo);
@@ -833,7 +842,11 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
         const u32x4v p0 = {q0[0], q0[1], q0[2], q0[3]}, p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]};
         const int kc = k * a.C + sl * 8;                     // K index of the lane's first channel (8 | kc: inside one slab)
         uint8_t* o = a.out + (((size_t)(kc >> 5) * a.out_np + mm) * 32 + (kc & 31)) * 2;
-        if (live) {
+        if (live && a.nt) {          // the columns are far larger than L2 and read once, later: keep them out of the gathers' way
+            __builtin_nontemporal_store(p0, reinterpret_cast<u32x4v*>(o));
+            __builtin_nontemporal_store(p1, reinterpret_cast<u32x4v*>(o + a.out_pstride));
+            if (a.fmt == 0) __builtin_nontemporal_store(p2, reinterpret_cast<u32x4v*>(o + 2 * a.out_pstride));
+        } else if (live) {
             *reinterpret_cast<u32x4v*>(o) = p0;
             *reinterpret_cast<u32x4v*>(o + a.out_pstride) = p1;
             if (a.fmt == 0) *reinterpret_cast<u32x4v*>(o + 2 * a.out_pstride) = p2;
@@ -869,7 +882,13 @@ extern "C" int stm_dcn_sample_planar_fmt_f32(const float* x, const float* offset
     a.om_ld = om_ld; a.M = (int)M; a.out_np = out_np > 0 ? out_np : (int)M; a.fmt = fmt; a.range_flag = stm_internal_range_flag();
     a.out_pstride = (out_plane_stride > 0 ? out_plane_stride : (long long)(9 * g->C / 32) * a.out_np * 32) * 2;
     const int ppw = 512 / g->C;                                  // pixels per wave
-    const dim3 grid(stm_cdiv(M, 4 * ppw));
+    const int nblk = stm_cdiv(M, 4 * ppw);
+    { const char* e = getenv("STM_DCN_XCD"); a.xcd = e ? atoi(e) : 1; }
+    // nontemporal column stores: 248 -> 115 us on layer2 at batch 32 together with the XCD order (5.6 TB/s algorithmic), but
+    // 34 -> 45 us with 512 channels (one pixel per wave, 1-KB runs per tap) -- so up to 256 channels only
+    { const char* e = getenv("STM_DCN_NT"); a.nt = e ? atoi(e) : (g->C <= 256 ? 1 : 0); }
+    a.per_xcd = stm_cdiv(nblk, 8);
+    const dim3 grid(a.xcd ? 8 * a.per_xcd : nblk);
     if (g->C == 128) hipLaunchKernelGGL(dcn_sample_planar_kernel<16>, grid, dim3(256), 0, stm_hs(stream), a);
     else if (g->C == 256) hipLaunchKernelGGL(dcn_sample_planar_kernel<32>, grid, dim3(256), 0, stm_hs(stream), a);
     else hipLaunchKernelGGL(dcn_sample_planar_kernel<64>, grid, dim3(256), 0, stm_hs(stream), a);
