@@ -1342,6 +1342,16 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx_kernel(const PlanarArgs
 #endif
 }
 
+// Streaming kernels below: workgroup ids are dealt round-robin to the 8 XCDs; a launch of 8 * per_xcd workgroups maps id ->
+// (id & 7) * per_xcd + (id >> 3), so each XCD works on a contiguous run of pixels (neighbouring rows share input lines in
+// one L2 instead of eight).  Returns -1 for the padding workgroups.
+__device__ __forceinline__ int64_t xcd_contiguous_block(int64_t nblocks)
+{
+    const int64_t per_xcd = (nblocks + 7) >> 3;
+    const int64_t b = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    return b < nblocks ? b : -1;
+}
+
 // fp32 [n pixels][C] (NHWC) -> three bf16 planes [3][C/32][n][32] (entry into the planar format from a foreign producer);
 // thread = 8 channels of one pixel
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint8_t* __restrict__ planes, int64_t n, int C,
@@ -1384,9 +1394,11 @@ __global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float
                                                                     int W, int C, int Ho, int Wo, float sy, float sx, int fmt,
                                                                     int* range_flag)
 {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int c8n = C >> 3;
     const int64_t n = (int64_t)B * Ho * Wo;
+    const int64_t blk = xcd_contiguous_block((n * c8n + 255) >> 8);
+    if (blk < 0) return;
+    const int64_t idx = blk * 256 + threadIdx.x;
     if (idx >= n * c8n) return;
     const int64_t pix = idx / c8n;
     const int c8 = (int)(idx - pix * c8n);
@@ -1416,15 +1428,15 @@ __global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float
         f16_range_check8(v, range_flag);
 #pragma unroll
         for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
-        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-        *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(dst));
+        __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(dst + plane_b));
         return;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
-    *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-    *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-    *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+    __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(dst));
+    __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(dst + plane_b));
+    __builtin_nontemporal_store(u32x4{q2[0], q2[1], q2[2], q2[3]}, reinterpret_cast<u32x4*>(dst + 2 * plane_b));
 }
 
 // ResNet stem tail (backbone.py:73: relu(bn1(conv1)) -> MaxPool2d(3, 2, 1)) on the raw fp32 NHWC convolution output, written as
@@ -1434,9 +1446,11 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_planes_kernel(const flo
                                                                       uint8_t* __restrict__ planes, int B, int H, int W, int C, int Ho, int Wo,
                                                                       int fmt, int* range_flag)
 {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int c8n = C >> 3;
     const int64_t n = (int64_t)B * Ho * Wo;
+    const int64_t blk = xcd_contiguous_block((n * c8n + 255) >> 8);
+    if (blk < 0) return;
+    const int64_t idx = blk * 256 + threadIdx.x;
     if (idx >= n * c8n) return;
     const int64_t pix = idx / c8n;
     const int c8 = (int)(idx - pix * c8n);
@@ -1473,15 +1487,15 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_planes_kernel(const flo
         f16_range_check8(v, range_flag);
 #pragma unroll
         for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
-        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-        *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(dst));
+        __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(dst + plane_b));
         return;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
-    *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-    *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-    *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+    __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(dst));
+    __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(dst + plane_b));
+    __builtin_nontemporal_store(u32x4{q2[0], q2[1], q2[2], q2[3]}, reinterpret_cast<u32x4*>(dst + 2 * plane_b));
 }
 
 // Weights [Cout][Cin][kh][kw] fp32 -> packed [n_tile][slab][plane][row 0..127][swizzled 16-B chunk][8 bf16]; rows past
@@ -1746,7 +1760,7 @@ extern "C" int stm_resize_bilinear_planes_f32(const float* x, void* planes, int 
     const int64_t n = (int64_t)B * Ho * Wo;
     // scale as ATen computes it for align_corners=false without an explicit scale factor: input size / output size
     const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
-    hipLaunchKernelGGL(resize_bilinear_planes_kernel, dim3(stm_cdiv(n * (C / 8), 256)), dim3(256), 0, stm_hs(stream), x,
+    hipLaunchKernelGGL(resize_bilinear_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(n * (C / 8), 256), 8)), dim3(256), 0, stm_hs(stream), x,
                        static_cast<uint8_t*>(planes), B, H, W, C, Ho, Wo, sy, sx, fmt, g_range_flag);
     STM_CHECK_LAUNCH("resize_bilinear_planes_kernel");
     return STM_OK;
@@ -1762,7 +1776,7 @@ extern "C" int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bia
     STM_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)planes % 16 == 0, STM_EINVAL, "stm_bias_relu_maxpool_planes_f32: 16-byte alignment required");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;     // MaxPool2d(kernel 3, stride 2, padding 1), floor mode
     const int64_t n = (int64_t)B * Ho * Wo;
-    hipLaunchKernelGGL(bias_relu_maxpool_planes_kernel, dim3(stm_cdiv(n * (C / 8), 256)), dim3(256), 0, stm_hs(stream), x, bias,
+    hipLaunchKernelGGL(bias_relu_maxpool_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(n * (C / 8), 256), 8)), dim3(256), 0, stm_hs(stream), x, bias,
                        static_cast<uint8_t*>(planes), B, H, W, C, Ho, Wo, fmt, g_range_flag);
     STM_CHECK_LAUNCH("bias_relu_maxpool_planes_kernel");
     return STM_OK;
