@@ -31,6 +31,7 @@ struct ImcolArgs {
     int th, cch, R, LW, halo, tiles_y;
     int blk;  // 1: tile-blocked column buffer cols[b][row tile][C*K][tile positions] (each workgroup writes one
               // contiguous region); 0: plain cols[b][C*K][Ho*Wo]
+    int nt;   // nontemporal column stores (the columns are read once, by the GEMM, and are far larger than L2)
     int dbg;  // ablation switch for profiling builds of variant 3 (0 = normal): 1 = no staging / LDS reads, 2 = no stores
 };
 
@@ -310,10 +311,20 @@ __global__ __launch_bounds__(NTHR, MINW) void deform_im2col_lds(ImcolArgs a)
             }
             float* c_ = cb + (int64_t)(4 * q) * cs;
             if constexpr (NP == 4) {
-                *reinterpret_cast<float4*>(c_) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
-                *reinterpret_cast<float4*>(c_ + cs) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
-                *reinterpret_cast<float4*>(c_ + 2 * cs) = make_float4(acc[0].z, acc[1].z, acc[2].z, acc[3].z);
-                *reinterpret_cast<float4*>(c_ + 3 * cs) = make_float4(acc[0].w, acc[1].w, acc[2].w, acc[3].w);
+                typedef float f4nt __attribute__((ext_vector_type(4)));
+                const f4nt o0 = {acc[0].x, acc[1].x, acc[2].x, acc[3].x}, o1 = {acc[0].y, acc[1].y, acc[2].y, acc[3].y};
+                const f4nt o2 = {acc[0].z, acc[1].z, acc[2].z, acc[3].z}, o3 = {acc[0].w, acc[1].w, acc[2].w, acc[3].w};
+                if (a.nt) {
+                    __builtin_nontemporal_store(o0, reinterpret_cast<f4nt*>(c_));
+                    __builtin_nontemporal_store(o1, reinterpret_cast<f4nt*>(c_ + cs));
+                    __builtin_nontemporal_store(o2, reinterpret_cast<f4nt*>(c_ + 2 * cs));
+                    __builtin_nontemporal_store(o3, reinterpret_cast<f4nt*>(c_ + 3 * cs));
+                } else {
+                    *reinterpret_cast<f4nt*>(c_) = o0;
+                    *reinterpret_cast<f4nt*>(c_ + cs) = o1;
+                    *reinterpret_cast<f4nt*>(c_ + 2 * cs) = o2;
+                    *reinterpret_cast<f4nt*>(c_ + 3 * cs) = o3;
+                }
             } else {
                 c_[0] = acc[0].x;
                 c_[cs] = acc[0].y;
@@ -520,10 +531,20 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
             }
             float* c_ = cq + sbase[it];
             if (a.dbg == 2 && acc[0].x != 123456.789f) continue;  // ablation: keep the values live, skip the stores
-            *reinterpret_cast<float4*>(c_) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
-            *reinterpret_cast<float4*>(c_ + cs) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
-            *reinterpret_cast<float4*>(c_ + 2 * cs) = make_float4(acc[0].z, acc[1].z, acc[2].z, acc[3].z);
-            *reinterpret_cast<float4*>(c_ + 3 * cs) = make_float4(acc[0].w, acc[1].w, acc[2].w, acc[3].w);
+            typedef float f4nt __attribute__((ext_vector_type(4)));
+            const f4nt o0 = {acc[0].x, acc[1].x, acc[2].x, acc[3].x}, o1 = {acc[0].y, acc[1].y, acc[2].y, acc[3].y};
+            const f4nt o2 = {acc[0].z, acc[1].z, acc[2].z, acc[3].z}, o3 = {acc[0].w, acc[1].w, acc[2].w, acc[3].w};
+            if (a.nt) {
+                __builtin_nontemporal_store(o0, reinterpret_cast<f4nt*>(c_));
+                __builtin_nontemporal_store(o1, reinterpret_cast<f4nt*>(c_ + cs));
+                __builtin_nontemporal_store(o2, reinterpret_cast<f4nt*>(c_ + 2 * cs));
+                __builtin_nontemporal_store(o3, reinterpret_cast<f4nt*>(c_ + 3 * cs));
+            } else {
+                *reinterpret_cast<f4nt*>(c_) = o0;
+                *reinterpret_cast<f4nt*>(c_ + cs) = o1;
+                *reinterpret_cast<f4nt*>(c_ + 2 * cs) = o2;
+                *reinterpret_cast<f4nt*>(c_ + 3 * cs) = o3;
+            }
         }
     }
 }
@@ -576,6 +597,7 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     a.th = a.cch = a.R = a.LW = a.halo = a.tiles_y = 0;
     a.dbg = env_int("STM_IM2COL_DEBUG", 0);
     a.blk = env_int("STM_IM2COL_BLOCKED", 0);
+    a.nt = env_int("STM_IM2COL_NT", 0);   // measured: no difference for the LDS-staged variants (172 us either way at batch 8)
 
     if (variant == 0) variant = env_int("STM_IM2COL_VARIANT", 0);
     bool tiled_ok = (Cg % 4 == 0);
