@@ -36,6 +36,18 @@ static inline int stm_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b)
 
 // ---- device helpers -----------------------------------------------------------------------------
 
+// Workgroup ids are dealt round-robin to the 8 XCDs of the chip, each with its own L2.  Kernels whose neighbouring
+// workgroups re-read the same lines (gathers, windows, per-image tables) launch 8 * ceil(nblocks / 8) workgroups and map
+// id -> (id & 7) * per_xcd + (id >> 3): each XCD then works on a contiguous run of logical blocks and the shared lines are
+// fetched through one L2 instead of eight.  Returns -1 for the padding workgroups.
+__device__ __forceinline__ int64_t stm_xcd_block(int64_t nblocks)
+{
+    const int64_t per_xcd = (nblocks + 7) >> 3;
+    const int64_t b = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    return b < nblocks ? b : -1;
+}
+static inline unsigned stm_xcd_grid(int64_t nblocks) { return (unsigned)(8 * ((nblocks + 7) / 8)); }
+
 // Canonical exp (oracle/stm_oracle.c: stm_exp_f64): identical IEEE operation sequence in double, rounded
 // once to fp32.  Compiled with -ffp-contract=off; every fused step is an explicit fma().
 __device__ __forceinline__ double stm_exp_f64(double x)

@@ -196,10 +196,13 @@ __device__ __forceinline__ float bilinear_roi(const float* __restrict__ im, int 
 // neighbouring channels of one small feature window (L1/L2 resident: 633 x 24 x 40 floats = 2.4 MB)
 __global__ void roi_align_avg_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
                                      float* __restrict__ out, int C, int H, int W, int n, int PH, int PW, float scale,
-                                     int sampling_ratio, int aligned)
+                                     int sampling_ratio, int aligned, int xcd)
 {
     int64_t total = (int64_t)n * C * PH * PW;
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // RoIs arrive sorted by image: XCD-contiguous block order keeps an image's feature maps in one L2
+    const int64_t blk = xcd ? stm_xcd_block((total + blockDim.x - 1) / blockDim.x) : (int64_t)blockIdx.x;
+    if (blk < 0) return;
+    int64_t t = blk * blockDim.x + threadIdx.x;
     if (t >= total) return;
     int px = t % PW;
     int64_t r = t / PW;
@@ -268,8 +271,10 @@ extern "C" int stm_roi_align_avg_f32(const float* feat, const float* rois, float
     STM_REQUIRE(feat && rois && out, STM_ENULL, "stm_roi_align_avg_f32: feat/rois/out must be non-NULL");
     STM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0, STM_EINVAL, "stm_roi_align_avg_f32: bad sizes");
     int64_t total = (int64_t)n * C * PH * PW;
-    hipLaunchKernelGGL(roi_align_avg_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), feat, rois, out, C,
-                       H, W, n, PH, PW, spatial_scale, sampling_ratio, aligned);
+    const char* ex = getenv("STM_XCD_ORDER");
+    const int xcd = ex ? atoi(ex) : 1;
+    hipLaunchKernelGGL(roi_align_avg_kernel, dim3(xcd ? stm_xcd_grid(stm_cdiv(total, 256)) : stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream),
+                       feat, rois, out, C, H, W, n, PH, PW, spatial_scale, sampling_ratio, aligned, xcd);
     STM_CHECK_LAUNCH("roi_align_avg_kernel");
     return STM_OK;
 }
