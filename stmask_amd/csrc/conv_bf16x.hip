@@ -1908,8 +1908,9 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         const int ring64 = getenv("STM_CONV_RING64") ? atoi(getenv("STM_CONV_RING64")) : 3;
         // measured in the graph (bench.py --layer-table): the ring wins on the short K loops (<= 36 slabs: 35 -> 30 us,
         // 46 -> 36 us, 45 -> 37 us), where its two-slab head start hides the first DMA latency, and loses on the long and
-        // the split-K ones (100 -> 114 us at 72 slabs), where two resident two-buffer workgroups already cover each other
-        if (a.fmt == 1 && full && (ring64 == 3 ? (a.splitk == 1 && a.slabs <= 40) : ring64 == 4)) rc64 = launch_planar<2, 1, 1, 1, 1, 3>(a, tiles, stream);
+        // the split-K ones (100 -> 114 us at 72 slabs), where two resident two-buffer workgroups already cover each other;
+        // under 12 slabs the layer is HBM-bound and the two-buffer loop's 48 KB (three workgroups per CU) wins: 302 vs 389 us
+        if (a.fmt == 1 && full && (ring64 == 3 ? (a.splitk == 1 && a.slabs >= 12 && a.slabs <= 40) : ring64 == 4)) rc64 = launch_planar<2, 1, 1, 1, 1, 3>(a, tiles, stream);
         else if (a.fmt == 1) rc64 = launch_planar<2, 1, 1, 1, 1>(a, tiles, stream);
         else if (mf16) rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
         else rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 0>(a, tiles, stream) : launch_planar<2, 1, 1, 0>(a, tiles, stream);

@@ -13,6 +13,7 @@ Built by fuse.optimize_for_inference(net, planar=True) from the (BN-folded) modu
 head; FPN and proto-net still run planar.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -85,7 +86,15 @@ class PlanarConv:
         if cg <= 64 or (cg % 128 != 0 and cg % 128 <= 64 and cg < 256):
             return 64
         tiles128 = -(-M // 128) * -(-self.O // 128)
-        return 64 if tiles128 < 400 else 128
+        if tiles128 < 400:
+            return 64
+        # short K, wide output (the bottlenecks' expanding 1x1 convs with their residual): HBM-bound, and three resident
+        # 128 x 64 workgroups per CU (48 KB each) keep more loads and stores in flight than one 256 x 128 workgroup:
+        # 393 -> 302 us (64 -> 256 channels at 96x160, batch 32), 213 -> 175 us, 123 -> 112 us (scripts/ab_shortk.py)
+        slabs = self.C * self.kh * self.kw // 32
+        if slabs <= int(os.environ.get("STM_TILE64_MAX_SLABS", "8")):
+            return 64
+        return 128
 
     def __call__(self, xp, shape, out="planes", x_off=0, out_planes=None, out_f32=None, out_off=0, residual=None, x_ch_off=0,
                  out_ch_off=0):
