@@ -342,6 +342,15 @@ int stm_resize_bilinear_planes_f32(const float* x, void* planes, int B, int H, i
 int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bias, void* planes, int B, int H, int W, int C, int fmt,
                                      stm_stream_t stream);
 
+/* CandidateShift's RoI features (TF_utils.py:30-39: feats = relu(cat([corr, T2S_prev, T2S], 1)); mmcv roi_align(feats, rois,
+ * 7, spatial_scale 1, sampling_ratio 0, aligned) -- bbox_feat_extractor) as planes for TemporalNet's first convolution
+ * (track_to_segment_head.py:20): t2s_prev / t2s fp32 NHWC [B][H][W][C1], corr fp32 NCHW [B][Cc][H][W], rois [n][5] =
+ * (image, x1, y1, x2, y2).  planes [P][Cpad/32][n*PH*PW][32], Cpad = 2*C1 + Cc rounded up to 32, pixel = (roi, py, px),
+ * channel order [T2S_prev | T2S | corr | zeros] -- the consumer's weights are permuted to match.  Same arithmetic as
+ * stm_roi_align_avg_f32 on the concatenated map. */
+int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s, const float* corr, const float* rois, void* planes, int B,
+                             int H, int W, int C1, int Cc, int n, int PH, int PW, int fmt, stm_stream_t stream);
+
 /* fp16 plane format (fmt 1) range guard.  A value with |x| > 65504 (or inf / nan) has no fp16 plane representation and
  * would poison the following layers silently (inf - inf = nan, and a ReLU epilogue maps nan to 0).  Every producer of
  * fp16 planes (stm_split_planes_fmt_f32, the stm_conv2d_planar_* epilogues, stm_dcn_sample_planar_fmt_f32) therefore

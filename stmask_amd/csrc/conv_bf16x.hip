@@ -1498,6 +1498,110 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_planes_kernel(const flo
     __builtin_nontemporal_store(u32x4{q2[0], q2[1], q2[2], q2[3]}, reinterpret_cast<u32x4*>(dst + 2 * plane_b));
 }
 
+// CandidateShift's RoI features (TF_utils.py:30-39: relu(cat(corr, T2S_prev, T2S)) -> mmcv roi_align 7x7, aligned, adaptive
+// sampling grid) written straight into the planes TemporalNet's first convolution reads: no concatenated feature map, no
+// fp32 RoI tensor, no pad / permute / split passes.  Channel order of the planes: [T2S_prev (C1) | T2S (C1) | corr (Cc) |
+// zeros] -- the two feature maps are NHWC, so a lane's 8 channels are two 16-byte loads per corner and the lanes of a
+// wave read one contiguous run; the correlation volume is NCHW (strided, 19 % of the channels).  The arithmetic is
+// roi_align_avg_kernel's, operation for operation (temporal.hip), with the ReLU applied to the sampled inputs.
+struct RoiPlanesArgs {
+    const float* t2s_prev;   // [B][H][W][C1]
+    const float* t2s;        // [B][H][W][C1]
+    const float* corr;       // [B][Cc][H][W]
+    const float* rois;       // [n][5] = (image, x1, y1, x2, y2) in feature-map pixels
+    uint8_t* planes;         // [P][Cpad/32][n*PH*PW][32]
+    int n, H, W, C1, Cc, Cpad, PH, PW, fmt;
+    int* range_flag;
+};
+
+__global__ __launch_bounds__(256) void roi_align_planes_kernel(const RoiPlanesArgs a)
+{
+    const int gpp = a.Cpad >> 3;                                   // 8-channel groups per output pixel
+    const int64_t npix = (int64_t)a.n * a.PH * a.PW;
+    const int64_t blk = xcd_contiguous_block((npix * gpp + 255) >> 8);
+    if (blk < 0) return;
+    const int64_t idx = blk * 256 + threadIdx.x;
+    if (idx >= npix * gpp) return;
+    const int64_t pix = idx / gpp;
+    const int g = (int)(idx - pix * gpp);
+    const int ri = (int)(pix / (a.PH * a.PW));
+    const int pp = (int)(pix - (int64_t)ri * a.PH * a.PW);
+    const int py = pp / a.PW, px = pp - py * a.PW;
+    const float* roi = a.rois + 5 * ri;
+    const int b = (int)roi[0];
+    const float sw_ = roi[1] - 0.5f, sh_ = roi[2] - 0.5f, ew_ = roi[3] - 0.5f, eh_ = roi[4] - 0.5f;   // aligned, scale 1
+    const float rw = ew_ - sw_, rh = eh_ - sh_;
+    const float bh = rh / (float)a.PH, bw = rw / (float)a.PW;
+    const int gh = (int)ceilf(rh / (float)a.PH), gw = (int)ceilf(rw / (float)a.PW);
+    const float count = (float)max(gh * gw, 1);
+    const int c0 = g * 8;
+    // source of this lane's 8 channels
+    const bool from_prev = c0 < a.C1, from_cur = !from_prev && c0 < 2 * a.C1;
+    const float* nhwc = from_prev ? a.t2s_prev + (size_t)b * a.H * a.W * a.C1 + c0
+                                  : a.t2s + (size_t)b * a.H * a.W * a.C1 + (c0 - a.C1);
+    const int cc0 = c0 - 2 * a.C1;                                 // first correlation channel of the lane (NCHW source)
+    const float* nchw = a.corr + ((size_t)b * a.Cc + (cc0 > 0 ? cc0 : 0)) * a.H * a.W;
+    const int HW = a.H * a.W;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int iy = 0; iy < gh; ++iy) {
+        const float ys = sh_ + (float)py * bh + ((float)iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+            const float xs = sw_ + (float)px * bw + ((float)ix + 0.5f) * bw / (float)gw;
+            float y = ys, x = xs;
+            if (y < -1.0f || y > (float)a.H || x < -1.0f || x > (float)a.W) continue;     // the sample contributes 0
+            if (y <= 0.0f) y = 0.0f;
+            if (x <= 0.0f) x = 0.0f;
+            int y_low = (int)y, x_low = (int)x, y_high, x_high;
+            if (y_low >= a.H - 1) { y_high = y_low = a.H - 1; y = (float)y_low; } else y_high = y_low + 1;
+            if (x_low >= a.W - 1) { x_high = x_low = a.W - 1; x = (float)x_low; } else x_high = x_low + 1;
+            const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.0f - ly, hx = 1.0f - lx;
+            const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+            const int o1 = y_low * a.W + x_low, o2 = y_low * a.W + x_high, o3 = y_high * a.W + x_low, o4 = y_high * a.W + x_high;
+            float v1[8], v2[8], v3[8], v4[8];
+            if (from_prev || from_cur) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(nhwc + (size_t)o1 * a.C1 + 4 * h);
+                    const f32x4 q2 = *reinterpret_cast<const f32x4*>(nhwc + (size_t)o2 * a.C1 + 4 * h);
+                    const f32x4 q3 = *reinterpret_cast<const f32x4*>(nhwc + (size_t)o3 * a.C1 + 4 * h);
+                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(nhwc + (size_t)o4 * a.C1 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v1[4 * h + e] = q1[e]; v2[4 * h + e] = q2[e]; v3[4 * h + e] = q3[e]; v4[4 * h + e] = q4[e]; }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool real = cc0 + e < a.Cc;
+                    const float* im = nchw + (size_t)(real ? e : 0) * HW;
+                    v1[e] = real ? im[o1] : 0.0f; v2[e] = real ? im[o2] : 0.0f; v3[e] = real ? im[o3] : 0.0f; v4[e] = real ? im[o4] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                acc[e] += w1 * fmaxf(v1[e], 0.0f) + w2 * fmaxf(v2[e], 0.0f) + w3 * fmaxf(v3[e], 0.0f) + w4 * fmaxf(v4[e], 0.0f);
+        }
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = acc[e] / count;
+    unsigned q0[4], q1[4], q2[4];
+    const size_t plane_b = (size_t)npix * a.Cpad * 2;
+    uint8_t* dst = a.planes + (((size_t)(g >> 2) * npix + pix) * 32 + (g & 3) * 8) * 2;
+    if (a.fmt == 1) {
+        f16_range_check8(v, a.range_flag);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
+        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
+    *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+    *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+    *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+}
+
 // Weights [Cout][Cin][kh][kw] fp32 -> packed [n_tile][slab][plane][row 0..127][swizzled 16-B chunk][8 bf16]; rows past
 // Cout are zero.  One thread per (n_tile, slab, row, chunk).
 __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp, int Cout,
@@ -1779,6 +1883,25 @@ extern "C" int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bia
     hipLaunchKernelGGL(bias_relu_maxpool_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(n * (C / 8), 256), 8)), dim3(256), 0, stm_hs(stream), x, bias,
                        static_cast<uint8_t*>(planes), B, H, W, C, Ho, Wo, fmt, g_range_flag);
     STM_CHECK_LAUNCH("bias_relu_maxpool_planes_kernel");
+    return STM_OK;
+}
+
+extern "C" int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s, const float* corr, const float* rois, void* planes, int B,
+                                        int H, int W, int C1, int Cc, int n, int PH, int PW, int fmt, stm_stream_t stream)
+{
+    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_roi_align_planes_f32: fmt must be 0 or 1");
+    STM_REQUIRE(t2s_prev && t2s && corr && rois && planes, STM_ENULL, "stm_roi_align_planes_f32: NULL argument");
+    STM_REQUIRE(B > 0 && H > 0 && W > 0 && C1 > 0 && C1 % 8 == 0 && Cc > 0 && n > 0 && PH > 0 && PW > 0, STM_EINVAL,
+                "stm_roi_align_planes_f32: bad sizes (C1 = %d must be a multiple of 8)", C1);
+    STM_REQUIRE((uintptr_t)t2s_prev % 16 == 0 && (uintptr_t)t2s % 16 == 0 && (uintptr_t)planes % 16 == 0, STM_EINVAL,
+                "stm_roi_align_planes_f32: 16-byte alignment required");
+    RoiPlanesArgs a;
+    a.t2s_prev = t2s_prev; a.t2s = t2s; a.corr = corr; a.rois = rois; a.planes = static_cast<uint8_t*>(planes);
+    a.n = n; a.H = H; a.W = W; a.C1 = C1; a.Cc = Cc; a.Cpad = (2 * C1 + Cc + 31) / 32 * 32; a.PH = PH; a.PW = PW; a.fmt = fmt;
+    a.range_flag = g_range_flag;
+    const int64_t threads = (int64_t)n * PH * PW * (a.Cpad / 8);
+    hipLaunchKernelGGL(roi_align_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(threads, 256), 8)), dim3(256), 0, stm_hs(stream), a);
+    STM_CHECK_LAUNCH("roi_align_planes_kernel");
     return STM_OK;
 }
 

@@ -531,6 +531,24 @@ def bias_relu_maxpool_planes(x_nhwc, bias, fmt=0):
     return planes, (Ho, Wo)
 
 
+def roi_align_planes(t2s_prev_nhwc, t2s_nhwc, corr_nchw, rois, output_size=7, fmt=0):
+    """relu(cat([corr, T2S_prev, T2S], 1)) -> roi_align(output_size, aligned, adaptive grid) as planes
+    [P, Cpad/32, n*ph*pw, 32] with channel order [T2S_prev | T2S | corr | zero padding] (stm_roi_align_planes_f32)."""
+    _dev(t2s_prev_nhwc, t2s_nhwc, corr_nchw, rois)
+    a, b, c, rois = _f32c(t2s_prev_nhwc), _f32c(t2s_nhwc), _f32c(corr_nchw), _f32c(rois)
+    B, H, W, C1 = a.shape
+    if tuple(b.shape) != (B, H, W, C1) or c.shape[0] != B or tuple(c.shape[2:]) != (H, W):
+        raise StmError(f"roi_align_planes: shapes {tuple(a.shape)}, {tuple(b.shape)}, {tuple(c.shape)} do not match")
+    Cc, n = c.shape[1], rois.shape[0]
+    ph, pw = _pair(output_size)
+    cpad = -(-(2 * C1 + Cc) // 32) * 32
+    planes = torch.empty(2 if fmt == 1 else 3, cpad // 32, n * ph * pw, 32, device=a.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    if n:
+        check(_lib.lib().stm_roi_align_planes_f32(_p(a), _p(b), _p(c), _p(rois), _p(planes), c_i(B), c_i(H), c_i(W), c_i(C1), c_i(Cc), c_i(n),
+                                                  c_i(ph), c_i(pw), c_i(fmt), _stream()), "stm_roi_align_planes_f32")
+    return planes
+
+
 def planes_to_f32(planes):
     """[P, S, N, 32] planes -> fp32 [N, 32*S]."""
     v = planes[0].float()

@@ -104,15 +104,28 @@ class BatchedClipPipeline:
         P = cfg.correlation_patch_size
         corr = ops.corr_patch(P4_prev, P4, P, 1, scale=1.0 / P4.shape[1], leaky_slope=0.1)
         corr = corr.view(P4.shape[0], P * P, P4.shape[2], P4.shape[3])
-        feats = F.relu(torch.cat([corr, T2S_prev, T2S], dim=1))
         fh, fw = P4.shape[2:]
         box_ref = prev["box"]
         rois = torch.cat([clip_of_row.float().unsqueeze(1), sanitize_coordinates_hw(box_ref, fh, fw)], dim=1)
-        roi_feats = ops.roi_align(feats, rois, 7)
-        self.timer.toc("tf_corr_roi")
-        n = roi_feats.shape[0]
         ptn = getattr(net, "_planar_temporal", None)
-        if ptn is not None:      # planar convolution: any RoI count, one launch per layer
+        a_prev, a_cur = T2S_prev.permute(0, 2, 3, 1), T2S.permute(0, 2, 3, 1)
+        fused = (ptn is not None and ptn.ncorr == P * P and a_prev.is_contiguous() and a_cur.is_contiguous()
+                 and 2 * T2S.shape[1] + P * P == ptn.cin)
+        if fused:
+            # ReLU + concatenation + RoIAlign + channel padding + split in one kernel: the RoI features leave as the planes
+            # TemporalNet's first convolution reads (the feature maps are channels_last views of the head's fp32 output)
+            n = rois.shape[0]
+            xp = ops.roi_align_planes(a_prev, a_cur, corr, rois, 7, fmt=ptn.fmt)
+            self.timer.toc("tf_corr_roi")
+            loc_shift, coeff_shift = ptn.forward_planes(xp, n)
+        else:
+            feats = F.relu(torch.cat([corr, T2S_prev, T2S], dim=1))
+            roi_feats = ops.roi_align(feats, rois, 7)
+            self.timer.toc("tf_corr_roi")
+            n = roi_feats.shape[0]
+        if fused:
+            pass
+        elif ptn is not None:      # planar convolution: any RoI count, one launch per layer
             loc_shift, coeff_shift = ptn(roi_feats)
         else:
             n_pad = -(-n // ROI_CHUNKS[-1]) * ROI_CHUNKS[-1]

@@ -481,10 +481,15 @@ class PlanarTemporalNet:
     640 with zero weights; any number of RoIs goes through in one launch per layer, so the fixed-shape RoI blocks the
     dense-conv library needed (one kernel selection per shape) disappear."""
 
-    def __init__(self, tn):
+    def __init__(self, tn, corr_channels=121):
         w1 = tn.conv1.weight.detach()
         self.cin = w1.shape[1]
         self.cpad = -(-self.cin // 32) * 32
+        # input channel order of the planes: [T2S_prev | T2S | corr | zero padding] (stm_roi_align_planes_f32 writes them so:
+        # the two NHWC feature maps first, 8-channel groups aligned); the module's order is [corr | T2S_prev | T2S]
+        self.ncorr = corr_channels if 0 < corr_channels < self.cin and (self.cin - corr_channels) % 16 == 0 else 0
+        self.perm = torch.cat([torch.arange(self.ncorr, self.cin), torch.arange(0, self.ncorr)]).to(w1.device)
+        w1 = w1.index_select(1, self.perm)
         w1 = F.pad(w1, (0, 0, 0, 0, 0, self.cpad - self.cin))
         self.c1 = PlanarConv(w1, tn.conv1.bias, 1, tn.conv1.padding, relu=True, algo_frac=self.cin / self.cpad)
         self.c2 = PlanarConv(tn.conv2.weight, tn.conv2.bias, 1, tn.conv2.padding, relu=True)
@@ -495,8 +500,11 @@ class PlanarTemporalNet:
     def __call__(self, roi_feats):
         """roi_feats [n, 633, 7, 7] fp32 -> (loc shift [n, 4], coeff shift [n, 32])."""
         n, c, h, w = roi_feats.shape
-        x = F.pad(roi_feats.permute(0, 2, 3, 1), (0, self.cpad - c)).contiguous()       # NHWC, channels padded
-        xp = ops.split_planes(x, self.fmt)
+        x = F.pad(roi_feats.index_select(1, self.perm.to(roi_feats.device)).permute(0, 2, 3, 1), (0, self.cpad - c)).contiguous()   # NHWC, padded
+        return self.forward_planes(ops.split_planes(x, self.fmt), n, h, w)
+
+    def forward_planes(self, xp, n, h=7, w=7):
+        """xp: the RoI features as planes [P, cpad/32, n*h*w, 32] in this object's channel order (ops.roi_align_planes)."""
         shape = ("img", n, h, w)
         y = self.c3(self.c2(self.c1(xp, shape), shape), shape, out="f32")                # [n*h*w, 1024]
         pooled = y.view(n, h * w, -1).mean(dim=1)                                        # AvgPool2d((7, 7)) on a 7x7 map

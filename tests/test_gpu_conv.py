@@ -447,3 +447,29 @@ def test_bias_relu_maxpool_planes_equals_torch_chain(case, fmt):
     pl0, _ = ops.bias_relu_maxpool_planes(x.to(DEV), None, fmt=fmt)
     ref0 = F.max_pool2d(torch.relu(x).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
     assert torch.equal(pl0.cpu(), ops.split_planes(ref0.to(DEV), fmt=fmt).cpu())
+
+
+@pytest.mark.parametrize("fmt", [1, 0])
+def test_roi_align_planes_equals_cat_relu_roialign_split(fmt):
+    """stm_roi_align_planes_f32 == relu(cat(corr, T2S_prev, T2S)) -> stm_roi_align_avg_f32 -> channel reorder + zero pad ->
+    stm_split_planes_fmt_f32, bit for bit (same arithmetic, operation for operation); boxes of all sizes, at the borders,
+    degenerate, and on every image of the batch; the RoIAlign itself is pinned to the oracle in test_gpu_kernels.py."""
+    B, H, W, C1, Cc = 3, 12, 20, 32, 9
+    g = torch.Generator().manual_seed(5)
+    prev, cur = rnd(B, H, W, C1, seed=1), rnd(B, H, W, C1, seed=2)
+    corr = rnd(B, Cc, H, W, seed=3)
+    n = 41
+    x1 = torch.rand(n, generator=g) * W * 1.1 - 1.0
+    y1 = torch.rand(n, generator=g) * H * 1.1 - 1.0
+    bw = torch.rand(n, generator=g) ** 2 * W
+    bh = torch.rand(n, generator=g) ** 2 * H
+    rois = torch.stack([torch.randint(0, B, (n,), generator=g).float(), x1, y1, x1 + bw, y1 + bh], 1)
+    rois[0, 1:] = torch.tensor([3.0, 4.0, 3.0, 4.0])            # empty box
+    rois[1, 1:] = torch.tensor([0.0, 0.0, float(W), float(H)])  # whole map
+    pl = ops.roi_align_planes(prev.to(DEV), cur.to(DEV), corr.to(DEV), rois.to(DEV), 7, fmt=fmt)
+    feats = torch.relu(torch.cat([corr, prev.permute(0, 3, 1, 2), cur.permute(0, 3, 1, 2)], 1)).contiguous()
+    ref = ops.roi_align(feats.to(DEV), rois.to(DEV), 7)                                   # [n, Cc + 2 C1, 7, 7]
+    ref = torch.cat([ref[:, Cc:], ref[:, :Cc]], 1).permute(0, 2, 3, 1)                    # [T2S_prev | T2S | corr], NHWC
+    cpad = pl.shape[1] * 32
+    ref = torch.nn.functional.pad(ref, (0, cpad - ref.shape[-1])).contiguous()
+    assert torch.equal(pl.cpu(), ops.split_planes(ref, fmt=fmt).cpu().view_as(pl.cpu()))
