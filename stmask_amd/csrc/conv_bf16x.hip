@@ -540,7 +540,8 @@ __device__ __forceinline__ void park16(f32x4 (&acc)[4][2 * NJ], f32x4 (&accl)[4]
 }
 
 // bias + residual + ReLU + stores of one 8-channel segment (pixel m, channels co .. co+7, nvalid of them real); v = raw sums
-__device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int co, int nvalid, float (&v)[8])
+__device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int co, int nvalid, float (&v)[8], bool have_pre = false,
+                                                f16x8 pre0 = f16x8{}, f16x8 pre1 = f16x8{})   // pre0 / pre1: this segment's fp16 residual planes, already loaded
 {
     const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
     // element index of (pixel m, channel co) in a slab-major planar buffer with np pixels per slab
@@ -556,8 +557,8 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         if (a.res_pl) {
             const size_t ri = pidx(m, co, a.res_np) * 2;
             if (a.fmt == 1) {
-                const f16x8 p0 = *reinterpret_cast<const f16x8*>(a.res_pl + ri);
-                const f16x8 p1 = *reinterpret_cast<const f16x8*>(a.res_pl + ri + rpl * 2);
+                const f16x8 p0 = have_pre ? pre0 : *reinterpret_cast<const f16x8*>(a.res_pl + ri);
+                const f16x8 p1 = have_pre ? pre1 : *reinterpret_cast<const f16x8*>(a.res_pl + ri + rpl * 2);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)p0[e] + (float)p1[e] * (1.0f / STM_F16_LOW_SCALE);
             } else {
@@ -653,6 +654,22 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
     const int co = grp * a.cout_g + cog;
     const int nvalid = min(8, a.cout_g - cog);         // channels of this segment that exist (<= 0: none)
     if (nvalid <= 0) return;
+    // fp16 residual planes: all passes' loads first.  Taken pass by pass they sit behind the previous pass's stores (the
+    // compiler must assume the output aliases the residual), one 32-byte load per lane in flight -- the HBM-bound layers
+    // (expanding 1x1 convolutions of the bottlenecks) then run at the latency of four dependent round trips.  The fragment
+    // and accumulator registers are dead here, so the 8 * LPR registers cost nothing.
+    // (64-channel tiles only: with LPR = 8 the 64 extra registers push the 256 x 128 kernel into scratch -- 380 -> 1065 us)
+    const bool pre = NJ == 1 && a.vec_epilogue && a.res_pl != nullptr && a.fmt == 1 && !(a.dbg & 16);
+    f16x8 r0[LPR], r1[LPR];
+    if (pre) {
+#pragma unroll
+        for (int pass = 0; pass < LPR; ++pass) {
+            const int m = min(m0 + wm * 64 + pass * (64 / LPR) + prow, a.M - 1);
+            const size_t ri = (((size_t)(co >> 5) * a.res_np + m) * 32 + (co & 31)) * 2;
+            r0[pass] = *reinterpret_cast<const f16x8*>(a.res_pl + ri);
+            r1[pass] = *reinterpret_cast<const f16x8*>(a.res_pl + ri + a.res_pstride);
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < LPR; ++pass) {
         const int pr = pass * (64 / LPR) + prow;
@@ -661,7 +678,8 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        epilogue_store8(a, m, co, nvalid, v);
+        if (pre) epilogue_store8(a, m, co, nvalid, v, true, r0[pass], r1[pass]);
+        else epilogue_store8(a, m, co, nvalid, v);
     }
 }
 
