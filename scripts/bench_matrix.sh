@@ -6,10 +6,13 @@ run
 run --overlap early
 run --overlap off
 run --planes bf16x3
-run --no-planar
-run --config STMask_plus_resnet50_ada_config
-run --config STMask_plus_base_ali_config
-run --config STMask_plus_base_ali_config --height 736 --width 1280 --clips 4
+run --clips 8
+run --clips 8 --overlap early
+run --clips 8 --planes bf16x3
+run --clips 8 --no-planar
+run --clips 8 --config STMask_plus_resnet50_ada_config
+run --clips 8 --config STMask_plus_base_ali_config
+run --clips 4 --config STMask_plus_base_ali_config --height 736 --width 1280
 run --clips 16
-run --clips 32
+run --clips 64
 grep -o '^== .*\|"value": [0-9.]*\|"achieved": [0-9.]*' $OUT | paste - - - - 2>/dev/null | cut -c1-200
