@@ -105,7 +105,7 @@ def main():
                          "planes / 6 products (no fp16 range limit); both are fp32-equivalent to 2e-6 of sum|x w|")
     ap.add_argument("--layer-table", action="store_true", help="per-layer-shape timing table of the planar convolution on stderr")
     ap.add_argument("--no-planar", dest="planar", action="store_false",
-                    help="FPN / proto-net / head convolutions through MIOpen instead of the bf16-split matrix-core kernel")
+                    help="FPN / proto-net / head convolutions through MIOpen instead of the split-operand matrix-core kernel")
     ap.add_argument("--fp16-backbone", action="store_true",
                     help="BASELINE config 5 flavour: ResNet trunk under fp16 autocast (implies --no-fuse); NOT the headline metric")
     ap.add_argument("--pipeline", default="batched", choices=["batched", "per-clip"],
@@ -135,7 +135,7 @@ def main():
     if args.fuse:
         from stmask_amd.fuse import optimize_for_inference
         # BN folded into conv / DCN weights, bias (+residual) + ReLU as one epilogue pass; FPN / proto-net / shared head
-        # on stm_conv2d_planar_f32 (fp32-equivalent bf16-split MFMA convolution, all FPN levels per launch)
+        # on stm_conv2d_planar_f32 (fp32-equivalent split-operand MFMA convolution, all FPN levels per launch)
         optimize_for_inference(net, planar=args.planar and args.channels_last, planes=args.planes)
     if args.channels_last:
         net = net.to(memory_format=torch.channels_last)  # dense convs NHWC (17.0 vs 20.6 ms trunk at batch 8)
@@ -226,7 +226,7 @@ def main():
                        "launches": len(timing), "avg_launch_us": round(ker_ms * 1e3 / n_launch, 2),
                        "algorithmic_bytes_per_launch": int(ker_bytes / n_launch)}
         if conv_t:
-            # dominant kernel of the step: the bf16-split convolution.  achieved = fp32-equivalent algorithmic flops
+            # dominant kernel of the step: the split-operand convolution.  achieved = fp32-equivalent algorithmic flops
             # (2*M*Cout*Cin*kh*kw of the reference layers, zero-padded channels excluded) / launch time; peak = dense 16-bit
             # MFMA peak / n_prod, because each fp32 product is carried by n_prod MFMA products (3 fp16 or 6 bf16).
             n_prod = 3 if args.planes == "fp16x2" else 6

@@ -1,5 +1,6 @@
-"""Planar inference graph: FPN prediction / downsample layers, the proto-net and the shared prediction head run on
-stm_conv2d_planar_f32 (include/stmask_hip.h) -- activations stay in the three-plane bf16 split between layers, the
+"""Planar inference graph: the ResNet bottlenecks, FPN laterals / prediction / downsample layers, the proto-net, the shared
+prediction head and TemporalNet run on stm_conv2d_planar_f32 (include/stmask_hip.h) -- activations stay split into planes
+between layers (two fp16 planes by default, three bf16 planes on request: set_format / DESIGN.md section 1), the
 five FPN levels of the shared head go through every layer in ONE launch (pixel axis = concatenated levels), the four
 branch towers are one Cout=1024 layer followed by one grouped layer, and the per-kernel-shape output layers are one
 grouped launch each.  Values are those of the reference's fp32 convolutions to fp32 rounding (tests/test_gpu_conv.py,
@@ -9,8 +10,9 @@ tests/test_gpu_model.py); what changes is the schedule:
     here: 1 + 1 + 1 + 3 launches for all levels together.
 
 Built by fuse.optimize_for_inference(net, planar=True) from the (BN-folded) modules; parameters are read once and packed
-(stm_conv_pack_weights_f32).  Heads with FCB branches (use_dcn_class / track / mask) keep their module path for the
-head; FPN and proto-net still run planar.
+(stm_conv_pack_weights_fmt_f32).  The FCB class branch (use_dcn_class) runs FeatureAlign's deformable convolution per
+level on the NCHW kernels and its trailing conv planar; FCB on the track / mask branches keeps the module path for the
+head (FPN and proto-net still run planar).
 """
 import ctypes
 import os
@@ -98,7 +100,7 @@ class PlanarConv:
 
     def __call__(self, xp, shape, out="planes", x_off=0, out_planes=None, out_f32=None, out_off=0, residual=None, x_ch_off=0,
                  out_ch_off=0):
-        """xp: [3, S, N, 32] bf16 (channel-slab-major planes).  shape: ("img", B, H, W) -> pixels [x_off, x_off + B*H*W)
+        """xp: [P, S, N, 32] planes in this layer's format (channel-slab major; 2 x fp16 or 3 x bf16).  shape: ("img", B, H, W) -> pixels [x_off, x_off + B*H*W)
         of xp are one image batch; ("levels", B, [(H, W), ...]) -> all of xp, concatenated levels.  The layer reads
         groups*C channels starting at channel x_ch_off.  out: "planes" | "f32" | "both" allocates dense outputs
         ([3, O/32, M, 32] / [M, O]) unless out_planes / out_f32 are given, then pixels [out_off, ...) are written."""
@@ -514,8 +516,9 @@ class PlanarTemporalNet:
 class PlanarBackbone:
     """ResNet bottlenecks (backbone.py:38-58 of the reference, eval BatchNorm folded) with every 1x1 convolution, the
     plain 3x3 convolutions and the stride-s downsample projections on the planar convolution; residual add + ReLU in
-    conv3's epilogue.  The stem (7x7, 3 input channels) stays on the dense-conv library; the deformable 3x3 layers stay on
-    deform im2col + fp32 MFMA GEMM (they take / return NCHW fp32: one layout change either side)."""
+    conv3's epilogue.  The stem's 7x7 convolution (3 input channels) stays on the dense-conv library, its bias + ReLU +
+    max-pool go straight to planes (stm_bias_relu_maxpool_planes_f32); the deformable 3x3 layers run as planar offset conv
+    -> planar sampler (columns as planes) -> planar 1x1 convolution over 9C channels (other DCN shapes: NCHW kernels)."""
 
     OM_PLANAR_MIN_PIXELS = 0    # offset / mask conv of a DCN layer on the planar kernel from this many output pixels (with
                                 # split-K the small stages are fine there too: 547-549 vs 538-539 frames/s with the library)
