@@ -359,6 +359,15 @@ int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s, const floa
  * the guard.  One registration per process (one process per GPU). */
 int stm_planar_set_range_flag(int* device_flag);
 
+/* General form: x is pixel-major with a pixel stride of x_ld floats (>= C: a channel slice of a wider NHWC tensor is
+ * fine), has_mask = 1 the modulated form above (offsets then mask logits, dcn_v2), has_mask = 0 mmcv's DeformConv2d as
+ * FeatureAlign uses it (Featurealign.py:44-58; 2K offsets per pixel, 3x3 / 3x5 / 5x3 taps, C = 256).  The columns of the
+ * g->B * Ho * Wo output pixels are written at pixels [out_pixel_offset, ...) of planes with out_np pixels per slab, so the
+ * FPN levels of a shared head can share one column buffer.  Tap-major K order: k * C + c. */
+int stm_deform_sample_planar_f32(const float* x, int x_ld, const float* offsets, int om_ld, int has_mask, void* planes, int out_np,
+                                 int out_pixel_offset, long long out_plane_stride, const stm_deform_geom* g, int fmt,
+                                 stm_stream_t stream);
+
 /* plane-format aware form (fmt as in stm_conv_geom: 0 = bf16 x 3, 1 = fp16 x 2) */
 int stm_dcn_sample_planar_fmt_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
                                   long long out_plane_stride, const stm_deform_geom* g, int fmt, stm_stream_t stream);

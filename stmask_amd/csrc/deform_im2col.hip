@@ -751,10 +751,11 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 
 struct SampleArgs {
-    const float* x;      // [B, H, W, C]
-    const float* om;     // [B*Ho*Wo, om_ld]: 2K offsets (dy, dx per tap) then K mask logits
+    const float* x;      // [B, H, W, x_ld >= C]: pixel-major, C channels used
+    const float* om;     // [B*Ho*Wo, om_ld]: 2K offsets (dy, dx per tap), then K mask logits in the modulated (DCNv2) form
     uint8_t* out;        // planes [3][K*C/32][out_np][32] bf16
     int B, H, W, C, Ho, Wo, sh, sw, ph, pw, dh, dw;
+    int x_ld, kw, out_pix0;      // pixel stride of x (floats); kernel width (tap k = (k / kw, k % kw)); first output pixel in the planes
     int om_ld, out_np, M, fmt;   // fmt 0: three bf16 planes, 1: two fp16 planes
     int* range_flag;             // fmt 1: raised when a sampled value has no fp16 representation (may be null)
     int xcd, per_xcd, nt;        // XCD-contiguous workgroup order (workgroups per XCD); nontemporal column stores
@@ -785,10 +786,13 @@ __device__ __forceinline__ void split2_planes(float a, float b, unsigned& p0, un
     p2 = __builtin_bit_cast(unsigned, l);
 }
 
-template <int LPP>   // lanes per pixel: C = 8 * LPP (16, 32 or 64 lanes -> 4, 2 or 1 pixels per wave), 8 channels per lane
+// lanes per pixel: C = 8 * LPP (16, 32 or 64 lanes -> 4, 2 or 1 pixels per wave), 8 channels per lane; K = kh * kw taps (< LPP);
+// MASK: modulated (dcn_v2.DCN: sigmoid mask logits after the offsets) or plain (mmcv DeformConv2d of FeatureAlign)
+template <int LPP, int K = 9, bool MASK = true>
 __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs a)
 {
-    constexpr int K = 9, PPW = 64 / LPP;
+    constexpr int PPW = 64 / LPP;
+    static_assert(K <= LPP, "one sub-lane per tap");
     const int lane = threadIdx.x & 63, sl = lane % LPP;
     // workgroup ids are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of pixels, so that an input row is
     // gathered through one L2 instead of all eight
@@ -804,17 +808,17 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
     const int b = mm / (a.Ho * a.Wo);
     const int rem = mm - b * (a.Ho * a.Wo);
     const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-    const float* xb = a.x + (size_t)b * a.H * a.W * a.C + sl * 8;
+    const float* xb = a.x + (size_t)b * a.H * a.W * a.x_ld + sl * 8;
     // sub-lane k (< 9) of each pixel group prepares tap k: corner weights with the mask folded in and clamped corner
     // offsets; the tap loop broadcasts them inside the group, so the per-tap work is 8 vector loads, 32 FMAs, the split and
     // three 16-byte stores per lane -- not LPP copies of the coefficient arithmetic
     float cw1 = 0.f, cw2 = 0.f, cw3 = 0.f, cw4 = 0.f;
     int ca1 = 0, ca2 = 0, ca3 = 0, ca4 = 0;
     if (sl < K) {
-        const int i = sl / 3, j = sl - 3 * i;
+        const int i = sl / a.kw, j = sl - a.kw * i;
         const float* omp = a.om + (size_t)mm * a.om_ld;
         const float dy = omp[2 * sl], dx = omp[2 * sl + 1];
-        const float mk = sigmoidf_dev(omp[2 * K + sl]);
+        const float mk = MASK ? sigmoidf_dev(omp[2 * K + sl]) : 1.0f;
         const float fy = (float)(ho * a.sh - a.ph + i * a.dh) + dy;
         const float fx = (float)(wo * a.sw - a.pw + j * a.dw) + dx;
         if (fy > -1.0f && fx > -1.0f && fy < (float)a.H && fx < (float)a.W) {
@@ -827,10 +831,10 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
             cw2 = (t && r) ? hh * lw * mk : 0.f;
             cw3 = (bt && l) ? lh * hw * mk : 0.f;
             cw4 = (bt && r) ? lh * lw * mk : 0.f;
-            ca1 = (hl * a.W + wl) * a.C;
-            ca2 = (hl * a.W + wh_i) * a.C;
-            ca3 = (hh_i * a.W + wl) * a.C;
-            ca4 = (hh_i * a.W + wh_i) * a.C;
+            ca1 = (hl * a.W + wl) * a.x_ld;
+            ca2 = (hl * a.W + wh_i) * a.x_ld;
+            ca3 = (hh_i * a.W + wl) * a.x_ld;
+            ca4 = (hh_i * a.W + wh_i) * a.x_ld;
         }
     }
     typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
         }
         const u32x4v p0 = {q0[0], q0[1], q0[2], q0[3]}, p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]};
         const int kc = k * a.C + sl * 8;                     // K index of the lane's first channel (8 | kc: inside one slab)
-        uint8_t* o = a.out + (((size_t)(kc >> 5) * a.out_np + mm) * 32 + (kc & 31)) * 2;
+        uint8_t* o = a.out + (((size_t)(kc >> 5) * a.out_np + a.out_pix0 + mm) * 32 + (kc & 31)) * 2;
         if (live && a.nt) {          // the columns are far larger than L2 and read once, later: keep them out of the gathers' way
             __builtin_nontemporal_store(p0, reinterpret_cast<u32x4v*>(o));
             __builtin_nontemporal_store(p1, reinterpret_cast<u32x4v*>(o + a.out_pstride));
@@ -886,23 +890,42 @@ extern "C" int stm_dcn_sample_planar_f32(const float* x, const float* offset_mas
     return stm_dcn_sample_planar_fmt_f32(x, offset_mask, om_ld, planes, out_np, out_plane_stride, g, 0, stream);
 }
 
+extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const float* offsets, int om_ld, int has_mask, void* planes, int out_np,
+                                            int out_pixel_offset, long long out_plane_stride, const stm_deform_geom* g, int fmt,
+                                            stm_stream_t stream);
 extern "C" int stm_dcn_sample_planar_fmt_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
                                              long long out_plane_stride, const stm_deform_geom* g, int fmt, stm_stream_t stream)
 {
-    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_dcn_sample_planar_f32: fmt must be 0 or 1");
-    STM_REQUIRE(x && offset_mask && planes && g, STM_ENULL, "stm_dcn_sample_planar_f32: NULL argument");
-    STM_REQUIRE(g->kh == 3 && g->kw == 3 && g->dg == 1, STM_EUNSUPPORTED, "stm_dcn_sample_planar_f32: 3x3 kernels, one deformable group");
-    STM_REQUIRE(g->C == 128 || g->C == 256 || g->C == 512, STM_EUNSUPPORTED, "stm_dcn_sample_planar_f32: C must be 128, 256 or 512 (got %d)", g->C);
-    STM_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->Ho > 0 && g->Wo > 0 && om_ld >= 27, STM_EINVAL, "stm_dcn_sample_planar_f32: bad geometry");
+    STM_REQUIRE(g, STM_ENULL, "stm_dcn_sample_planar_f32: NULL argument");
+    return stm_deform_sample_planar_f32(x, g->C, offset_mask, om_ld, 1, planes, out_np, 0, out_plane_stride, g, fmt, stream);
+}
+
+extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const float* offsets, int om_ld, int has_mask, void* planes, int out_np,
+                                            int out_pixel_offset, long long out_plane_stride, const stm_deform_geom* g, int fmt,
+                                            stm_stream_t stream)
+{
+    const char* who = "stm_deform_sample_planar_f32";
+    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "%s: fmt must be 0 or 1", who);
+    STM_REQUIRE(x && offsets && planes && g, STM_ENULL, "%s: NULL argument", who);
+    const int K = g->kh * g->kw;
+    STM_REQUIRE(g->dg == 1 && (K == 9 || (K == 15 && !has_mask)), STM_EUNSUPPORTED,
+                "%s: one deformable group; 3x3 taps, or 3x5 / 5x3 without mask (got %dx%d, dg %d)", who, g->kh, g->kw, g->dg);
+    STM_REQUIRE(g->C == 128 || g->C == 256 || g->C == 512, STM_EUNSUPPORTED, "%s: C must be 128, 256 or 512 (got %d)", who, g->C);
+    STM_REQUIRE(has_mask || g->C == 256, STM_EUNSUPPORTED, "%s: the mask-free form is built for C = 256 (got %d)", who, g->C);
+    STM_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->Ho > 0 && g->Wo > 0 && om_ld >= (has_mask ? 3 : 2) * K && x_ld >= g->C && x_ld % 4 == 0 &&
+                out_pixel_offset >= 0, STM_EINVAL, "%s: bad geometry", who);
     const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
-    STM_REQUIRE(M < ((int64_t)1 << 30) && (int64_t)g->B * g->H * g->W * g->C < ((int64_t)1 << 31), STM_EUNSUPPORTED,
-                "stm_dcn_sample_planar_f32: tensor too large for 32-bit indexing");
+    STM_REQUIRE(M < ((int64_t)1 << 30) && (int64_t)g->B * g->H * g->W * x_ld < ((int64_t)1 << 31), STM_EUNSUPPORTED,
+                "%s: tensor too large for 32-bit indexing", who);
+    STM_REQUIRE(out_np <= 0 || out_pixel_offset + M <= out_np, STM_EINVAL, "%s: output pixels [%d, %lld) exceed the planes (%d)", who,
+                out_pixel_offset, (long long)(out_pixel_offset + M), out_np);
     SampleArgs a;
-    a.x = x; a.om = offset_mask; a.out = static_cast<uint8_t*>(planes);
+    a.x = x; a.om = offsets; a.out = static_cast<uint8_t*>(planes);
     a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.Ho = g->Ho; a.Wo = g->Wo;
     a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw; a.dh = g->dh; a.dw = g->dw;
+    a.x_ld = x_ld; a.kw = g->kw; a.out_pix0 = out_pixel_offset;
     a.om_ld = om_ld; a.M = (int)M; a.out_np = out_np > 0 ? out_np : (int)M; a.fmt = fmt; a.range_flag = stm_internal_range_flag();
-    a.out_pstride = (out_plane_stride > 0 ? out_plane_stride : (long long)(9 * g->C / 32) * a.out_np * 32) * 2;
+    a.out_pstride = (out_plane_stride > 0 ? out_plane_stride : (long long)(K * g->C / 32) * a.out_np * 32) * 2;
     const int ppw = 512 / g->C;                                  // pixels per wave
     const int nblk = stm_cdiv(M, 4 * ppw);
     { const char* e = getenv("STM_DCN_XCD"); a.xcd = e ? atoi(e) : 1; }
@@ -911,9 +934,11 @@ extern "C" int stm_dcn_sample_planar_fmt_f32(const float* x, const float* offset
     { const char* e = getenv("STM_DCN_NT"); a.nt = e ? atoi(e) : (g->C <= 256 ? 1 : 0); }
     a.per_xcd = stm_cdiv(nblk, 8);
     const dim3 grid(a.xcd ? 8 * a.per_xcd : nblk);
-    if (g->C == 128) hipLaunchKernelGGL(dcn_sample_planar_kernel<16>, grid, dim3(256), 0, stm_hs(stream), a);
-    else if (g->C == 256) hipLaunchKernelGGL(dcn_sample_planar_kernel<32>, grid, dim3(256), 0, stm_hs(stream), a);
-    else hipLaunchKernelGGL(dcn_sample_planar_kernel<64>, grid, dim3(256), 0, stm_hs(stream), a);
+    if (!has_mask && K == 15) hipLaunchKernelGGL((dcn_sample_planar_kernel<32, 15, false>), grid, dim3(256), 0, stm_hs(stream), a);
+    else if (!has_mask) hipLaunchKernelGGL((dcn_sample_planar_kernel<32, 9, false>), grid, dim3(256), 0, stm_hs(stream), a);
+    else if (g->C == 128) hipLaunchKernelGGL((dcn_sample_planar_kernel<16>), grid, dim3(256), 0, stm_hs(stream), a);
+    else if (g->C == 256) hipLaunchKernelGGL((dcn_sample_planar_kernel<32>), grid, dim3(256), 0, stm_hs(stream), a);
+    else hipLaunchKernelGGL((dcn_sample_planar_kernel<64>), grid, dim3(256), 0, stm_hs(stream), a);
     STM_CHECK_LAUNCH("dcn_sample_planar_kernel");
     return STM_OK;
 }

@@ -181,6 +181,28 @@ def gemm_bias(A, Bm, bias=None, relu=False):
     return C[0] if squeeze else C
 
 
+def deform_sample_planar(x_pix, B, H, W, C, offsets, kernel_size, padding, out, out_off, fmt=0):
+    """mmcv DeformConv2d's sampling half (no mask, stride 1, one deformable group) for the planar graph: x_pix fp32
+    [B*H*W, ld >= C] (a channel slice of a wider pixel-major tensor: only the row stride must be a multiple of 4 floats),
+    offsets fp32 [B*H*W, 2*kh*kw] pixel-major -> columns written at pixels [out_off, out_off + B*H*W) of the planes
+    out [P, kh*kw*C/32, N, 32] (K index = tap*C + channel).  stm_deform_sample_planar_f32."""
+    _dev(x_pix, offsets, out)
+    if x_pix.dtype != torch.float32 or x_pix.dim() != 2 or x_pix.stride(1) != 1 or x_pix.shape[0] != B * H * W or x_pix.shape[1] != C:
+        raise StmError(f"deform_sample_planar: x must be fp32 [B*H*W, C] with unit channel stride, got {tuple(x_pix.shape)} {x_pix.stride()}")
+    offsets = _f32c(offsets)
+    kh, kw = _pair(kernel_size)
+    ph, pw = _pair(padding)
+    if offsets.shape[0] != B * H * W or offsets.shape[1] != 2 * kh * kw:
+        raise StmError(f"deform_sample_planar: offsets {tuple(offsets.shape)} != {(B * H * W, 2 * kh * kw)}")
+    if out.dim() != 4 or out.shape[1] * 32 != kh * kw * C or not out.is_contiguous():
+        raise StmError(f"deform_sample_planar: planes {tuple(out.shape)} do not hold {kh * kw * C} column channels")
+    g = DeformGeom(B, C, H, W, kh, kw, 1, 1, ph, pw, 1, 1, 1, H, W)
+    check(_lib.lib().stm_deform_sample_planar_f32(_p(x_pix), c_i(x_pix.stride(0)), _p(offsets), c_i(offsets.shape[1]), c_i(0), _p(out),
+                                                  c_i(out.shape[2]), c_i(out_off), c_l(0), ctypes.byref(g), c_i(fmt), _stream()),
+          "stm_deform_sample_planar_f32")
+    return out
+
+
 def fcb_ali_offsets(loc, kh, kw):
     """Featurealign.py:46-69: loc [B,4,H,W] -> offsets [B,2*kh*kw,H,W]."""
     _dev(loc)

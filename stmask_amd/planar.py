@@ -10,9 +10,9 @@ tests/test_gpu_model.py); what changes is the schedule:
     here: 1 + 1 + 1 + 3 launches for all levels together.
 
 Built by fuse.optimize_for_inference(net, planar=True) from the (BN-folded) modules; parameters are read once and packed
-(stm_conv_pack_weights_fmt_f32).  The FCB class branch (use_dcn_class) runs FeatureAlign's deformable convolution per
-level on the NCHW kernels and its trailing conv planar; FCB on the track / mask branches keeps the module path for the
-head (FPN and proto-net still run planar).
+(stm_conv_pack_weights_fmt_f32).  The FCB class branch (use_dcn_class) runs FeatureAlign's deformable convolution as
+planar sampler + planar 1x1 convolution over all levels (stm_deform_sample_planar_f32) and its trailing conv planar; FCB
+on the track / mask branches keeps the module path for the head (FPN and proto-net still run planar).
 """
 import ctypes
 import os
@@ -272,6 +272,15 @@ class PlanarGraph:
                 fa = head.conf_layer[k]
                 entry.append(fa)
                 entry.append(PlanarConv(fa.conv.weight, fa.conv.bias, 1, fa.conv.padding, relu=False, tile_n=64))
+                # FeatureAlign's DeformConv2d as planar sampler (columns [pixel][tap*C + c] for all levels) + planar 1x1
+                # convolution over kh*kw*C channels (+ ReLU); offsets as one [pixels, 4] x [4, 2K] product (ada)
+                ad = fa.conv_adaption
+                O, Cin, akh, akw = ad.weight.shape
+                if ad.deform_groups == 1 and Cin == 256 and akh * akw in (9, 15):
+                    wk = ad.weight.detach().permute(0, 2, 3, 1).reshape(O, akh * akw * Cin, 1, 1)
+                    entry.append(PlanarConv(wk, None, 1, 0, relu=True))
+                else:
+                    entry.append(None)
             self.finals.append(tuple(entry))
         self.head = head
 
@@ -418,14 +427,37 @@ class PlanarGraph:
             t2_32, t2 = self.tower2(t1, lv, out="both")               # the class branch also leaves as fp32 for the sampler
             toc("head_towers")
             # conf_x per level as NCHW fp32 (shared by the three kernel shapes)
-            conf_x = [t2_32[starts[l]:starts[l + 1], 0:cw].reshape(B, hh, ww, cw).permute(0, 3, 1, 2).contiguous()
-                      for l, (hh, ww) in enumerate(sizes)]
+            conf_x = None
             outs = []
-            for small, trk, fa, fconv in self.finals:
+            for small, trk, fa, fconv, adconv in self.finals:
                 buf = torch.empty(ntot, 3 * P, device=dev, dtype=torch.float32)   # [conf | centerness+bbox | mask] groups
                 small(t2, lv, out="f32", out_f32=buf, x_ch_off=cw, out_ch_off=P)
-                feat_k = torch.empty(ntot, cw, device=dev, dtype=torch.float32)
                 npri = head.num_priors
+                if adconv is not None and npri == 1 and os.environ.get("STM_FCB_PLANAR", "1") != "0":
+                    # all-planar class branch: offsets pixel-major, sampler per level into one column buffer, one 1x1 conv
+                    kh, kw = fa.kernel_size
+                    K = kh * kw
+                    bbox_pix = buf[:, P + npri:P + npri + 4]                       # [ntot, 4] box regression of this shape
+                    if fa.use_pred_offset:
+                        off = bbox_pix @ fa.conv_offset.weight.view(2 * K, 4).t()   # Featurealign.py:40-43 (1x1 conv, no bias)
+                    NP_, pdt_ = _planes_dtype(self.fmt)
+                    cols = torch.empty(NP_, K * cw // 32, ntot, 32, device=dev, dtype=pdt_)
+                    for l, (hh, ww) in enumerate(sizes):
+                        sl = slice(starts[l], starts[l + 1])
+                        if fa.use_pred_offset:
+                            off_l = off[sl]
+                        else:
+                            loc_l = bbox_pix[sl].reshape(B, hh, ww, 4).permute(0, 3, 1, 2).contiguous()
+                            off_l = ops.fcb_ali_offsets(loc_l, kh, kw).permute(0, 2, 3, 1).reshape(-1, 2 * K)
+                        ops.deform_sample_planar(t2_32[sl, 0:cw], B, hh, ww, cw, off_l, (kh, kw), fa.padding, cols, starts[l], self.fmt)
+                    feat_pl = adconv(cols, ("img", 1, 1, ntot))                  # DeformConv2d's GEMM + ReLU
+                    fconv(feat_pl, lv, out="f32", out_f32=buf)                   # conf logits into columns [0, n_cls)
+                    outs.append((buf, trk(t2, lv, out="f32", x_ch_off=3 * cw)))
+                    continue
+                if conf_x is None:
+                    conf_x = [t2_32[starts[l]:starts[l + 1], 0:cw].reshape(B, hh, ww, cw).permute(0, 3, 1, 2).contiguous()
+                              for l, (hh, ww) in enumerate(sizes)]
+                feat_k = torch.empty(ntot, cw, device=dev, dtype=torch.float32)
                 for l, (hh, ww) in enumerate(sizes):
                     sl = slice(starts[l], starts[l + 1])
                     bbox_cur = buf[sl, P + npri:P + npri + 4 * npri].reshape(B, hh, ww, 4 * npri).permute(0, 3, 1, 2).contiguous()

@@ -528,3 +528,27 @@ def test_dcn_sample_planar_equals_im2col(B, C, H, W, stride):
     if B * H * W <= 1000:
         o_cols = oracle.deform_im2col(x, om[:, 0:18].contiguous(), torch.sigmoid(om[:, 18:27]), (3, 3), stride, 1, 1, 1)
         assert (cols.cpu() - o_cols).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("kh,kw", [(3, 3), (3, 5), (5, 3)])
+def test_deform_sample_planar_mask_free_equals_im2col(kh, kw):
+    """stm_deform_sample_planar_f32 without mask (mmcv DeformConv2d of FeatureAlign: 3x3 / 3x5 / 5x3 taps, C = 256) on a
+    channel slice of a wider pixel-major tensor, written at a pixel offset of a shared column buffer: the values of
+    stm_deform_im2col_f32 (v1, no mask) on the same inputs, bit for bit."""
+    B, C, H, W, wide = 2, 256, 7, 9, 384
+    K = kh * kw
+    xw = rnd(B * H * W, wide, seed=kh)                                # pixel-major, 384 channels; the layer reads [64, 320)
+    x = xw[:, 64:64 + C]
+    off = rnd(B * H * W, 2 * K, seed=kw + 7, scale=1.5)               # pixel-major offsets (dy, dx per tap)
+    x_nchw = x.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+    off_nchw = off.reshape(B, H, W, 2 * K).permute(0, 3, 1, 2).contiguous()
+    cols = ops.deform_im2col(x_nchw.to(DEV), off_nchw.to(DEV), None, (kh, kw), 1, ((kh - 1) // 2, (kw - 1) // 2), 1, 1)   # [B, C*K, H*W]
+    ref = cols.view(B, C, K, H * W).permute(0, 3, 2, 1).reshape(B * H * W, K * C)                  # [pixel, k*C + c]
+    for fmt in (0, 1):
+        ntot, pix0 = B * H * W + 37, 21
+        out = torch.zeros(2 if fmt == 1 else 3, K * C // 32, ntot, 32, device=DEV, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+        xd = xw.to(DEV)
+        ops.deform_sample_planar(xd[:, 64:64 + C], B, H, W, C, off.to(DEV), (kh, kw), ((kh - 1) // 2, (kw - 1) // 2), out, pix0, fmt)
+        got = out[:, :, pix0:pix0 + B * H * W].contiguous()
+        assert torch.equal(got, ops.split_planes(ref.contiguous(), fmt=fmt).view_as(got)), (kh, kw, fmt)
+        assert torch.count_nonzero(out[:, :, :pix0]) == 0 and torch.count_nonzero(out[:, :, pix0 + B * H * W:]) == 0
