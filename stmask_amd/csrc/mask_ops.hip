@@ -238,13 +238,17 @@ struct HeadArgs {
     float *conf, *loc, *mask, *track, *cen;
     int B, K, n_levels, n_cls, mask_dim, embed, gpad, small_ld, trk_ld, N;
     int lvl_start[9], lvl_hw[8], lvl_off[8];
+    int vec4, xcd;   // track rows as float4 (embed % 4 == 0 <= 256, 16-byte aligned strides); XCD-contiguous block order
 };
 
+// 16 lanes per (image, prior) row, four rows per wave: the rows are short (41 + 4 + 32 + 1 + 128 floats), so a whole wave per
+// row left most lanes idle in every access (41, 4, 32, 1 of 64); here the track embedding moves as float4 per lane when the
+// strides allow, and the L2 norm is a 16-lane reduction.
 __global__ __launch_bounds__(256) void head_assemble_kernel(const HeadArgs a)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, n)
-    if (row >= (int64_t)a.B * a.N) return;
+    const int sub = threadIdx.x & 15;
+    const int64_t row = (int64_t)stm_xcd_block_or_plain(a.xcd, ((int64_t)a.B * a.N + 15) >> 4) * 16 + (threadIdx.x >> 4);      // (b, n)
+    if (row < 0 || row >= (int64_t)a.B * a.N) return;
     const int b = (int)(row / a.N), n = (int)(row - (int64_t)b * a.N);
     int l = 0;
 #pragma unroll
@@ -257,17 +261,39 @@ __global__ __launch_bounds__(256) void head_assemble_kernel(const HeadArgs a)
     const float* sm = a.small[k] + src * a.small_ld;
     const float* tk = a.trk[k] + src * a.trk_ld;
     const int64_t o = (int64_t)b * a.N + n;
-    for (int c = lane; c < a.n_cls; c += 64) a.conf[o * a.n_cls + c] = sm[c];
-    if (lane < 4) a.loc[o * 4 + lane] = sm[a.gpad + 1 + lane];
-    for (int c = lane; c < a.mask_dim; c += 64) a.mask[o * a.mask_dim + c] = sm[2 * a.gpad + c];
-    if (lane == 0) a.cen[(int64_t)b * a.N + a.lvl_off[l] + (int64_t)k * hw + p] = tanhf(sm[a.gpad]);
+    for (int c = sub; c < a.n_cls; c += 16) a.conf[o * a.n_cls + c] = sm[c];
+    if (sub < 4) a.loc[o * 4 + sub] = sm[a.gpad + 1 + sub];
+    for (int c = sub; c < a.mask_dim; c += 16) a.mask[o * a.mask_dim + c] = sm[2 * a.gpad + c];
+    if (sub == 0) a.cen[(int64_t)b * a.N + a.lvl_off[l] + (int64_t)k * hw + p] = tanhf(sm[a.gpad]);
     // track: x / max(||x||_2, 1e-12) (F.normalize, prediction_head_FC.py:177)
     float ss = 0.0f;
-    for (int c = lane; c < a.embed; c += 64) { const float v = tk[c]; ss = fmaf(v, v, ss); }
+    if (a.vec4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 v[4];                                                   // embed <= 256: at most four float4 per lane
+        const int nv = a.embed >> 2;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
-    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-    for (int c = lane; c < a.embed; c += 64) a.track[o * a.embed + c] = tk[c] * inv;
+        for (int q = 0; q < 4; ++q) {
+            const int c4 = sub + 16 * q;
+            if (c4 < nv) {
+                v[q] = *reinterpret_cast<const f4*>(tk + 4 * c4);
+                ss = fmaf(v[q].x, v[q].x, ss); ss = fmaf(v[q].y, v[q].y, ss); ss = fmaf(v[q].z, v[q].z, ss); ss = fmaf(v[q].w, v[q].w, ss);
+            }
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c4 = sub + 16 * q;
+            if (c4 < nv) *reinterpret_cast<f4*>(a.track + o * a.embed + 4 * c4) = v[q] * inv;
+        }
+    } else {
+        for (int c = sub; c < a.embed; c += 16) { const float v = tk[c]; ss = fmaf(v, v, ss); }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        for (int c = sub; c < a.embed; c += 16) a.track[o * a.embed + c] = tk[c] * inv;
+    }
 }
 
 }  // namespace
@@ -301,7 +327,10 @@ extern "C" int stm_head_assemble_f32(const float* const* small, const float* con
     a.lvl_start[8] = 0;
     a.N = off;
     const int64_t rows = (int64_t)a.B * a.N;
-    hipLaunchKernelGGL(head_assemble_kernel, dim3(stm_cdiv(rows, 4)), dim3(256), 0, stm_hs(stream), a);
+    a.vec4 = a.embed % 4 == 0 && a.embed <= 256 && a.trk_ld % 4 == 0 && ((uintptr_t)track % 16) == 0;
+    for (int k = 0; k < a.K; ++k) a.vec4 = a.vec4 && ((uintptr_t)a.trk[k] % 16) == 0;
+    a.xcd = 1;
+    hipLaunchKernelGGL(head_assemble_kernel, dim3(stm_xcd_grid(stm_cdiv(rows, 16))), dim3(256), 0, stm_hs(stream), a);
     STM_CHECK_LAUNCH("head_assemble_kernel");
     return STM_OK;
 }

@@ -46,6 +46,7 @@ __device__ __forceinline__ int64_t stm_xcd_block(int64_t nblocks)
     const int64_t b = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     return b < nblocks ? b : -1;
 }
+__device__ __forceinline__ int64_t stm_xcd_block_or_plain(int xcd, int64_t nblocks) { return xcd ? stm_xcd_block(nblocks) : (int64_t)blockIdx.x; }
 static inline unsigned stm_xcd_grid(int64_t nblocks) { return (unsigned)(8 * ((nblocks + 7) / 8)); }
 
 // Canonical exp (oracle/stm_oracle.c: stm_exp_f64): identical IEEE operation sequence in double, rounded
