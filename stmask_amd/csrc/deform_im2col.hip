@@ -759,6 +759,7 @@ struct SampleArgs {
     int om_ld, out_np, M, fmt;   // fmt 0: three bf16 planes, 1: two fp16 planes
     int* range_flag;             // fmt 1: raised when a sampled value has no fp16 representation (may be null)
     int xcd, per_xcd, nt;        // XCD-contiguous workgroup order (workgroups per XCD); nontemporal column stores
+    int prefetch;                // streaming touch of the centre pixels ahead of the gathers
     long long out_pstride;   // bytes
 };
 
@@ -809,6 +810,16 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
     const int rem = mm - b * (a.Ho * a.Wo);
     const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
     const float* xb = a.x + (size_t)b * a.H * a.W * a.x_ld + sl * 8;
+    // Touch the undeformed centre pixel of this output pixel first: a coalesced streaming load (the lanes of a pixel read its
+    // C contiguous floats, consecutive pixels consecutive lines) that brings the neighbourhood the gathers are about to hit
+    // into L2 with full memory-level parallelism.  With the input cold in HBM the gathers' own first-touch misses cost as
+    // much as the whole rest of the kernel (230 vs 119 us on layer2 at batch 32); the value is only kept alive, never used.
+    typedef float f32x4p __attribute__((ext_vector_type(4)));
+    f32x4p pf = {0.f, 0.f, 0.f, 0.f};
+    if (a.prefetch) {
+        const int cy = min(max(ho * a.sh - a.ph + a.dh, 0), a.H - 1), cx = min(max(wo * a.sw - a.pw + a.dw, 0), a.W - 1);
+        pf = *reinterpret_cast<const f32x4p*>(xb + (size_t)(cy * a.W + cx) * a.x_ld);
+    }
     // sub-lane k (< 9) of each pixel group prepares tap k: corner weights with the mask folded in and clamped corner
     // offsets; the tap loop broadcasts them inside the group, so the per-tap work is 8 vector loads, 32 FMAs, the split and
     // three 16-byte stores per lane -- not LPP copies of the coefficient arithmetic
@@ -878,6 +889,7 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
             if (a.fmt == 0) *reinterpret_cast<u32x4v*>(o + 2 * a.out_pstride) = p2;
         }
     }
+    asm volatile("" ::"v"(pf));      // the touch above stays in the program
 }
 
 }  // namespace
@@ -933,6 +945,7 @@ extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const floa
     // 34 -> 45 us with 512 channels (one pixel per wave, 1-KB runs per tap) -- so up to 256 channels only
     { const char* e = getenv("STM_DCN_NT"); a.nt = e ? atoi(e) : (g->C <= 256 ? 1 : 0); }
     a.per_xcd = stm_cdiv(nblk, 8);
+    { const char* e = getenv("STM_DCN_PREFETCH"); a.prefetch = e ? atoi(e) : 1; }
     const dim3 grid(a.xcd ? 8 * a.per_xcd : nblk);
     if (!has_mask && K == 15) hipLaunchKernelGGL((dcn_sample_planar_kernel<32, 15, false>), grid, dim3(256), 0, stm_hs(stream), a);
     else if (!has_mask) hipLaunchKernelGGL((dcn_sample_planar_kernel<32, 9, false>), grid, dim3(256), 0, stm_hs(stream), a);
