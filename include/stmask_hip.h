@@ -351,6 +351,13 @@ int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bias, void* pl
 int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s, const float* corr, const float* rois, void* planes, int B,
                              int H, int W, int C1, int Cc, int n, int PH, int PW, int fmt, stm_stream_t stream);
 
+/* Stem entry (backbone.py:73 / resnet conv1: kh x kw convolution, stride s, on a Cin-channel frame with kw * Cin <= 32): x fp32
+ * NHWC [B][H][W][Cin] -> planes R [P][1][B*H*Wo][32], Wo = (W + 2 pw - kw) / sw + 1, R[b][y][ox][j] = x[b][y][sw*ox - pw + j / Cin]
+ * [j % Cin] for j < kw * Cin (zero outside the frame and for j >= kw * Cin).  The stem is then the (kh x 1), stride (sh, 1),
+ * padding (ph, 0) planar convolution over R with weights w'[o][j][ky][0] = w[o][j % Cin][ky][j / Cin]. */
+int stm_stem_rows_planes_f32(const float* x, void* planes, int B, int H, int W, int Cin, int kw, int sw, int pw, int fmt,
+                             stm_stream_t stream);
+
 /* fp16 plane format (fmt 1) range guard.  A value with |x| > 65504 (or inf / nan) has no fp16 plane representation and
  * would poison the following layers silently (inf - inf = nan, and a ReLU epilogue maps nan to 0).  Every producer of
  * fp16 planes (stm_split_planes_fmt_f32, the stm_conv2d_planar_* epilogues, stm_dcn_sample_planar_fmt_f32) therefore

@@ -1620,6 +1620,50 @@ __global__ __launch_bounds__(256) void roi_align_planes_kernel(const RoiPlanesAr
     *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
 }
 
+// Stem entry (backbone.py:73, the 7x7 / stride-2 convolution on the 3-channel frame): the kw * Cin = 21 values one kernel row
+// reads for output column ox are contiguous in the NHWC frame, starting at column sw*ox - pw.  This kernel lays them out as
+// the 32-channel slab of a planar tensor R[b][y][ox][32] (channels >= kw*Cin zero, columns outside the frame zero), which
+// turns the stem into a (kh x 1) convolution with stride (sh, 1) over R on the planar kernel: K = kh * 32 = 224 for 147
+// real products, no im2col buffer, no library call.  thread = 8 channels of one R pixel.
+__global__ __launch_bounds__(256) void stem_rows_planes_kernel(const float* __restrict__ x, uint8_t* __restrict__ planes, int B, int H, int W,
+                                                              int Cin, int kw, int sw, int pw, int Wo, int fmt, int* range_flag)
+{
+    const int64_t n = (int64_t)B * H * Wo;
+    const int64_t blk = xcd_contiguous_block((n * 4 + 255) >> 8);
+    if (blk < 0) return;
+    const int64_t idx = blk * 256 + threadIdx.x;
+    if (idx >= n * 4) return;
+    const int64_t pix = idx >> 2;
+    const int g = (int)(idx & 3);
+    const int ox = (int)(pix % Wo);
+    const int64_t row = pix / Wo;                                   // b * H + y
+    const float* src = x + row * (int64_t)W * Cin;
+    const int c0 = (sw * ox - pw) * Cin;                            // first float of the patch within the frame row
+    const int lim = W * Cin, real = kw * Cin;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = g * 8 + e, c = c0 + j;
+        v[e] = (j < real && c >= 0 && c < lim) ? src[c] : 0.0f;
+    }
+    unsigned q0[4], q1[4], q2[4];
+    const size_t plane_b = (size_t)n * 32 * 2;
+    uint8_t* dst = planes + ((size_t)pix * 32 + g * 8) * 2;
+    if (fmt == 1) {
+        f16_range_check8(v, range_flag);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
+        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
+    *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+    *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+    *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+}
+
 // Weights [Cout][Cin][kh][kw] fp32 -> packed [n_tile][slab][plane][row 0..127][swizzled 16-B chunk][8 bf16]; rows past
 // Cout are zero.  One thread per (n_tile, slab, row, chunk).
 __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp, int Cout,
@@ -1920,6 +1964,23 @@ extern "C" int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s,
     const int64_t threads = (int64_t)n * PH * PW * (a.Cpad / 8);
     hipLaunchKernelGGL(roi_align_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(threads, 256), 8)), dim3(256), 0, stm_hs(stream), a);
     STM_CHECK_LAUNCH("roi_align_planes_kernel");
+    return STM_OK;
+}
+
+extern "C" int stm_stem_rows_planes_f32(const float* x, void* planes, int B, int H, int W, int Cin, int kw, int sw, int pw, int fmt,
+                                        stm_stream_t stream)
+{
+    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_stem_rows_planes_f32: fmt must be 0 or 1");
+    STM_REQUIRE(x && planes, STM_ENULL, "stm_stem_rows_planes_f32: x/planes must be non-NULL");
+    STM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && kw > 0 && sw > 0 && pw >= 0 && kw * Cin <= 32, STM_EINVAL,
+                "stm_stem_rows_planes_f32: sizes must be positive and kw * Cin (%d) at most 32", kw * Cin);
+    STM_REQUIRE((uintptr_t)planes % 16 == 0, STM_EINVAL, "stm_stem_rows_planes_f32: 16-byte alignment required");
+    const int Wo = (W + 2 * pw - kw) / sw + 1;
+    STM_REQUIRE(Wo > 0 && (int64_t)H * W * Cin < ((int64_t)1 << 31), STM_EINVAL, "stm_stem_rows_planes_f32: bad geometry");
+    const int64_t n = (int64_t)B * H * Wo;
+    hipLaunchKernelGGL(stem_rows_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(n * 4, 256), 8)), dim3(256), 0, stm_hs(stream), x,
+                       static_cast<uint8_t*>(planes), B, H, W, Cin, kw, sw, pw, Wo, fmt, g_range_flag);
+    STM_CHECK_LAUNCH("stem_rows_planes_kernel");
     return STM_OK;
 }
 

@@ -571,6 +571,19 @@ def roi_align_planes(t2s_prev_nhwc, t2s_nhwc, corr_nchw, rois, output_size=7, fm
     return planes
 
 
+def stem_rows_planes(x_nhwc, kw, sw, pw, fmt=0):
+    """fp32 frame [B,H,W,Cin] (kw*Cin <= 32) -> planes R [P, 1, B*H*Wo, 32]: the kw*Cin contiguous values one kernel row reads for
+    each output column (stm_stem_rows_planes_f32); returns (planes, Wo)."""
+    _dev(x_nhwc)
+    x = _f32c(x_nhwc)
+    B, H, W, Cin = x.shape
+    Wo = (W + 2 * pw - kw) // sw + 1
+    planes = torch.empty(2 if fmt == 1 else 3, 1, B * H * Wo, 32, device=x.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    check(_lib.lib().stm_stem_rows_planes_f32(_p(x), _p(planes), c_i(B), c_i(H), c_i(W), c_i(Cin), c_i(kw), c_i(sw), c_i(pw), c_i(fmt),
+                                              _stream()), "stm_stem_rows_planes_f32")
+    return planes, Wo
+
+
 def planes_to_f32(planes):
     """[P, S, N, 32] planes -> fp32 [N, 32*S]."""
     v = planes[0].float()

@@ -548,8 +548,9 @@ class PlanarTemporalNet:
 class PlanarBackbone:
     """ResNet bottlenecks (backbone.py:38-58 of the reference, eval BatchNorm folded) with every 1x1 convolution, the
     plain 3x3 convolutions and the stride-s downsample projections on the planar convolution; residual add + ReLU in
-    conv3's epilogue.  The stem's 7x7 convolution (3 input channels) stays on the dense-conv library, its bias + ReLU +
-    max-pool go straight to planes (stm_bias_relu_maxpool_planes_f32); the deformable 3x3 layers run as planar offset conv
+    conv3's epilogue.  The stem's 7x7 / stride-2 convolution (3 input channels) is a (7 x 1) planar convolution over the
+    row-patch tensor of stm_stem_rows_planes_f32, its bias + ReLU + max-pool go straight to planes
+    (stm_bias_relu_maxpool_planes_f32); the deformable 3x3 layers run as planar offset conv
     -> planar sampler (columns as planes) -> planar 1x1 convolution over 9C channels (other DCN shapes: NCHW kernels)."""
 
     OM_PLANAR_MIN_PIXELS = 0    # offset / mask conv of a DCN layer on the planar kernel from this many output pixels (with
@@ -561,6 +562,14 @@ class PlanarBackbone:
         self.fmt = FMT
         self.planes_only = False    # fuse: the planar FPN takes the stage outputs as planes; their fp32 copies are not made
         self.out_planes = None      # [(planes, B, H, W)] of the last call, one entry per stage
+        # stem: w'[o][j][ky][0] = w[o][j % Cin][ky][j / Cin] over the row-patch tensor of stm_stem_rows_planes_f32
+        c1 = bb.conv1
+        O, Cin, kh, kw = c1.weight.shape
+        self.stem = None
+        if kw * Cin <= 32 and c1.groups == 1 and tuple(c1.dilation) == (1, 1):
+            w = c1.weight.detach().permute(0, 2, 3, 1).reshape(O, kh, kw * Cin)          # [o][ky][kx*Cin + c]
+            w = F.pad(w, (0, 32 - kw * Cin)).permute(0, 2, 1).reshape(O, 32, kh, 1).contiguous()
+            self.stem = PlanarConv(w, None, (c1.stride[0], 1), (c1.padding[0], 0), relu=False, algo_frac=kw * Cin / 32.0)
         self.blocks = []
         for layer in bb.layers:
             blks = []
@@ -593,9 +602,19 @@ class PlanarBackbone:
         if (isinstance(bb.bn1, torch.nn.Identity) and c1.out_channels % 32 == 0 and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1
                 and not mp.ceil_mode and mp.dilation == 1):
             # stem tail in one pass: folded-BN bias + ReLU + 3x3/2 max-pool of the raw 7x7 convolution output, straight to planes
-            y = F.conv2d(x, c1.weight, None, c1.stride, c1.padding, c1.dilation, c1.groups)
-            B, C = y.shape[:2]
-            xp, (H, W) = ops.bias_relu_maxpool_planes(_nhwc(y), c1.bias, self.fmt)
+            if self.stem is not None and os.environ.get("STM_STEM_PLANAR", "1") != "0":
+                # the 7x7 / stride-2 convolution itself as a (7 x 1) planar convolution over the row-patch tensor R
+                B = x.shape[0]
+                kh, kw = c1.kernel_size
+                rp, Wo = ops.stem_rows_planes(_nhwc(x), kw, c1.stride[1], c1.padding[1], self.fmt)
+                y = self.stem(rp, ("img", B, x.shape[2], Wo), out="f32")
+                Ho = (x.shape[2] + 2 * c1.padding[0] - kh) // c1.stride[0] + 1
+                y = y.view(B, Ho, Wo, c1.out_channels)
+            else:
+                y = _nhwc(F.conv2d(x, c1.weight, None, c1.stride, c1.padding, c1.dilation, c1.groups))
+                B = y.shape[0]
+            C = c1.out_channels
+            xp, (H, W) = ops.bias_relu_maxpool_planes(y, c1.bias, self.fmt)
         else:
             x = bb.maxpool(bb.relu(bb.bn1(bb.conv1(x))))        # conv1 carries the folded BN + ReLU after fuse
             B, C, H, W = x.shape

@@ -473,3 +473,33 @@ def test_roi_align_planes_equals_cat_relu_roialign_split(fmt):
     cpad = pl.shape[1] * 32
     ref = torch.nn.functional.pad(ref, (0, cpad - ref.shape[-1])).contiguous()
     assert torch.equal(pl.cpu(), ops.split_planes(ref, fmt=fmt).cpu().view_as(pl.cpu()))
+
+
+@pytest.mark.parametrize("fmt", [1, 0])
+def test_stem_row_patches_plus_planar_conv_equals_7x7_stride2(fmt):
+    """stm_stem_rows_planes_f32 + a (7 x 1), stride (2, 1) planar convolution over the row-patch tensor == the stem's 7x7 /
+    stride-2 / padding-3 convolution on the 3-channel frame (oracle, fp64 accumulation) to the planar kernel's stated bound;
+    odd and even frame sizes, borders included."""
+    from stmask_amd import planar
+    from stmask_amd.planar import PlanarConv
+    planar.set_format(fmt)
+    try:
+        for (B, H, W) in [(2, 24, 36), (1, 17, 23)]:
+            x = rnd(B, H, W, 3, seed=H)
+            w = rnd(64, 3, 7, 7, seed=5, scale=147 ** -0.5)
+            ref = oracle.conv2d_nhwc(x, w, None, None, stride=2, padding=3)
+            mag = oracle.conv2d_nhwc(x.abs(), w.abs(), None, None, stride=2, padding=3)
+            rp, Wo = ops.stem_rows_planes(x.to(DEV), 7, 2, 3, fmt)
+            assert Wo == ref.shape[2]
+            # the row-patch tensor holds the 21 contiguous values of each kernel row
+            R = planes_to_f32(rp.cpu()).view(B, H, Wo, 32)
+            xp = torch.nn.functional.pad(x, (0, 0, 3, 3))
+            for ox in (0, 1, Wo - 1):
+                want = xp[:, :, 2 * ox:2 * ox + 7, :].reshape(B, H, 21)
+                assert (R[:, :, ox, :21] - want).abs().max().item() <= 2.0 ** -21 * 4 and torch.count_nonzero(R[:, :, ox, 21:]) == 0
+            wk = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(64, 7, 21), (0, 11)).permute(0, 2, 1).reshape(64, 32, 7, 1).contiguous()
+            conv = PlanarConv(wk.to(DEV), None, (2, 1), (3, 0), relu=False)
+            y = conv(rp, ("img", B, H, Wo), out="f32").cpu().view(ref.shape)
+            assert ((y - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
+    finally:
+        planar.set_format(1)
