@@ -95,14 +95,28 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const float* __restrict_
 // grid: (ceil(n2/256), n1); row i of m1 staged in LDS, one thread per column j
 __global__ __launch_bounds__(256) void mask_iou_pairs_kernel(const unsigned long long* __restrict__ b1,
                                                              const unsigned long long* __restrict__ b2, int n2, int words,
-                                                             float* __restrict__ out)
+                                                             float* __restrict__ out, const int* __restrict__ g1,
+                                                             const int* __restrict__ g2)
 {
     extern __shared__ unsigned long long arow[];
     const int i = blockIdx.y;
+    // group ids (the clip a mask belongs to in the batched pipeline): pairs of different groups are never compared by the
+    // caller -- their IoU is left at 0 and their words are not read.  Rows of a group are contiguous, so a workgroup whose
+    // 256 columns all belong to other groups leaves at once.
+    const int gi = g1 ? g1[i] : 0;
+    if (g2) {
+        const int j0 = blockIdx.x * 256, j1 = min(j0 + 255, n2 - 1);
+        if (g2[j0] > gi || g2[j1] < gi) {                  // sorted group ids: no column of this block can match
+            const int j = j0 + threadIdx.x;
+            if (j < n2) out[(int64_t)i * n2 + j] = 0.0f;
+            return;
+        }
+    }
     for (int t = threadIdx.x; t < words; t += 256) arow[t] = b1[(int64_t)i * words + t];
     __syncthreads();
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n2) return;
+    if (g2 && g2[j] != gi) { out[(int64_t)i * n2 + j] = 0.0f; return; }
     int inter = 0, a1 = 0, a2 = 0;
     const unsigned long long* q = b2 + (int64_t)j * words;
     for (int t = 0; t < words; ++t) {
@@ -150,9 +164,18 @@ extern "C" size_t stm_mask_iou_workspace_bytes(int n1, int n2, int hw)
     return ((size_t)n1 + (size_t)n2) * words * 8 + 64;
 }
 
+extern "C" int stm_mask_iou_grouped_f32(const float* m1, int n1, const float* m2, int n2, int hw, float thr, float* out, const int* group1,
+                                        const int* group2, void* workspace, size_t workspace_bytes, stm_stream_t stream);
 extern "C" int stm_mask_iou_f32(const float* m1, int n1, const float* m2, int n2, int hw, float thr, float* out,
                                 void* workspace, size_t workspace_bytes, stm_stream_t stream)
 {
+    return stm_mask_iou_grouped_f32(m1, n1, m2, n2, hw, thr, out, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int stm_mask_iou_grouped_f32(const float* m1, int n1, const float* m2, int n2, int hw, float thr, float* out, const int* group1,
+                                        const int* group2, void* workspace, size_t workspace_bytes, stm_stream_t stream)
+{
+    STM_REQUIRE((group1 == nullptr) == (group2 == nullptr), STM_EINVAL, "stm_mask_iou_grouped_f32: give both group arrays or neither");
     STM_REQUIRE(n1 >= 0 && n2 >= 0 && hw > 0, STM_EINVAL, "stm_mask_iou_f32: bad sizes");
     if (n1 == 0 || n2 == 0) return STM_OK;
     STM_REQUIRE(m1 && m2 && out, STM_ENULL, "stm_mask_iou_f32: m1/m2/out must be non-NULL");
@@ -166,7 +189,7 @@ extern "C" int stm_mask_iou_f32(const float* m1, int n1, const float* m2, int n2
     hipLaunchKernelGGL(mask_pack_kernel, dim3(stm_cdiv(words, 4), n2), dim3(256), 0, stm_hs(stream), m2, b2, hw, words, thr);
     STM_CHECK_LAUNCH("mask_pack_kernel");
     hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n2, 256), n1), dim3(256), (size_t)words * 8, stm_hs(stream), b1,
-                       b2, n2, words, out);
+                       b2, n2, words, out, group1, group2);
     STM_CHECK_LAUNCH("mask_iou_pairs_kernel");
     return STM_OK;
 }

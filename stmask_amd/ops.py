@@ -363,9 +363,10 @@ def lincomb_sigmoid_crop(proto, coeff, boxes=None, apply_tanh=True, n_dev=None, 
     return out
 
 
-def mask_iou(m1, m2, thr=0.5):
-    """box_utils.py:435-447 on (m > thr).  m1 [n1,h,w], m2 [n2,h,w] soft masks -> [n1,n2]."""
-    _dev(m1, m2)
+def mask_iou(m1, m2, thr=0.5, group1=None, group2=None):
+    """box_utils.py:435-447 on (m > thr).  m1 [n1,h,w], m2 [n2,h,w] soft masks -> [n1,n2].  group1 / group2 (int32, group2
+    sorted): only pairs of the same group are computed, the others stay 0 (stm_mask_iou_grouped_f32)."""
+    _dev(m1, m2, group1, group2)
     m1, m2 = _f32c(m1), _f32c(m2)
     n1, n2 = m1.shape[0], m2.shape[0]
     out = torch.zeros(n1, n2, dtype=torch.float32, device=m1.device)
@@ -374,6 +375,12 @@ def mask_iou(m1, m2, thr=0.5):
     hw = m1[0].numel()
     need = _lib.lib().stm_mask_iou_workspace_bytes(c_i(n1), c_i(n2), c_i(hw))
     ws = _workspace(need, m1.device, "miou")
+    if group1 is not None:
+        if group1.dtype != torch.int32 or group2.dtype != torch.int32 or group1.numel() != n1 or group2.numel() != n2:
+            raise StmError("mask_iou: group arrays must be int32 of lengths n1 and n2")
+        check(_lib.lib().stm_mask_iou_grouped_f32(_p(m1), c_i(n1), _p(m2), c_i(n2), c_i(hw), c_f(thr), _p(out), _p(group1.contiguous()),
+                                                  _p(group2.contiguous()), _p(ws), c_sz(ws.numel()), _stream()), "stm_mask_iou_grouped_f32")
+        return out
     check(_lib.lib().stm_mask_iou_f32(_p(m1), c_i(n1), _p(m2), c_i(n2), c_i(hw), c_f(thr), _p(out), _p(ws), c_sz(ws.numel()),
                                       _stream()), "stm_mask_iou_f32")
     return out

@@ -252,7 +252,7 @@ class BatchedClipPipeline:
                 cos = det["track"] @ prev["track"].t()
                 cos = (torch.cat([cos.new_zeros(D, 1), cos], dim=1) + 1) / 2
                 biou = ops.jaccard(det["box"], prev["box"])
-                miou = ops.mask_iou(det["mask"], prev["mask"])
+                miou = ops.mask_iou(det["mask"], prev["mask"], group1=det["clip"], group2=prev["clip"])   # same-clip pairs only
                 dummy = torch.full((D, 1), 0.3, device=dev)
                 c = cfg.match_coeff
                 comp = cos + c[0] * det["score"].view(-1, 1) + c[1] * torch.cat([dummy, miou], 1) \

@@ -552,3 +552,19 @@ def test_deform_sample_planar_mask_free_equals_im2col(kh, kw):
         got = out[:, :, pix0:pix0 + B * H * W].contiguous()
         assert torch.equal(got, ops.split_planes(ref.contiguous(), fmt=fmt).view_as(got)), (kh, kw, fmt)
         assert torch.count_nonzero(out[:, :, :pix0]) == 0 and torch.count_nonzero(out[:, :, pix0 + B * H * W:]) == 0
+
+
+def test_mask_iou_grouped_equals_full_masked_by_group():
+    """stm_mask_iou_grouped_f32 (the batched pipeline's form: only pairs of the same clip) == stm_mask_iou_f32 with the
+    pairs of different groups set to 0; group sizes that straddle the 256-column blocks, empty groups included."""
+    g = torch.Generator().manual_seed(3)
+    n1, n2, h, w = 37, 700, 24, 40
+    m1, m2 = torch.rand(n1, h, w, generator=g), torch.rand(n2, h, w, generator=g)
+    g2 = torch.sort(torch.randint(0, 9, (n2,), generator=g)).values.to(torch.int32)
+    g2[g2 == 4] = 5                                   # an empty group in the middle
+    g1 = torch.randint(0, 9, (n1,), generator=g).to(torch.int32)
+    full = ops.mask_iou(m1.to(DEV), m2.to(DEV)).cpu()
+    got = ops.mask_iou(m1.to(DEV), m2.to(DEV), group1=g1.to(DEV), group2=g2.to(DEV)).cpu()
+    same = g1[:, None] == g2[None, :]
+    assert torch.equal(got, torch.where(same, full, torch.zeros_like(full)))
+    assert same.any() and (~same).any()
