@@ -234,7 +234,7 @@ def main():
             c_ms = sum(t[0].elapsed_time(t[1]) for t in conv_t)
             c_fl = sum(t[2] for t in conv_t)
             tf = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
-            res["roofline"] = {"bound": "mfma", "kernel": f"conv_planar_kernel ({split} split conv: backbone 1x1/3x3, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
+            res["roofline"] = {"bound": "mfma", "kernel": f"conv_planar_kernel ({split} split conv: stem, backbone 1x1/3x3 and DCN GEMMs, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
                                "achieved": round(tf, 1), "peak": round(BF16_MFMA_PEAK_TF / n_prod, 1), "unit": "TFLOP/s",
                                "frac": round(tf / (BF16_MFMA_PEAK_TF / n_prod), 4),
                                "traffic": pmc_traffic("conv_planar") if (args.clips == DEFAULT_CLIPS and args.config == "STMask_plus_resnet50_config") else None,
