@@ -92,6 +92,14 @@ def _bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
+def _mask_iou(m1, m2, thr=0.5, group1=None, group2=None):
+    """ops.mask_iou's contract: with groups, only pairs of the same group (clip) are computed, the rest are 0."""
+    iou = orc.mask_iou(m1, m2, thr)
+    if group1 is not None:
+        iou = iou * (group1.view(-1, 1) == group2.view(1, -1)).to(iou.dtype)
+    return iou
+
+
 _PATCH = {
     "bias_act_": _bias_act_,
     "deform_conv": _deform_conv,
@@ -110,7 +118,7 @@ _PATCH = {
     "detect_cc": _detect_cc,
     "jaccard": orc.jaccard,
     "lincomb_sigmoid_crop": _lincomb,
-    "mask_iou": orc.mask_iou,
+    "mask_iou": _mask_iou,
 }
 
 
