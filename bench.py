@@ -3,21 +3,30 @@
 
 Metric (BASELINE.json): frames/sec at 360x640 (tensor 384x640 after /32 padding), R50-DCN-FPN, fp32.
 Workload (configs[1]): STMask_plus_resnet50_config (FCA, DCNv2 backbone, temporal fusion as the config has it),
-random seeded weights, synthetic clips.  A "step" advances every local clip by one frame: the frames of all local
-clips go through backbone / FPN / proto-net / heads as one batch, then candidate generation, Fast NMS, mask lincomb,
-correlation + RoIAlign + TemporalNet temporal fusion and the tracker run per clip.  Inputs are resident in HBM before
-the timed region.  N > 1: clips are sharded over ranks (weak scaling, `--clips` per GPU) with one RCCL all-gather of
-fixed-shape detections per step.
+random seeded weights, synthetic clips of T = 16 frames.  A "step" advances every local clip by one
+frame: the frames of all local clips go through backbone / FPN / proto-net / heads as one batch, then candidate
+generation, Fast NMS, mask lincomb, correlation + RoIAlign + TemporalNet temporal fusion and the tracker.  Inputs are
+resident in HBM before the timed region.
+
+N > 1: clips are sharded over ranks (weak scaling, `--clips` per GPU) with one RCCL all-gather of fixed-shape detections
+per step.  `python bench.py --gpus N` run as typed (no RANK in the environment) starts the N ranks itself -- the parent,
+before it touches the GPU, runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>`
+as a child process, relays rank 0's JSON line and exits with the child's code.  Under torch.distributed.run (RANK set)
+it is one rank.
 
 Extra objects on the JSON line:
-  roofline     deformable-im2col kernel, timed live with HIP events on its launch stream inside the timed region;
-               achieved = algorithmic bytes / measured time; peak 8 TB/s HBM3E.
-  cpu_baseline the CPU oracle path ("port": torch-CPU trunk + oracle C kernels) on this box's host cores, rank 0, N=1,
-               on a bounded sample of the same workload (a few frames of one clip).
+  roofline        dominant kernel (conv_planar_kernel), timed live with HIP events on its launch stream inside the timed region
+  roofline_im2col deformable sampler (the kernel north_star names), same method, HBM bound
+  cpu_baseline    the CPU oracle path ("port": torch-CPU trunk + oracle C kernels) on this box's host cores, rank 0, N=1,
+                  on a bounded sample of the same workload (a few frames of one clip)
+  parity          masks / boxes of the HIP path against that oracle run on the same clip and weights (outside the timed region)
+  extras          N=1 only, short untimed-by-the-driver side measurements: 8 clips / 1 clip per GPU, bf16x3 planes
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,219 +36,427 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from stmask_amd import dist as sdist  # noqa: E402
-from stmask_amd import ops, synthetic  # noqa: E402
-from stmask_amd.config import get_cfg  # noqa: E402
-from stmask_amd.model import STMask  # noqa: E402
-from stmask_amd.pipeline import BatchedClipPipeline, ClipPipeline  # noqa: E402
-
-BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+DEFAULT_CLIPS = 32          # plateau of the throughput curve (999 frames/s at 8 clips, 1167 at 16, 1250-1280 at 32, 1300 at 64);
+                            # SURVEY §8(d) names 8 clips/GPU: that line and the single-stream (1 clip) line ride along in `extras`
+CLIP_FRAMES = 16            # clips of T = 16 frames
+PMC_FILE = "r02_pmc_traffic.json"
 
 
-DEFAULT_CLIPS = 32   # the PMC passes behind profiles/r01_pmc_traffic.json are taken at this batch
-
-
-def pmc_traffic(kernel=None):
-    """HBM bytes per launch (im2col by default, or the named kernel entry) from the committed rocprofv3 PMC passes
-    (bench.py cannot collect PMC counters about itself): profiles/r01_pmc_traffic.json, produced by
-    `scripts/gpu_round.sh pmc` on the same command and batch."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            d = json.load(fh)
-        return int((d[kernel] if kernel else d)["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def cpu_baseline(cfg_name, h, w, budget_s=25.0):
-    """Oracle path on the host cores: same model / weights / clip, CPU tensors, oracle kernels."""
-    import oracle
-    from oracle.cpu_path import oracle_ops
-    cores = min(len(os.sched_getaffinity(0)), 32)  # more threads than this slow the small convs down
-    torch.set_num_threads(cores)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    oracle.set_num_threads(cores)
-    net = STMask(get_cfg(cfg_name))
-    net.eval()
-    synthetic.fill_state_dict(net, seed=0, bg_bias=synthetic.BENCH_BG_BIAS)
-    frames = synthetic.synthetic_clip(4, h, w, seed=0)
-    n, t_total = 0, 0.0
-    with oracle_ops(), torch.no_grad():
-        for t in range(frames.shape[0]):
-            t0 = time.perf_counter()
-            net(frames[t:t + 1], img_meta=[{"is_first": t == 0, "video_id": 0, "frame_id": t}])
-            dt = time.perf_counter() - t0
-            if t > 0:  # frame 0 carries one-off costs (prior cache, oneDNN primitive creation)
-                n += 1
-                t_total += dt
-            if t_total > budget_s:
-                break
-    return {"value": round(n / t_total, 3), "unit": "frames/s", "cores": cores,
-            "kind": "port", "sample": f"{n} frames of one {h}x{w} clip after 1 warm-up frame, batch 1, "
-            f"torch-CPU trunk + oracle C kernels ({oracle.num_threads()} OpenMP threads)"}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--clips", type=int, default=DEFAULT_CLIPS,
-                    help="clips per GPU = frames per step per GPU (throughput: 919 frames/s at 8, 1060 at 16, 1100-1120 from 32 up; "
-                         "32 clips step in 29 ms, i.e. 32 live 30-fps streams per GPU)")
+    ap.add_argument("--clips", type=int, default=DEFAULT_CLIPS, help="clips per GPU = frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=CLIP_FRAMES, help="frames per synthetic clip (the tracker resets every T steps)")
     ap.add_argument("--config", default="STMask_plus_resnet50_config")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the parity block that needs it)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 8-clip / 1-clip / bf16x3 side measurements")
     ap.add_argument("--nchw", dest="channels_last", action="store_false", help="keep the dense convs in NCHW")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="keep BatchNorm / bias / ReLU as separate kernels")
     ap.add_argument("--overlap", choices=("late", "early", "off"), default="late",
                     help="next frame's trunk on a second stream: 'late' = after this frame's temporal-fusion convolutions are "
                          "enqueued (default: big kernels never share the GPU, per-kernel timings stay clean), 'early' = at the "
-                         "start of the step (about +10 %% frames/s, but kernels of the two streams stretch each other), 'off'")
+                         "start of the step, 'off'")
     ap.add_argument("--no-overlap", dest="overlap", action="store_const", const="off", help="same as --overlap off")
-    ap.add_argument("--planes", choices=["fp16x2", "bf16x3"], default="fp16x2",
-                    help="operand split of the planar MFMA convolutions: two fp16 planes / 3 products (default) or three bf16 "
-                         "planes / 6 products (no fp16 range limit); both are fp32-equivalent to 2e-6 of sum|x w|")
+    ap.add_argument("--planes", choices=["fp16x2", "bf16x3", "fp16x1"], default="fp16x2",
+                    help="operand format of the planar MFMA convolutions: two fp16 planes / 3 products (default, fp32-equivalent), "
+                         "three bf16 planes / 6 products (fp32-equivalent, no fp16 range limit), or fp16x1 = ONE fp16 plane / one "
+                         "product (BASELINE config 5: genuine fp16 convolutions with fp32 accumulation, ~1e-3 relative)")
     ap.add_argument("--layer-table", action="store_true", help="per-layer-shape timing table of the planar convolution on stderr")
     ap.add_argument("--no-planar", dest="planar", action="store_false",
-                    help="FPN / proto-net / head convolutions through MIOpen instead of the split-operand matrix-core kernel")
-    ap.add_argument("--fp16-backbone", action="store_true",
-                    help="BASELINE config 5 flavour: ResNet trunk under fp16 autocast (implies --no-fuse); NOT the headline metric")
+                    help="dense convolutions through MIOpen instead of the planar matrix-core kernel")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="do not capture the trunk in a HIP graph")
     ap.add_argument("--pipeline", default="batched", choices=["batched", "per-clip"],
                     help="batched: all clips' post-processing in concatenated tensors; per-clip: reference-shaped layer API")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" is RCCL on ROCm; gloo for the CPU launch test')
+    ap.add_argument("--launch-check", action="store_true",
+                    help="host-only check of the multi-rank plumbing (self-launch, rendezvous, clip sharding, all-gather, max-over-"
+                         "ranks timing, JSON relay) with synthetic detection rows instead of the model; needs no GPU")
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
-    if use_dist:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
 
-    # MIOpen immediate mode: measured identical steady-state speed to find mode on this trunk (scripts/bench_trunk.py:
-    # 20.6 vs 21.0 ms at batch 8) without minutes of solver search per new shape
-    torch.backends.cudnn.benchmark = False
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher
+def self_launch(args, argv):
+    """Parent of an N-rank run.  Touches no GPU API; starts torch.distributed.run as a child and relays its output."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks finished without a result line\n")
+        rc = 1
+    return rc
+
+
+def launch_check(args, rank, world):
+    """The N>1 contract without the model: every rank packs deterministic rows for its clips (clip c of rank r = global clip
+    r + c*world), steps are bracketed by barriers, the all-gather result is verified on every rank."""
+    from stmask_amd import dist as sdist
+    top_k = 8
+
+    def rows(step):
+        p = torch.zeros(args.clips, top_k, sdist.DET_COLS)
+        for c in range(args.clips):
+            g = rank + c * world
+            p[c, :, 0] = g
+            p[c, :, 1] = step
+            p[c, : 1 + g % top_k, 7] = 1.0
+        return p
+
+    ok = True
+    for t in range(args.warmup):
+        sdist.all_gather_detections(rows(t))
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, args.warmup + args.steps):
+        full = sdist.all_gather_detections(rows(t))
+        for r in range(world):
+            blk = full[r * args.clips:(r + 1) * args.clips]
+            want = torch.tensor([r + c * world for c in range(args.clips)], dtype=torch.float32)
+            ok = ok and bool((blk[:, 0, 0] == want).all()) and bool((blk[:, 0, 1] == t).all())
+    if dist.is_initialized():
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist.is_initialized():
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        flag = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if rank == 0:
+        frames = world * args.clips * args.steps
+        print(json.dumps({"metric": "launch-check (no model): gathered detection rows/s", "value": round(frames / elapsed, 2),
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "launch_check": True, "gather_ok": ok,
+                          "config": {"workload": "launch check", "clips_per_gpu": args.clips, "frames_per_step": world * args.clips,
+                                     "parallelism": f"clip-dp{world}", "backend": args.backend}}), flush=True)
+    return 0 if ok else 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the named kernel from the committed rocprofv3 PMC passes (bench.py cannot collect PMC counters
+    about itself): profiles/r02_pmc_traffic.json, produced by `scripts/gpu_round.sh pmc` on this command and batch."""
+    for name in (PMC_FILE, "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                d = json.load(fh)
+            return int(d[kernel]["traffic_bytes_per_launch"]), name
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, None
+
+
+def backbone_tag(cfg):
+    depth = {(3, 4, 6, 3): "R50", (3, 4, 23, 3): "R101"}.get(tuple(cfg.backbone_layers), "ResNet")
+    return depth + ("-DCN" if any(cfg.backbone_dcn_layers) else "") + "-FPN"
+
+
+def heads_tag(cfg):
+    fcb = ("+FCB(ada)" if cfg.use_pred_offset else "+FCB(ali)") if cfg.use_dcn_class else ""
+    return "FCA" + fcb + (" + temporal fusion" if cfg.temporal_fusion_module else "")
+
+
+def image_tag(h, w):
+    """Tensor size -> the image size it is the /32 padding of (360x640 -> 384x640, 720x1280 -> 736x1280)."""
+    known = {(384, 640): "360x640", (736, 1280): "720x1280"}
+    return known.get((h, w), f"{h}x{w}")
+
+
+def build_net(args, dev, planes=None):
+    from stmask_amd import synthetic
+    from stmask_amd.config import get_cfg
+    from stmask_amd.model import STMask
+    planes = planes or args.planes
     net = STMask(get_cfg(args.config))
     net.eval()
     synthetic.fill_state_dict(net, seed=0, bg_bias=synthetic.BENCH_BG_BIAS)
     net = net.to(dev)
-    if args.fp16_backbone:
-        args.fuse = False
-        net.backbone_fp16 = True
     if args.fuse:
         from stmask_amd.fuse import optimize_for_inference
-        # BN folded into conv / DCN weights, bias (+residual) + ReLU as one epilogue pass; FPN / proto-net / shared head
-        # on stm_conv2d_planar_f32 (fp32-equivalent split-operand MFMA convolution, all FPN levels per launch)
-        optimize_for_inference(net, planar=args.planar and args.channels_last, planes=args.planes)
+        # BN folded into conv / DCN weights, bias (+residual) + ReLU as one epilogue pass; every dense convolution on
+        # stm_conv2d_planar_f32 (split-operand MFMA convolution, all FPN levels per launch)
+        optimize_for_inference(net, planar=args.planar and args.channels_last, planes=planes)
     if args.channels_last:
-        net = net.to(memory_format=torch.channels_last)  # dense convs NHWC (17.0 vs 20.6 ms trunk at batch 8)
-        # ... except TemporalNet: on 7x7 RoI tiles MIOpen is 1.5x faster in NCHW (scripts/bench_temporalnet.py)
+        net = net.to(memory_format=torch.channels_last)
         net.TemporalNet = net.TemporalNet.to(memory_format=torch.contiguous_format)
-    T = 8
-    # clip c of this rank = global clip rank + c*world (stmask_amd.dist.shard_clips); inputs resident in HBM
-    clips = torch.stack([synthetic.synthetic_clip(T, args.height, args.width, seed=rank + c * world)
-                         for c in range(args.clips)]).to(dev)  # [clips, T, 3, H, W]
-    pipe = BatchedClipPipeline(net, args.clips) if args.pipeline == "batched" else ClipPipeline(net, args.clips)
-    if args.pipeline == "batched":
-        pipe.prefetch_early = args.overlap == "early"
+    return net
 
-    fmt = torch.channels_last if args.channels_last else torch.contiguous_format
-    frames_t = [clips[:, t].contiguous(memory_format=fmt) for t in range(T)]  # resident, in the trunk's layout
 
-    def step(t):
-        if args.pipeline == "batched" and args.overlap != "off":
+class Runner:
+    """One pipeline over resident synthetic clips; step(t) = every local clip advances one frame + the detection all-gather."""
+
+    def __init__(self, args, dev, rank, world, clips, planes=None, net=None):
+        from stmask_amd import synthetic
+        from stmask_amd.pipeline import BatchedClipPipeline, ClipPipeline
+        self.args, self.dev, self.clips_n, self.T = args, dev, clips, args.frames
+        self.net = net if net is not None else build_net(args, dev, planes)
+        # clip c of this rank = global clip rank + c*world (stmask_amd.dist.shard_clips); inputs resident in HBM
+        clip_t = torch.stack([synthetic.synthetic_clip(self.T, args.height, args.width, seed=rank + c * world)
+                              for c in range(clips)]).to(dev)                      # [clips, T, 3, H, W]
+        fmt = torch.channels_last if args.channels_last else torch.contiguous_format
+        self.frames_t = [clip_t[:, t].contiguous(memory_format=fmt) for t in range(self.T)]   # in the trunk's layout
+        del clip_t
+        self.batched = args.pipeline == "batched"
+        self.pipe = BatchedClipPipeline(self.net, clips) if self.batched else ClipPipeline(self.net, clips)
+        if self.batched:
+            self.pipe.prefetch_early = args.overlap == "early"
+            self.pipe.use_graph = bool(getattr(args, "graph", True)) and args.fuse and args.planar and args.channels_last
+        self.tracked_sum = 0.0
+        self.tracked_steps = 0
+
+    def step(self, t):
+        from stmask_amd import dist as sdist
+        T, pipe = self.T, self.pipe
+        if self.batched and self.args.overlap != "off":
             # the next frame's trunk starts on a second stream while this frame's tracker logic (tiny launches, two host
             # reads) runs; every step still enqueues exactly one trunk
-            out = pipe.step(frames_t[t % T], is_first=(t % T == 0), next_frames=frames_t[(t + 1) % T])
+            out = pipe.step(self.frames_t[t % T], is_first=(t % T == 0), next_frames=self.frames_t[(t + 1) % T])
         else:
-            out = pipe.step(frames_t[t % T], is_first=(t % T == 0))
-        packed = out if args.pipeline == "batched" else sdist.pack_detections(out, top_k=net.cfg.nms_top_k, device=dev)
+            out = pipe.step(self.frames_t[t % T], is_first=(t % T == 0))
+        if self.batched:
+            self.tracked_sum += sum(pipe.prev_n) / max(self.clips_n, 1)
+            self.tracked_steps += 1
+        packed = out if self.batched else sdist.pack_detections(out, top_k=self.net.cfg.nms_top_k, device=self.dev)
         return sdist.all_gather_detections(packed)
 
-    for t in range(args.warmup):
-        step(t)
-    torch.cuda.synchronize()
+    def timed(self, warmup, steps, use_dist=False, collect=False):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; returns (seconds, last output, timings)."""
+        from stmask_amd import ops
+        for t in range(warmup):
+            self.step(t)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        if collect:
+            ops.im2col_timing(True)
+            ops.conv_timing(True)
+        self.tracked_sum, self.tracked_steps = 0.0, 0
+        tm = getattr(self.pipe, "timer", None)
+        if tm is not None and tm.on:
+            tm.acc.clear()   # diagnosis runs: stage times of the timed steps only
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = None
+        for t in range(warmup, warmup + steps):
+            out = self.step(t)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        timing = ops.im2col_timing(False) if collect else None
+        conv_t = (ops.conv_timing(False) or []) if collect else None
+        return elapsed, out, timing, conv_t
+
+
+def cpu_baseline(args, budget_s=25.0, n_frames=4):
+    """Oracle path on the host cores: same model / weights / clip, CPU tensors, oracle kernels.  Returns the baseline object
+    and the per-frame detection dicts (the parity block compares the HIP path against them)."""
+    import oracle
+    from oracle.cpu_path import oracle_ops
+    from stmask_amd import synthetic
+    from stmask_amd.config import get_cfg
+    from stmask_amd.model import STMask
+    cores = min(len(os.sched_getaffinity(0)), 32)  # more threads than this slow the small convs down
+    torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    oracle.set_num_threads(cores)
+    net = STMask(get_cfg(args.config))
+    net.eval()
+    synthetic.fill_state_dict(net, seed=0, bg_bias=synthetic.BENCH_BG_BIAS)
+    frames = synthetic.synthetic_clip(args.frames, args.height, args.width, seed=0)[:n_frames]
+    n, t_total, dets = 0, 0.0, []
+    with oracle_ops(), torch.no_grad():
+        for t in range(frames.shape[0]):
+            t0 = time.perf_counter()
+            out = net(frames[t:t + 1], img_meta=[{"is_first": t == 0, "video_id": 0, "frame_id": t}])
+            dt = time.perf_counter() - t0
+            dets.append({k: v.clone() for k, v in out[0]["detection"].items() if torch.is_tensor(v)})
+            if t > 0:  # frame 0 carries one-off costs (prior cache, oneDNN primitive creation)
+                n += 1
+                t_total += dt
+            if t_total > budget_s:
+                break
+    base = {"value": round(n / t_total, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frames of one {args.height}x{args.width} clip after 1 warm-up frame, batch 1, "
+                      f"torch-CPU trunk + oracle C kernels ({oracle.num_threads()} OpenMP threads)"}
+    return base, dets
+
+
+def parity_block(args, dev, net, ref_dets):
+    """BASELINE.json's "mask L2 vs ref": clip 0 through the HIP path (the benchmark's inference graph, batch 1) against the CPU
+    oracle run of the same clip and weights.  Instances are matched by box IoU (> 0.5, same class); reported over all frames:
+    matched fraction, max box delta, per-mask RMS L2 and max-abs of the soft masks [n,96,160].  The kernel-level figure
+    (`mask_*_same_inputs`: HIP lincomb + crop fed the oracle's own prototypes / coefficients / boxes) is north_star's
+    contract; the end-to-end figure adds the fp32 rounding differences of the two trunks."""
+    import oracle
+    from stmask_amd import ops, synthetic
+    from stmask_amd.pipeline import BatchedClipPipeline
+    frames = synthetic.synthetic_clip(args.frames, args.height, args.width, seed=0)[:len(ref_dets)].to(dev)
+    fmt = torch.channels_last if args.channels_last else torch.contiguous_format
+    pipe = BatchedClipPipeline(net, 1)
+    n_ref = n_hip = n_match = 0
+    box_d = l2 = mx = l2_k = mx_k = 0.0
+    for t, ref in enumerate(ref_dets):
+        pipe.step(frames[t:t + 1].contiguous(memory_format=fmt), is_first=(t == 0))
+        got = pipe.detections()[0]
+        gb, rb = got["box"].cpu(), ref["box"]
+        n_ref += rb.shape[0]
+        n_hip += gb.shape[0]
+        if rb.shape[0] == 0 or gb.shape[0] == 0:
+            continue
+        iou = oracle.jaccard(gb, rb)
+        iou = iou * (got["class"].cpu()[:, None] == ref["class"][None, :]).float()
+        best, j = iou.max(dim=1)
+        sel = torch.nonzero(best > 0.5).view(-1)
+        if sel.numel() == 0:
+            continue
+        n_match += int(sel.numel())
+        gm, rm = got["mask"].cpu()[sel], ref["mask"][j[sel]]
+        d = gm - rm
+        box_d = max(box_d, float((gb[sel] - rb[j[sel]]).abs().max()))
+        l2 = max(l2, float(d.pow(2).mean(dim=(1, 2)).sqrt().max()))
+        mx = max(mx, float(d.abs().max()))
+        # kernel-level: the oracle's own inputs through the HIP lincomb + crop
+        km = ops.lincomb_sigmoid_crop(ref["proto"].to(dev), ref["mask_coeff"].to(dev), ref["box"].to(dev), apply_tanh=True).cpu()
+        dk = km - ref["mask"]
+        l2_k = max(l2_k, float(dk.pow(2).mean(dim=(1, 2)).sqrt().max()))
+        mx_k = max(mx_k, float(dk.abs().max()))
+    return {"frames": len(ref_dets), "instances_ref": n_ref, "instances_hip": n_hip, "matched": n_match,
+            "matched_frac": round(n_match / max(n_ref, 1), 4), "box_max_abs": box_d,
+            "mask_l2": l2, "mask_max_abs": mx, "mask_l2_same_inputs": l2_k, "mask_max_abs_same_inputs": mx_k,
+            "mask_l2_def": "max over matched instances of sqrt(mean((m_hip - m_ref)^2)) over the 96x160 soft mask",
+            "ref": "CPU oracle path (cpu_baseline leg), same clip / weights; arithmetic of the HIP side: " + args.planes}
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args, argv))        # nothing above touched the GPU
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+
+    if args.launch_check:
+        if use_dist:
+            dist.init_process_group(args.backend if args.backend == "gloo" or torch.cuda.is_available() else "gloo",
+                                    rank=rank, world_size=world)
+        rc = launch_check(args, rank, world)
+        if use_dist:
+            dist.destroy_process_group()
+        sys.exit(rc)
+
+    from stmask_amd import ops
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if use_dist:
-        dist.barrier()
-    ops.im2col_timing(True)
-    ops.conv_timing(True)
-    if getattr(pipe, "timer", None) is not None and pipe.timer.on:
-        pipe.timer.acc.clear()   # diagnosis runs: stage times of the timed steps only
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(args.warmup, args.warmup + args.steps):
-        out = step(t)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    timing = ops.im2col_timing(False)
-    conv_t = ops.conv_timing(False) or []
+        dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev if args.backend == "nccl" else None)
+
+    # MIOpen immediate mode (only --no-planar graphs reach the library at all)
+    torch.backends.cudnn.benchmark = False
+    run = Runner(args, dev, rank, world, args.clips)
+    net = run.net
+    cfg = net.cfg
+    elapsed, out, timing, conv_t = run.timed(args.warmup, args.steps, use_dist, collect=True)
     if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    if getattr(pipe, "timer", None) is not None and pipe.timer.on and rank == 0:
-        print("stage ms/step:", {k: round(v / args.steps * 1e3, 2) for k, v in pipe.timer.acc.items()},
-              file=sys.stderr, flush=True)
+    tm = getattr(run.pipe, "timer", None)
+    if tm is not None and tm.on and rank == 0:
+        print("stage ms/step:", {k: round(v / args.steps * 1e3, 2) for k, v in tm.acc.items()}, file=sys.stderr, flush=True)
     frames = world * args.clips * args.steps
     n_det = int((out[..., 7] > 0).sum().item())
     if rank == 0:
+        planar_graph = args.fuse and args.planar and args.channels_last
+        n_prod = {"fp16x2": 3, "bf16x3": 6, "fp16x1": 1}[args.planes]
+        arith = {"fp16x2": "fp32 in / fp32 out / fp32 accumulate; dense convs as 2 fp16 planes x 3 MFMA products (max error 2e-6 of "
+                           "sum|x w| vs fp64, tests/test_gpu_conv.py)",
+                 "bf16x3": "fp32 in / fp32 out / fp32 accumulate; dense convs as 3 bf16 planes x 6 MFMA products (max error 2e-6 of "
+                           "sum|x w| vs fp64, no range limit)",
+                 "fp16x1": "fp16 activations and weights in the dense convolutions, fp32 accumulate / bias / residual / "
+                           "post-processing (max error 2e-3 of sum|x w| vs fp64, tests/test_gpu_conv.py)"}[args.planes]
+        img = image_tag(args.height, args.width)
+        res = {
+            "metric": f"frames/sec at {img} {backbone_tag(cfg)} (STMask hot path, "
+                      + ("fp32" if args.planes != "fp16x1" or not planar_graph else "fp16 convs / fp32 accumulate") + ")",
+            "value": round(frames / elapsed, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if (args.planes != "fp16x1" or not planar_graph) else "f16-convs/f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {backbone_tag(cfg)} {heads_tag(cfg)}, {args.height}x{args.width} tensor "
+                                   f"({img} image padded to /32), {args.clips} clips/GPU x 1 frame per step, clips of "
+                                   f"T={args.frames} frames, random seeded weights",
+                       "clips_per_gpu": args.clips, "frames_per_clip": args.frames, "frames_per_step": world * args.clips,
+                       "detections_last_step": n_det,
+                       "tracked_instances_mean": round(run.tracked_sum / max(run.tracked_steps, 1), 1),
+                       "parallelism": f"clip-dp{world}",
+                       "pipeline": args.pipeline + (f"+next-trunk-overlap-{args.overlap}" if (run.batched and args.overlap != "off") else "")
+                                   + ("+trunk-hip-graph" if getattr(run.pipe, "graph_active", False) else ""),
+                       "inference_graph": ("bn-folded+fused-epilogues" + ("+planar-%s-convs" % args.planes if planar_graph else ""))
+                                          if args.fuse else "reference-ops",
+                       "arithmetic": arith if planar_graph else "fp32",
+                       "memory_format": "channels_last" if args.channels_last else "nchw",
+                       "why_32_clips": "SURVEY §8(d) names 8 clips/GPU; throughput plateaus from 32 (extras.clips8 / extras.clips1 "
+                                       "carry the 8-clip and single-stream lines)"},
+        }
         ker_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
         ker_bytes = sum(b for _, _, b in timing)
         n_launch = max(len(timing), 1)
         achieved = ker_bytes / (ker_ms * 1e-3) / 1e9 if ker_ms > 0 else 0.0
-        res = {
-            "metric": "frames/sec at 360x640 R50-DCN-FPN (STMask hot path, fp32)", "value": round(frames / elapsed, 2),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if not args.fp16_backbone else "f16-backbone/f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: R50-DCN-FPN FCA + temporal fusion, {args.height}x{args.width} "
-                                   f"tensor (360x640 padded), {args.clips} clips/GPU x 1 frame per step, random seeded weights",
-                       "clips_per_gpu": args.clips, "frames_per_step": world * args.clips,
-                       "detections_last_step": n_det, "parallelism": f"clip-dp{world}",
-                       "pipeline": args.pipeline + (f"+next-trunk-overlap-{args.overlap}" if (args.pipeline == "batched" and args.overlap != "off") else ""),
-                       "inference_graph": ("bn-folded+fused-epilogues" + ("+planar-%s-convs" % args.planes if (args.planar and args.channels_last) else ""))
-                                          if args.fuse else "reference-ops",
-                       "arithmetic": ("fp32 in / fp32 out / fp32 accumulate; dense convs as "
-                                      + ("2 fp16 planes x 3 MFMA products" if args.planes == "fp16x2" else "3 bf16 planes x 6 MFMA products")
-                                      + " (max error 2e-6 of sum|x w| vs fp64, tests/test_gpu_conv.py)") if (args.fuse and args.planar and args.channels_last)
-                                     else "fp32",
-                       "memory_format": "channels_last" if args.channels_last else "nchw"},
-        }
-        planar_dcn = args.fuse and args.planar and args.channels_last
-        im2col_roof = {"bound": "hbm", "kernel": ("dcn_sample_planar_kernel (deformable im2col of the 7 DCN layers, NHWC in, plane columns out)"
-                                                   if planar_dcn else "deform_im2col_lds (7 DCN layers)") + ", all launches of the timed region",
+        default_wl = args.clips == DEFAULT_CLIPS and args.config == "STMask_plus_resnet50_config" and args.planes == "fp16x2"
+        tr_s, src_s = pmc_traffic("dcn_sample_planar") if (default_wl and planar_graph) else (None, None)
+        im2col_roof = {"bound": "hbm", "kernel": ("dcn_sample_planar_kernel (deformable im2col of the DCN layers, NHWC in, plane columns out)"
+                                                   if planar_graph else "deform_im2col_lds (DCN layers)") + ", all launches of the timed region",
                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(achieved / HBM_PEAK_GBS, 4),
-                       "traffic": pmc_traffic("dcn_sample_planar" if planar_dcn else None)
-                                  if (args.clips == DEFAULT_CLIPS and args.config == "STMask_plus_resnet50_config") else None,
-                       "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)",
+                       "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr_s,
+                       "traffic_source": f"profiles/{src_s} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)" if src_s else None,
                        "launches": len(timing), "avg_launch_us": round(ker_ms * 1e3 / n_launch, 2),
                        "algorithmic_bytes_per_launch": int(ker_bytes / n_launch)}
         if conv_t:
-            # dominant kernel of the step: the split-operand convolution.  achieved = fp32-equivalent algorithmic flops
+            # dominant kernel of the step: the planar convolution.  achieved = fp32-equivalent algorithmic flops
             # (2*M*Cout*Cin*kh*kw of the reference layers, zero-padded channels excluded) / launch time; peak = dense 16-bit
-            # MFMA peak / n_prod, because each fp32 product is carried by n_prod MFMA products (3 fp16 or 6 bf16).
-            n_prod = 3 if args.planes == "fp16x2" else 6
-            split = "fp16x2-plane" if args.planes == "fp16x2" else "bf16x3-plane"
+            # MFMA peak / n_prod, because each product of the reference is carried by n_prod MFMA products (3 fp16, 6 bf16, 1)
             c_ms = sum(t[0].elapsed_time(t[1]) for t in conv_t)
             c_fl = sum(t[2] for t in conv_t)
             tf = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
-            res["roofline"] = {"bound": "mfma", "kernel": f"conv_planar_kernel ({split} split conv: stem, backbone 1x1/3x3 and DCN GEMMs, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
+            tr_c, src_c = pmc_traffic("conv_planar") if default_wl else (None, None)
+            res["roofline"] = {"bound": "mfma", "kernel": f"conv_planar_kernel ({args.planes} planes: stem, backbone 1x1/3x3 and DCN GEMMs, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
                                "achieved": round(tf, 1), "peak": round(BF16_MFMA_PEAK_TF / n_prod, 1), "unit": "TFLOP/s",
-                               "frac": round(tf / (BF16_MFMA_PEAK_TF / n_prod), 4),
-                               "traffic": pmc_traffic("conv_planar") if (args.clips == DEFAULT_CLIPS and args.config == "STMask_plus_resnet50_config") else None,
-                               "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction); average over all launches",
-                               "peak_note": f"fp32-equivalent: 2500 TFLOP/s dense 16-bit MFMA / {n_prod} products per fp32 product (fp32 MFMA peak is 157)",
+                               "frac": round(tf / (BF16_MFMA_PEAK_TF / n_prod), 4), "traffic": tr_c,
+                               "traffic_source": f"profiles/{src_c} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction); average over all launches" if src_c else None,
+                               "peak_note": f"2500 TFLOP/s dense 16-bit MFMA / {n_prod} MFMA product(s) per product of the reference (fp32 MFMA peak is 157)",
                                "launches": len(conv_t), "avg_launch_us": round(c_ms * 1e3 / len(conv_t), 2),
                                "ms_per_step": round(c_ms / args.steps, 3),
                                "algorithmic_gflop_per_launch": round(c_fl / len(conv_t) / 1e9, 2)}
@@ -256,8 +473,41 @@ def main():
                           file=sys.stderr)
         else:
             res["roofline"] = im2col_roof
+        if world == 1 and not args.no_extras and run.batched:
+            # side measurements on the same process and box (short; the headline above is untouched by them)
+            extras = {}
+            del run.frames_t
+            torch.cuda.empty_cache()
+            for name, clips, planes in (("clips8", 8, None), ("clips1", 1, None), ("bf16x3", args.clips, "bf16x3")):
+                if (planes is None and clips == args.clips) or (planes == args.planes) or (planes and not planar_graph):
+                    continue
+                try:
+                    r2 = Runner(args, dev, rank, world, clips, planes=planes, net=(net if planes is None else None))
+                    steps = args.steps if clips >= 8 else 3 * args.steps
+                    el, _, _, _ = r2.timed(args.warmup, steps)
+                    extras[name] = {"value": round(clips * steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3),
+                                    "clips_per_gpu": clips, "planes": planes or args.planes, "steps": steps,
+                                    "tracked_instances_mean": round(r2.tracked_sum / max(r2.tracked_steps, 1), 1)}
+                    del r2
+                    torch.cuda.empty_cache()
+                except Exception as e:  # a side measurement never takes the headline down
+                    extras[name] = {"error": repr(e)[:200]}
+            if "clips1" in extras and "value" in extras["clips1"]:
+                extras["clips1"]["context"] = "single-stream regime of the reference's own FPS table (README.md:102: 29.3 FPS on a 2080 Ti, batch 1)"
+            if "bf16x3" in extras and "value" in extras["bf16x3"]:
+                res["value_bf16x3"] = extras["bf16x3"]["value"]
+            if planar_graph and args.planes == "fp16x2":
+                from stmask_amd import planar as _pl
+                _pl.set_format(1)
+            res["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.config, args.height, args.width)
+            base, ref_dets = cpu_baseline(args)
+            res["cpu_baseline"] = base
+            try:
+                res["parity"] = parity_block(args, dev, net, ref_dets)
+                res["mask_l2"], res["mask_max_abs"] = res["parity"]["mask_l2"], res["parity"]["mask_max_abs"]
+            except Exception as e:
+                res["parity"] = {"error": repr(e)[:300]}
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

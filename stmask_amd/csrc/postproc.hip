@@ -269,6 +269,86 @@ __global__ __launch_bounds__(NMS_THREADS) void cc_nms_kernel(const float* __rest
                 if (pos < Kp) keys[pos] = ((unsigned long long)ord_desc(s) << 32) | (unsigned int)row;
             }
         }
+        __syncthreads();
+        if (n_cand > Kp) {
+            // More candidates than the LDS sort holds (only possible with N > NMS_MAX_KEYS priors, e.g. 58 860 at 736x1280).
+            // Only the top_k best (score descending, row ascending) ever matter, so select exactly those: a radix select
+            // (four 8-bit passes over the rows) finds the score key of the top_k-th best candidate; all strictly better
+            // candidates enter the sort, and of the candidates that tie with that key the first ones in row order.
+            // Deterministic and identical to sorting everything (the reference sorts all candidates, detection_TF.py:93).
+            int* hist = reinterpret_cast<int*>(keys);                 // the key array is rebuilt below
+            int& sel_bin = wave_cnt[NMS_WAVES + 1];
+            int& sel_acc = wave_cnt[NMS_WAVES + 2];
+            int& running = wave_cnt[NMS_WAVES + 3];
+            unsigned int prefix = 0, pmask = 0;
+            int want = top_k;                                          // 1-based rank, among the rows matching `prefix`
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                __syncthreads();
+                for (int i = tid; i < 256; i += NMS_THREADS) hist[i] = 0;
+                __syncthreads();
+                for (int row = tid; row < K_cap; row += NMS_THREADS) {
+                    const float s = rs[row];
+                    if (s == s) {
+                        const unsigned int k32 = ord_desc(s);
+                        if ((k32 & pmask) == prefix) atomicAdd(&hist[(k32 >> shift) & 255u], 1);
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int acc = 0, bin = 0;
+                    for (; bin < 255; ++bin) {
+                        if (acc + hist[bin] >= want) break;
+                        acc += hist[bin];
+                    }
+                    sel_bin = bin;
+                    sel_acc = acc;
+                }
+                __syncthreads();
+                prefix |= (unsigned int)sel_bin << shift;
+                pmask |= 255u << shift;
+                want -= sel_acc;
+            }
+            __syncthreads();
+            const unsigned int tkey = prefix;                          // `want` (>= 1) candidates with this key are needed
+            for (int i = tid; i < Kp; i += NMS_THREADS) keys[i] = ~0ull;
+            if (tid == 0) { n_cand = 0; running = 0; }
+            __syncthreads();
+            for (int row = tid; row < K_cap; row += NMS_THREADS) {
+                const float s = rs[row];
+                if (s == s && ord_desc(s) < tkey) {
+                    const int pos = atomicAdd(&n_cand, 1);             // < top_k of them
+                    keys[pos] = ((unsigned long long)ord_desc(s) << 32) | (unsigned int)row;
+                }
+            }
+            __syncthreads();
+            const int n_better = n_cand;
+            for (int base = 0; base < K_cap; base += NMS_THREADS) {    // ties, in row order, until `want` are in
+                const int row = base + tid;
+                bool f = false;
+                if (row < K_cap) {
+                    const float s = rs[row];
+                    f = (s == s) && ord_desc(s) == tkey;
+                }
+                const unsigned long long bal = __ballot(f);
+                const int lane_prefix = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) wave_cnt[wave] = __popcll(bal);
+                __syncthreads();
+                int wp = 0, tot = 0;
+                for (int w = 0; w < NMS_WAVES; ++w) {
+                    const int c = wave_cnt[w];
+                    if (w < wave) wp += c;
+                    tot += c;
+                }
+                const int start = running;
+                const int pos = start + wp + lane_prefix;
+                if (f && pos < want) keys[n_better + pos] = ((unsigned long long)tkey << 32) | (unsigned int)row;
+                __syncthreads();
+                if (tid == 0) running = start + tot;
+                __syncthreads();
+                if (start + tot >= want) break;                        // uniform
+            }
+            if (tid == 0) n_cand = n_better + min(running, want);
+        }
     }
     __syncthreads();
     const int nc = min(n_cand, Kp);

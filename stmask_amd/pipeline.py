@@ -94,6 +94,8 @@ class BatchedClipPipeline:
         self._pending = None        # (frames, (fpn_outs, pred), event): trunk of the NEXT frame, running on the side stream
         self._side = None
         self.prefetch_early = False  # True: start the next trunk at the beginning of step() instead of after the TF convolutions
+        self.use_graph = False       # capture the trunk in a HIP graph (one graph per input buffer; see _trunk)
+        self.graph_active = False
 
     # -- stage helpers ------------------------------------------------------------------------------------------------
     def _shift_prev(self, P4, T2S, proto, dev):

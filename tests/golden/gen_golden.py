@@ -233,6 +233,74 @@ def gen_model(cfg_name, tag, hw=(128, 192), n_frames=3, temporal_fusion=True):
     save(f"model_{tag}.npz", **out)
 
 
+def gen_model_nontf(cfg_name, tag, hw=(128, 192), n_frames=3):
+    """Row a18: the reference's non-TF post-processing, Detect.detect (detection.py:98-137) + Track.track (track.py:56-179).
+    Detect.__call__ cannot run (it reads result['bbox_idx'], detection.py:91, a key cc_fast_nms never sets), so its body is
+    driven from here exactly as __call__ does it (detection.py:69-90) minus that line: transpose conf, decode, detect(batch_idx,
+    ...), result['proto'] = proto; then Track.track(result, meta) per frame as STMask.forward does (STMask.py:323-327)."""
+    from datasets.config import cfg, set_cfg
+    set_cfg(cfg_name)
+    cfg.temporal_fusion_module = False
+    import STMask as stmask_mod
+    from layers.box_utils import decode
+    net = stmask_mod.STMask()
+    net.eval()
+    synthetic.fill_state_dict(net, seed=0)
+    frames = synthetic.synthetic_clip(n_frames, hw[0], hw[1], seed=0)
+    out = {"frames_hw": np.array(hw), "n_frames": np.array(n_frames)}
+    with torch.no_grad():
+        for t in range(n_frames):
+            _, po = net.forward_single(frames[t:t + 1])
+            po["conf"] = torch.softmax(po["conf"], -1)
+            po["mask_coeff"] = cfg.mask_proto_coeff_activation(po["mask_coeff"])      # STMask.py:324
+            pri = po["priors"].squeeze(0)
+            conf_t = po["conf"].view(1, pri.size(0), -1).transpose(2, 1).contiguous()   # detection.py:77-78
+            boxes = decode(po["loc"][0], pri)
+            res = net.detect.detect(0, conf_t, boxes, po["centerness"], po["mask_coeff"], po["track"], po["proto"], None)
+            res["proto"] = po["proto"][0]
+            out[f"t{t}_nms_box"], out[f"t{t}_nms_class"], out[f"t{t}_nms_score"] = res["box"], res["class"], res["score"]
+            res = net.Track.track(res, {"is_first": t == 0, "video_id": 0, "frame_id": t})
+            for k in ("box", "score", "class", "box_ids", "mask_coeff", "mask"):
+                v = res.get(k, torch.zeros(0))
+                out[f"t{t}_{k}"] = torch.zeros(0) if v is None else v
+            print(tag, "frame", t, "n_nms", len(out[f"t{t}_nms_box"]), "n_out", len(res["box"]))
+    save(f"model_{tag}.npz", **out)
+
+
+def gen_model_full(cfg_name, tag, hw=(384, 640), row_step=16):
+    """ONE full-size frame through the reference's STMask.forward (eval, oracle ops plugged in) at the benchmark's
+    own weights (synthetic.BENCH_BG_BIAS).  Stored: float64 checksums (sum, sum |.|) of every head output, strided slices of
+    them, and the frame's detections (boxes / classes / scores / soft masks)."""
+    from datasets.config import cfg, set_cfg
+    set_cfg(cfg_name)
+    cfg.temporal_fusion_module = True
+    import STMask as stmask_mod
+    net = stmask_mod.STMask()
+    net.eval()
+    synthetic.fill_state_dict(net, seed=0, bg_bias=synthetic.BENCH_BG_BIAS)
+    frame = synthetic.synthetic_clip(1, hw[0], hw[1], seed=0)
+    out = {"frames_hw": np.array(hw), "row_step": np.array(row_step)}
+    with torch.no_grad():
+        fpn_outs, po = net.forward_single(frame)
+        full = {"loc": po["loc"][0], "conf_logits": po["conf"][0], "mask_coeff": po["mask_coeff"][0],
+                "centerness": po["centerness"][0], "track": po["track"][0], "proto": po["proto"][0], "P4": fpn_outs[1][0]}
+        for k, v in full.items():
+            out[f"sum_{k}"] = np.array([v.double().sum().item(), v.double().abs().sum().item(), float(v.abs().max())])
+        for k in ("loc", "conf_logits", "mask_coeff", "centerness"):
+            out[f"s_{k}"] = full[k][::row_step]
+        out["s_track"] = full["track"][::row_step, ::8]
+        out["s_proto"] = full["proto"][::4, ::4]
+        out["s_P4"] = full["P4"][::16]
+        out["n_priors"] = np.array(full["loc"].shape[0])
+        res = net(frame, img_meta=[{"is_first": True, "video_id": 0, "frame_id": 0}])[0]["detection"]
+        n = min(len(res["box"]), 48)
+        for k in ("box", "score", "class", "box_ids", "mask_coeff", "mask", "centerness"):
+            out[f"det_{k}"] = res[k][:n]
+        out["det_n"] = np.array(len(res["box"]))
+        print(tag, "full-size frame", hw, "priors", full["loc"].shape[0], "detections", len(res["box"]))
+    save(f"model_full_{tag}.npz", **out)
+
+
 from synth_results import synth_video_results  # noqa: E402  (tests/golden/synth_results.py, shared with the test)
 
 
@@ -275,9 +343,15 @@ def main():
         gen_model("STMask_plus_resnet50_ali_config", "r50_ali")
     if "results_json" in which:
         gen_results_json()
+    if "model_nontf" in which:
+        gen_model_nontf("STMask_plus_resnet50_config", "r50_fca_nontf")
+    if "model_full" in which:
+        gen_model_full("STMask_plus_resnet50_config", "r50_fca")
+        gen_model_full("STMask_plus_resnet50_ada_config", "r50_ada")
+        gen_model_full("STMask_plus_base_ali_config", "r101_ali")
+    if "model_full_720p" in which:
+        gen_model_full("STMask_plus_base_ali_config", "r101_ali_736x1280", hw=(736, 1280), row_step=64)
     if "model_extra" in which:
-        # NB: the reference's non-TF path (Detect/Track, STMask.py:323-327) cannot produce a golden: Detect.__call__
-        # reads result['bbox_idx'] (detection.py:93), a key its cc_fast_nms never sets -> KeyError on the first frame.
         gen_model("STMask_plus_base_ali_config", "r101_ali", hw=(96, 160), n_frames=2)
 
 
