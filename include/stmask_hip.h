@@ -149,12 +149,23 @@ int stm_generate_candidates_f32(const float* loc, const float* priors, const flo
  *   score_out, box_out [top_k,4]; count_out (device int).
  *   k_dev: optional device pointer holding the real K (<= K) -- lets the whole chain run without a host
  *   sync.  `batch` independent problems are strided by K rows (outputs by top_k rows).
- *   Indices are bit-exact against the oracle.  K <= 16384 (one workgroup sorts in LDS).
+ *   Indices are bit-exact against the oracle.  K <= 16384 (one workgroup sorts in LDS); beyond: STM_EUNSUPPORTED,
+ *   use stm_cc_fast_nms_ws_f32.
  * ------------------------------------------------------------------------------------------------- */
 int stm_cc_fast_nms_f32(const float* conf, const float* boxes, const float* centerness, int K, int ncls,
                         const int* k_dev, float iou_thr, int top_k, int batch, int64_t* idx_out,
                         int64_t* cls_out, float* score_out, float* box_out, int* count_out,
                         stm_stream_t stream);
+
+/* The same for ANY number of candidate rows (736x1280 frames have 58 860 priors, and a weakly trained head can pass most of
+ * them): the per-row scores go to `workspace` (stm_cc_fast_nms_workspace_bytes(K, batch) = 4*K*batch + 256 bytes) and the NMS
+ * workgroup, when K exceeds the 16 384 keys its LDS sort holds, first radix-selects exactly the top_k best (score desc, row
+ * asc) candidates -- the result is the one sorting everything gives (detection_TF.py:93).  No k_dev form. */
+size_t stm_cc_fast_nms_workspace_bytes(int K, int batch);
+int stm_cc_fast_nms_ws_f32(const float* conf, const float* boxes, const float* centerness, int K, int ncls,
+                           float iou_thr, int top_k, int batch, int64_t* idx_out, int64_t* cls_out,
+                           float* score_out, float* box_out, int* count_out, void* workspace,
+                           size_t workspace_bytes, stm_stream_t stream);
 
 /* Per-class Fast NMS.  Replaces: Detect_TF.fast_nms (detection_TF.py:136-204) == Detect.fast_nms
  * (detection.py:211-263).  Outputs have capacity max_det.  workspace: stm_fast_nms_workspace_bytes. */

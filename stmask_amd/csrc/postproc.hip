@@ -609,7 +609,7 @@ extern "C" int stm_cc_fast_nms_f32(const float* conf, const float* boxes, const 
                 ncls, batch);
     STM_REQUIRE(top_k > 0 && top_k <= NMS_MAX_TOPK, STM_EINVAL, "stm_cc_fast_nms_f32: top_k=%d not in 1..%d", top_k,
                 NMS_MAX_TOPK);
-    STM_REQUIRE(K <= NMS_MAX_KEYS, STM_EUNSUPPORTED, "stm_cc_fast_nms_f32: K=%d > %d candidates", K, NMS_MAX_KEYS);
+    STM_REQUIRE(K <= NMS_MAX_KEYS, STM_EUNSUPPORTED, "stm_cc_fast_nms_f32: K=%d > %d candidates (use stm_cc_fast_nms_ws_f32)", K, NMS_MAX_KEYS);
     if (K == 0) {
         (void)hipMemsetAsync(count_out, 0, sizeof(int) * batch, stm_hs(stream));
         return STM_OK;
@@ -623,6 +623,41 @@ extern "C" int stm_cc_fast_nms_f32(const float* conf, const float* boxes, const 
     hipLaunchKernelGGL(cc_nms_kernel<0>, dim3(batch), dim3(NMS_THREADS), lds, stm_hs(stream), conf, boxes, centerness,
                        (const float*)nullptr, K, ncls, k_dev, iou_thr, top_k, Kp, idx_out, cls_out, score_out, box_out,
                        count_out);
+    STM_CHECK_LAUNCH("cc_nms_kernel");
+    return STM_OK;
+}
+
+extern "C" size_t stm_cc_fast_nms_workspace_bytes(int K, int batch) { return (size_t)batch * (size_t)(K > 0 ? K : 0) * 4 + 256; }
+
+extern "C" int stm_cc_fast_nms_ws_f32(const float* conf, const float* boxes, const float* centerness, int K, int ncls, float iou_thr,
+                                      int top_k, int batch, int64_t* idx_out, int64_t* cls_out, float* score_out, float* box_out,
+                                      int* count_out, void* workspace, size_t workspace_bytes, stm_stream_t stream)
+{
+    STM_REQUIRE(idx_out && cls_out && score_out && count_out, STM_ENULL, "stm_cc_fast_nms_ws_f32: outputs must be non-NULL");
+    STM_REQUIRE(K >= 0 && ncls >= 2 && ncls <= 160 && batch > 0 && batch <= 65535, STM_EINVAL,
+                "stm_cc_fast_nms_ws_f32: bad sizes K=%d ncls=%d batch=%d", K, ncls, batch);
+    STM_REQUIRE(top_k > 0 && top_k <= NMS_MAX_TOPK, STM_EINVAL, "stm_cc_fast_nms_ws_f32: top_k=%d not in 1..%d", top_k, NMS_MAX_TOPK);
+    if (K == 0) {
+        (void)hipMemsetAsync(count_out, 0, sizeof(int) * batch, stm_hs(stream));
+        return STM_OK;
+    }
+    STM_REQUIRE(conf && boxes, STM_ENULL, "stm_cc_fast_nms_ws_f32: conf/boxes must be non-NULL");
+    STM_REQUIRE(workspace && workspace_bytes >= stm_cc_fast_nms_workspace_bytes(K, batch), STM_EWORKSPACE,
+                "stm_cc_fast_nms_ws_f32: workspace %zu < %zu", workspace_bytes, stm_cc_fast_nms_workspace_bytes(K, batch));
+    STM_REQUIRE((uintptr_t)boxes % 16 == 0 && (uintptr_t)workspace % 16 == 0 && (!box_out || (uintptr_t)box_out % 16 == 0), STM_EINVAL,
+                "stm_cc_fast_nms_ws_f32: boxes / workspace / box_out must be 16-byte aligned");
+    float* score_all = reinterpret_cast<float*>(workspace);
+    const size_t lds1 = (size_t)256 * ncls * sizeof(float);
+    allow_big_lds(row_stats_kernel, lds1);
+    // every row is a candidate here (the caller filtered already): threshold -inf
+    hipLaunchKernelGGL(row_stats_kernel, dim3(stm_cdiv(K, 256), batch), dim3(256), lds1, stm_hs(stream), (const float*)nullptr,
+                       (const float*)nullptr, conf, centerness, K, ncls, -INFINITY, (float4*)nullptr, (int64_t*)nullptr, score_all);
+    STM_CHECK_LAUNCH("row_stats_kernel");
+    const int Kp = next_pow2(min(K, NMS_MAX_KEYS));
+    const size_t lds = nms_lds_bytes(Kp, top_k);
+    allow_big_lds(cc_nms_kernel<1>, lds);
+    hipLaunchKernelGGL(cc_nms_kernel<1>, dim3(batch), dim3(NMS_THREADS), lds, stm_hs(stream), conf, boxes, centerness, score_all, K, ncls,
+                       (const int*)nullptr, iou_thr, top_k, Kp, idx_out, cls_out, score_out, box_out, count_out);
     STM_CHECK_LAUNCH("cc_nms_kernel");
     return STM_OK;
 }

@@ -268,6 +268,9 @@ def generate_candidates(loc, priors, conf, thresh=0.05):
     return keep_idx, cand_box, count
 
 
+NMS_LDS_KEYS = 16384   # keys the one-workgroup Fast NMS sorts in LDS (csrc/postproc.hip NMS_MAX_KEYS)
+
+
 def cc_fast_nms(conf, boxes, centerness, iou_thr=0.5, top_k=200, k_dev=None):
     """detection_TF.py:85-134 on candidate rows.  conf [K,ncls] or [B,K,ncls].  Returns padded
     (idx [B,top_k] int64, cls, score, box [B,top_k,4], count [B] int32) -- all on device, no sync."""
@@ -285,9 +288,16 @@ def cc_fast_nms(conf, boxes, centerness, iou_thr=0.5, top_k=200, k_dev=None):
     sc = torch.empty(B, top_k, dtype=torch.float32, device=dev)
     bx = torch.empty(B, top_k, 4, dtype=torch.float32, device=dev)
     cnt = torch.empty(B, dtype=torch.int32, device=dev)
-    check(_lib.lib().stm_cc_fast_nms_f32(_p(conf), _p(boxes), _p(cen), c_i(K), c_i(ncls), _p(k_dev), c_f(iou_thr),
-                                         c_i(top_k), c_i(B), _p(idx), _p(cls), _p(sc), _p(bx), _p(cnt), _stream()),
-          "stm_cc_fast_nms_f32")
+    if K > NMS_LDS_KEYS and k_dev is None:
+        # more candidate rows than the one-workgroup LDS sort holds: scores to a workspace, exact top-k select in the kernel
+        ws = _workspace(_lib.lib().stm_cc_fast_nms_workspace_bytes(c_i(K), c_i(B)), dev, "ccnms")
+        check(_lib.lib().stm_cc_fast_nms_ws_f32(_p(conf), _p(boxes), _p(cen), c_i(K), c_i(ncls), c_f(iou_thr), c_i(top_k), c_i(B),
+                                                _p(idx), _p(cls), _p(sc), _p(bx), _p(cnt), _p(ws), c_sz(ws.numel()), _stream()),
+              "stm_cc_fast_nms_ws_f32")
+    else:
+        check(_lib.lib().stm_cc_fast_nms_f32(_p(conf), _p(boxes), _p(cen), c_i(K), c_i(ncls), _p(k_dev), c_f(iou_thr),
+                                             c_i(top_k), c_i(B), _p(idx), _p(cls), _p(sc), _p(bx), _p(cnt), _stream()),
+              "stm_cc_fast_nms_f32")
     if squeeze:
         return idx[0], cls[0], sc[0], bx[0], cnt[0]
     return idx, cls, sc, bx, cnt

@@ -401,6 +401,25 @@ def test_fused_detect_more_candidates_than_the_lds_sort_holds(quantum):
     assert torch.equal(again[0], idx) and torch.equal(again[2], sc)
 
 
+def test_cc_fast_nms_more_rows_than_the_lds_sort_holds():
+    """The reference-shaped call (candidate rows in, Detect_TF.cc_fast_nms) with K = 57 000 rows -- what a 736x1280 frame of the
+    FCB(ali) config produces with synthetic weights -- goes through stm_cc_fast_nms_ws_f32 and equals the oracle."""
+    K = 57000
+    g = torch.Generator().manual_seed(21)
+    conf = torch.softmax(torch.randn(K, 41, generator=g) * 2, -1)
+    c = torch.rand(K, 2, generator=g)
+    wh = torch.rand(K, 2, generator=g) * 0.2 + 0.01
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 1)
+    cen = torch.tanh(torch.randn(K, generator=g) + 1)
+    idx, cls, sc, bx, cnt = ops.cc_fast_nms(conf.to(DEV), boxes.to(DEV), cen.to(DEV), 0.5, 200)
+    o_idx, o_cls, o_sc = oracle.cc_fast_nms(conf, boxes, cen, 0.5, 200)
+    n = int(cnt)
+    assert n == len(o_idx) and torch.equal(idx[:n].cpu(), o_idx) and torch.equal(cls[:n].cpu(), o_cls)
+    assert torch.equal(sc[:n].cpu(), o_sc) and torch.equal(bx[:n].cpu(), boxes[o_idx])
+    with pytest.raises(StmError, match="use stm_cc_fast_nms_ws_f32"):      # the LDS-only entry point stays loud
+        ops.cc_fast_nms(conf.to(DEV), boxes.to(DEV), cen.to(DEV), 0.5, 200, k_dev=torch.tensor([K], dtype=torch.int32, device=DEV))
+
+
 @pytest.mark.parametrize("p", CASES)
 def test_fused_detect_equals_chain(golden_postproc, p):
     """stm_detect_cc (decode + threshold + NMS, no host sync) == generate_candidate -> cc_fast_nms of the reference."""

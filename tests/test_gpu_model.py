@@ -1,7 +1,7 @@
-"""GPU end-to-end parity: the MI355X model (MIOpen dense convs + hand-written HIP kernels) on the seeded clips the
-reference's own Python produced the goldens for.  Trunk outputs can only agree to ~1e-4 between oneDNN (CPU) and MIOpen
-(GPU), so near-threshold candidates may flip; the contract asserted here is: raw head outputs / prototypes within 1e-3
-relative, and for the detections both sides report, masks within 1e-4 L2-per-pixel RMS where the instance sets agree.
+"""GPU end-to-end tests of the MI355X model: inference-graph variants against the module path and the reference goldens,
+the clip pipelines against each other, the drop-in import names.  The tight, unconditional comparisons with the
+reference's goldens (head outputs, every matched instance of every clip frame, full-size frames, row a18) live in
+tests/test_gpu_parity.py.
 """
 import pytest
 import torch
@@ -22,41 +22,7 @@ def build(name, dev="cuda"):
     return net.to(dev)
 
 
-@pytest.mark.parametrize("name,tag", CASES)
-def test_head_outputs_match_reference(name, tag):
-    g = load_golden(f"model_{tag}.npz")
-    h, w = [int(v) for v in g["frames_hw"]]
-    net = build(name)
-    frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0).cuda()
-    with torch.no_grad():
-        fpn_outs, po = net.forward_single(frames[:1])
-    assert torch.equal(po["priors"][0].cpu(), g["f0_priors"])
-    for k, gk in [("loc", "f0_loc"), ("conf", "f0_conf_logits"), ("mask_coeff", "f0_mask_coeff"),
-                  ("centerness", "f0_centerness"), ("proto", "f0_proto")]:
-        ref = g[gk]
-        err = (po[k][0].cpu() - ref).abs().max().item()
-        assert err < 1e-3 * max(1.0, ref.abs().max().item()), (k, err)
-    assert (fpn_outs[1][0, ::16].cpu() - g["f0_P4"]).abs().max() < 1e-3
-
-
-@pytest.mark.parametrize("name,tag", CASES)
-def test_clip_detections_match_reference(name, tag):
-    g = load_golden(f"model_{tag}.npz")
-    h, w = [int(v) for v in g["frames_hw"]]
-    net = build(name)
-    frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0)
-    outs = run_clip(net, frames, "cuda")
-    for t, det in enumerate(outs):
-        ref_ids = g[f"t{t}_box_ids"].tolist()
-        got_ids = det["box_ids"].cpu().tolist() if det["box"].numel() else []
-        n_ref, n_got = len(ref_ids), len(got_ids)
-        assert abs(n_got - n_ref) <= max(2, n_ref // 10), (t, n_got, n_ref)
-        if n_got == n_ref and got_ids == ref_ids and torch.equal(det["class"].cpu(), g[f"t{t}_class"]):
-            assert (det["box"].cpu() - g[f"t{t}_box"]).abs().max() < 1e-3
-            d = det["mask"].cpu() - g[f"t{t}_mask"]
-            rms = d.pow(2).mean(dim=(1, 2)).sqrt()
-            # soft masks are sigmoid outputs: a trunk delta of 1e-4 moves them by at most that
-            assert rms.median() < 1e-4, rms.median()
+# head outputs and clip detections against the reference goldens: tests/test_gpu_parity.py (tight, unconditional)
 
 
 def test_reference_layer_api_dropins():
@@ -169,15 +135,12 @@ def test_planar_graph_matches_module_path_and_reference(name, tag, planes):
     for k, gk in [("loc", "f0_loc"), ("conf", "f0_conf_logits"), ("mask_coeff", "f0_mask_coeff"),
                   ("centerness", "f0_centerness"), ("proto", "f0_proto")]:
         ref = g[gk]
-        assert (b[k][0].cpu() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), k
+        assert (b[k][0].cpu() - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item()), k
+    from test_gpu_parity import check_frame
     outs = run_clip(opt_net, frames.contiguous(memory_format=torch.channels_last), "cuda")
     for t, det in enumerate(outs):
-        ref_ids = g[f"t{t}_box_ids"].tolist()
-        got_ids = det["box_ids"].cpu().tolist() if det["box"].numel() else []
-        assert abs(len(got_ids) - len(ref_ids)) <= max(2, len(ref_ids) // 10)
-        if got_ids == ref_ids and torch.equal(det["class"].cpu(), g[f"t{t}_class"]):
-            d = det["mask"].cpu() - g[f"t{t}_mask"]
-            assert d.pow(2).mean(dim=(1, 2)).sqrt().median() < 1e-4
+        check_frame((tag, planes, t), det, g[f"t{t}_box"], g[f"t{t}_class"], g[f"t{t}_mask"], min_frac=0.98, tol_box=3e-6,
+                    tol_rms=1e-4, tol_abs=2e-4)
 
 
 @pytest.mark.parametrize("fmt", [1, 0])

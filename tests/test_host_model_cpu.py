@@ -160,11 +160,33 @@ def test_optimized_inference_graph_keeps_reference_parity(name, tag):
     assert all(k in keys_after for k in keys_before if ".bn" not in k and "downsample.1" not in k and "bn1" not in k)
 
 
+def test_non_tf_detect_track_matches_reference_on_cpu():
+    """Row a18: Detect.detect + Track.track (detection.py:98-137, track.py:56-179) over a 3-frame clip against the golden
+    the reference's own methods produced (gen_golden.py model_nontf: Detect.__call__ itself raises KeyError('bbox_idx') at
+    detection.py:91, so the generator drives detect(batch_idx, ...) and track(det, meta) directly, as __call__ would)."""
+    g = load_golden("model_r50_fca_nontf.npz")
+    h, w = [int(v) for v in g["frames_hw"]]
+    cfg = get_cfg("STMask_plus_resnet50_config")
+    cfg.temporal_fusion_module = False
+    net = STMask(cfg)
+    net.eval()
+    synthetic.fill_state_dict(net, seed=0)
+    frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0)
+    with oracle_ops(), torch.no_grad():
+        outs = run_clip(net, frames)
+    for t, det in enumerate(outs):
+        n_ref = g[f"t{t}_box"].shape[0]
+        assert det["box"].shape[0] == n_ref and n_ref > 10, (t, det["box"].shape[0], n_ref)
+        assert torch.equal(det["class"], g[f"t{t}_class"]) and torch.equal(det["box_ids"], g[f"t{t}_box_ids"])
+        assert (det["box"] - g[f"t{t}_box"]).abs().max() < 1e-5 and (det["score"] - g[f"t{t}_score"]).abs().max() < 1e-5
+        assert (det["mask_coeff"] - g[f"t{t}_mask_coeff"]).abs().max() < 1e-5
+        assert (det["mask"] != g[f"t{t}_mask"]).sum() <= 2        # binary masks (track.py:88)
+    assert outs[1]["box"].shape[0] < g["t1_nms_box"].shape[0]     # the clip exercises remove_false_inst (track.py:171-177)
+
+
 def test_non_tf_detect_track_path_is_self_consistent():
-    """Row a18 (Detect / Track without temporal fusion).  The reference cannot generate a golden for this path: its
-    Detect.__call__ reads result['bbox_idx'] (detection.py:93), a key its cc_fast_nms never sets, so the first frame
-    raises KeyError.  The mirror implements the intended behaviour; checked here for internal consistency: frame-0
-    detections equal the TF path's Fast-NMS output, ids persist on an unchanged second frame."""
+    """Row a18, internal consistency besides the golden above: frame-0 detections get ids 0..n-1, ids persist on an
+    unchanged second frame."""
     cfg = get_cfg("STMask_plus_resnet50_config")
     cfg.temporal_fusion_module = False
     net = STMask(cfg)
