@@ -400,7 +400,6 @@ def main():
     n_det = int((out[..., 7] > 0).sum().item())
     if rank == 0:
         planar_graph = args.fuse and args.planar and args.channels_last
-        n_prod = {"fp16x2": 3, "bf16x3": 6, "fp16x1": 1}[args.planes]
         arith = {"fp16x2": "fp32 in / fp32 out / fp32 accumulate; dense convs as 2 fp16 planes x 3 MFMA products (max error 2e-6 of "
                            "sum|x w| vs fp64, tests/test_gpu_conv.py)",
                  "bf16x3": "fp32 in / fp32 out / fp32 accumulate; dense convs as 3 bf16 planes x 6 MFMA products (max error 2e-6 of "
@@ -450,13 +449,18 @@ def main():
             # MFMA peak / n_prod, because each product of the reference is carried by n_prod MFMA products (3 fp16, 6 bf16, 1)
             c_ms = sum(t[0].elapsed_time(t[1]) for t in conv_t)
             c_fl = sum(t[2] for t in conv_t)
+            c_mfma = sum(t[2] * t[4] for t in conv_t)          # MFMA flops actually issued (n_prod products per reference product)
             tf = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
+            eff_peak = BF16_MFMA_PEAK_TF * c_fl / c_mfma if c_mfma > 0 else BF16_MFMA_PEAK_TF
             tr_c, src_c = pmc_traffic("conv_planar") if default_wl else (None, None)
             res["roofline"] = {"bound": "mfma", "kernel": f"conv_planar_kernel ({args.planes} planes: stem, backbone 1x1/3x3 and DCN GEMMs, FPN, proto-net, shared head, TemporalNet; all launches of the timed region)",
-                               "achieved": round(tf, 1), "peak": round(BF16_MFMA_PEAK_TF / n_prod, 1), "unit": "TFLOP/s",
-                               "frac": round(tf / (BF16_MFMA_PEAK_TF / n_prod), 4), "traffic": tr_c,
+                               "achieved": round(tf, 1), "peak": round(eff_peak, 1), "unit": "TFLOP/s",
+                               "frac": round(tf / eff_peak, 4), "traffic": tr_c,
                                "traffic_source": f"profiles/{src_c} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction); average over all launches" if src_c else None,
-                               "peak_note": f"2500 TFLOP/s dense 16-bit MFMA / {n_prod} MFMA product(s) per product of the reference (fp32 MFMA peak is 157)",
+                               "peak_note": "algorithmic (reference) flops against 2500 TFLOP/s dense 16-bit MFMA divided by the MFMA products issued per "
+                                            "reference product (3 for fp16x2 layers, 6 for bf16x3, 1 for fp16x1 layers; flop-weighted over the launches) "
+                                            "-- i.e. frac = issued MFMA flops / time / 2500 (fp32 MFMA peak is 157)",
+                               "mfma_tflops_issued": round(c_mfma / (c_ms * 1e-3) / 1e12, 1) if c_ms > 0 else 0.0,
                                "launches": len(conv_t), "avg_launch_us": round(c_ms * 1e3 / len(conv_t), 2),
                                "ms_per_step": round(c_ms / args.steps, 3),
                                "algorithmic_gflop_per_launch": round(c_fl / len(conv_t) / 1e9, 2)}
@@ -476,6 +480,8 @@ def main():
         if world == 1 and not args.no_extras and run.batched:
             # side measurements on the same process and box (short; the headline above is untouched by them)
             extras = {}
+            from stmask_amd import planar as _pl
+            saved_fmt = (_pl.FMT, _pl.BACKBONE_FMT)
             del run.frames_t
             torch.cuda.empty_cache()
             for name, clips, planes in (("clips8", 8, None), ("clips1", 1, None), ("bf16x3", args.clips, "bf16x3")):
@@ -496,9 +502,7 @@ def main():
                 extras["clips1"]["context"] = "single-stream regime of the reference's own FPS table (README.md:102: 29.3 FPS on a 2080 Ti, batch 1)"
             if "bf16x3" in extras and "value" in extras["bf16x3"]:
                 res["value_bf16x3"] = extras["bf16x3"]["value"]
-            if planar_graph and args.planes == "fp16x2":
-                from stmask_amd import planar as _pl
-                _pl.set_format(1)
+            _pl.set_format(*saved_fmt)
             res["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             base, ref_dets = cpu_baseline(args)

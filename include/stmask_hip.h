@@ -248,7 +248,7 @@ typedef struct stm_conv_geom {
     int Ho, Wo, Cout;     /* output [B, Ho, Wo, Cout] */
     int kh, kw, sh, sw, ph, pw;
     int x_ld, out_ld, res_ld; /* elements between consecutive pixels of x / out / residual; 0 = dense (groups*C / Cout / Cout) */
-    int planes;           /* 3 or 2, must match the packed weights */
+    int planes;           /* planes of the format: 3 (fmt 0; 2 = its looser three-product mode), 2 (fmt 1), 1 (fmt 2) */
     /* --- the fields below are read by stm_conv2d_planar_f32 only; all zero = one dense ungrouped image batch --- */
     int groups;           /* grouped convolution: C input channels and Cout/groups output channels PER GROUP (0 = 1);
                              Cout/groups must be a multiple of 128 when groups > 1 */
@@ -267,11 +267,17 @@ typedef struct stm_conv_geom {
                              11 bits (three products: half the matrix work, same fp32-level error; 22 bits of x for
                              6.1e-5 <= |x| <= 65504, absolute error < 1.5e-11 below.  Beyond 65504 a value has no
                              representation: see stm_planar_set_range_flag);
-                             planes must then be 2 and the weights packed with stm_conv_pack_weights_fmt_f32 */
-    float out_scale;      /* fmt 1: 1 / wscale of the packed weights (0 = 1) */
+                             planes must then be 2 and the weights packed with stm_conv_pack_weights_fmt_f32;
+                             2 = ONE fp16 plane: genuine fp16 activations and weights, one MFMA product, fp32 accumulation,
+                             bias / residual / ReLU in fp32 (BASELINE config 5, "fp16 MFMA backbone convs"; error ~2^-11
+                             per product, stated tolerance 2e-3 of sum |x w|); planes = 1.  Plane 0 of a fmt-1 tensor IS
+                             the fmt-2 tensor of the same values */
+    float out_scale;      /* fmt 1 / 2: 1 / wscale of the packed weights (0 = 1) */
     int tile_n;           /* output-channel tile the weights were packed for: 0 / 128 (stm_conv_pack_weights_f32) or 64
                              (stm_conv_pack_weights_tiled_f32): 128 x 64 tiles, two workgroups per CU -- narrow layers
                              (few output channels) and layers with few pixel tiles */
+    int out_fmt_plus1;    /* 0: out_planes in `fmt`; k + 1: out_planes in format k.  Only fmt 2 -> out format 1 is
+                             supported (the last fp16 layer of a ResNet stage hands both planes to the fp32-equivalent FPN) */
 } stm_conv_geom;
 
 /* bytes of the packed (pre-split, pre-tiled) weight image; 0 on bad arguments */
@@ -283,14 +289,11 @@ int stm_conv_pack_weights_f32(const float* weight, void* packed, int Cout, int C
 size_t stm_conv_packed_weight_bytes_tiled(int Cout, int Cin, int kh, int kw, int planes, int tile_n);
 int stm_conv_pack_weights_tiled_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int planes,
                                     int tile_n, stm_stream_t stream);
-/* plane-format aware forms: fmt 0 = bf16 x 3 (as above), fmt 1 = fp16 x 2 with the weights multiplied by the power of two
- * `wscale` (bring max |w| to ~2^10; pass 1 / wscale as stm_conv_geom.out_scale) */
+/* plane-format aware forms: fmt 0 = bf16 x 3 (as above), fmt 1 = fp16 x 2 / fmt 2 = fp16 x 1 with the weights multiplied by
+ * the power of two `wscale` (bring max |w| to ~2^10; pass 1 / wscale as stm_conv_geom.out_scale) */
 int stm_conv_pack_weights_fmt_f32(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int tile_n, int fmt,
                                   float wscale, stm_stream_t stream);
 int stm_split_planes_fmt_f32(const float* x, void* planes, int64_t n_pixels, int C, int fmt, stm_stream_t stream);
-/* out = act(conv(x, weight) + bias + residual); bias [Cout] or NULL, residual NHWC or NULL, relu 0/1 */
-int stm_conv2d_nhwc_f32(const float* x, const void* packed_weight, const float* bias, const float* residual, float* out,
-                        const stm_conv_geom* g, int relu, stm_stream_t stream);
 
 /* Planar form of the same convolution: activations travel between layers ALREADY split, as bf16 planes in
  * channel-slab-major order [planes][C/32][pixels][32]: the 32-channel slab of one pixel is one 64-byte line and
@@ -374,12 +377,13 @@ int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s, const floa
 int stm_stem_rows_planes_f32(const float* x, void* planes, int B, int H, int W, int Cin, int kw, int sw, int pw, int fmt,
                              stm_stream_t stream);
 
-/* fp16 plane format (fmt 1) range guard.  A value with |x| > 65504 (or inf / nan) has no fp16 plane representation and
+/* fp16 plane formats (fmt 1, fmt 2) range guard.  A value with |x| > 65504 (or inf / nan) has no fp16 plane representation and
  * would poison the following layers silently (inf - inf = nan, and a ReLU epilogue maps nan to 0).  Every producer of
  * fp16 planes (stm_split_planes_fmt_f32, the stm_conv2d_planar_* epilogues, stm_dcn_sample_planar_fmt_f32) therefore
  * writes 1 to *device_flag when it meets one.  The flag is sticky: the caller zeroes it, reads it with whatever
  * device-to-host read it does anyway, and must discard the results if it is set.  NULL (the initial state) disables
- * the guard.  One registration per process (one process per GPU). */
+ * the guard.  The registration is PER DEVICE: it applies to the device that is current when this is called, and kernels
+ * launched on device d raise device d's flag (a process driving several GPUs registers one flag on each). */
 int stm_planar_set_range_flag(int* device_flag);
 
 /* General form: x is pixel-major with a pixel stride of x_ld floats (>= C: a channel slice of a wider NHWC tensor is

@@ -2,7 +2,7 @@
 """Per-kernel micro-benchmarks at BASELINE shapes (R50-DCN @384x640), interleaved rounds in ONE process, HIP-event
 timing on the launch stream.  Prints achieved GB/s (algorithmic bytes) or TFLOP/s next to the gfx950 peaks.
 
-  python scripts/bench_kernels.py [--batch 8] [--what im2col,gemm,corr,lincomb,nms,roi] [--env-sweep]
+  python scripts/bench_kernels.py [--batch 8] [--what im2col,gemm,corr,lincomb,nms,roi]
 """
 import argparse
 import itertools
@@ -151,73 +151,13 @@ def bench_roi(ns=(10, 50, 150)):
         print(f"roi_align n={n}: {ms * 1e3:8.1f} us", flush=True)
 
 
-def env_sweep3(B):
-    """tile sweep of variant 3 (coefficients once per workgroup): items per thread x channels per workgroup x halo"""
-    best = {}
-    for name, C, H, W, s in R50_DCN:
-        for items, cch, halo in itertools.product((256, 512, 768), (8, 16, 32, 64), (2, 3)):
-            os.environ.update(STM_IM2COL_ITEMS=str(items), STM_IM2COL_CCH=str(cch), STM_IM2COL_HALO=str(halo))
-            try:
-                tot, nb = _one(B, C, H, W, s, variant=3)
-            except Exception:
-                continue
-            if name not in best or tot < best[name][0]:
-                best[name] = (tot, items, cch, halo, nb)
-            print(f"sweep3 {name} items={items} cch={cch} halo={halo}: {tot * 1e3:8.1f} us {nb / tot / 1e6:7.0f} GB/s", flush=True)
-    for k in ("STM_IM2COL_ITEMS", "STM_IM2COL_CCH", "STM_IM2COL_HALO"):
-        os.environ.pop(k, None)
-    print("BEST3", json.dumps({k: dict(us=v[0] * 1e3, items=v[1], cch=v[2], halo=v[3], gbs=v[4] / v[0] / 1e6) for k, v in best.items()}))
-    tot = sum(v[0] for v in best.values())
-    nb = sum(v[4] for v in best.values())
-    print(f"BEST3 TOTAL {tot * 1e3:.1f} us {nb / tot / 1e6:.0f} GB/s")
-
-
-def env_sweep(B):
-    """tile-shape sweep of the LDS im2col kernel (STM_IM2COL_TH / CCH / HALO / LDS_KB)"""
-    best = {}
-    for name, C, H, W, s in R50_DCN:
-        for th, cch, halo in itertools.product((0, 2, 4, 8, 12), (4, 8, 16, 32), (1, 2, 3)):
-            os.environ.update(STM_IM2COL_TH=str(th), STM_IM2COL_CCH=str(cch), STM_IM2COL_HALO=str(halo),
-                              STM_IM2COL_LDS_KB="150")
-            try:
-                tot, nb = _one(B, C, H, W, s)
-            except Exception as e:  # invalid combination for this layer
-                continue
-            key = name
-            if key not in best or tot < best[key][0]:
-                best[key] = (tot, th, cch, halo, nb)
-            print(f"sweep {name} th={th} cch={cch} halo={halo}: {tot * 1e3:8.1f} us {nb / tot / 1e6:7.0f} GB/s", flush=True)
-    for k in ("STM_IM2COL_TH", "STM_IM2COL_CCH", "STM_IM2COL_HALO", "STM_IM2COL_LDS_KB"):
-        os.environ.pop(k, None)
-    print("BEST", json.dumps({k: dict(us=v[0] * 1e3, th=v[1], cch=v[2], halo=v[3], gbs=v[4] / v[0] / 1e6) for k, v in best.items()}))
-
-
-def _one(B, C, H, W, s, variant=2):
-    Ho, Wo = ops.conv_out_hw(H, W, 3, 3, s, s, 1, 1, 1, 1)
-    x = torch.randn(B, C, H, W, device=DEV)
-    om = torch.randn(B, 27, Ho, Wo, device=DEV)
-    om[:, :18] = torch.rand(B, 18, Ho, Wo, device=DEV) * 4 - 2   # U(-2,2) like the synthetic DCN offset biases
-    cols = torch.empty(B, C * 9, Ho * Wo, device=DEV)
-    nbytes = 4 * B * (C * H * W + 27 * Ho * Wo + C * 9 * Ho * Wo)
-    ms = timeit(lambda: ops.deform_im2col(x, None, None, 3, s, 1, 1, 1, variant=variant, fused_om=om, out=cols), rounds=3, iters=5)
-    return ms, nbytes
-
-
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--what", default="im2col,gemm,dconv,corr,lincomb,nms,roi")
-    ap.add_argument("--env-sweep", action="store_true")
-    ap.add_argument("--env-sweep3", action="store_true")
     a = ap.parse_args()
     what = a.what.split(",")
     print(torch.cuda.get_device_name(0), flush=True)
-    if a.env_sweep3:
-        env_sweep3(a.batch)
-        sys.exit(0)
-    if a.env_sweep:
-        env_sweep(a.batch)
-        sys.exit(0)
     if "im2col" in what:
         bench_im2col(a.batch)
         bench_im2col(1, label="(B=1)")

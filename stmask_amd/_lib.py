@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
     "stm_jaccard_f32", "stm_lincomb_sigmoid_crop_f32", "stm_mask_iou_workspace_bytes", "stm_mask_iou_f32",
     "stm_bias_act_f32", "stm_mask_rle_workspace_bytes", "stm_mask_resize_rle_f32",
-    "stm_conv_packed_weight_bytes", "stm_conv_pack_weights_f32", "stm_conv2d_nhwc_f32",
+    "stm_conv_packed_weight_bytes", "stm_conv_pack_weights_f32",
     "stm_split_bf16_planes_f32", "stm_conv2d_planar_f32", "stm_conv_packed_weight_bytes_tiled",
     "stm_conv_pack_weights_tiled_f32", "stm_preprocess_u8_f32", "stm_head_assemble_f32", "stm_conv2d_planar_ws_f32", "stm_dcn_sample_planar_f32", "stm_conv_pack_weights_fmt_f32", "stm_split_planes_fmt_f32", "stm_dcn_sample_planar_fmt_f32", "stm_planar_set_range_flag", "stm_resize_bilinear_planes_f32", "stm_bias_relu_maxpool_planes_f32", "stm_roi_align_planes_f32", "stm_deform_sample_planar_f32", "stm_stem_rows_planes_f32", "stm_mask_iou_grouped_f32", "stm_cc_fast_nms_workspace_bytes", "stm_cc_fast_nms_ws_f32",
 ]
@@ -38,7 +38,7 @@ class ConvGeom(ctypes.Structure):
     _fields_ = ([(n, c_i) for n in ("B", "H", "W", "C", "Ho", "Wo", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "x_ld",
                                     "out_ld", "res_ld", "planes", "groups", "n_levels")] +
                 [("lvl_start", c_i * 9), ("lvl_h", c_i * 8), ("lvl_w", c_i * 8),
-                 ("x_plane_stride", c_l), ("out_plane_stride", c_l), ("res_plane_stride", c_l), ("x_np", c_i), ("out_np", c_i), ("res_np", c_i), ("group_cout", c_i * 8), ("fmt", c_i), ("out_scale", c_f), ("tile_n", c_i)])
+                 ("x_plane_stride", c_l), ("out_plane_stride", c_l), ("res_plane_stride", c_l), ("x_np", c_i), ("out_np", c_i), ("res_np", c_i), ("group_cout", c_i * 8), ("fmt", c_i), ("out_scale", c_f), ("tile_n", c_i), ("out_fmt_plus1", c_i)])
 
 
 class HeadLayout(ctypes.Structure):

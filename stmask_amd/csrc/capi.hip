@@ -1,5 +1,8 @@
 // capi.hip -- error reporting and versioning of the C ABI (include/stmask_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "stm_common.h"
 
@@ -15,3 +18,13 @@ void stm_set_error(const char* fmt, ...)
 
 extern "C" int stm_version(void) { return STM_ABI_VERSION; }
 extern "C" const char* stm_last_error_string(void) { return g_err; }
+
+static std::atomic<int> g_env_gen{0};
+int stm_env_generation() { return g_env_gen.load(std::memory_order_relaxed); }
+int stm_env_int_uncached(const char* name, int dflt)
+{
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+// test / A-B aid (not in include/stmask_hip.h): re-read every STM_* switch at its next use
+extern "C" void stm_debug_reload_tunables() { g_env_gen.fetch_add(1, std::memory_order_relaxed); }

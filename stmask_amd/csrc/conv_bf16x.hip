@@ -24,8 +24,6 @@
 #include <mutex>
 #include <unordered_map>
 
-static long long* g_conv_trace = nullptr;   // see stm_debug_conv_set_trace
-
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -38,27 +36,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CV_BM = 128;            // output pixels per workgroup
 constexpr int CV_BN = 128;            // output channels per workgroup
 constexpr int CV_BK = 32;             // input channels per K-slab (one tap)
-constexpr int CV_PLANE_B = 128 * 64;  // bytes of one bf16 plane of a 128 x 32 tile
-constexpr unsigned CV_OOB = 0x80000000u;
-
-struct ConvArgs {
-    const float* x;
-    const uint8_t* wp;
-    const float* bias;
-    const float* res;
-    float* out;
-    int B, H, W, C, Ho, Wo, Cout;
-    int kh, kw, sh, sw, ph, pw;
-    int x_ld, out_ld, res_ld;
-    int relu;
-    int M;        // B * Ho * Wo
-    int n_tiles;  // ceil(Cout / 128)
-    int m_tiles;
-    int slabs;    // kh * kw * C / 32
-    unsigned x_bytes;
-    long long* trace;  // timing instrumentation (stm_debug_conv_set_trace): per-phase clock stamps of workgroup 0
-    int dbg;      // STM_CONV_DEBUG ablation bits (timing experiments only): 1 no MFMA, 2 no global loads, 4 no split, 8 no LDS writes
-};
 
 // 16-B chunk swizzle of the 64-B LDS rows: chunk ^ f((row >> 2) & 3) with f = (0, 2, 3, 1).  f being a permutation keeps the
 // row-major fragment reads of the 32x32x16 MFMA operands conflict-free (16-lane groups of ds_read_b128 see four row
@@ -112,353 +89,40 @@ __device__ __forceinline__ void f16_range_check8(const float (&v)[8], int* flag)
     if (m > 0x477fe000u && flag) *reinterpret_cast<volatile int*>(flag) = 1;
 }
 
-static int* g_range_flag = nullptr;
-
-template <int NPL>
-__global__ __launch_bounds__(256, 2) void conv_bf16x_kernel(const ConvArgs a)
+// Write 8 consecutive channels of one pixel into a planar tensor: dst = address of the 16-byte group in plane 0, plane_b = bytes
+// between planes.  fmt 0: three bf16 planes; 1: two fp16 planes (h, (x - h) * 2048); 2: ONE fp16 plane (h only -- the genuine
+// fp16 activation format of BASELINE config 5; plane 0 of a fmt-1 tensor is a valid fmt-2 tensor).  nt: nontemporal stores.
+__device__ __forceinline__ void store_planes8(uint8_t* dst, size_t plane_b, const float (&v)[8], int fmt, int* range_flag, bool nt)
 {
-    extern __shared__ __align__(16) uint8_t smem[];
-    uint8_t* xs = smem;                      // [NPL][128 rows][64 B]
-    uint8_t* ws = smem + NPL * CV_PLANE_B;   // [NPL][128 rows][64 B]
-
-    // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of
-    // tiles; the n-tiles of one pixel tile sit next to each other (same activations, same L2).
-    const int tiles = a.m_tiles * a.n_tiles;
-    const int per_xcd = (tiles + 7) >> 3;
-    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (logical >= tiles) return;
-    const int nt = logical % a.n_tiles;
-    const int mt = logical / a.n_tiles;
-    const int m0 = mt * CV_BM, n0 = nt * CV_BN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-
-    // activation staging: thread -> rows (tid>>2) and (tid>>2)+64, channels 8*(tid&3) .. +7 of the slab
-    const int oct = tid & 3;
-    int iy0[2], ix0[2], pbase[2];
+    unsigned q0[4], q1[4], q2[4];
+    if (fmt == 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (tid >> 2) + 64 * i;
-        const bool ok = m < a.M;
-        const int mm = ok ? m : 0;
-        const int b = mm / (a.Ho * a.Wo);
-        const int rem = mm - b * (a.Ho * a.Wo);
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        iy0[i] = ok ? oy * a.sh - a.ph : -(1 << 20);
-        ix0[i] = ox * a.sw - a.pw;
-        pbase[i] = b * a.H * a.W;
+        for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
+    } else {
+        f16_range_check8(v, range_flag);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
     }
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-    const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * (NPL * CV_PLANE_B);
-
-    u32x4 xv[2][2];
-    u32x4 wv[2 * NPL];
-    const int taps = a.kh * a.kw;
-    int s_tap = 0, s_c = 0;   // (tap, channel slab) of the slab being FETCHED; K runs channel-slab outer, tap inner, so the
-                              // kh*kw shifted re-reads of one 32-channel slice of the pixel neighbourhood hit L2
-    auto fetch = [&](int slab) {
-        if (a.dbg & 2) return;
-        const int ky = s_tap / a.kw, kx = s_tap - ky * a.kw;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned off = in ? (unsigned)(((pbase[i] + iy * a.W + ix) * a.x_ld + s_c * CV_BK + oct * 8) * 4) : CV_OOB;
-            xv[i][0] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-            xv[i][1] = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 16, 0, 0);
-        }
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wtile + (size_t)min(slab, a.slabs - 1) * (NPL * CV_PLANE_B));
-#pragma unroll
-        for (int j = 0; j < 2 * NPL; ++j) wv[j] = wsrc[tid + 256 * j];
-        if (++s_tap == taps) { s_tap = 0; ++s_c; }
-    };
-    auto stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            u32x4 p0, p1, p2;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // (whole-vector bit cast: __builtin_bit_cast of a single vector ELEMENT reads element 0 on this compiler)
-                const f32x4 f = __builtin_bit_cast(f32x4, xv[i][h]);
-                const f32x2 v0 = {f.x, f.y};
-                const f32x2 v1 = {f.z, f.w};
-                unsigned q0, q1, q2, r0, r1, r2;
-                if (a.dbg & 4) {
-                    q0 = q1 = q2 = xv[i][h].x; r0 = r1 = r2 = xv[i][h].z;
-                } else {
-                    split2(v0, q0, q1, q2);
-                    split2(v1, r0, r1, r2);
-                }
-                if (h == 0) { p0.x = q0; p0.y = r0; p1.x = q1; p1.y = r1; p2.x = q2; p2.y = r2; }
-                else        { p0.z = q0; p0.w = r0; p1.z = q1; p1.w = r1; p2.z = q2; p2.w = r2; }
-            }
-            if (a.dbg & 8) continue;
-            const int row = (tid >> 2) + 64 * i;
-            uint8_t* dst = xs + lds_off(row, oct);
-            *reinterpret_cast<u32x4*>(dst) = p0;
-            *reinterpret_cast<u32x4*>(dst + CV_PLANE_B) = p1;
-            if (NPL == 3) *reinterpret_cast<u32x4*>(dst + 2 * CV_PLANE_B) = p2;
-        }
-        if (a.dbg & 8) return;
-#pragma unroll
-        for (int j = 0; j < 2 * NPL; ++j) *reinterpret_cast<u32x4*>(ws + (tid + 256 * j) * 16) = wv[j];
-    };
-
-    // two accumulators per tile: the leading product x0 w0 in one, the five correction products (2^-8 and smaller) in
-    // the other, so the corrections are not rounded at the magnitude of the running sum
-    f32x16 acc[2][2], accl[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
-
-    const int lrow = lane & 31, lh = lane >> 5;
-    fetch(0);
-    for (int s = 0; s < a.slabs; ++s) {
-        if (a.dbg & 32) __builtin_amdgcn_s_setprio(1);
-        stage();
-        if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
-        fetch(s + 1);   // in flight behind the MFMAs (past the end: a harmless re-read, no branch)
-        if (a.dbg & 16) __builtin_amdgcn_s_setprio(1);
-        if (!(a.dbg & 1))
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][NPL], bf[2][NPL];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) {
-                    af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * CV_PLANE_B + lds_off(wm * 64 + i * 32 + lrow, 2 * ks + lh));
-                    bf[i][p] = *reinterpret_cast<const bf16x8*>(ws + p * CV_PLANE_B + lds_off(wn * 64 + i * 32 + lrow, 2 * ks + lh));
-                }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x16 c = accl[i][j];
-                    if constexpr (NPL == 3) {
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-                    }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-                    accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (a.dbg & 16) __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
-    }
-
-    // epilogue: C/D layout col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = n0 + wn * 64 + j * 32 + lrow;
-        if (co >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[co] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
-                float v = (acc[i][j][r] + accl[i][j][r]) + bv;
-                if (a.res) v += a.res[(size_t)m * a.res_ld + co];
-                if (a.relu) v = v > 0.0f ? v : 0.0f;
-                a.out[(size_t)m * a.out_ld + co] = v;
-            }
+    const int np = fmt == 0 ? 3 : (fmt == 1 ? 2 : 1);
+    if (nt) {
+        __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(dst));
+        if (np > 1) __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(dst + plane_b));
+        if (np > 2) __builtin_nontemporal_store(u32x4{q2[0], q2[1], q2[2], q2[3]}, reinterpret_cast<u32x4*>(dst + 2 * plane_b));
+    } else {
+        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        if (np > 1) *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        if (np > 2) *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
     }
 }
 
-// ---- ping-pong variant: 512 threads = two groups of four waves (one wave of each group per SIMD), each group owning a
-// 128-pixel half of a 256 x 128 output tile and both sharing the weight tile.  The groups run half a K-slab apart: in
-// every phase one group issues its 48 (x6) MFMAs while the other splits and stages its next activation slab plus half
-// of the next weight slab, then a workgroup barrier swaps the roles.  Two independent 256-thread workgroups on a CU do
-// NOT settle into this alternation by themselves (measured: their MFMA phases coincide and the staging time adds to,
-// instead of hiding under, the matrix time); the barrier-enforced anti-phase does.
-//   group 0: stage slab s in phase 2s,     compute it in phase 2s+1
-//   group 1: stage slab s in phase 2s+1,   compute it in phase 2s+2      (phase 0: its half of weight slab 0)
-// weight slab s lives in buffer s&1 from the end of phase 2s to the end of phase 2s+2.  Global fetches for the next
-// stage are issued at the END of a stage phase, so they fly for the barrier wait plus the whole compute phase.
-template <int NPL>
-__global__ __launch_bounds__(512, 1) void conv_bf16x_pp_kernel(const ConvArgs a)
+// the sticky fp16-range flag, one per device (a process that drives several GPUs registers one flag on each)
+constexpr int STM_MAX_DEVICES = 32;
+static int* g_range_flags[STM_MAX_DEVICES] = {};
+static int* current_range_flag()
 {
-    extern __shared__ __align__(16) uint8_t smem[];
-    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wq = (tid >> 6) & 3;
-    uint8_t* xs = smem + grp * (NPL * CV_PLANE_B);        // this group's activation tile [NPL][128][64 B]
-    uint8_t* wsm = smem + 2 * (NPL * CV_PLANE_B);         // weight tiles [2][NPL][128][64 B]
-
-    const int tiles = a.m_tiles * a.n_tiles;              // m_tiles counts 256-pixel tiles here
-    const int per_xcd = (tiles + 7) >> 3;
-    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (logical >= tiles) return;
-    const int nt = logical % a.n_tiles;
-    const int mt = logical / a.n_tiles;
-    const int m0 = mt * (2 * CV_BM) + grp * CV_BM, n0 = nt * CV_BN;
-    const int wm = wq & 1, wn = wq >> 1;
-
-    const int oct = t & 3;
-    int iy0[2], ix0[2], pbase[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (t >> 2) + 64 * i;
-        const bool ok = m < a.M;
-        const int mm = ok ? m : 0;
-        const int b = mm / (a.Ho * a.Wo);
-        const int rem = mm - b * (a.Ho * a.Wo);
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        iy0[i] = ok ? oy * a.sh - a.ph : -(1 << 20);
-        ix0[i] = ox * a.sw - a.pw;
-        pbase[i] = b * a.H * a.W;
-    }
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-    const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * (NPL * CV_PLANE_B);
-    const int taps = a.kh * a.kw, S = a.slabs;
-
-    u32x4 xv0, xv1, xv2, xv3;   // rows 0/1 x halves 0/1 (named: arrays captured by reference have gone to scratch before)
-    u32x4 wv[NPL];
-    int s_tap = 0, s_c = 0;
-#define PP_FETCH_X()                                                                                                      \
-    {                                                                                                                     \
-        const int ky = s_tap / a.kw, kx = s_tap - ky * a.kw;                                                              \
-        {                                                                                                                 \
-            const int iy = iy0[0] + ky, ix = ix0[0] + kx;                                                                 \
-            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;                                 \
-            const unsigned off = in ? (unsigned)(((pbase[0] + iy * a.W + ix) * a.x_ld + s_c * CV_BK + oct * 8) * 4) : CV_OOB; \
-            xv0 = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);                                                   \
-            xv1 = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 16, 0, 0);                                              \
-        }                                                                                                                 \
-        {                                                                                                                 \
-            const int iy = iy0[1] + ky, ix = ix0[1] + kx;                                                                 \
-            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;                                 \
-            const unsigned off = in ? (unsigned)(((pbase[1] + iy * a.W + ix) * a.x_ld + s_c * CV_BK + oct * 8) * 4) : CV_OOB; \
-            xv2 = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);                                                   \
-            xv3 = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 16, 0, 0);                                              \
-        }                                                                                                                 \
-        if (++s_tap == taps) { s_tap = 0; ++s_c; }                                                                        \
-    }
-#define PP_FETCH_W(slab)                                                                                                  \
-    {                                                                                                                     \
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(wtile + (size_t)min((slab), S - 1) * (NPL * CV_PLANE_B)) +      \
-                            grp * (256 * NPL) + t;                                                                        \
-        _Pragma("unroll") for (int j = 0; j < NPL; ++j) wv[j] = wsrc[256 * j];                                            \
-    }
-#define PP_STAGE_ROW(row, va, vb)                                                                                         \
-    {                                                                                                                     \
-        const f32x4 fa = __builtin_bit_cast(f32x4, va), fb = __builtin_bit_cast(f32x4, vb);                               \
-        unsigned q0[4], q1[4], q2[4];                                                                                     \
-        split2(f32x2{fa.x, fa.y}, q0[0], q1[0], q2[0]);                                                                   \
-        split2(f32x2{fa.z, fa.w}, q0[1], q1[1], q2[1]);                                                                   \
-        split2(f32x2{fb.x, fb.y}, q0[2], q1[2], q2[2]);                                                                   \
-        split2(f32x2{fb.z, fb.w}, q0[3], q1[3], q2[3]);                                                                   \
-        const u32x4 p0 = {q0[0], q0[1], q0[2], q0[3]}, p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]}; \
-        uint8_t* dst = xs + lds_off((row), oct);                                                                          \
-        *reinterpret_cast<u32x4*>(dst) = p0;                                                                              \
-        *reinterpret_cast<u32x4*>(dst + CV_PLANE_B) = p1;                                                                 \
-        if (NPL == 3) *reinterpret_cast<u32x4*>(dst + 2 * CV_PLANE_B) = p2;                                               \
-    }
-#define PP_STAGE_W(buf)                                                                                                   \
-    {                                                                                                                     \
-        u32x4* wdst = reinterpret_cast<u32x4*>(wsm + (buf) * (NPL * CV_PLANE_B)) + grp * (256 * NPL) + t;                 \
-        _Pragma("unroll") for (int j = 0; j < NPL; ++j) wdst[256 * j] = wv[j];                                            \
-    }
-
-    f32x16 acc[2][2], accl[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
-
-    const int lrow = lane & 31, lh = lane >> 5;
-    // prologue fetches: group 0 needs X(0) and its half of W(0); group 1 its half of W(0) first
-    if (grp == 0) PP_FETCH_X();
-    PP_FETCH_W(0);
-
-    const bool tr = a.trace != nullptr && blockIdx.x == 0 && (tid & 255) == 0;
-#define PP_STAMP(k) if (tr && p < 64) a.trace[(grp * 64 + p) * 8 + (k)] = clock64();
-    for (int p = 0; p <= 2 * S; ++p) {
-        const int q = p - grp;
-        PP_STAMP(0);
-        if (q < 0) {                                   // group 1, phase 0: its half of weight slab 0
-            PP_STAGE_W(0);
-            PP_FETCH_X();
-            PP_FETCH_W(1);
-        } else if ((q & 1) == 0) {                     // stage slab s = q/2 (+ this group's half of weight slab s+grp)
-            const int sl = q >> 1;
-            if (sl < S) {
-                if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(1); }
-                if (a.dbg & 32) __builtin_amdgcn_s_setprio(2);
-                PP_STAGE_ROW(t >> 2, xv0, xv1);
-                PP_STAGE_ROW((t >> 2) + 64, xv2, xv3);
-                if (sl + grp < S) PP_STAGE_W((sl + grp) & 1);
-                if (tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_STAMP(2); }
-                PP_FETCH_X();
-                PP_FETCH_W(sl + 1 + grp);
-                if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
-                PP_STAMP(3);
-            }
-        } else if (!(a.dbg & 1)) {                     // compute slab s = (q-1)/2
-            const uint8_t* ws = wsm + ((q >> 1) & 1) * (NPL * CV_PLANE_B);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[2][NPL], bf[2][NPL];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) {
-                        af[i][pl] = *reinterpret_cast<const bf16x8*>(xs + pl * CV_PLANE_B + lds_off(wm * 64 + i * 32 + lrow, 2 * ks + lh));
-                        bf[i][pl] = *reinterpret_cast<const bf16x8*>(ws + pl * CV_PLANE_B + lds_off(wn * 64 + i * 32 + lrow, 2 * ks + lh));
-                    }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        f32x16 c = accl[i][j];
-                        if constexpr (NPL == 3) {
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-                        }
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-                        accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                    }
-            }
-            PP_STAMP(4);
-        }
-        PP_STAMP(5);
-        __syncthreads();
-        PP_STAMP(6);
-    }
-#undef PP_STAMP
-#undef PP_FETCH_X
-#undef PP_FETCH_W
-#undef PP_STAGE_ROW
-#undef PP_STAGE_W
-
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = n0 + wn * 64 + j * 32 + lrow;
-        if (co >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[co] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
-                float v = (acc[i][j][r] + accl[i][j][r]) + bv;
-                if (a.res) v += a.res[(size_t)m * a.res_ld + co];
-                if (a.relu) v = v > 0.0f ? v : 0.0f;
-                a.out[(size_t)m * a.out_ld + co] = v;
-            }
-    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= STM_MAX_DEVICES) return nullptr;
+    return g_range_flags[dev];
 }
 
 // ---- planar variant: the activation arrives ALREADY split, as NPL bf16 planes [NPL][B*H*W][x_ld] (the format the
@@ -489,17 +153,14 @@ struct PlanarArgs {
     int group_real[8];                               // output channels per group that are not zero padding (MFMA tiles past them are skipped)
     int n_levels;                                    // > 0: pixels are the concatenation of n_levels images sizes
     int lvl_start[9], lvl_h[8], lvl_w[8];
-    int fmt;                  // 0: three bf16 planes (six products), 1: two fp16 planes (three products)
+    int fmt;                  // input / residual planes: 0 three bf16 planes (six products), 1 two fp16 planes (three), 2 one fp16 plane (one)
+    int out_fmt;              // format of out_pl (normally fmt; a fmt-2 layer may write fmt 1 for a consumer that wants both planes)
     float out_scale;          // 1 / (power-of-two weight scale of the packed image)
     int* range_flag;          // fmt 1: set to 1 when an output has no fp16 representation (see f16_range_check8); may be null
     int nt_out;               // fmt 1: nontemporal plane stores (outputs far larger than L2)
     int splitk, kslabs, ldp;  // split-K: K-slabs per split, fp32 partial sums [splitk][M][ldp] in `partial`
     float* partial;
-    int* tickets;           // split-K: one counter per output tile (zero between launches); the part that draws the last
-                            // ticket adds the parts and runs the epilogue.  Null: planar_splitk_finish_kernel does it
-    int dbg;                // STM_CONV_DEBUG timing ablations (results wrong): 1 no DMA in the loop, 2 no barrier, 4 no MFMA
     int vec_epilogue;       // Cout, out_ld, res_ld multiples of 8 and 16-byte aligned pointers: vector epilogue
-    long long* trace;
 };
 
 // Epilogue shared by the planar kernels: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes.
@@ -509,21 +170,6 @@ struct PlanarArgs {
 // instead of 192 two-byte ones.  Otherwise the same 8-channel segments are written element by element, guarded.
 template <int NJ>
 __device__ __forceinline__ float* park_base(uint8_t* smem, int wave) { return reinterpret_cast<float*>(smem) + wave * (64 * (32 * NJ + 4)); }
-
-template <int NJ>   // v_mfma_f32_32x32x16: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-__device__ __forceinline__ void park32(f32x16 (&acc)[2][NJ], f32x16 (&accl)[2][NJ], uint8_t* smem, int wave, int lane, float ls = 1.0f)
-{
-    constexpr int EP_LD = 32 * NJ + 4;
-    float* park = park_base<NJ>(smem, wave);
-    const int lrow = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                park[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EP_LD + j * 32 + lrow] = acc[i][j][r] + accl[i][j][r] * ls;
-}
 
 template <int NJ>   // v_mfma_f32_16x16x32: col = lane & 15, row = 4 (lane >> 4) + r
 __device__ __forceinline__ void park16(f32x4 (&acc)[4][2 * NJ], f32x4 (&accl)[4][2 * NJ], uint8_t* smem, int wave, int lane, float ls = 1.0f)
@@ -556,7 +202,11 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         }
         if (a.res_pl) {
             const size_t ri = pidx(m, co, a.res_np) * 2;
-            if (a.fmt == 1) {
+            if (a.fmt == 2) {
+                const f16x8 p0 = have_pre ? pre0 : *reinterpret_cast<const f16x8*>(a.res_pl + ri);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)p0[e];
+            } else if (a.fmt == 1) {
                 const f16x8 p0 = have_pre ? pre0 : *reinterpret_cast<const f16x8*>(a.res_pl + ri);
                 const f16x8 p1 = have_pre ? pre1 : *reinterpret_cast<const f16x8*>(a.res_pl + ri + rpl * 2);
 #pragma unroll
@@ -579,26 +229,8 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
             *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
         }
         if (a.out_pl) {
-            unsigned q0[4], q1[4], q2[4];
             uint8_t* o = a.out_pl + pidx(m, co, a.out_np) * 2;
-            if (a.fmt == 1) {
-                f16_range_check8(v, a.range_flag);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
-                if (a.nt_out) {
-                    __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(o));
-                    __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(o + opl * 2));
-                } else {
-                    *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-                    *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
-                *reinterpret_cast<u32x4*>(o) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-                *reinterpret_cast<u32x4*>(o + opl * 2) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-                *reinterpret_cast<u32x4*>(o + opl * 4) = u32x4{q2[0], q2[1], q2[2], q2[3]};
-            }
+            store_planes8(o, opl * 2, v, a.out_fmt, a.range_flag, a.nt_out != 0);
         }
         return;
     }
@@ -611,9 +243,10 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         if (a.res_f32) x += a.res_f32[(size_t)m * a.res_ld + co + e];
         if (resp) {
             const size_t ri = pidx(m, co + e, a.res_np);
-            if (a.fmt == 1) {
+            if (a.fmt >= 1) {
                 const _Float16* rh = reinterpret_cast<const _Float16*>(a.res_pl);
-                x += (float)rh[ri] + (float)rh[ri + rpl] * (1.0f / STM_F16_LOW_SCALE);
+                x += (float)rh[ri];
+                if (a.fmt == 1) x += (float)rh[ri + rpl] * (1.0f / STM_F16_LOW_SCALE);
             } else {
                 x += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
             }
@@ -622,11 +255,11 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co + e] = x;
         if (outp) {
             const size_t oi = pidx(m, co + e, a.out_np);
-            if (a.fmt == 1) {
+            if (a.out_fmt >= 1) {
                 _Float16* oh = reinterpret_cast<_Float16*>(a.out_pl);
                 const _Float16 h = (_Float16)x;
                 oh[oi] = h;
-                oh[oi + opl] = (_Float16)((x - (float)h) * STM_F16_LOW_SCALE);
+                if (a.out_fmt == 1) oh[oi + opl] = (_Float16)((x - (float)h) * STM_F16_LOW_SCALE);
                 if (!(fabsf(x) <= 65504.0f) && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
             } else {
                 const __bf16 h = (__bf16)x;
@@ -659,7 +292,7 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
     // (expanding 1x1 convolutions of the bottlenecks) then run at the latency of four dependent round trips.  The fragment
     // and accumulator registers are dead here, so the 8 * LPR registers cost nothing.
     // (64-channel tiles only: with LPR = 8 the 64 extra registers push the 256 x 128 kernel into scratch -- 380 -> 1065 us)
-    const bool pre = NJ == 1 && a.vec_epilogue && a.res_pl != nullptr && a.fmt == 1 && !(a.dbg & 16);
+    const bool pre = NJ == 1 && a.vec_epilogue && a.res_pl != nullptr && a.fmt >= 1;
     f16x8 r0[LPR], r1[LPR];
     if (pre) {
 #pragma unroll
@@ -667,7 +300,7 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
             const int m = min(m0 + wm * 64 + pass * (64 / LPR) + prow, a.M - 1);
             const size_t ri = (((size_t)(co >> 5) * a.res_np + m) * 32 + (co & 31)) * 2;
             r0[pass] = *reinterpret_cast<const f16x8*>(a.res_pl + ri);
-            r1[pass] = *reinterpret_cast<const f16x8*>(a.res_pl + ri + a.res_pstride);
+            r1[pass] = a.fmt == 1 ? *reinterpret_cast<const f16x8*>(a.res_pl + ri + a.res_pstride) : r0[pass];   // fmt 2: one plane
         }
     }
 #pragma unroll
@@ -703,16 +336,12 @@ __global__ __launch_bounds__(256) void planar_splitk_finish_kernel(const PlanarA
     epilogue_store8(a, m, grp * a.cout_g + cog, min(8, a.cout_g - cog), v);
 }
 
-template <int NJ>
-__device__ __forceinline__ void planar_epilogue(const PlanarArgs& a, f32x16 (&acc)[2][NJ], f32x16 (&accl)[2][NJ], uint8_t* smem, int wave,
-                                                int lane, int m0, int n0g, int grp, int wm, int wn, float ls = 1.0f)
-{
-    __syncthreads();                                   // all fragment reads of the last slab are done
-    park32<NJ>(acc, accl, smem, wave, lane, ls);
-    planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
-}
-
-template <int NPL, int MG, int NJ, int MF, int DT = 0, int ST = 2, int ABL = 0>   // ABL: timing ablations of the ring loop (results wrong): 1 no DMA, 2 no barrier, 4 no fragment reads, 8 no wait for the DMAs; ST = 3: three-buffer LDS ring with fragment prefetch (fp16 format); DT = 1: fp16 planes / v_mfma_f32_16x16x32_f16 (NPL 2, MF 1 only); MF = 1: v_mfma_f32_16x16x32_bf16 (less energy per flop; the chip is power-limited here), 0: 32x32x16
+// NPL planes per operand; tile = 128*MG pixels x 64*NJ channels; DT = 1: fp16 planes (v_mfma_f32_16x16x32_f16), 0: bf16 planes
+// (v_mfma_f32_16x16x32_bf16 -- the 16x16x32 shape spends less energy per flop than 32x32x16 and the chip is power-limited here:
+// 593 vs 656 us on the 145-GF proto layer); ST = 3: three-buffer LDS ring with fragment prefetch (fp16 formats), 2: two buffers.
+// ABL (builds with -DSTM_ABLATE only): timing ablations of the ring loop, RESULTS ARE WRONG -- 1 no DMA, 2 no barrier, 4 no
+// fragment reads, 8 no wait for the DMAs.
+template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
@@ -724,7 +353,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     constexpr int NWAVES = 4 * MG;
     constexpr int WDMA = (BN / 16) * NPL / NWAVES;   // weight DMA instructions (1 KB each) per wave per slab
     static_assert((BN / 16) * NPL % NWAVES == 0, "weight tile must split evenly over the waves");
-    static_assert(ST == 2 || (ST == 3 && MF == 1 && DT == 1 && NPL == 2), "the three-buffer ring is built for the fp16 format");
+    static_assert(ST == 2 || (ST == 3 && DT == 1 && NPL <= 2), "the three-buffer ring is built for the fp16 formats");
 
     const int tiles = a.m_tiles * a.n_tiles * a.splitk;
     const int per_xcd = (tiles + 7) >> 3;
@@ -808,14 +437,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         }
     };
 
-    f32x16 acc[2][NJ], accl[2][NJ];            // MF == 0
-    f32x4 acc16[4][2 * NJ], accl16[4][2 * NJ];   // MF == 1 (the unused set is dead code)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
+    f32x4 acc16[4][2 * NJ], accl16[4][2 * NJ];   // main products / plane-correction products (v_mfma_f32_16x16x32 C layout)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -823,14 +445,6 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc16[i][j][r] = 0.0f; accl16[i][j][r] = 0.0f; }
 
-    const int lrow = lane & 31, lh = lane >> 5;
-#ifdef STM_CONV_TRACE
-    const bool tr = a.trace != nullptr && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4 * MG - 1);
-#define PL_STAMP(k) if (tr && s < 64) a.trace[((wave != 0) * 64 + s) * 8 + (k)] = clock64();
-#else
-    const bool tr = false;
-#define PL_STAMP(k)
-#endif
     if constexpr (ST == 3) {
         // ---- three-buffer ring (fp16 format) ------------------------------------------------------------------------
         // With two buffers every K-slab opens with a barrier followed by a burst of fragment reads (12 ds_read_b128 per
@@ -841,7 +455,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         // freed, each weight fragment as soon as the last MFMA of slab s that uses its predecessor has issued (the MFMAs
         // run column-tile-major for that).  One barrier per slab as before, placed mid-slab.
         constexpr int NDMA = 2 * NPL + WDMA;             // DMA instructions per wave and slab
-        constexpr int NM = 12 * NJ;                      // MFMAs per half
+        constexpr int MPC = NPL == 2 ? 6 : 2;            // MFMAs per 16-column tile and half: 2 row tiles x (3 plane products | 1)
+        constexpr int NM = 2 * NJ * MPC;                 // MFMAs per half
 #define MM16(x_, y_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x_), __builtin_bit_cast(f16x8, y_), c_, 0, 0, 0)
         const int r16 = lane & 15, kc = lane >> 4;
         int xoff[4], woff[2 * NJ];                       // fragment byte offsets within a buffer (plane 0)
@@ -877,17 +492,22 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                 dma_w(min((S_) + 2, s_end - 1), dmb);                                                                           \
             }                                                                                                                   \
             _Pragma("unroll") for (int j = 0; j < 2 * NJ; ++j) {                                                                \
-                /* the two MFMAs of a correction accumulator are kept two instructions apart */                                 \
-                const f32x4 c0 = MM16(af0[0][1], bf[j][0], accl16[0][j]);                                                       \
-                const f32x4 c1 = MM16(af0[1][1], bf[j][0], accl16[1][j]);                                                       \
-                acc16[0][j] = MM16(af0[0][0], bf[j][0], acc16[0][j]);                                                           \
-                accl16[0][j] = MM16(af0[0][0], bf[j][1], c0);                                                                   \
-                acc16[1][j] = MM16(af0[1][0], bf[j][0], acc16[1][j]);                                                           \
-                accl16[1][j] = MM16(af0[1][0], bf[j][1], c1);                                                                   \
+                if constexpr (NPL == 2) {                                                                                       \
+                    /* the two MFMAs of a correction accumulator are kept two instructions apart */                             \
+                    const f32x4 c0 = MM16(af0[0][NPL - 1], bf[j][0], accl16[0][j]);                                             \
+                    const f32x4 c1 = MM16(af0[1][NPL - 1], bf[j][0], accl16[1][j]);                                             \
+                    acc16[0][j] = MM16(af0[0][0], bf[j][0], acc16[0][j]);                                                       \
+                    accl16[0][j] = MM16(af0[0][0], bf[j][NPL - 1], c0);                                                         \
+                    acc16[1][j] = MM16(af0[1][0], bf[j][0], acc16[1][j]);                                                       \
+                    accl16[1][j] = MM16(af0[1][0], bf[j][NPL - 1], c1);                                                         \
+                } else {                                                                                                        \
+                    acc16[0][j] = MM16(af0[0][0], bf[j][0], acc16[0][j]);                                                       \
+                    acc16[1][j] = MM16(af0[1][0], bf[j][0], acc16[1][j]);                                                       \
+                }                                                                                                               \
             }                                                                                                                   \
             _Pragma("unroll") for (int k = 0; k < NM; ++k) {                                                                    \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    /* one MFMA (16 cycles) */                \
-                if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         /* second half's activation fragments */  \
+                if (k < 2 * NPL) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* second half's activation fragments */  \
                 if (DMA_) {                                                                                                     \
                     __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                /* VALU / SALU of the DMA addresses */    \
                     if (k % (NM / NDMA) == NM / NDMA - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* a DMA */      \
@@ -910,13 +530,16 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                         af0[i][p] = *reinterpret_cast<const bf16x8*>(xn + xoff[i] + p * (BM * 64));                             \
             }                                                                                                                   \
             _Pragma("unroll") for (int j = 0; j < 2 * NJ; ++j) {                                                                \
-                {                                                                                                               \
-                    const f32x4 c0 = MM16(af1[0][1], bf[j][0], accl16[2][j]);                                                   \
-                    const f32x4 c1 = MM16(af1[1][1], bf[j][0], accl16[3][j]);                                                   \
+                if constexpr (NPL == 2) {                                                                                       \
+                    const f32x4 c0 = MM16(af1[0][NPL - 1], bf[j][0], accl16[2][j]);                                             \
+                    const f32x4 c1 = MM16(af1[1][NPL - 1], bf[j][0], accl16[3][j]);                                             \
                     acc16[2][j] = MM16(af1[0][0], bf[j][0], acc16[2][j]);                                                       \
-                    accl16[2][j] = MM16(af1[0][0], bf[j][1], c0);                                                               \
+                    accl16[2][j] = MM16(af1[0][0], bf[j][NPL - 1], c0);                                                         \
                     acc16[3][j] = MM16(af1[1][0], bf[j][0], acc16[3][j]);                                                       \
-                    accl16[3][j] = MM16(af1[1][0], bf[j][1], c1);                                                               \
+                    accl16[3][j] = MM16(af1[1][0], bf[j][NPL - 1], c1);                                                         \
+                } else {                                                                                                        \
+                    acc16[2][j] = MM16(af1[0][0], bf[j][0], acc16[2][j]);                                                       \
+                    acc16[3][j] = MM16(af1[1][0], bf[j][0], acc16[3][j]);                                                       \
                 }                                                                                                               \
                 if (PRE_ && !(ABL & 4)) {                                                                                       \
                     _Pragma("unroll") for (int p = 0; p < NPL; ++p)                                                             \
@@ -926,8 +549,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
             if (PRE_) {                                                                                                         \
                 _Pragma("unroll") for (int k = 0; k < NM; ++k) {                                                                \
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                          \
-                    if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
-                    else if (k >= 6 && ((k - 6) % 6) < NPL) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  \
+                    if (k < 2 * NPL) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+                    else if (k >= MPC && ((k - MPC) % MPC) < NPL) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
                     if (DMA_) {                                                                                                 \
                         __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                                                      \
                         if (k % (NM / NDMA) == NM / NDMA - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
@@ -958,11 +581,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     dma_x(s_begin & 1);
     dma_w(s_begin, s_begin & 1);
     for (int s = s_begin; s < s_end; ++s) {
-        PL_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of slab s has landed
-        PL_STAMP(1);
-        if (!(a.dbg & 2)) __syncthreads();                   // ... everyone's has, and buffer (s+1)&1 is no longer read
-        PL_STAMP(2);
+        __syncthreads();                   // ... everyone's has, and buffer (s+1)&1 is no longer read
         const uint8_t* xs = smem + (s & 1) * BUF;
         const uint8_t* ws = xs + XBUF;
         // Source order matters: an LDS-DMA is an LDS store to the compiler, so fragment reads cannot move above it.
@@ -970,49 +590,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         // schedule directives deal the DMA's address arithmetic and issue out between that half's MFMAs.  Issued as one
         // block ahead of the MFMAs the same ~60 instructions took 850-2800 cycles: the SIMD's other wave is issuing
         // MFMAs then and takes the issue slots.  Past the last slab the DMA re-reads it into the idle buffer (no branch).
-        if constexpr (MF == 0) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][NPL], bf[NJ][NPL];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p)
-                    af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + i * 32 + lrow, 2 * ks + lh));
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p)
-                    bf[j][p] = *reinterpret_cast<const bf16x8*>(ws + p * WPL + lds_off(wn * (32 * NJ) + j * 32 + lrow, 2 * ks + lh));
-            if (!(a.dbg & 1)) {
-                if (ks == 0) dma_x((s + 1) & 1);
-                else dma_w(min(s + 1, s_end - 1), (s + 1) & 1);
-            }
-            if (!(a.dbg & 4))
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    f32x16 c = accl[i][j];
-                    if constexpr (NPL == 3) {
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-                    }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-                    accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
-#pragma unroll
-            for (int k = 0; k < 4 * NJ * NPL; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // one MFMA
-                if (ks == 0) __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);       // VALU / SALU of the DMA addresses
-                else __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
-                if (k % 3 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // a DMA
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        } else {
+        {
             // 16x16x32: one instruction covers the slab's 32 channels; lane (l & 15, l >> 4) holds row l & 15, chunk l >> 4
 #define MFMA16(x_, y_, c_, i0_, i1_, i2_) \
     (DT == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x_), __builtin_bit_cast(f16x8, y_), c_, 0, 0, 0) \
@@ -1038,22 +616,22 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     #pragma unroll
                         for (int p = 0; p < NPL; ++p)
                             af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + (2 * hf + i) * 16 + r16, kc));
-                    if (!(a.dbg & 1)) {
-                        if (hf == 0) dma_x((s + 1) & 1);
-                        else dma_w(min(s + 1, s_end - 1), (s + 1) & 1);
-                    }
+                    if (hf == 0) dma_x((s + 1) & 1);
+                    else dma_w(min(s + 1, s_end - 1), (s + 1) & 1);
     #pragma unroll
                     for (int i = 0; i < 2; ++i)
     #pragma unroll
                         for (int j = 0; j < 2 * NJ; ++j) {
-                            f32x4 c = accl16[2 * hf + i][j];
-                            if constexpr (NPL == 3) {
-                                c = MFMA16(af[i][2], bf[j][0], c, 0, 0, 0);
-                                c = MFMA16(af[i][0], bf[j][2], c, 0, 0, 0);
-                                c = MFMA16(af[i][1], bf[j][1], c, 0, 0, 0);
+                            if constexpr (NPL >= 2) {
+                                f32x4 c = accl16[2 * hf + i][j];
+                                if constexpr (NPL == 3) {
+                                    c = MFMA16(af[i][NPL - 1], bf[j][0], c, 0, 0, 0);
+                                    c = MFMA16(af[i][0], bf[j][NPL - 1], c, 0, 0, 0);
+                                    c = MFMA16(af[i][1], bf[j][1], c, 0, 0, 0);
+                                }
+                                c = MFMA16(af[i][1], bf[j][0], c, 0, 0, 0);
+                                accl16[2 * hf + i][j] = MFMA16(af[i][0], bf[j][1], c, 0, 0, 0);
                             }
-                            c = MFMA16(af[i][1], bf[j][0], c, 0, 0, 0);
-                            accl16[2 * hf + i][j] = MFMA16(af[i][0], bf[j][1], c, 0, 0, 0);
                             acc16[2 * hf + i][j] = MFMA16(af[i][0], bf[j][0], acc16[2 * hf + i][j], 0, 0, 0);
                         }
     #pragma unroll
@@ -1074,23 +652,23 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     #pragma unroll
                         for (int p = 0; p < NPL; ++p)
                             af[i][p] = *reinterpret_cast<const bf16x8*>(xs + p * (BM * 64) + lds_off(wm * 64 + (2 * hf + i) * 16 + r16, kc));
-                    if (!(a.dbg & 1)) {
-                        if (hf == 0) dma_x((s + 1) & 1);
-                        else dma_w(min(s + 1, s_end - 1), (s + 1) & 1);
-                    }
+                    if (hf == 0) dma_x((s + 1) & 1);
+                    else dma_w(min(s + 1, s_end - 1), (s + 1) & 1);
     #pragma unroll
                     for (int i = 0; i < 2; ++i)
     #pragma unroll
                         for (int j = 0; j < 2 * NJ; ++j) {
                             if (j >= jn) continue;
-                            f32x4 c = accl16[2 * hf + i][j];
-                            if constexpr (NPL == 3) {
-                                c = MFMA16(af[i][2], bf[j][0], c, 0, 0, 0);
-                                c = MFMA16(af[i][0], bf[j][2], c, 0, 0, 0);
-                                c = MFMA16(af[i][1], bf[j][1], c, 0, 0, 0);
+                            if constexpr (NPL >= 2) {
+                                f32x4 c = accl16[2 * hf + i][j];
+                                if constexpr (NPL == 3) {
+                                    c = MFMA16(af[i][NPL - 1], bf[j][0], c, 0, 0, 0);
+                                    c = MFMA16(af[i][0], bf[j][NPL - 1], c, 0, 0, 0);
+                                    c = MFMA16(af[i][1], bf[j][1], c, 0, 0, 0);
+                                }
+                                c = MFMA16(af[i][1], bf[j][0], c, 0, 0, 0);
+                                accl16[2 * hf + i][j] = MFMA16(af[i][0], bf[j][1], c, 0, 0, 0);
                             }
-                            c = MFMA16(af[i][1], bf[j][0], c, 0, 0, 0);
-                            accl16[2 * hf + i][j] = MFMA16(af[i][0], bf[j][1], c, 0, 0, 0);
                             acc16[2 * hf + i][j] = MFMA16(af[i][0], bf[j][0], acc16[2 * hf + i][j], 0, 0, 0);
                         }
     #pragma unroll
@@ -1104,17 +682,13 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                 }
             }
 }
-        PL_STAMP(4);
     }
     }
 #undef MFMA16
-#undef PL_STAMP
-    if (tr) a.trace[(wave != 0) * 512 + 7] = clock64();
 
     __syncthreads();                                   // all fragment reads of the last slab are done
     constexpr float LS = DT == 1 ? 1.0f / STM_F16_LOW_SCALE : 1.0f;   // fp16 planes: the corrections carry the low-plane scale
-    if constexpr (MF == 0) park32<NJ>(acc, accl, smem, wave, lane, LS);
-    else park16<NJ>(acc16, accl16, smem, wave, lane, LS);
+    park16<NJ>(acc16, accl16, smem, wave, lane, LS);
     if (a.splitk > 1) {
         // raw fp32 partial sums of this K range; planar_splitk_finish_kernel adds the parts and runs the epilogue
         constexpr int EP_LD = 32 * NJ + 4, LPR = 4 * NJ;
@@ -1131,232 +705,9 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
             *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
             *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
         }
-        if (a.tickets) {
-            // fused reduction: every part publishes its sums (device-scope release), then draws a ticket of its tile; the part
-            // that draws the last one knows all others are published, adds the parts in part order (the order the separate
-            // finishing kernel uses: same bits) and runs the epilogue.  It leaves the counter at zero for the next launch.
-            __threadfence();
-            __syncthreads();
-            int* sh = reinterpret_cast<int*>(smem);
-            if (tid == 0) sh[0] = atomicAdd(a.tickets + tile, 1);
-            __syncthreads();
-            if (sh[0] == a.splitk - 1) {
-                __threadfence();
-                constexpr int SEGS = BN / 8;
-                for (int sg = tid; sg < BM * SEGS; sg += 256 * MG) {
-                    const int pr = sg / SEGS, cs8 = (sg - pr * SEGS) * 8;
-                    const int m = m0 + pr;
-                    const int cog = n0g + cs8;
-                    const int nvalid = min(8, a.cout_g - cog);
-                    if (m >= a.M || nvalid <= 0) continue;
-                    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    for (int k = 0; k < a.splitk; ++k) {
-                        const float* p = a.partial + ((size_t)k * a.M + m) * a.ldp + nt * BN + cs8;
-                        const f32x4 p0 = *reinterpret_cast<const f32x4*>(p), p1 = *reinterpret_cast<const f32x4*>(p + 4);
-                        v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
-                    }
-                    epilogue_store8(a, m, grp * a.cout_g + cog, nvalid, v);
-                }
-                if (tid == 0) a.tickets[tile] = 0;
-            }
-        }
     } else {
         planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
     }
-    if (tr) a.trace[(wave != 0) * 512 + 15] = clock64();
-#endif
-}
-
-// ---- kx-reuse variant for stride-1 "same" convolutions with kw >= 3 (head towers, proto-net, output layers, TemporalNet,
-// FPN prediction layers, plain bottleneck 3x3): the ablations of the kernel above show it limited by on-chip data
-// movement as much as by the matrix pipe (MFMA + fragment reads alone 464 us, LDS-DMA + fragment reads alone 382 us, both
-// 650 us on the 145-GF proto layer; 72 KB per K-slab and CU, one slab in flight).  Here the activation tile of one
-// (channel slab, ky) is staged ONCE with pw extra pixel rows either side and serves all kw taps of that kernel row: tap kx
-// of tile pixel r is LDS row r + kx (the flat pixel index moves by one per x), masked to zero where x + kx - pw leaves the
-// image row (which also covers rows that wrapped to the neighbouring image row).  Activation DMA bytes drop by kw; the
-// weight tile is staged per tap as before.  256 x 128 tiles, 8 waves; LDS: two activation buffers of (256+16) rows and two
-// weight buffers = 150 KB.
-template <int NPL, int DT = 0>
-__global__ __launch_bounds__(512, 1) void conv_planar_kx_kernel(const PlanarArgs a)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __align__(16) uint8_t smem[];
-    constexpr int NJ = 2, BM = 256, BN = 128;
-    constexpr int XROWS = BM + 16, XPL = XROWS * 64, XBUF = NPL * XPL, WBUF = NPL * CV_PLANE_B;
-    constexpr int NWAVES = 8, WDMA = 8 * NPL / NWAVES;
-    uint8_t* const wbase = smem + 2 * XBUF;
-
-    const int tiles = a.m_tiles * a.n_tiles;
-    const int per_xcd = (tiles + 7) >> 3;
-    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (logical >= tiles) return;
-    const int nt = logical % a.n_tiles;
-    const int mt = logical / a.n_tiles;
-    const int m0 = mt * BM;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % 4, wn = wave / 4;
-    const int grp = nt / a.ntpg;
-    const int n0g = (nt - grp * a.ntpg) * BN;
-
-    auto decode = [&](int m, int& iy0, int& ox, int& base, int& H, int& W) {
-        const bool ok = m >= 0 && m < a.M;
-        const int mm = ok ? m : 0;
-        H = a.H; W = a.W;
-        int first = 0;
-        if (a.n_levels > 0) {
-#pragma unroll
-            for (int l = 0; l < 8; ++l)
-                if (l < a.n_levels && mm >= a.lvl_start[l]) { first = a.lvl_start[l]; H = a.lvl_h[l]; W = a.lvl_w[l]; }
-        }
-        const int local = mm - first;
-        const int b = local / (H * W);
-        const int rem = local - b * (H * W);
-        const int oy = rem / W;
-        ox = rem - oy * W;
-        iy0 = ok ? oy - a.ph : -(1 << 20);
-        base = (first + b * H * W) * 64;
-    };
-    // activation DMA duties: lds rows of groups {wave, wave + 8} (16 rows each) and, shared, the extra group 16
-    int d_iy0[3], d_ox[3], d_base[3], d_h[3], d_w[3];
-    const int slot = lane & 3;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int g = t < 2 ? wave + 8 * t : 16;
-        const int j = g * 16 + (lane >> 2);                 // lds row; tile pixel j - pw
-        decode(m0 + j - a.pw, d_iy0[t], d_ox[t], d_base[t], d_h[t], d_w[t]);
-        d_base[t] += (slot ^ swz(j)) << 4;
-    }
-    // fragment rows of this lane (tile pixels wm*64 + i*32 + lane%32): x coordinate and row width for the kx masks
-    int f_ox[2], f_w[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int t0, t1, t2;
-        decode(m0 + wm * 64 + i * 32 + (lane & 31), t0, f_ox[i], t1, t2, f_w[i]);
-    }
-    __amdgpu_buffer_rsrc_t xr[NPL];
-#pragma unroll
-    for (int p = 0; p < NPL; ++p)
-        xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
-    const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * WBUF;
-    const int S = a.slabs, cslabs = a.C / CV_BK;
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* glb_ptr;
-
-    auto dma_x = [&](int cs, int ky, int xi) {
-        uint8_t* xb = smem + xi * XBUF;
-        const int slab_off = (grp * cslabs + cs) * (a.x_np * 64);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int iy = d_iy0[t] + ky;
-            const unsigned oob = (unsigned)iy >= (unsigned)d_h[t];
-            const unsigned off = (unsigned)(d_base[t] + (iy * d_w[t] + d_ox[t]) * 64 + slab_off) | (oob << 31);
-            const int g = t < 2 ? wave + 8 * t : 16;
-            if (t < 2) {
-#pragma unroll
-                for (int p = 0; p < NPL; ++p)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(xb + p * XPL + g * 1024), 16, off, 0, 0, 0);
-            } else {
-                // the 17th row group: one plane per wave (waves 3.. repeat planes: identical writes), so every wave issues
-                // the same number of DMA instructions
-                const int p = wave % NPL;                   // wave-uniform: scalar branches
-                if (p == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[0], (lds_ptr)(xb + g * 1024), 16, off, 0, 0, 0);
-                else if (p == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[1], (lds_ptr)(xb + XPL + g * 1024), 16, off, 0, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[NPL - 1], (lds_ptr)(xb + (NPL - 1) * XPL + g * 1024), 16, off, 0, 0, 0);
-            }
-        }
-    };
-    auto dma_w = [&](int slab, int buf) {
-        uint8_t* wb = wbase + buf * WBUF;
-        const uint8_t* wsrc = wtile + (size_t)slab * WBUF;
-#pragma unroll
-        for (int j = 0; j < WDMA; ++j) {
-            const int wi = wave + NWAVES * j;
-            __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + wi * 1024 + lane * 16), (lds_ptr)(wb + wi * 1024), 16, 0, 0);
-        }
-    };
-
-#define KX_MFMA(x_, y_, c_, i0_, i1_, i2_) \
-    (DT == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x_), __builtin_bit_cast(f16x8, y_), c_, 0, 0, 0) \
-             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, y_, c_, 0, 0, 0))
-    f32x16 acc[2][NJ], accl[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
-
-    const int lrow = lane & 31, lh = lane >> 5;
-    int cs = 0, ky = 0, kx = 0, xi = 0;
-    bool x_in_flight = false;
-    dma_x(0, 0, 0);
-    dma_w(0, 0);
-    for (int s = 0; s < S; ++s) {
-        // this step's weight tile must have landed; an activation tile issued AFTER it in the previous step (2*NPL+1 DMA
-        // instructions per wave, needed only at the next kx == 0) may stay in flight: the counter retires in issue order
-        if (x_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPL + 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(a.dbg & 2)) __syncthreads();
-        const uint8_t* xs = smem + xi * XBUF;
-        const uint8_t* ws = wbase + (s & 1) * WBUF;
-        // the next (channel slab, ky) tile, once per kernel row: a whole row of taps (kw steps) ahead of its first use
-        int ncs = cs, nky = ky + 1;
-        if (nky == a.kh) { nky = 0; ++ncs; }
-        const bool stage_x = kx == 0 && ncs < cslabs;
-        // masks of this tap: x + kx - pw inside the image row
-        unsigned msk[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) msk[i] = ((unsigned)(f_ox[i] + kx - a.pw) < (unsigned)f_w[i]) ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][NPL], bf[NJ][NPL];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) {
-                    u32x4 v = *reinterpret_cast<const u32x4*>(xs + p * XPL + lds_off(wm * 64 + i * 32 + lrow + kx, 2 * ks + lh));
-                    v.x &= msk[i]; v.y &= msk[i]; v.z &= msk[i]; v.w &= msk[i];
-                    af[i][p] = __builtin_bit_cast(bf16x8, v);
-                }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p)
-                    bf[j][p] = *reinterpret_cast<const bf16x8*>(ws + p * CV_PLANE_B + lds_off(wn * 64 + j * 32 + lrow, 2 * ks + lh));
-            if (ks == 0) {
-                if (!(a.dbg & 8)) dma_w(min(s + 1, S - 1), (s + 1) & 1);             // weights first (see the wait above)
-                if (stage_x && !(a.dbg & 1)) dma_x(ncs, nky, xi ^ 1);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    f32x16 c = accl[i][j];
-                    if constexpr (NPL == 3) {
-                        c = KX_MFMA(af[i][2], bf[j][0], c, 0, 0, 0);
-                        c = KX_MFMA(af[i][0], bf[j][2], c, 0, 0, 0);
-                        c = KX_MFMA(af[i][1], bf[j][1], c, 0, 0, 0);
-                    }
-                    c = KX_MFMA(af[i][1], bf[j][0], c, 0, 0, 0);
-                    accl[i][j] = KX_MFMA(af[i][0], bf[j][1], c, 0, 0, 0);
-                    acc[i][j] = KX_MFMA(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
-            if (ks == 0) {
-#pragma unroll
-                for (int k = 0; k < 4 * NJ * NPL; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);
-                    if (k % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        x_in_flight = stage_x && !(a.dbg & 1);
-        if (++kx == a.kw) { kx = 0; xi ^= 1; if (++ky == a.kh) { ky = 0; ++cs; } }
-    }
-    #undef KX_MFMA
-    planar_epilogue<NJ>(a, acc, accl, smem, wave, lane, m0, n0g, grp, wm, wn, DT == 1 ? 1.0f / STM_F16_LOW_SCALE : 1.0f);
 #endif
 }
 
@@ -1382,27 +733,10 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     const int c8 = (int)(idx - pix * c8n);
     const float* src = x + pix * C + c8 * 8;
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
-    unsigned q0[4], q1[4], q2[4];
     const size_t plane_b = (size_t)n * C * 2;
     uint8_t* dst = planes + (((size_t)(c8 >> 2) * n + pix) * 32 + (c8 & 3) * 8) * 2;
-    if (fmt == 1) {
-        const float v8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        f16_range_check8(v8, range_flag);
-        split2_f16(f32x2{a0.x, a0.y}, q0[0], q1[0]);
-        split2_f16(f32x2{a0.z, a0.w}, q0[1], q1[1]);
-        split2_f16(f32x2{a1.x, a1.y}, q0[2], q1[2]);
-        split2_f16(f32x2{a1.z, a1.w}, q0[3], q1[3]);
-        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-        *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-        return;
-    }
-    split2(f32x2{a0.x, a0.y}, q0[0], q1[0], q2[0]);
-    split2(f32x2{a0.z, a0.w}, q0[1], q1[1], q2[1]);
-    split2(f32x2{a1.x, a1.y}, q0[2], q1[2], q2[2]);
-    split2(f32x2{a1.z, a1.w}, q0[3], q1[3], q2[3]);
-    *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-    *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-    *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+    const float v8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    store_planes8(dst, plane_b, v8, fmt, range_flag, false);
 }
 
 // Bilinear resize (F.interpolate(mode="bilinear", align_corners=False): make_net.py's InterpolateModule between the proto-net
@@ -1439,22 +773,9 @@ __global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[4 * h + e] = ly0 * (lx0 * a[e] + lx1 * bq[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
     }
-    unsigned q0[4], q1[4], q2[4];
     const size_t plane_b = (size_t)n * C * 2;
     uint8_t* dst = planes + (((size_t)(c8 >> 2) * n + pix) * 32 + (c8 & 3) * 8) * 2;
-    if (fmt == 1) {
-        f16_range_check8(v, range_flag);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
-        __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(dst));
-        __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(dst + plane_b));
-        return;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
-    __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(dst));
-    __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(dst + plane_b));
-    __builtin_nontemporal_store(u32x4{q2[0], q2[1], q2[2], q2[3]}, reinterpret_cast<u32x4*>(dst + 2 * plane_b));
+    store_planes8(dst, plane_b, v, fmt, range_flag, true);
 }
 
 // ResNet stem tail (backbone.py:73: relu(bn1(conv1)) -> MaxPool2d(3, 2, 1)) on the raw fp32 NHWC convolution output, written as
@@ -1498,22 +819,9 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_planes_kernel(const flo
         const float t = v[e] + (bias ? bias[c8 * 8 + e] : 0.0f);
         v[e] = t > 0.0f ? t : 0.0f;
     }
-    unsigned q0[4], q1[4], q2[4];
     const size_t plane_b = (size_t)n * C * 2;
     uint8_t* dst = planes + (((size_t)(c8 >> 2) * n + pix) * 32 + (c8 & 3) * 8) * 2;
-    if (fmt == 1) {
-        f16_range_check8(v, range_flag);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
-        __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(dst));
-        __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(dst + plane_b));
-        return;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
-    __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(dst));
-    __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(dst + plane_b));
-    __builtin_nontemporal_store(u32x4{q2[0], q2[1], q2[2], q2[3]}, reinterpret_cast<u32x4*>(dst + 2 * plane_b));
+    store_planes8(dst, plane_b, v, fmt, range_flag, true);
 }
 
 // CandidateShift's RoI features (TF_utils.py:30-39: relu(cat(corr, T2S_prev, T2S)) -> mmcv roi_align 7x7, aligned, adaptive
@@ -1602,22 +910,9 @@ __global__ __launch_bounds__(256) void roi_align_planes_kernel(const RoiPlanesAr
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = acc[e] / count;
-    unsigned q0[4], q1[4], q2[4];
     const size_t plane_b = (size_t)npix * a.Cpad * 2;
     uint8_t* dst = a.planes + (((size_t)(g >> 2) * npix + pix) * 32 + (g & 3) * 8) * 2;
-    if (a.fmt == 1) {
-        f16_range_check8(v, a.range_flag);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
-        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-        *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-        return;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
-    *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-    *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-    *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+    store_planes8(dst, plane_b, v, a.fmt, a.range_flag, false);
 }
 
 // Stem entry (backbone.py:73, the 7x7 / stride-2 convolution on the 3-channel frame): the kw * Cin = 21 values one kernel row
@@ -1646,22 +941,9 @@ __global__ __launch_bounds__(256) void stem_rows_planes_kernel(const float* __re
         const int j = g * 8 + e, c = c0 + j;
         v[e] = (j < real && c >= 0 && c < lim) ? src[c] : 0.0f;
     }
-    unsigned q0[4], q1[4], q2[4];
     const size_t plane_b = (size_t)n * 32 * 2;
     uint8_t* dst = planes + ((size_t)pix * 32 + g * 8) * 2;
-    if (fmt == 1) {
-        f16_range_check8(v, range_flag);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
-        *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-        *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-        return;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split2(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e], q2[e]);
-    *reinterpret_cast<u32x4*>(dst) = u32x4{q0[0], q0[1], q0[2], q0[3]};
-    *reinterpret_cast<u32x4*>(dst + plane_b) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-    *reinterpret_cast<u32x4*>(dst + 2 * plane_b) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+    store_planes8(dst, plane_b, v, fmt, range_flag, false);
 }
 
 // Weights [Cout][Cin][kh][kw] fp32 -> packed [n_tile][slab][plane][row 0..127][swizzled 16-B chunk][8 bf16]; rows past
@@ -1687,7 +969,7 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
             v.x = w[((size_t)co * C + c0 + 2 * e) * (kh * kw) + tap];
             v.y = w[((size_t)co * C + c0 + 2 * e + 1) * (kh * kw) + tap];
         }
-        if (fmt == 1) { pl[2][e] = 0; split2_f16(v * wscale, pl[0][e], pl[1][e]); }
+        if (fmt >= 1) { pl[2][e] = 0; split2_f16(v * wscale, pl[0][e], pl[1][e]); }
         else split2(v, pl[0][e], pl[1][e], pl[2][e]);
     }
     const int wpl = bn * 64;
@@ -1698,7 +980,7 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
     }
 }
 
-template <int NPL, int MG, int NJ, int MF, int DT = 0, int ST = 2, int ABL = 0>
+template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0>
 int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
 {
     size_t lds = (size_t)ST * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
@@ -1706,30 +988,48 @@ int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
     if (lds < park) lds = park;
     static bool lds_reserved = false;   // per instantiation; the attribute is sticky, setting it again each launch only costs host time
     if (!lds_reserved) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, MF, DT, ST, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
         lds_reserved = true;
     }
-    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, MF, DT, ST, ABL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
+    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kernel");
     return STM_OK;
 }
 
-template <int NPL, int DT = 0>
-int launch_planar_kx(const PlanarArgs& a, int tiles, stm_stream_t stream)
+// Launch tunables: read from the environment ONCE (first launch), never per launch.  Defaults are the measured best (DESIGN.md
+// section 9); the variables exist for A/B runs.  stm_debug_reload_tunables() (capi.hip) makes the next launch re-read them.
+struct ConvTunables {
+    int ring = 3;          // STM_CONV_RING: 2 = two-buffer loop on the 128-wide tiles, 3 = three-buffer ring (fp16 formats)
+    int ring64 = 3;        // STM_CONV_RING64: 2 never / 4 always the ring on 128 x 64 tiles, 3 = by K length (rule below)
+    int splitk = 0;        // STM_CONV_SPLITK: force this many K parts (0 = rule)
+    int sk_target = 768;   // STM_CONV_SK_TARGET: workgroups the split-K rule of the 64-wide tiles aims at
+    int mg = 0;            // STM_CONV_MG: force 128 (1) or 256 (2) pixel tiles
+    long long nt_mb = 0;   // STM_CONV_NT: nontemporal plane stores for outputs of at least this many MB (0 = off; no gain measured)
+    int scalar_epilogue = 0;   // STM_CONV_SCALAR_EPILOGUE: element-wise epilogue stores (tests)
+    int abl = 0;           // STM_CONV_ABL (builds with -DSTM_ABLATE only)
+};
+ConvTunables read_tunables()
 {
-    const size_t lds = (size_t)2 * NPL * (2 * CV_BM + 16) * 64 + (size_t)2 * NPL * CV_PLANE_B;   // >= the epilogue's 139 KB park (NPL 3)
-    const size_t park = (size_t)8 * 64 * 68 * sizeof(float);
-    const size_t need = lds < park ? park : lds;
-    static bool lds_reserved = false;
-    if (!lds_reserved) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kx_kernel<NPL, DT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)need) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", need);
-        lds_reserved = true;
-    }
-    hipLaunchKernelGGL((conv_planar_kx_kernel<NPL, DT>), dim3(8 * stm_cdiv(tiles, 8)), dim3(512), need, stm_hs(stream), a);
-    STM_CHECK_LAUNCH("conv_planar_kx_kernel");
-    return STM_OK;
+    ConvTunables t;
+    auto geti = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
+    t.ring = (int)geti("STM_CONV_RING", t.ring);
+    t.ring64 = (int)geti("STM_CONV_RING64", t.ring64);
+    t.splitk = (int)geti("STM_CONV_SPLITK", 0);
+    t.sk_target = (int)geti("STM_CONV_SK_TARGET", t.sk_target);
+    t.mg = (int)geti("STM_CONV_MG", 0);
+    t.nt_mb = geti("STM_CONV_NT", 0);
+    t.scalar_epilogue = (int)geti("STM_CONV_SCALAR_EPILOGUE", 0);
+    t.abl = (int)geti("STM_CONV_ABL", 0);
+    return t;
+}
+const ConvTunables& tunables()
+{
+    static ConvTunables t;
+    static int gen = -1;
+    const int g = stm_env_generation();
+    if (gen != g) { t = read_tunables(); gen = g; }
+    return t;
 }
 
 bool geom_ok(const stm_conv_geom* g, const char* who)
@@ -1745,41 +1045,25 @@ bool geom_ok(const stm_conv_geom* g, const char* who)
         stm_set_error("%s: Ho/Wo do not match the convolution arithmetic", who);
         return false;
     }
-    if (g->planes != 2 && g->planes != 3) { stm_set_error("%s: planes must be 2 or 3", who); return false; }
+    if (g->planes < 1 || g->planes > 3) { stm_set_error("%s: planes must be 1, 2 or 3", who); return false; }
     return true;
-}
-
-// split-K tile tickets: one zeroed 16 KB block per stream, owned by the library (the kernels leave it zeroed)
-constexpr int SPLITK_MAX_TILES = 4096;
-int* splitk_tickets(hipStream_t stream)
-{
-    static std::mutex mu;
-    static std::unordered_map<hipStream_t, int*> blocks;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = blocks.find(stream);
-    if (it != blocks.end()) return it->second;
-    int* p = nullptr;
-    if (hipMalloc(&p, SPLITK_MAX_TILES * sizeof(int)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, SPLITK_MAX_TILES * sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }   // synchronous: done before any launch
-    blocks[stream] = p;
-    return p;
 }
 
 }  // namespace
 
-int* stm_internal_range_flag() { return g_range_flag; }
+int* stm_internal_range_flag() { return current_range_flag(); }
 extern "C" int stm_planar_set_range_flag(int* device_flag)
 {
-    g_range_flag = device_flag;
+    int dev = 0;
+    STM_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STM_MAX_DEVICES, STM_EINVAL,
+                "stm_planar_set_range_flag: no current device (or more than %d devices)", STM_MAX_DEVICES);
+    g_range_flags[dev] = device_flag;       // the flag of the CURRENT device: kernels launched on device d raise flag d
     return STM_OK;
 }
 
-// debugging aid (not part of include/stmask_hip.h): device buffer of 2*64*8 int64 receiving workgroup 0's per-phase clocks
-extern "C" void stm_debug_conv_set_trace(void* dev_buf) { g_conv_trace = static_cast<long long*>(dev_buf); }
-
 extern "C" size_t stm_conv_packed_weight_bytes_tiled(int Cout, int Cin, int kh, int kw, int planes, int tile_n)
 {
-    if (Cout <= 0 || Cin <= 0 || Cin % CV_BK || kh <= 0 || kw <= 0 || (planes != 2 && planes != 3) || (tile_n != 64 && tile_n != 128))
+    if (Cout <= 0 || Cin <= 0 || Cin % CV_BK || kh <= 0 || kw <= 0 || (planes < 1 || planes > 3) || (tile_n != 64 && tile_n != 128))
         return 0;
     return (size_t)stm_cdiv(Cout, tile_n) * (kh * kw * (Cin / CV_BK)) * planes * (tile_n * 64);
 }
@@ -1813,8 +1097,8 @@ extern "C" int stm_conv_pack_weights_fmt_f32(const float* weight, void* packed, 
                                              float wscale, stm_stream_t stream)
 {
     STM_REQUIRE(weight && packed, STM_ENULL, "stm_conv_pack_weights_fmt_f32: weight/packed must be non-NULL");
-    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_conv_pack_weights_fmt_f32: fmt must be 0 (bf16 x 3) or 1 (fp16 x 2)");
-    const int planes = fmt == 1 ? 2 : 3;
+    STM_REQUIRE(fmt >= 0 && fmt <= 2, STM_EINVAL, "stm_conv_pack_weights_fmt_f32: fmt must be 0 (bf16 x 3), 1 (fp16 x 2) or 2 (fp16 x 1)");
+    const int planes = fmt == 1 ? 2 : (fmt == 2 ? 1 : 3);
     STM_REQUIRE(stm_conv_packed_weight_bytes_tiled(Cout, Cin, kh, kw, planes, tile_n) > 0, STM_EINVAL,
                 "stm_conv_pack_weights_fmt_f32: bad sizes Cout=%d Cin=%d (multiple of 32) k=%dx%d tile_n=%d (64 or 128)", Cout, Cin, kh, kw,
                 tile_n);
@@ -1823,7 +1107,7 @@ extern "C" int stm_conv_pack_weights_fmt_f32(const float* weight, void* packed, 
     const int slabs = kh * kw * (Cin / CV_BK), n_tiles = stm_cdiv(Cout, tile_n);
     const int64_t total = (int64_t)n_tiles * slabs * tile_n * 4;
     hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), weight,
-                       static_cast<uint8_t*>(packed), Cout, Cin, kh, kw, slabs, n_tiles, planes, tile_n, fmt, fmt == 1 ? wscale : 1.0f);
+                       static_cast<uint8_t*>(packed), Cout, Cin, kh, kw, slabs, n_tiles, planes, tile_n, fmt, fmt >= 1 ? wscale : 1.0f);
     STM_CHECK_LAUNCH("conv_pack_weights_kernel");
     return STM_OK;
 }
@@ -1834,68 +1118,6 @@ extern "C" int stm_conv_pack_weights_f32(const float* weight, void* packed, int 
     return stm_conv_pack_weights_tiled_f32(weight, packed, Cout, Cin, kh, kw, planes, CV_BN, stream);
 }
 
-extern "C" int stm_conv2d_nhwc_f32(const float* x, const void* packed_weight, const float* bias, const float* residual,
-                                   float* out, const stm_conv_geom* g, int relu, stm_stream_t stream)
-{
-    STM_REQUIRE(x && packed_weight && out, STM_ENULL, "stm_conv2d_nhwc_f32: x/packed_weight/out must be non-NULL");
-    if (!geom_ok(g, "stm_conv2d_nhwc_f32")) return STM_EINVAL;
-    const int x_ld = g->x_ld ? g->x_ld : g->C, out_ld = g->out_ld ? g->out_ld : g->Cout, res_ld = g->res_ld ? g->res_ld : g->Cout;
-    STM_REQUIRE(x_ld >= g->C && x_ld % 4 == 0 && out_ld >= g->Cout && res_ld >= g->Cout, STM_EINVAL,
-                "stm_conv2d_nhwc_f32: bad leading dimensions x_ld=%d out_ld=%d res_ld=%d", x_ld, out_ld, res_ld);
-    STM_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)packed_weight % 16 == 0, STM_EINVAL,
-                "stm_conv2d_nhwc_f32: x and packed_weight must be 16-byte aligned");
-    const int64_t x_bytes = ((int64_t)g->B * g->H * g->W - 1) * x_ld * 4 + (int64_t)g->C * 4;
-    STM_REQUIRE(x_bytes < ((int64_t)1 << 31), STM_EUNSUPPORTED, "stm_conv2d_nhwc_f32: input larger than 2 GiB (%lld bytes)",
-                (long long)x_bytes);
-    ConvArgs a;
-    a.x = x; a.wp = static_cast<const uint8_t*>(packed_weight); a.bias = bias; a.res = residual; a.out = out;
-    a.B = g->B; a.H = g->H; a.W = g->W; a.C = g->C; a.Ho = g->Ho; a.Wo = g->Wo; a.Cout = g->Cout;
-    a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw; a.ph = g->ph; a.pw = g->pw;
-    a.x_ld = x_ld; a.out_ld = out_ld; a.res_ld = res_ld; a.relu = relu;
-    const int64_t M = (int64_t)g->B * g->Ho * g->Wo;
-    STM_REQUIRE(M < ((int64_t)1 << 30), STM_EUNSUPPORTED, "stm_conv2d_nhwc_f32: too many output pixels");
-    a.M = (int)M;
-    a.n_tiles = stm_cdiv(g->Cout, CV_BN);
-    a.m_tiles = stm_cdiv(M, CV_BM);
-    a.slabs = g->kh * g->kw * (g->C / CV_BK);
-    a.x_bytes = (unsigned)x_bytes;
-    const char* dbg = getenv("STM_CONV_DEBUG");
-    a.dbg = dbg ? atoi(dbg) : 0;
-    a.trace = g_conv_trace;
-    // 256-pixel ping-pong tiles when they still give every CU work; 128-pixel tiles (two workgroups per CU) otherwise
-    const char* fk = getenv("STM_CONV_KERNEL");
-    const int forced = fk ? atoi(fk) : 0;
-    const int64_t pp_tiles = (int64_t)stm_cdiv(M, 2 * CV_BM) * a.n_tiles;
-    const bool use_pp = forced ? forced == 2 : pp_tiles >= 192;
-    if (use_pp) {
-        a.m_tiles = stm_cdiv(M, 2 * CV_BM);
-        const dim3 grid(8 * stm_cdiv(pp_tiles, 8));
-        const size_t lds = (size_t)4 * g->planes * CV_PLANE_B;
-        if (g->planes == 3) {
-            STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x_pp_kernel<3>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
-                        STM_ELAUNCH, "stm_conv2d_nhwc_f32: cannot reserve %zu bytes of LDS", lds);
-            hipLaunchKernelGGL(conv_bf16x_pp_kernel<3>, grid, dim3(512), lds, stm_hs(stream), a);
-        } else {
-            STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x_pp_kernel<2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
-                        STM_ELAUNCH, "stm_conv2d_nhwc_f32: cannot reserve %zu bytes of LDS", lds);
-            hipLaunchKernelGGL(conv_bf16x_pp_kernel<2>, grid, dim3(512), lds, stm_hs(stream), a);
-        }
-        STM_CHECK_LAUNCH("conv_bf16x_pp_kernel");
-        return STM_OK;
-    }
-    const int tiles = a.m_tiles * a.n_tiles;
-    const dim3 grid(8 * stm_cdiv(tiles, 8));
-    const size_t lds = (size_t)2 * g->planes * CV_PLANE_B + ((a.dbg & 64) ? (48 << 10) : 0);
-    if (g->planes == 3)
-        hipLaunchKernelGGL(conv_bf16x_kernel<3>, grid, dim3(256), lds, stm_hs(stream), a);
-    else
-        hipLaunchKernelGGL(conv_bf16x_kernel<2>, grid, dim3(256), lds, stm_hs(stream), a);
-    STM_CHECK_LAUNCH("conv_bf16x_kernel");
-    return STM_OK;
-}
-
 extern "C" int stm_split_planes_fmt_f32(const float* x, void* planes, int64_t n_pixels, int C, int fmt, stm_stream_t stream);
 extern "C" int stm_split_bf16_planes_f32(const float* x, void* planes, int64_t n_pixels, int C, stm_stream_t stream)
 {
@@ -1904,13 +1126,13 @@ extern "C" int stm_split_bf16_planes_f32(const float* x, void* planes, int64_t n
 
 extern "C" int stm_split_planes_fmt_f32(const float* x, void* planes, int64_t n_pixels, int C, int fmt, stm_stream_t stream)
 {
-    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_split_planes_fmt_f32: fmt must be 0 or 1");
+    STM_REQUIRE(fmt >= 0 && fmt <= 2, STM_EINVAL, "stm_split_planes_fmt_f32: fmt must be 0 (bf16 x 3), 1 (fp16 x 2) or 2 (fp16 x 1)");
     STM_REQUIRE(x && planes, STM_ENULL, "stm_split_bf16_planes_f32: x/planes must be non-NULL");
     STM_REQUIRE(n_pixels > 0 && C > 0 && C % 32 == 0, STM_EINVAL, "stm_split_bf16_planes_f32: n_pixels (%lld) > 0 and C (%d) a multiple of 32",
                 (long long)n_pixels, C);
     STM_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)planes % 16 == 0, STM_EINVAL, "stm_split_bf16_planes_f32: 16-byte alignment required");
     hipLaunchKernelGGL(split_planes_kernel, dim3(stm_cdiv(n_pixels * (C / 8), 256)), dim3(256), 0, stm_hs(stream), x,
-                       static_cast<uint8_t*>(planes), n_pixels, C, fmt, g_range_flag);
+                       static_cast<uint8_t*>(planes), n_pixels, C, fmt, current_range_flag());
     STM_CHECK_LAUNCH("split_planes_kernel");
     return STM_OK;
 }
@@ -1918,7 +1140,7 @@ extern "C" int stm_split_planes_fmt_f32(const float* x, void* planes, int64_t n_
 extern "C" int stm_resize_bilinear_planes_f32(const float* x, void* planes, int B, int H, int W, int C, int Ho, int Wo, int fmt,
                                               stm_stream_t stream)
 {
-    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_resize_bilinear_planes_f32: fmt must be 0 or 1");
+    STM_REQUIRE(fmt >= 0 && fmt <= 2, STM_EINVAL, "stm_resize_bilinear_planes_f32: fmt must be 0, 1 or 2");
     STM_REQUIRE(x && planes, STM_ENULL, "stm_resize_bilinear_planes_f32: x/planes must be non-NULL");
     STM_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 32 == 0, STM_EINVAL,
                 "stm_resize_bilinear_planes_f32: sizes must be positive and C (%d) a multiple of 32", C);
@@ -1927,7 +1149,7 @@ extern "C" int stm_resize_bilinear_planes_f32(const float* x, void* planes, int 
     // scale as ATen computes it for align_corners=false without an explicit scale factor: input size / output size
     const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
     hipLaunchKernelGGL(resize_bilinear_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(n * (C / 8), 256), 8)), dim3(256), 0, stm_hs(stream), x,
-                       static_cast<uint8_t*>(planes), B, H, W, C, Ho, Wo, sy, sx, fmt, g_range_flag);
+                       static_cast<uint8_t*>(planes), B, H, W, C, Ho, Wo, sy, sx, fmt, current_range_flag());
     STM_CHECK_LAUNCH("resize_bilinear_planes_kernel");
     return STM_OK;
 }
@@ -1935,7 +1157,7 @@ extern "C" int stm_resize_bilinear_planes_f32(const float* x, void* planes, int 
 extern "C" int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bias, void* planes, int B, int H, int W, int C, int fmt,
                                                 stm_stream_t stream)
 {
-    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_bias_relu_maxpool_planes_f32: fmt must be 0 or 1");
+    STM_REQUIRE(fmt >= 0 && fmt <= 2, STM_EINVAL, "stm_bias_relu_maxpool_planes_f32: fmt must be 0, 1 or 2");
     STM_REQUIRE(x && planes, STM_ENULL, "stm_bias_relu_maxpool_planes_f32: x/planes must be non-NULL");
     STM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0, STM_EINVAL,
                 "stm_bias_relu_maxpool_planes_f32: sizes must be positive and C (%d) a multiple of 32", C);
@@ -1943,7 +1165,7 @@ extern "C" int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bia
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;     // MaxPool2d(kernel 3, stride 2, padding 1), floor mode
     const int64_t n = (int64_t)B * Ho * Wo;
     hipLaunchKernelGGL(bias_relu_maxpool_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(n * (C / 8), 256), 8)), dim3(256), 0, stm_hs(stream), x, bias,
-                       static_cast<uint8_t*>(planes), B, H, W, C, Ho, Wo, fmt, g_range_flag);
+                       static_cast<uint8_t*>(planes), B, H, W, C, Ho, Wo, fmt, current_range_flag());
     STM_CHECK_LAUNCH("bias_relu_maxpool_planes_kernel");
     return STM_OK;
 }
@@ -1951,7 +1173,7 @@ extern "C" int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bia
 extern "C" int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s, const float* corr, const float* rois, void* planes, int B,
                                         int H, int W, int C1, int Cc, int n, int PH, int PW, int fmt, stm_stream_t stream)
 {
-    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_roi_align_planes_f32: fmt must be 0 or 1");
+    STM_REQUIRE(fmt >= 0 && fmt <= 2, STM_EINVAL, "stm_roi_align_planes_f32: fmt must be 0, 1 or 2");
     STM_REQUIRE(t2s_prev && t2s && corr && rois && planes, STM_ENULL, "stm_roi_align_planes_f32: NULL argument");
     STM_REQUIRE(B > 0 && H > 0 && W > 0 && C1 > 0 && C1 % 8 == 0 && Cc > 0 && n > 0 && PH > 0 && PW > 0, STM_EINVAL,
                 "stm_roi_align_planes_f32: bad sizes (C1 = %d must be a multiple of 8)", C1);
@@ -1960,7 +1182,7 @@ extern "C" int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s,
     RoiPlanesArgs a;
     a.t2s_prev = t2s_prev; a.t2s = t2s; a.corr = corr; a.rois = rois; a.planes = static_cast<uint8_t*>(planes);
     a.n = n; a.H = H; a.W = W; a.C1 = C1; a.Cc = Cc; a.Cpad = (2 * C1 + Cc + 31) / 32 * 32; a.PH = PH; a.PW = PW; a.fmt = fmt;
-    a.range_flag = g_range_flag;
+    a.range_flag = current_range_flag();
     const int64_t threads = (int64_t)n * PH * PW * (a.Cpad / 8);
     hipLaunchKernelGGL(roi_align_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(threads, 256), 8)), dim3(256), 0, stm_hs(stream), a);
     STM_CHECK_LAUNCH("roi_align_planes_kernel");
@@ -1970,7 +1192,7 @@ extern "C" int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s,
 extern "C" int stm_stem_rows_planes_f32(const float* x, void* planes, int B, int H, int W, int Cin, int kw, int sw, int pw, int fmt,
                                         stm_stream_t stream)
 {
-    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "stm_stem_rows_planes_f32: fmt must be 0 or 1");
+    STM_REQUIRE(fmt >= 0 && fmt <= 2, STM_EINVAL, "stm_stem_rows_planes_f32: fmt must be 0, 1 or 2");
     STM_REQUIRE(x && planes, STM_ENULL, "stm_stem_rows_planes_f32: x/planes must be non-NULL");
     STM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && kw > 0 && sw > 0 && pw >= 0 && kw * Cin <= 32, STM_EINVAL,
                 "stm_stem_rows_planes_f32: sizes must be positive and kw * Cin (%d) at most 32", kw * Cin);
@@ -1979,7 +1201,7 @@ extern "C" int stm_stem_rows_planes_f32(const float* x, void* planes, int B, int
     STM_REQUIRE(Wo > 0 && (int64_t)H * W * Cin < ((int64_t)1 << 31), STM_EINVAL, "stm_stem_rows_planes_f32: bad geometry");
     const int64_t n = (int64_t)B * H * Wo;
     hipLaunchKernelGGL(stem_rows_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(n * 4, 256), 8)), dim3(256), 0, stm_hs(stream), x,
-                       static_cast<uint8_t*>(planes), B, H, W, Cin, kw, sw, pw, Wo, fmt, g_range_flag);
+                       static_cast<uint8_t*>(planes), B, H, W, Cin, kw, sw, pw, Wo, fmt, current_range_flag());
     STM_CHECK_LAUNCH("stem_rows_planes_kernel");
     return STM_OK;
 }
@@ -1994,7 +1216,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     STM_REQUIRE(g, STM_ENULL, "%s: geometry is NULL", who);
     const int groups = g->groups > 0 ? g->groups : 1;
     STM_REQUIRE(g->C > 0 && g->C % CV_BK == 0 && g->Cout > 0 && g->Cout % groups == 0 && g->kh > 0 && g->kw > 0 &&
-                (g->planes == 2 || g->planes == 3), STM_EINVAL, "%s: bad channel / kernel / planes arguments", who);
+                (g->planes >= 1 && g->planes <= 3), STM_EINVAL, "%s: bad channel / kernel / planes arguments", who);
     const int cout_g = g->Cout / groups;
     const int bn = g->tile_n ? g->tile_n : CV_BN;      // must be the tile width the weights were packed for
     STM_REQUIRE(bn == 64 || bn == 128, STM_EINVAL, "%s: tile_n must be 64 or 128", who);
@@ -2048,34 +1270,33 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     a.n_levels = g->n_levels > 0 ? g->n_levels : 0;
     for (int l = 0; l < 8; ++l) { a.lvl_start[l] = g->lvl_start[l]; a.lvl_h[l] = g->lvl_h[l]; a.lvl_w[l] = g->lvl_w[l]; }
     a.lvl_start[8] = g->lvl_start[8];
+    const ConvTunables& tn = tunables();
     a.vec_epilogue = (cout_g % 8 == 0) && (!out_f32 || out_ld % 4 == 0) && (!residual_f32 || res_ld % 4 == 0) && ((uintptr_t)out_f32 % 16 == 0) &&
                      ((uintptr_t)out_planes % 16 == 0) && ((uintptr_t)residual_f32 % 16 == 0) && ((uintptr_t)residual_planes % 16 == 0) &&
-                     (ops % 8 == 0) && (rps % 8 == 0) && !getenv("STM_CONV_SCALAR_EPILOGUE");
-    a.trace = g_conv_trace;
-    { const char* dbg = getenv("STM_CONV_DEBUG"); a.dbg = dbg ? atoi(dbg) : 0; }
-    // MFMA shape: v_mfma_f32_16x16x32_bf16 by default -- same flops per cycle as 32x32x16 on paper, but this kernel runs
-    // the board into its power limit (rocm-smi: 1378 W, 2.0 GHz; the MFMA-only ablation 1244 W at 2.34 GHz) and the 16x16x32
-    // form spends less energy per flop: 593 vs 656 us on the 145-GF proto layer.  STM_CONV_MFMA=32 selects the other form.
-    const char* fm = getenv("STM_CONV_MFMA");
-    const bool mf16 = fm ? atoi(fm) != 32 : true;
-    a.fmt = g->fmt == 1 ? 1 : 0;
-    a.out_scale = (g->fmt == 1 && g->out_scale > 0.0f) ? g->out_scale : 1.0f;
-    a.range_flag = g_range_flag;
-    { const char* e = getenv("STM_CONV_NT"); const int64_t thr = e ? atoll(e) : 0; a.nt_out = thr > 0 && M * (int64_t)g->Cout * 4 >= thr * 1000000; }
-    STM_REQUIRE(a.fmt == 0 || g->planes == 2, STM_EINVAL, "%s: the fp16 format has two planes", who);
-    a.splitk = 1; a.kslabs = a.slabs; a.partial = nullptr; a.tickets = nullptr; a.ldp = a.n_tiles * bn;
+                     (ops % 8 == 0) && (rps % 8 == 0) && !tn.scalar_epilogue;
+    a.fmt = (g->fmt >= 0 && g->fmt <= 2) ? g->fmt : 0;
+    a.out_fmt = g->out_fmt_plus1 > 0 ? g->out_fmt_plus1 - 1 : a.fmt;
+    STM_REQUIRE(a.out_fmt >= 0 && a.out_fmt <= 2 && (a.out_fmt == a.fmt || (a.fmt == 2 && a.out_fmt == 1)), STM_EINVAL,
+                "%s: output format %d cannot be produced by a format-%d layer", who, a.out_fmt, a.fmt);
+    a.out_scale = (a.fmt >= 1 && g->out_scale > 0.0f) ? g->out_scale : 1.0f;
+    a.range_flag = current_range_flag();
+    a.nt_out = tn.nt_mb > 0 && M * (int64_t)g->Cout * 4 >= tn.nt_mb * 1000000;
+    const int want_planes = a.fmt == 0 ? 3 : (a.fmt == 1 ? 2 : 1);
+    STM_REQUIRE(g->planes == want_planes || (a.fmt == 0 && g->planes == 2), STM_EINVAL, "%s: format %d has %d planes (planes = %d)", who, a.fmt,
+                want_planes, g->planes);
+    a.splitk = 1; a.kslabs = a.slabs; a.partial = nullptr; a.ldp = a.n_tiles * bn;
     // split-K for grids that would leave most CUs idle over a long K (small feature maps: ResNet stages 3/4, P5-P7):
-    // parts write fp32 partial sums into the caller's workspace, planar_splitk_finish_kernel adds them and runs the epilogue
+    // parts write fp32 partial sums into the caller's workspace, planar_splitk_finish_kernel adds them and runs the epilogue.
+    // (A fused reduction -- the part drawing a tile's last ticket adds the parts -- was built and measured: its device-scope
+    // fences cost an L2 write-back / invalidate per workgroup, 665 vs 919 frames/s; removed.)
     auto plan_splitk = [&](int tiles) {
-        const char* fs = getenv("STM_CONV_SPLITK");
-        int sk = fs ? atoi(fs) : 0;
+        int sk = tn.splitk;
         if (sk <= 0) {
             sk = 1;
             if (bn == 64) {
                 // 128 x 64 tiles run two workgroups per CU; a grid of at most one workgroup per CU spends its time in
                 // the staging latency of each K-slab, so split K until ~3 workgroups per CU are resident or queued
-                const int target = getenv("STM_CONV_SK_TARGET") ? atoi(getenv("STM_CONV_SK_TARGET")) : 768;
-                if (tiles <= 256 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, target / tiles), a.slabs / 10);
+                if (tiles <= 256 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, tn.sk_target / tiles), a.slabs / 10);
             } else if (tiles < 128 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, 256 / tiles), a.slabs / 12);
         }
         if (sk < 2) return;
@@ -2083,74 +1304,63 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         sk = stm_cdiv(a.slabs, per);
         if (sk < 2 || !workspace || (size_t)sk * M * a.ldp * sizeof(float) > workspace_bytes || ((uintptr_t)workspace % 16)) return;
         a.splitk = sk; a.kslabs = per; a.partial = static_cast<float*>(workspace);
-        // The fused reduction (last ticket of a tile adds the parts) saves the finishing launch but needs device-scope
-        // release / acquire fences around the ticket, i.e. an L2 write-back and invalidate per workgroup on this part:
-        // 665 frames/s against 919 with the separate finishing kernel.  Opt-in (STM_CONV_SPLITK_FUSED=1), kept for the record.
-        const char* ff = getenv("STM_CONV_SPLITK_FUSED");
-        if (tiles <= SPLITK_MAX_TILES && ff && atoi(ff) == 1) a.tickets = splitk_tickets(stm_hs(stream));
     };
     auto finish_splitk = [&]() -> int {
-        if (a.splitk < 2 || a.tickets) return STM_OK;
+        if (a.splitk < 2) return STM_OK;
         const int64_t total = M * groups * ((cout_g + 7) / 8);
         hipLaunchKernelGGL(planar_splitk_finish_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), a, bn);
         STM_CHECK_LAUNCH("planar_splitk_finish_kernel");
         return STM_OK;
     };
+    int rc;
     if (bn == 64) {
         // 128 x 64 tiles, 72 KB of LDS: two independent workgroups per CU, each one's barrier / staging gaps filled by
         // the other's MFMAs
         a.m_tiles = stm_cdiv(M, CV_BM);
         plan_splitk(a.m_tiles * a.n_tiles);
         const int tiles = a.m_tiles * a.n_tiles * a.splitk;
-        int rc64;
         // the three-buffer ring (72 KB: still two workgroups per CU) has no skip of zero-padded column tiles: layers whose
         // every group fills its 64-channel tile take it, the narrow ones keep the guarded two-buffer loop
         bool full = cout_g % 64 == 0;
         for (int gi = 0; gi < groups && gi < 8; ++gi) full = full && a.group_real[gi] == cout_g;
-        const int ring64 = getenv("STM_CONV_RING64") ? atoi(getenv("STM_CONV_RING64")) : 3;
         // measured in the graph (bench.py --layer-table): the ring wins on the short K loops (<= 36 slabs: 35 -> 30 us,
         // 46 -> 36 us, 45 -> 37 us), where its two-slab head start hides the first DMA latency, and loses on the long and
         // the split-K ones (100 -> 114 us at 72 slabs), where two resident two-buffer workgroups already cover each other;
         // under 12 slabs the layer is HBM-bound and the two-buffer loop's 48 KB (three workgroups per CU) wins: 302 vs 389 us
-        if (a.fmt == 1 && full && (ring64 == 3 ? (a.splitk == 1 && a.slabs >= 12 && a.slabs <= 40) : ring64 == 4)) rc64 = launch_planar<2, 1, 1, 1, 1, 3>(a, tiles, stream);
-        else if (a.fmt == 1) rc64 = launch_planar<2, 1, 1, 1, 1>(a, tiles, stream);
-        else if (mf16) rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
-        else rc64 = g->planes == 3 ? launch_planar<3, 1, 1, 0>(a, tiles, stream) : launch_planar<2, 1, 1, 0>(a, tiles, stream);
-        return rc64 != STM_OK ? rc64 : finish_splitk();
+        const bool ring = full && (tn.ring64 == 3 ? (a.splitk == 1 && a.slabs >= 12 && a.slabs <= 40) : tn.ring64 == 4);
+        if (a.fmt == 2) rc = ring ? launch_planar<1, 1, 1, 1, 3>(a, tiles, stream) : launch_planar<1, 1, 1, 1>(a, tiles, stream);
+        else if (a.fmt == 1) rc = ring ? launch_planar<2, 1, 1, 1, 3>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
+        else rc = g->planes == 3 ? launch_planar<3, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1>(a, tiles, stream);
+        return rc != STM_OK ? rc : finish_splitk();
     }
-    const char* fk = getenv("STM_CONV_MG");
-    const int forced = fk ? atoi(fk) : 0;
     // 256-pixel tiles once there are enough of them, else 128-pixel tiles.  (A cost model of rounds x tile time x measured
     // efficiency was tried for this choice and for the 64-channel tile: 478-483 frames/s against 502-509 with these plain
-    // thresholds in the same session -- rejected.)
+    // thresholds in the same session -- rejected.  So was a kx-reuse kernel that stages each activation row once per kernel
+    // row: 1.8x fewer DMA bytes, no gain -- 654 vs 670 us on the 145-GF proto layer -- removed.)
     const int64_t t2 = (int64_t)stm_cdiv(M, 2 * CV_BM) * a.n_tiles;
-    const int mg = forced ? forced : (t2 >= 192 ? 2 : 1);
+    const int mg = tn.mg ? tn.mg : (t2 >= 192 ? 2 : 1);
     a.m_tiles = stm_cdiv(M, CV_BM * mg);
-    // stride-1 "same" convolutions with a kernel row of >= 3 taps: stage each activation row tile once per kernel row
-    const char* fkx = getenv("STM_CONV_KX");
-    // (measured: no gain over the per-tap kernel -- 654 vs 670 us on the 145-GF proto layer although it moves 1.8x fewer
-    // bytes; the ablations in DESIGN.md section 6 show why -- so it is opt-in: STM_CONV_KX=1)
-    const bool kx_ok = mg == 2 && g->kw >= 3 && g->kw <= 5 && g->sh == 1 && g->sw == 1 && 2 * g->pw == g->kw - 1 &&
-                       2 * g->ph == g->kh - 1 && fkx && atoi(fkx) == 1;
-    if (kx_ok && a.fmt == 1) return launch_planar_kx<2, 1>(a, a.m_tiles * a.n_tiles, stream);
-    if (kx_ok) return g->planes == 3 ? launch_planar_kx<3>(a, a.m_tiles * a.n_tiles, stream) : launch_planar_kx<2>(a, a.m_tiles * a.n_tiles, stream);
     plan_splitk(a.m_tiles * a.n_tiles);
     const int tiles = a.m_tiles * a.n_tiles * a.splitk;
-    int rc;
-    const int ring = getenv("STM_CONV_RING") ? atoi(getenv("STM_CONV_RING")) : 3;   // 2: the two-buffer loop (A/B runs)
-    const int abl = getenv("STM_CONV_ABL") ? atoi(getenv("STM_CONV_ABL")) : 0;   // timing ablations (wrong results)
-    if (a.fmt == 1 && ring == 3 && mg == 2 && abl)
-        rc = abl == 1 ? launch_planar<2, 2, 2, 1, 1, 3, 1>(a, tiles, stream) : abl == 2 ? launch_planar<2, 2, 2, 1, 1, 3, 2>(a, tiles, stream)
-           : abl == 3 ? launch_planar<2, 2, 2, 1, 1, 3, 3>(a, tiles, stream) : abl == 5 ? launch_planar<2, 2, 2, 1, 1, 3, 5>(a, tiles, stream)
-           : abl == 8 ? launch_planar<2, 2, 2, 1, 1, 3, 8>(a, tiles, stream)
-                      : launch_planar<2, 2, 2, 1, 1, 3, 7>(a, tiles, stream);
-    else if (a.fmt == 1 && ring == 3) rc = mg == 2 ? launch_planar<2, 2, 2, 1, 1, 3>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 1, 3>(a, tiles, stream);
-    else if (a.fmt == 1) rc = mg == 2 ? launch_planar<2, 2, 2, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 1>(a, tiles, stream);
-    else if (mf16) {
-        if (g->planes == 3) rc = mg == 2 ? launch_planar<3, 2, 2, 1>(a, tiles, stream) : launch_planar<3, 1, 2, 1>(a, tiles, stream);
+    const bool ring = tn.ring == 3;
+#ifdef STM_ABLATE
+    if (a.fmt == 1 && ring && mg == 2 && tn.abl) {      // timing ablations of the ring loop: RESULTS ARE WRONG
+        const int abl = tn.abl;
+        rc = abl == 1 ? launch_planar<2, 2, 2, 1, 3, 1>(a, tiles, stream) : abl == 2 ? launch_planar<2, 2, 2, 1, 3, 2>(a, tiles, stream)
+           : abl == 3 ? launch_planar<2, 2, 2, 1, 3, 3>(a, tiles, stream) : abl == 5 ? launch_planar<2, 2, 2, 1, 3, 5>(a, tiles, stream)
+           : abl == 8 ? launch_planar<2, 2, 2, 1, 3, 8>(a, tiles, stream)
+                      : launch_planar<2, 2, 2, 1, 3, 7>(a, tiles, stream);
+        return rc != STM_OK ? rc : finish_splitk();
+    }
+#endif
+    if (a.fmt == 2) {
+        if (ring) rc = mg == 2 ? launch_planar<1, 2, 2, 1, 3>(a, tiles, stream) : launch_planar<1, 1, 2, 1, 3>(a, tiles, stream);
+        else rc = mg == 2 ? launch_planar<1, 2, 2, 1>(a, tiles, stream) : launch_planar<1, 1, 2, 1>(a, tiles, stream);
+    } else if (a.fmt == 1) {
+        if (ring) rc = mg == 2 ? launch_planar<2, 2, 2, 1, 3>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 3>(a, tiles, stream);
         else rc = mg == 2 ? launch_planar<2, 2, 2, 1>(a, tiles, stream) : launch_planar<2, 1, 2, 1>(a, tiles, stream);
-    } else if (g->planes == 3) rc = mg == 2 ? launch_planar<3, 2, 2, 0>(a, tiles, stream) : launch_planar<3, 1, 2, 0>(a, tiles, stream);
-    else rc = mg == 2 ? launch_planar<2, 2, 2, 0>(a, tiles, stream) : launch_planar<2, 1, 2, 0>(a, tiles, stream);
+    } else if (g->planes == 3) rc = mg == 2 ? launch_planar<3, 2, 2>(a, tiles, stream) : launch_planar<3, 1, 2>(a, tiles, stream);
+    else rc = mg == 2 ? launch_planar<2, 2, 2>(a, tiles, stream) : launch_planar<2, 1, 2>(a, tiles, stream);
     return rc != STM_OK ? rc : finish_splitk();
 }
 

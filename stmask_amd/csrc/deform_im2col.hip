@@ -29,10 +29,6 @@ struct ImcolArgs {
     int B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, dg, Ho, Wo;
     // tiled variant only
     int th, cch, R, LW, halo, tiles_y;
-    int blk;  // 1: tile-blocked column buffer cols[b][row tile][C*K][tile positions] (each workgroup writes one
-              // contiguous region); 0: plain cols[b][C*K][Ho*Wo]
-    int nt;   // nontemporal column stores (the columns are read once, by the GEMM, and are far larger than L2)
-    int dbg;  // ablation switch for profiling builds of variant 3 (0 = normal): 1 = no staging / LDS reads, 2 = no stores
 };
 
 __device__ __forceinline__ float sigmoidf_dev(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -284,11 +280,10 @@ __global__ __launch_bounds__(NTHR, MINW) void deform_im2col_lds(ImcolArgs a)
             if (++wo == a.Wo) { wo = 0; ++ho; }
         }
 
-        // plain: row (c*K + k) has HWo positions; blocked: tile ty owns [C*K][NT] floats at offset ty * C*K*(th*Wo)
-        const int64_t cs = a.blk ? (int64_t)K * NT : (int64_t)K * HWo;
-        float* cb = a.blk ? a.cols + (int64_t)b * a.C * K * HWo + (int64_t)ty * a.C * K * (a.th * a.Wo) +
-                                ((int64_t)c0 * K + k) * NT + (nb - n0)
-                          : a.cols + (((int64_t)b * a.C + c0) * K + k) * HWo + nb;
+        // cols[b][c*K + k][HWo].  (A tile-blocked column buffer -- one contiguous region per workgroup -- was built and
+        // measured: no gain, and the GEMM's B loader pays for it; removed.)
+        const int64_t cs = (int64_t)K * HWo;
+        float* cb = a.cols + (((int64_t)b * a.C + c0) * K + k) * HWo + nb;
         for (int q = 0; q < nq; ++q) {
             const float4* tq = tile + q * RL;
             float4 acc[NP];
@@ -314,17 +309,10 @@ __global__ __launch_bounds__(NTHR, MINW) void deform_im2col_lds(ImcolArgs a)
                 typedef float f4nt __attribute__((ext_vector_type(4)));
                 const f4nt o0 = {acc[0].x, acc[1].x, acc[2].x, acc[3].x}, o1 = {acc[0].y, acc[1].y, acc[2].y, acc[3].y};
                 const f4nt o2 = {acc[0].z, acc[1].z, acc[2].z, acc[3].z}, o3 = {acc[0].w, acc[1].w, acc[2].w, acc[3].w};
-                if (a.nt) {
-                    __builtin_nontemporal_store(o0, reinterpret_cast<f4nt*>(c_));
-                    __builtin_nontemporal_store(o1, reinterpret_cast<f4nt*>(c_ + cs));
-                    __builtin_nontemporal_store(o2, reinterpret_cast<f4nt*>(c_ + 2 * cs));
-                    __builtin_nontemporal_store(o3, reinterpret_cast<f4nt*>(c_ + 3 * cs));
-                } else {
-                    *reinterpret_cast<f4nt*>(c_) = o0;
-                    *reinterpret_cast<f4nt*>(c_ + cs) = o1;
-                    *reinterpret_cast<f4nt*>(c_ + 2 * cs) = o2;
-                    *reinterpret_cast<f4nt*>(c_ + 3 * cs) = o3;
-                }
+                *reinterpret_cast<f4nt*>(c_) = o0;     // (nontemporal stores measured: no difference, 172 us either way at batch 8)
+                *reinterpret_cast<f4nt*>(c_ + cs) = o1;
+                *reinterpret_cast<f4nt*>(c_ + 2 * cs) = o2;
+                *reinterpret_cast<f4nt*>(c_ + 3 * cs) = o3;
             } else {
                 c_[0] = acc[0].x;
                 c_[cs] = acc[0].y;
@@ -420,7 +408,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
             const int k = item / items_per_k;
             const int nb = n0 + ((item - k * items_per_k) << 2);
             const int i = k / a.kw, j = k - i * a.kw;
-            sbase[it] = a.blk ? k * NT + (nb - n0) : k * HWo + nb;
+            sbase[it] = k * HWo + nb;
             float dyv[4], dxv[4], mv[4] = {1.f, 1.f, 1.f, 1.f};
             unpack(*reinterpret_cast<const float4*>(ob + (int64_t)(2 * k) * HWo + nb), dyv);
             unpack(*reinterpret_cast<const float4*>(ob + (int64_t)(2 * k + 1) * HWo + nb), dxv);
@@ -454,13 +442,12 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
     // ---- 2. walk the channel quads of this chunk through one LDS buffer
     const int step_r = 256 / a.LW, step_c = 256 - step_r * a.LW;
     const int r_first = tid / a.LW, c_first = tid - r_first * a.LW;
-    const int64_t cs = a.blk ? (int64_t)K * NT : (int64_t)K * HWo;
-    float* const cbase = a.blk ? a.cols + (int64_t)b * a.C * K * HWo + (int64_t)ty * a.C * K * (a.th * a.Wo) + (int64_t)c0 * cs
-                               : a.cols + ((int64_t)b * a.C + c0) * cs;
+    const int64_t cs = (int64_t)K * HWo;
+    float* const cbase = a.cols + ((int64_t)b * a.C + c0) * cs;
     for (int q = 0; q < nq; ++q) {
         const float* xq = a.x + ((int64_t)b * a.C + c0 + 4 * q) * HW;   // wave-uniform base of this quad
         if (q) __syncthreads();                                          // previous quad fully consumed
-        if (a.dbg != 1) {
+        {
             constexpr int SU = 4;
             int r = r_first, col = c_first;
             for (int base = tid; base < RL; base += 256 * SU) {
@@ -495,15 +482,7 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
             float4 acc[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                float4 v1, v2, v3, v4;
-                if (a.dbg == 1) {
-                    v1 = v2 = v3 = v4 = make_float4(1.f, 2.f, 3.f, 4.f);
-                } else {
-                    v1 = tile[la[it][p]];
-                    v2 = tile[lb[it][p]];
-                    v3 = tile[la[it][p] + a.LW];
-                    v4 = tile[lb[it][p] + a.LW];
-                }
+                const float4 v1 = tile[la[it][p]], v2 = tile[lb[it][p]], v3 = tile[la[it][p] + a.LW], v4 = tile[lb[it][p] + a.LW];
                 const float4 w = wq[it][p];
                 acc[p].x = bilerp(w.x, w.y, w.z, w.w, v1.x, v2.x, v3.x, v4.x);
                 acc[p].y = bilerp(w.x, w.y, w.z, w.w, v1.y, v2.y, v3.y, v4.y);
@@ -511,8 +490,8 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
                 acc[p].w = bilerp(w.x, w.y, w.z, w.w, v1.w, v2.w, v3.w, v4.w);
             }
             if (far[it]) {  // rare: offsets larger than the halo -> exact global gather (coordinates re-derived)
-                const int k = a.blk ? sbase[it] / NT : sbase[it] / HWo;
-                const int nb = a.blk ? n0 + (sbase[it] - k * NT) : sbase[it] - k * HWo;
+                const int k = sbase[it] / HWo;
+                const int nb = sbase[it] - k * HWo;
                 const int i = k / a.kw, j = k - i * a.kw;
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
@@ -530,30 +509,17 @@ __global__ __launch_bounds__(256) void deform_im2col_lds3(ImcolArgs a)
                     }
             }
             float* c_ = cq + sbase[it];
-            if (a.dbg == 2 && acc[0].x != 123456.789f) continue;  // ablation: keep the values live, skip the stores
             typedef float f4nt __attribute__((ext_vector_type(4)));
             const f4nt o0 = {acc[0].x, acc[1].x, acc[2].x, acc[3].x}, o1 = {acc[0].y, acc[1].y, acc[2].y, acc[3].y};
             const f4nt o2 = {acc[0].z, acc[1].z, acc[2].z, acc[3].z}, o3 = {acc[0].w, acc[1].w, acc[2].w, acc[3].w};
-            if (a.nt) {
-                __builtin_nontemporal_store(o0, reinterpret_cast<f4nt*>(c_));
-                __builtin_nontemporal_store(o1, reinterpret_cast<f4nt*>(c_ + cs));
-                __builtin_nontemporal_store(o2, reinterpret_cast<f4nt*>(c_ + 2 * cs));
-                __builtin_nontemporal_store(o3, reinterpret_cast<f4nt*>(c_ + 3 * cs));
-            } else {
-                *reinterpret_cast<f4nt*>(c_) = o0;
-                *reinterpret_cast<f4nt*>(c_ + cs) = o1;
-                *reinterpret_cast<f4nt*>(c_ + 2 * cs) = o2;
-                *reinterpret_cast<f4nt*>(c_ + 3 * cs) = o3;
-            }
+            *reinterpret_cast<f4nt*>(c_) = o0;
+            *reinterpret_cast<f4nt*>(c_ + cs) = o1;
+            *reinterpret_cast<f4nt*>(c_ + 2 * cs) = o2;
+            *reinterpret_cast<f4nt*>(c_ + 3 * cs) = o3;
         }
     }
 }
 
-int env_int(const char* name, int dflt)
-{
-    const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
 
 }  // namespace
 
@@ -595,11 +561,7 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     a.B = g->B; a.C = g->C; a.H = g->H; a.W = g->W; a.kh = g->kh; a.kw = g->kw; a.sh = g->sh; a.sw = g->sw;
     a.ph = g->ph; a.pw = g->pw; a.dh = g->dh; a.dw = g->dw; a.dg = g->dg; a.Ho = g->Ho; a.Wo = g->Wo;
     a.th = a.cch = a.R = a.LW = a.halo = a.tiles_y = 0;
-    a.dbg = env_int("STM_IM2COL_DEBUG", 0);
-    a.blk = env_int("STM_IM2COL_BLOCKED", 0);
-    a.nt = env_int("STM_IM2COL_NT", 0);   // measured: no difference for the LDS-staged variants (172 us either way at batch 8)
 
-    if (variant == 0) variant = env_int("STM_IM2COL_VARIANT", 0);
     bool tiled_ok = (Cg % 4 == 0);
     const bool auto_variant = (variant == 0);
     int auto_items = 0;
@@ -627,9 +589,9 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     }
 
     // ---- tiled: pick rows per tile / channels per block --------------------------------------------
-    const int halo = env_int("STM_IM2COL_HALO", 3);  // learned offsets of trained DCNs rarely exceed +-3 rows
+    const int halo = 3;                               // learned offsets of trained DCNs rarely exceed +-3 rows (beyond: exact global gather)
     const int LW = ((g->W + 2 + 3) / 4) * 4;          // +1 zero column each side, rounded up for the column swizzle
-    bool vec = !env_int("STM_IM2COL_NP1", 0) && (HWo % 4 == 0) && (off_bstride % 4 == 0) && (!mask || mask_bstride % 4 == 0) &&
+    bool vec = (HWo % 4 == 0) && (off_bstride % 4 == 0) && (!mask || mask_bstride % 4 == 0) &&
                ((uintptr_t)offset % 16 == 0) && (!mask || (uintptr_t)mask % 16 == 0) && ((uintptr_t)cols % 16 == 0);
     if (variant == 3 && vec) {
         // ---- variant 3: coefficients once per workgroup, channel quads streamed through one LDS buffer ----------
@@ -637,26 +599,20 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
         // >= ~3 workgroups per CU in flight (the quad loop amortises the set-up, the grid must still fill 256 CUs)
         int step3 = 1;
         while ((step3 * g->Wo) % 4 != 0) ++step3;
-        int th3 = env_int("STM_IM2COL_TH", 0);
-        const int max_items = min(768, max(256, env_int("STM_IM2COL_ITEMS", auto_items ? auto_items : 768)));  // 1..3 items per thread
-        if (th3 <= 0) {
-            th3 = (max_items * 4) / (g->Wo * K);
-            th3 = max(step3, (th3 / step3) * step3);
-        }
+        const int max_items = auto_items ? auto_items : 768;    // 1..3 items per thread
+        int th3 = (max_items * 4) / (g->Wo * K);
+        th3 = max(step3, (th3 / step3) * step3);
         th3 = min(th3, g->Ho);
         if (th3 < g->Ho) th3 = max(step3, (th3 / step3) * step3);
         const int items3 = (th3 * g->Wo / 4) * K;
         const int R3 = (th3 - 1) * g->sh + (g->kh - 1) * g->dh + 2 + 2 * halo;
         const size_t lds3 = (size_t)R3 * LW * sizeof(float4);
         if ((th3 * g->Wo) % 4 == 0 && items3 <= 768 && lds3 <= 160 * 1024) {
-            int cch3 = env_int("STM_IM2COL_CCH", 0);
             const int tiles3 = stm_cdiv(g->Ho, th3);
-            if (cch3 <= 0) {
-                cch3 = 4;
-                for (int c = 8; c <= Cg && c <= 64; c += 4)
-                    if (Cg % c == 0 && (int64_t)tiles3 * (g->C / c) * g->B >= 768) cch3 = c;
-                if (auto_variant && Cg % 32 == 0) cch3 = 32;  // sweep optimum for the wide layers this path is chosen for
-            }
+            int cch3 = 4;
+            for (int c = 8; c <= Cg && c <= 64; c += 4)
+                if (Cg % c == 0 && (int64_t)tiles3 * (g->C / c) * g->B >= 768) cch3 = c;
+            if (auto_variant && Cg % 32 == 0) cch3 = 32;      // sweep optimum for the wide layers this path is chosen for
             STM_REQUIRE(cch3 % 4 == 0 && Cg % cch3 == 0, STM_EINVAL, "stm_deform_im2col_f32: channels per block %d invalid",
                         cch3);
             a.th = th3; a.cch = cch3; a.R = R3; a.LW = LW; a.halo = halo; a.tiles_y = tiles3;
@@ -680,25 +636,18 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     // Tile choice (scripts/bench_kernels.py --env-sweep on MI355X): 8 channels per workgroup and as many output rows
     // as fit the LDS budget (up to 12) minimise halo re-reads; when 8 channels do not leave room for >= 4 rows
     // (wide stride-2 layers) fall back to 4 channels.  With 16-byte stores th*Wo must be a multiple of 4.
-    const size_t lds_budget = (size_t)env_int("STM_IM2COL_LDS_KB", 64) * 1024;
+    const size_t lds_budget = 64 * 1024;
     auto rows_of = [&](int th_) { return (th_ - 1) * g->sh + (g->kh - 1) * g->dh + 2 + 2 * halo; };
     auto fits = [&](int th_, int cch_) { return (size_t)(cch_ / 4) * rows_of(th_) * LW * sizeof(float4) <= lds_budget; };
     int step = 1;
     if (vec) while ((step * g->Wo) % 4 != 0) ++step;  // step in {1,2,4}
-    int th = env_int("STM_IM2COL_TH", 0), cch = env_int("STM_IM2COL_CCH", 0);
-    if (th <= 0 || cch <= 0) {
-        int want_c = (cch > 0) ? cch : ((Cg % 8 == 0) ? 8 : 4);
-        int t = (th > 0) ? th : min(12, g->Ho);
-        if (th <= 0) {
-            while (t > 4 && !fits(t, want_c)) --t;
-            if (!fits(t, want_c) && cch <= 0 && want_c == 8) {
-                want_c = 4;
-                t = min(8, g->Ho);
-                while (t > 1 && !fits(t, want_c)) --t;
-            }
-        }
-        th = t;
-        cch = want_c;
+    int cch = (Cg % 8 == 0) ? 8 : 4;
+    int th = min(12, g->Ho);
+    while (th > 4 && !fits(th, cch)) --th;
+    if (!fits(th, cch) && cch == 8) {
+        cch = 4;
+        th = min(8, g->Ho);
+        while (th > 1 && !fits(th, cch)) --th;
     }
     th = min(th, g->Ho);
     if (vec) {
@@ -715,21 +664,13 @@ extern "C" int stm_deform_im2col_f32(const float* x, const float* offset, int64_
     }
     a.th = th; a.cch = cch; a.R = R; a.LW = LW; a.halo = halo; a.tiles_y = stm_cdiv(g->Ho, th);
     dim3 grid(a.tiles_y * (g->C / cch), g->B);
-    const int nthr = env_int("STM_IM2COL_THREADS", 256);
     auto launch2 = [&](auto kern, int threads) {
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stm_hs(stream), a);
     };
-    if (vec) {
-        if (nthr == 512) launch2(deform_im2col_lds<4, 512>, 512);
-        else if (env_int("STM_IM2COL_OCC", 0) == 4) launch2(deform_im2col_lds<4, 256, 4>, 256);
-        else launch2(deform_im2col_lds<4, 256>, 256);
-    } else {
-        if (nthr == 1024) launch2(deform_im2col_lds<1, 1024>, 1024);
-        else if (nthr == 512) launch2(deform_im2col_lds<1, 512>, 512);
-        else launch2(deform_im2col_lds<1, 256>, 256);
-    }
+    if (vec) launch2(deform_im2col_lds<4, 256>, 256);
+    else launch2(deform_im2col_lds<1, 256>, 256);
     STM_CHECK_LAUNCH("deform_im2col_lds");
     return STM_OK;
 }
@@ -756,7 +697,7 @@ struct SampleArgs {
     uint8_t* out;        // planes [3][K*C/32][out_np][32] bf16
     int B, H, W, C, Ho, Wo, sh, sw, ph, pw, dh, dw;
     int x_ld, kw, out_pix0;      // pixel stride of x (floats); kernel width (tap k = (k / kw, k % kw)); first output pixel in the planes
-    int om_ld, out_np, M, fmt;   // fmt 0: three bf16 planes, 1: two fp16 planes
+    int om_ld, out_np, M, fmt;   // fmt 0: three bf16 planes, 1: two fp16 planes, 2: one fp16 plane
     int* range_flag;             // fmt 1: raised when a sampled value has no fp16 representation (may be null)
     int xcd, per_xcd, nt;        // XCD-contiguous workgroup order (workgroups per XCD); nontemporal column stores
     int prefetch;                // streaming touch of the centre pixels ahead of the gathers
@@ -865,7 +806,7 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = bilerp(w1, w2, w3, w4, x1[e], x2[e], x3[e], x4[e]);
         unsigned q0[4], q1[4], q2[4] = {0, 0, 0, 0};
-        if (a.fmt == 1) {
+        if (a.fmt >= 1) {
             unsigned mag = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) mag = max(mag, __builtin_bit_cast(unsigned, v[e]) & 0x7fffffffu);
@@ -881,11 +822,11 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
         uint8_t* o = a.out + (((size_t)(kc >> 5) * a.out_np + a.out_pix0 + mm) * 32 + (kc & 31)) * 2;
         if (live && a.nt) {          // the columns are far larger than L2 and read once, later: keep them out of the gathers' way
             __builtin_nontemporal_store(p0, reinterpret_cast<u32x4v*>(o));
-            __builtin_nontemporal_store(p1, reinterpret_cast<u32x4v*>(o + a.out_pstride));
+            if (a.fmt != 2) __builtin_nontemporal_store(p1, reinterpret_cast<u32x4v*>(o + a.out_pstride));
             if (a.fmt == 0) __builtin_nontemporal_store(p2, reinterpret_cast<u32x4v*>(o + 2 * a.out_pstride));
         } else if (live) {
             *reinterpret_cast<u32x4v*>(o) = p0;
-            *reinterpret_cast<u32x4v*>(o + a.out_pstride) = p1;
+            if (a.fmt != 2) *reinterpret_cast<u32x4v*>(o + a.out_pstride) = p1;
             if (a.fmt == 0) *reinterpret_cast<u32x4v*>(o + 2 * a.out_pstride) = p2;
         }
     }
@@ -917,7 +858,7 @@ extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const floa
                                             stm_stream_t stream)
 {
     const char* who = "stm_deform_sample_planar_f32";
-    STM_REQUIRE(fmt == 0 || fmt == 1, STM_EINVAL, "%s: fmt must be 0 or 1", who);
+    STM_REQUIRE(fmt >= 0 && fmt <= 2, STM_EINVAL, "%s: fmt must be 0, 1 or 2", who);
     STM_REQUIRE(x && offsets && planes && g, STM_ENULL, "%s: NULL argument", who);
     const int K = g->kh * g->kw;
     STM_REQUIRE(g->dg == 1 && (K == 9 || (K == 15 && !has_mask)), STM_EUNSUPPORTED,
@@ -940,12 +881,15 @@ extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const floa
     a.out_pstride = (out_plane_stride > 0 ? out_plane_stride : (long long)(K * g->C / 32) * a.out_np * 32) * 2;
     const int ppw = 512 / g->C;                                  // pixels per wave
     const int nblk = stm_cdiv(M, 4 * ppw);
-    { const char* e = getenv("STM_DCN_XCD"); a.xcd = e ? atoi(e) : 1; }
+    // A/B switches, read from the environment once: STM_DCN_XCD (XCD-contiguous block order), STM_DCN_NT (nontemporal column
+    // stores), STM_DCN_PREFETCH (centre-pixel touch); all on by default
+    const int env_xcd = STM_ENV_INT("STM_DCN_XCD", 1), env_nt = STM_ENV_INT("STM_DCN_NT", -1), env_prefetch = STM_ENV_INT("STM_DCN_PREFETCH", 1);
+    a.xcd = env_xcd;
     // nontemporal column stores: 248 -> 115 us on layer2 at batch 32 together with the XCD order (5.6 TB/s algorithmic), but
     // 34 -> 45 us with 512 channels (one pixel per wave, 1-KB runs per tap) -- so up to 256 channels only
-    { const char* e = getenv("STM_DCN_NT"); a.nt = e ? atoi(e) : (g->C <= 256 ? 1 : 0); }
+    a.nt = env_nt >= 0 ? env_nt : (g->C <= 256 ? 1 : 0);
     a.per_xcd = stm_cdiv(nblk, 8);
-    { const char* e = getenv("STM_DCN_PREFETCH"); a.prefetch = e ? atoi(e) : 1; }
+    a.prefetch = env_prefetch;
     const dim3 grid(a.xcd ? 8 * a.per_xcd : nblk);
     if (!has_mask && K == 15) hipLaunchKernelGGL((dcn_sample_planar_kernel<32, 15, false>), grid, dim3(256), 0, stm_hs(stream), a);
     else if (!has_mask) hipLaunchKernelGGL((dcn_sample_planar_kernel<32, 9, false>), grid, dim3(256), 0, stm_hs(stream), a);

@@ -28,6 +28,18 @@ void stm_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// A/B switches (STM_* environment variables) are read ONCE per process, at first use -- never per launch.
+// stm_debug_reload_tunables() (tests, A/B scripts; not part of the ABI header) bumps the generation so they are read again.
+int stm_env_generation();
+int stm_env_int_uncached(const char* name, int dflt);
+#define STM_ENV_INT(name, dflt)                                                          \
+    ([]() -> int {                                                                       \
+        static int v_ = 0, gen_ = -1;                                                    \
+        const int g_ = stm_env_generation();                                             \
+        if (gen_ != g_) { v_ = stm_env_int_uncached((name), (dflt)); gen_ = g_; }        \
+        return v_;                                                                       \
+    }())
+
 int* stm_internal_range_flag();   // conv_bf16x.hip: the device flag registered with stm_planar_set_range_flag (or null)
 
 static inline hipStream_t stm_hs(stm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

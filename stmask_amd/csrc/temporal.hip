@@ -240,11 +240,11 @@ extern "C" int stm_corr_patch_f32(const float* f1, const float* f2, float* out, 
     STM_REQUIRE(f1 && f2 && out, STM_ENULL, "stm_corr_patch_f32: f1/f2/out must be non-NULL");
     STM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, STM_EINVAL, "stm_corr_patch_f32: empty input");
     STM_REQUIRE(P > 0 && (P & 1) && dil > 0, STM_EINVAL, "stm_corr_patch_f32: patch_size must be odd, dilation > 0");
-    const char* force = getenv("STM_CORR_VARIANT");
+    const int force = STM_ENV_INT("STM_CORR_VARIANT", 0);        // 1: the generic kernel (tests)
     // tiled kernel: P = 11, rows of whole float4 quads, staging plan of <= 8 units per thread (W <= 44)
     bool tiled = (P == 11 && dil == 1 && H <= 65535 && B <= 65535 && W % 4 == 0 && CORR_CCK * 11 * (W / 4) <= 8 * 256 &&
                   ((uintptr_t)out % 16 == 0) && ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f2 % 16 == 0));
-    if (force && atoi(force) == 1) tiled = false;
+    if (force == 1) tiled = false;
     if (tiled) {
         int LW2 = ((W + 10 + 3) / 4) * 4;
         size_t lds = (size_t)(CORR_CCK * W + CORR_CCK * 11 * LW2) * sizeof(float);
@@ -271,8 +271,7 @@ extern "C" int stm_roi_align_avg_f32(const float* feat, const float* rois, float
     STM_REQUIRE(feat && rois && out, STM_ENULL, "stm_roi_align_avg_f32: feat/rois/out must be non-NULL");
     STM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0, STM_EINVAL, "stm_roi_align_avg_f32: bad sizes");
     int64_t total = (int64_t)n * C * PH * PW;
-    const char* ex = getenv("STM_XCD_ORDER");
-    const int xcd = ex ? atoi(ex) : 1;
+    const int xcd = STM_ENV_INT("STM_XCD_ORDER", 1);
     hipLaunchKernelGGL(roi_align_avg_kernel, dim3(xcd ? stm_xcd_grid(stm_cdiv(total, 256)) : stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream),
                        feat, rois, out, C, H, W, n, PH, PW, spatial_scale, sampling_ratio, aligned, xcd);
     STM_CHECK_LAUNCH("roi_align_avg_kernel");

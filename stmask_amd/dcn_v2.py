@@ -63,8 +63,6 @@ class DCN(DCNv2):
 
     def forward(self, input):
         om = self.conv_offset_mask(input)
-        if input.dtype != torch.float32:  # fp16-autocast trunk (BASELINE config 5): the deformable conv itself stays fp32
-            input, om = input.float(), om.float()
         # offsets = om[:, :2*dg*K], mask = sigmoid(om[:, 2*dg*K:]) -- read in place by the kernel
         return ops.deform_conv(input, None, None, self.weight, self.bias, self.stride, self.padding, self.dilation,
                                self.deformable_groups, relu=self.fuse_relu, fused_om=om)

@@ -97,7 +97,8 @@ def optimize_for_inference(net, planar=False, planes="fp16x2"):
     planar=True (GPU only) additionally routes FPN prediction/downsample layers, proto-net and the shared head through
     the split-operand matrix-core convolution (stmask_amd/planar.py); planes = "fp16x2" (two fp16 planes, three MFMA
     products per fp32 product; activations must stay inside fp16's range, the pipeline checks) or "bf16x3" (three bf16
-    planes, six products; any range).  Both carry fp32-level error (tests/test_gpu_conv.py)."""
+    planes, six products; any range) -- both carry fp32-level error (tests/test_gpu_conv.py) -- or "fp16x1": the
+    backbone in genuine fp16 (one plane, one product, fp32 accumulation; ~1e-3 relative), everything else fp16x2."""
     n_bn = fold_batchnorm(net)
     n_fused = 0
     bb = net.backbone
@@ -136,11 +137,14 @@ def optimize_for_inference(net, planar=False, planes="fp16x2"):
     if planar:
         from . import planar as _planar
         from .planar import PlanarBackbone, PlanarGraph, PlanarTemporalNet
-        if planes not in ("fp16x2", "bf16x3"):
-            raise ValueError("planes must be 'fp16x2' or 'bf16x3'")
-        _planar.set_format(1 if planes == "fp16x2" else 0)
+        if planes not in ("fp16x2", "bf16x3", "fp16x1"):
+            raise ValueError("planes must be 'fp16x2', 'bf16x3' or 'fp16x1'")
+        # fp16x1 (BASELINE config 5, "fp16 MFMA backbone convs"): the ResNet backbone's convolutions -- bottleneck 1x1 / 3x3,
+        # downsample projections, DCN offset convs and DCN GEMMs -- run on ONE fp16 plane (one MFMA product, fp32 accumulate);
+        # FPN, proto-net, heads and TemporalNet keep the fp32-equivalent fp16x2 format
+        _planar.set_format(0 if planes == "bf16x3" else 1, backbone_fmt=2 if planes == "fp16x1" else None)
         net._planar = PlanarGraph(net)
-        net._planar_backbone = PlanarBackbone(net.backbone)
+        net._planar_backbone = PlanarBackbone(net.backbone, selected=net.backbone_selected)
         net._planar_backbone.planes_only = True     # the planar FPN laterals read the stage outputs as planes
         if getattr(net, "TemporalNet", None) is not None:
             net._planar_temporal = PlanarTemporalNet(net.TemporalNet)

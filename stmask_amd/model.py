@@ -42,9 +42,6 @@ class STMask(nn.Module):
             self.Detect_TF = Detect_TF(cfg.num_classes, bkg_label=0, top_k=cfg.nms_top_k,
                                        conf_thresh=cfg.nms_conf_thresh, nms_thresh=cfg.nms_thresh, cfg=cfg)
             self.Track_TF = Track_TF(cfg=cfg)
-        # BASELINE config 5 ("fp16 MFMA backbone convs"): run the ResNet trunk under fp16 autocast (MIOpen fp16 MFMA kernels,
-        # fp32 accumulate); the deformable convs, FPN, proto-net, heads and all post-processing stay fp32
-        self.backbone_fp16 = False
         self.detect = Detect(cfg.num_classes, bkg_label=0, top_k=cfg.nms_top_k, conf_thresh=cfg.nms_conf_thresh,
                              nms_thresh=cfg.nms_thresh, cfg=cfg)
         self.Track = Track(cfg=cfg)
@@ -67,11 +64,7 @@ class STMask(nn.Module):
     # -- trunk + heads (reference STMask.py:205-282) ----------------------------------------------------------------
     def forward_single(self, x):
         planes = None      # planar form of the selected backbone outputs (PlanarBackbone only)
-        if self.backbone_fp16 and x.is_cuda:
-            with torch.autocast("cuda", dtype=torch.float16):
-                bb_outs = self.backbone(x)
-            bb_outs = tuple(o.float() for o in bb_outs)
-        elif getattr(self, "_planar_backbone", None) is not None:
+        if getattr(self, "_planar_backbone", None) is not None:
             bb_outs = self._planar_backbone(x)
             planes = [self._planar_backbone.out_planes[i] for i in self.backbone_selected]
         else:

@@ -438,21 +438,22 @@ def mask_resize_rle(masks, crop_h, crop_w, out_h, out_w, thr=0.5, max_runs=4096)
 def conv_pack_weights(weight, planes=3, tile_n=128, fmt=0):
     """OIHW fp32 weights -> the pre-split, pre-tiled image the convolution kernels stream (done once per layer).
     tile_n = 64 packs for the 128 x 64-tile planar kernel (stm_conv_geom.tile_n must say so too).
-    fmt = 1: two fp16 planes of weight * wscale (power of two bringing max |w| to ~2^10) -> returns (packed, 1 / wscale)."""
+    fmt = 1 / 2: two / one fp16 plane(s) of weight * wscale (power of two bringing max |w| to ~2^10) -> returns
+    (packed, 1 / wscale)."""
     _dev(weight)
     weight = _f32c(weight)
     O, C, kh, kw = weight.shape
-    if fmt == 1:
-        planes = 2
+    if fmt >= 1:
+        planes = 2 if fmt == 1 else 1
     nbytes = _lib.lib().stm_conv_packed_weight_bytes_tiled(c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes), c_i(tile_n))
     if nbytes == 0:
         raise StmError(f"conv_pack_weights: unsupported weight shape {tuple(weight.shape)} (Cin must be a multiple of 32)")
     packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
-    if fmt == 1:
+    if fmt >= 1:
         import math
         wmax = float(weight.abs().max())
         wscale = 2.0 ** (10 - math.floor(math.log2(wmax))) if wmax > 0 else 1.0
-        check(_lib.lib().stm_conv_pack_weights_fmt_f32(_p(weight), _p(packed), c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(tile_n), c_i(1),
+        check(_lib.lib().stm_conv_pack_weights_fmt_f32(_p(weight), _p(packed), c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(tile_n), c_i(fmt),
                                                        c_f(wscale), _stream()), "stm_conv_pack_weights_fmt_f32")
         return packed, 1.0 / wscale
     check(_lib.lib().stm_conv_pack_weights_tiled_f32(_p(weight), _p(packed), c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes),
@@ -460,27 +461,18 @@ def conv_pack_weights(weight, planes=3, tile_n=128, fmt=0):
     return packed
 
 
-def conv2d_nhwc(x, packed, weight_shape, bias=None, residual=None, stride=1, padding=0, relu=False, planes=3, out=None):
-    """y = act(conv2d(x, w) + bias + residual) on NHWC fp32 tensors ([B,H,W,C] contiguous, i.e. the storage of a torch
-    channels_last tensor); `packed` from conv_pack_weights, `weight_shape` the original (O, C, kh, kw)."""
-    _dev(x, packed, bias, residual)
-    x = _f32c(x)
-    O, C, kh, kw = weight_shape
-    B, H, W, Cx = x.shape
-    if Cx != C:
-        raise StmError(f"conv2d_nhwc: input has {Cx} channels, weights expect {C}")
-    (sh, sw), (ph, pw) = _pair(stride), _pair(padding)
-    Ho, Wo = conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, 1, 1)
-    if out is None:
-        out = torch.empty(B, Ho, Wo, O, device=x.device, dtype=torch.float32)
-    if residual is not None:
-        residual = _f32c(residual)
-        if tuple(residual.shape) != (B, Ho, Wo, O):
-            raise StmError(f"conv2d_nhwc: residual {tuple(residual.shape)} != output {(B, Ho, Wo, O)}")
-    g = _lib.ConvGeom(B, H, W, C, Ho, Wo, O, kh, kw, sh, sw, ph, pw, 0, 0, 0, planes)
-    check(_lib.lib().stm_conv2d_nhwc_f32(_p(x), _p(packed), _p(_f32c(bias) if bias is not None else None), _p(residual),
-                                         _p(out), ctypes.byref(g), c_i(1 if relu else 0), _stream()), "stm_conv2d_nhwc_f32")
-    return out
+def plane_layout(fmt):
+    """(number of planes, element type) of a planar format: 0 = bf16 x 3, 1 = fp16 x 2, 2 = fp16 x 1 (include/stmask_hip.h)."""
+    if fmt == 0:
+        return 3, torch.bfloat16
+    if fmt in (1, 2):
+        return (2 if fmt == 1 else 1), torch.float16
+    raise StmError(f"unknown planar format {fmt}")
+
+
+def _empty_planes(fmt, slabs, n, device):
+    P, dt = plane_layout(fmt)
+    return torch.empty(P, slabs, n, 32, device=device, dtype=dt)
 
 
 def split_planes(x, fmt=0):
@@ -493,7 +485,7 @@ def split_planes(x, fmt=0):
     N = x.numel() // C
     if C % 32:
         raise StmError(f"split_planes: channel count {C} is not a multiple of 32")
-    planes = torch.empty(2 if fmt == 1 else 3, C // 32, N, 32, device=x.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    planes = _empty_planes(fmt, C // 32, N, x.device)
     check(_lib.lib().stm_split_planes_fmt_f32(_p(x), _p(planes), c_l(N), c_i(C), c_i(fmt), _stream()), "stm_split_planes_fmt_f32")
     return planes
 
@@ -510,7 +502,8 @@ def planar_range_flag():
     flag = _range_flags.get(dev)
     if flag is None:
         flag = torch.zeros(1, device=f"cuda:{dev}", dtype=torch.int32)
-        check(_lib.lib().stm_planar_set_range_flag(_p(flag)), "stm_planar_set_range_flag")
+        with torch.cuda.device(dev):         # the library keeps one flag per device: register on the device that owns it
+            check(_lib.lib().stm_planar_set_range_flag(_p(flag)), "stm_planar_set_range_flag")
         _range_flags[dev] = flag
     return flag
 
@@ -549,7 +542,7 @@ def resize_bilinear_planes(x_nhwc, size, fmt=0):
     Ho, Wo = size
     if C % 32:
         raise StmError(f"resize_bilinear_planes: channel count {C} is not a multiple of 32")
-    planes = torch.empty(2 if fmt == 1 else 3, C // 32, B * Ho * Wo, 32, device=x.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    planes = _empty_planes(fmt, C // 32, B * Ho * Wo, x.device)
     check(_lib.lib().stm_resize_bilinear_planes_f32(_p(x), _p(planes), c_i(B), c_i(H), c_i(W), c_i(C), c_i(Ho), c_i(Wo), c_i(fmt), _stream()),
           "stm_resize_bilinear_planes_f32")
     return planes
@@ -564,7 +557,7 @@ def bias_relu_maxpool_planes(x_nhwc, bias, fmt=0):
     if C % 32:
         raise StmError(f"bias_relu_maxpool_planes: channel count {C} is not a multiple of 32")
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    planes = torch.empty(2 if fmt == 1 else 3, C // 32, B * Ho * Wo, 32, device=x.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    planes = _empty_planes(fmt, C // 32, B * Ho * Wo, x.device)
     check(_lib.lib().stm_bias_relu_maxpool_planes_f32(_p(x), _p(_f32c(bias)) if bias is not None else c_p(0), _p(planes), c_i(B), c_i(H), c_i(W),
                                                       c_i(C), c_i(fmt), _stream()), "stm_bias_relu_maxpool_planes_f32")
     return planes, (Ho, Wo)
@@ -581,7 +574,7 @@ def roi_align_planes(t2s_prev_nhwc, t2s_nhwc, corr_nchw, rois, output_size=7, fm
     Cc, n = c.shape[1], rois.shape[0]
     ph, pw = _pair(output_size)
     cpad = -(-(2 * C1 + Cc) // 32) * 32
-    planes = torch.empty(2 if fmt == 1 else 3, cpad // 32, n * ph * pw, 32, device=a.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    planes = _empty_planes(fmt, cpad // 32, n * ph * pw, a.device)
     if n:
         check(_lib.lib().stm_roi_align_planes_f32(_p(a), _p(b), _p(c), _p(rois), _p(planes), c_i(B), c_i(H), c_i(W), c_i(C1), c_i(Cc), c_i(n),
                                                   c_i(ph), c_i(pw), c_i(fmt), _stream()), "stm_roi_align_planes_f32")
@@ -595,7 +588,7 @@ def stem_rows_planes(x_nhwc, kw, sw, pw, fmt=0):
     x = _f32c(x_nhwc)
     B, H, W, Cin = x.shape
     Wo = (W + 2 * pw - kw) // sw + 1
-    planes = torch.empty(2 if fmt == 1 else 3, 1, B * H * Wo, 32, device=x.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    planes = _empty_planes(fmt, 1, B * H * Wo, x.device)
     check(_lib.lib().stm_stem_rows_planes_f32(_p(x), _p(planes), c_i(B), c_i(H), c_i(W), c_i(Cin), c_i(kw), c_i(sw), c_i(pw), c_i(fmt),
                                               _stream()), "stm_stem_rows_planes_f32")
     return planes, Wo
@@ -605,7 +598,8 @@ def planes_to_f32(planes):
     """[P, S, N, 32] planes -> fp32 [N, 32*S]."""
     v = planes[0].float()
     if planes.dtype == torch.float16:
-        v = v + planes[1].float() / F16_LOW_SCALE
+        if planes.shape[0] == 2:
+            v = v + planes[1].float() / F16_LOW_SCALE
     else:
         for p in range(1, planes.shape[0]):
             v = v + planes[p].float()
@@ -619,9 +613,9 @@ def conv2d_planar(xp, packed, weight_shape, hw, bias=None, residual=None, stride
     out: "planes" | "f32" | "both"; fp32 result [B*Ho*Wo, O].  fmt 1: fp16 planes, `packed` / `out_scale` from
     conv_pack_weights(..., fmt=1)."""
     _dev(xp, packed, bias, residual)
-    P, dt = (2, torch.float16) if fmt == 1 else (3, torch.bfloat16)
-    if fmt == 1:
-        planes = 2
+    P, dt = plane_layout(fmt)
+    if fmt >= 1:
+        planes = P
     if xp.dtype != dt or xp.dim() != 4 or xp.shape[0] != P or xp.shape[3] != 32 or not xp.is_contiguous():
         raise StmError(f"conv2d_planar: expected contiguous {dt} planes [{P},C/32,N,32], got {xp.dtype} {tuple(xp.shape)}")
     O, C, kh, kw = weight_shape
@@ -711,7 +705,7 @@ def dcn_sample_planar(x_nhwc, om, stride=1, padding=1, dilation=1, fmt=0):
     if om.shape[0] != M or om.shape[1] < 27:
         raise StmError(f"dcn_sample_planar: offset/mask matrix {tuple(om.shape)} does not match {M} output pixels x 27")
     g = DeformGeom(B, C, H, W, 3, 3, sh, sw, ph, pw, dh, dw, 1, Ho, Wo)
-    out = torch.empty(2 if fmt == 1 else 3, 9 * C // 32, M, 32, device=x.device, dtype=torch.float16 if fmt == 1 else torch.bfloat16)
+    out = _empty_planes(fmt, 9 * C // 32, M, x.device)
     timing = _im2col_timing
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -721,5 +715,5 @@ def dcn_sample_planar(x_nhwc, om, stride=1, padding=1, dilation=1, fmt=0):
     if timing is not None:
         e1.record()
         # algorithmic bytes: input once, 27 offset/mask values per output pixel, columns as planes (6 or 4 B / element)
-        timing.append((e0, e1, 4 * B * C * H * W + 4 * 27 * M + (4 if fmt == 1 else 6) * 9 * C * M))
+        timing.append((e0, e1, 4 * B * C * H * W + 4 * 27 * M + 2 * plane_layout(fmt)[0] * 9 * C * M))
     return out

@@ -30,19 +30,29 @@ def _pair(v):
 
 # Plane format of the graphs built next (fuse.optimize_for_inference sets it): 0 = three bf16 planes, six MFMA products per
 # fp32 product, any fp32 range; 1 = two fp16 planes, three products -- half the matrix work at the same fp32-level error,
-# activations limited to fp16's range (|x| < 65504; beyond it the outputs are non-finite and the pipeline raises).
+# activations limited to fp16's range (|x| < 65504; beyond it the outputs are non-finite and the pipeline raises);
+# 2 = ONE fp16 plane, one product: genuine fp16 convolutions with fp32 accumulation (~1e-3 relative; BASELINE config 5).
 FMT = 0
+# Format of the ResNet backbone's convolutions when it differs from FMT (fuse: planes="fp16x1" -> backbone 2, the rest 1)
+BACKBONE_FMT = None
+
+# A/B switches, read once at import (never per call)
+TILE64_MAX_SLABS = int(os.environ.get("STM_TILE64_MAX_SLABS", "8"))
+FCB_PLANAR = os.environ.get("STM_FCB_PLANAR", "1") != "0"
+STEM_PLANAR = os.environ.get("STM_STEM_PLANAR", "1") != "0"
 
 
-def set_format(fmt):
-    global FMT
-    if fmt not in (0, 1):
-        raise StmError("planar format must be 0 (bf16 x 3) or 1 (fp16 x 2)")
-    FMT = fmt
+def set_format(fmt, backbone_fmt=None):
+    global FMT, BACKBONE_FMT
+    if fmt not in (0, 1, 2) or backbone_fmt not in (None, 0, 1, 2):
+        raise StmError("planar format must be 0 (bf16 x 3), 1 (fp16 x 2) or 2 (fp16 x 1)")
+    if backbone_fmt is not None and backbone_fmt != fmt and (backbone_fmt, fmt) != (2, 1):
+        raise StmError("a backbone format different from the graph's is only built for fp16x1 under fp16x2")
+    FMT, BACKBONE_FMT = fmt, backbone_fmt
 
 
 def _planes_dtype(fmt):
-    return (2, torch.float16) if fmt == 1 else (3, torch.bfloat16)
+    return ops.plane_layout(fmt)
 
 
 class PlanarConv:
@@ -52,26 +62,27 @@ class PlanarConv:
     SPLITK_WS_BYTES = 64 << 20   # scratch for split-K partial sums (small feature maps with long K)
 
     def __init__(self, weight, bias, stride=1, padding=0, relu=False, groups=1, planes=3, algo_frac=1.0, tile_n=None,
-                 group_cout=None):
+                 group_cout=None, fmt=None, out_fmt=None):
         """algo_frac: share of the packed layer that is the reference's own arithmetic (zero-padded channels excluded);
         only used for the flop count of the live roofline measurement.  tile_n: 64 / 128 forces the output-channel tile,
         None picks per call from the problem size (weights are packed once per tile width used)."""
         self.weight = weight.detach().float().contiguous()
-        self.fmt = FMT
+        self.fmt = FMT if fmt is None else fmt
+        self.out_fmt = self.fmt if out_fmt is None else out_fmt     # format of the planes this layer writes (fmt 2 layers may write 1)
         self.algo_frac = algo_frac
         self.group_cout = list(group_cout) if group_cout else None   # real channels of zero-padded groups
         self.O, self.C, self.kh, self.kw = self.weight.shape
         (self.sh, self.sw), (self.ph, self.pw) = _pair(stride), _pair(padding)
-        self.relu, self.groups, self.planes, self.tile_n = relu, groups, (2 if self.fmt == 1 else planes), tile_n
+        self.relu, self.groups, self.planes, self.tile_n = relu, groups, (planes if self.fmt == 0 else ops.plane_layout(self.fmt)[0]), tile_n
         self._packed = {}
         self.out_scale = 1.0
         self.bias = bias.detach().float().contiguous() if bias is not None else None
 
     def packed(self, tile_n):
         if tile_n not in self._packed:
-            if self.fmt == 1:
+            if self.fmt >= 1:
                 ops.planar_range_flag()     # the producers of fp16 planes report |x| > 65504 through it
-                self._packed[tile_n], self.out_scale = ops.conv_pack_weights(self.weight, tile_n=tile_n, fmt=1)
+                self._packed[tile_n], self.out_scale = ops.conv_pack_weights(self.weight, tile_n=tile_n, fmt=self.fmt)
             else:
                 self._packed[tile_n] = ops.conv_pack_weights(self.weight, self.planes, tile_n)
         return self._packed[tile_n]
@@ -94,7 +105,7 @@ class PlanarConv:
         # 128 x 64 workgroups per CU (48 KB each) keep more loads and stores in flight than one 256 x 128 workgroup:
         # 393 -> 302 us (64 -> 256 channels at 96x160, batch 32), 213 -> 175 us, 123 -> 112 us (scripts/ab_shortk.py)
         slabs = self.C * self.kh * self.kw // 32
-        if slabs <= int(os.environ.get("STM_TILE64_MAX_SLABS", "8")):
+        if slabs <= TILE64_MAX_SLABS:
             return 64
         return 128
 
@@ -105,8 +116,9 @@ class PlanarConv:
         groups*C channels starting at channel x_ch_off.  out: "planes" | "f32" | "both" allocates dense outputs
         ([3, O/32, M, 32] / [M, O]) unless out_planes / out_f32 are given, then pixels [out_off, ...) are written."""
         NP, dt = _planes_dtype(self.fmt)
-        if xp.dtype != dt or xp.dim() != 4 or xp.shape[0] != NP or xp.shape[3] != 32 or not xp.is_contiguous():
+        if xp.dtype != dt or xp.dim() != 4 or xp.shape[0] < NP or xp.shape[3] != 32 or not xp.is_contiguous():
             raise StmError(f"PlanarConv: expected contiguous {dt} planes [{NP}, S, N, 32], got {xp.dtype} {tuple(xp.shape)}")
+        # (a fp16x1 layer handed a two-plane fp16 tensor reads plane 0 = RN16(x): the one-plane tensor of the same values)
         S, N = xp.shape[1], xp.shape[2]
         g = _lib.ConvGeom()
         g.C, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw = self.C, self.O, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw
@@ -137,8 +149,9 @@ class PlanarConv:
         g.x_np, g.x_plane_stride = N, S * N * 32
         g.tile_n = self.pick_tile(M)
         dev = xp.device
+        NPo, dto = _planes_dtype(self.out_fmt)
         if out in ("planes", "both") and out_planes is None:
-            out_planes, out_off_p = torch.empty(NP, -(-self.O // 32), M, 32, device=dev, dtype=dt), 0
+            out_planes, out_off_p = torch.empty(NPo, -(-self.O // 32), M, 32, device=dev, dtype=dto), 0
         else:
             out_off_p = out_off
         if out in ("f32", "both") and out_f32 is None:
@@ -159,6 +172,8 @@ class PlanarConv:
         r32 = rpl = 0
         if residual is not None:
             if residual.dtype == dt:
+                if residual.shape[0] < NP:
+                    raise StmError(f"PlanarConv: residual has {residual.shape[0]} plane(s), format {self.fmt} reads {NP}")
                 g.res_np, g.res_plane_stride = residual.shape[2], residual.shape[1] * residual.shape[2] * 32
                 rpl = residual.data_ptr()
             else:
@@ -171,6 +186,7 @@ class PlanarConv:
         x_ptr = xp.data_ptr() + ((x_ch_off // 32) * N + x_off) * 64
         packed = self.packed(g.tile_n)                     # (sets self.out_scale for the fp16 format)
         g.fmt, g.out_scale = self.fmt, self.out_scale
+        g.out_fmt_plus1 = 0 if self.out_fmt == self.fmt else self.out_fmt + 1
         ws = ops._workspace(self.SPLITK_WS_BYTES, dev, "conv_splitk")     # grow-only, shared: split-K partial sums
         rc = _lib.lib().stm_conv2d_planar_ws_f32(ctypes.c_void_p(x_ptr), ops._p(packed),
                                                  ops._p(self.bias), ctypes.c_void_p(r32), ctypes.c_void_p(rpl),
@@ -180,8 +196,10 @@ class PlanarConv:
         check(rc, "stm_conv2d_planar_f32")
         if timing is not None:
             e1.record()
+            # (start, end, algorithmic flops, layer key, MFMA products per product of the reference: 6 bf16x3 / 3 fp16x2 / 1 fp16x1)
             timing.append((e0, e1, 2.0 * M * self.O * self.C * self.kh * self.kw * self.algo_frac,
-                           (M, self.C, self.O, self.kh, self.sh, self.groups, g.tile_n)))
+                           (M, self.C, self.O, self.kh, self.sh, self.groups, g.tile_n),
+                           {0: 6 if self.planes == 3 else 3, 1: 3, 2: 1}[self.fmt]))
         if out == "both":
             return out_f32, out_planes
         return out_f32 if out == "f32" else out_planes
@@ -433,7 +451,7 @@ class PlanarGraph:
                 buf = torch.empty(ntot, 3 * P, device=dev, dtype=torch.float32)   # [conf | centerness+bbox | mask] groups
                 small(t2, lv, out="f32", out_f32=buf, x_ch_off=cw, out_ch_off=P)
                 npri = head.num_priors
-                if adconv is not None and npri == 1 and os.environ.get("STM_FCB_PLANAR", "1") != "0":
+                if adconv is not None and npri == 1 and FCB_PLANAR:
                     # all-planar class branch: offsets pixel-major, sampler per level into one column buffer, one 1x1 conv
                     kh, kw = fa.kernel_size
                     K = kh * kw
@@ -556,10 +574,14 @@ class PlanarBackbone:
     OM_PLANAR_MIN_PIXELS = 0    # offset / mask conv of a DCN layer on the planar kernel from this many output pixels (with
                                 # split-K the small stages are fine there too: 547-549 vs 538-539 frames/s with the library)
 
-    def __init__(self, bb):
+    def __init__(self, bb, selected=None):
+        """selected: indices of the stages whose outputs the FPN reads (they leave in the graph's format FMT even when the
+        backbone computes in fp16x1); None = all."""
         from .dcn_v2 import DCN
         self.bb = bb
-        self.fmt = FMT
+        self.fmt = FMT if BACKBONE_FMT is None else BACKBONE_FMT
+        self.graph_fmt = FMT
+        fmt = self.fmt
         self.planes_only = False    # fuse: the planar FPN takes the stage outputs as planes; their fp32 copies are not made
         self.out_planes = None      # [(planes, B, H, W)] of the last call, one entry per stage
         # stem: w'[o][j][ky][0] = w[o][j % Cin][ky][j / Cin] over the row-patch tensor of stm_stem_rows_planes_f32
@@ -569,29 +591,32 @@ class PlanarBackbone:
         if kw * Cin <= 32 and c1.groups == 1 and tuple(c1.dilation) == (1, 1):
             w = c1.weight.detach().permute(0, 2, 3, 1).reshape(O, kh, kw * Cin)          # [o][ky][kx*Cin + c]
             w = F.pad(w, (0, 32 - kw * Cin)).permute(0, 2, 1).reshape(O, 32, kh, 1).contiguous()
-            self.stem = PlanarConv(w, None, (c1.stride[0], 1), (c1.padding[0], 0), relu=False, algo_frac=kw * Cin / 32.0)
+            self.stem = PlanarConv(w, None, (c1.stride[0], 1), (c1.padding[0], 0), relu=False, algo_frac=kw * Cin / 32.0, fmt=fmt)
         self.blocks = []
-        for layer in bb.layers:
+        for si, layer in enumerate(bb.layers):
             blks = []
-            for blk in layer:
+            for bi, blk in enumerate(layer):
                 c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
-                e = {"c1": PlanarConv(c1.weight, c1.bias, 1, 0, relu=True),
-                     "c3": PlanarConv(c3.weight, c3.bias, 1, 0, relu=True)}
+                # the last block of a stage the FPN reads hands its output over in the graph's format (a fp16x1 layer can
+                # write both planes of fp16x2; plane 0 of that tensor is what the next fp16x1 stage reads)
+                to_graph = bi == len(layer) - 1 and (selected is None or si in selected)
+                e = {"c1": PlanarConv(c1.weight, c1.bias, 1, 0, relu=True, fmt=fmt),
+                     "c3": PlanarConv(c3.weight, c3.bias, 1, 0, relu=True, fmt=fmt, out_fmt=self.graph_fmt if to_graph else fmt)}
                 if isinstance(c2, DCN):
                     e["dcn"] = c2
                     om = c2.conv_offset_mask
-                    e["om"] = PlanarConv(om.weight, om.bias, om.stride, om.padding, relu=False)
+                    e["om"] = PlanarConv(om.weight, om.bias, om.stride, om.padding, relu=False, fmt=fmt)
                     # the deformable conv's GEMM as a planar 1x1 convolution over the sampled columns [pixel][tap*C + c]
                     O, Cin = c2.weight.shape[:2]
                     e["dcn_planar"] = (c2.kernel_size == (3, 3) and c2.deformable_groups == 1 and Cin in (128, 256, 512))
                     if e["dcn_planar"]:
                         wk = c2.weight.detach().permute(0, 2, 3, 1).reshape(O, 9 * Cin, 1, 1)
-                        e["dcn_conv"] = PlanarConv(wk, c2.bias, 1, 0, relu=True)
+                        e["dcn_conv"] = PlanarConv(wk, c2.bias, 1, 0, relu=True, fmt=fmt)
                 else:
-                    e["c2"] = PlanarConv(c2.weight, c2.bias, c2.stride, c2.padding, relu=True)
+                    e["c2"] = PlanarConv(c2.weight, c2.bias, c2.stride, c2.padding, relu=True, fmt=fmt)
                 if blk.downsample is not None:
                     d = blk.downsample[0]
-                    e["ds"] = PlanarConv(d.weight, d.bias, d.stride, 0, relu=False)
+                    e["ds"] = PlanarConv(d.weight, d.bias, d.stride, 0, relu=False, fmt=fmt)
                 e["stride"] = _pair(c2.stride)
                 blks.append(e)
             self.blocks.append(blks)
@@ -602,7 +627,7 @@ class PlanarBackbone:
         if (isinstance(bb.bn1, torch.nn.Identity) and c1.out_channels % 32 == 0 and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1
                 and not mp.ceil_mode and mp.dilation == 1):
             # stem tail in one pass: folded-BN bias + ReLU + 3x3/2 max-pool of the raw 7x7 convolution output, straight to planes
-            if self.stem is not None and os.environ.get("STM_STEM_PLANAR", "1") != "0":
+            if self.stem is not None and STEM_PLANAR:
                 # the 7x7 / stride-2 convolution itself as a (7 x 1) planar convolution over the row-patch tensor R
                 B = x.shape[0]
                 kh, kw = c1.kernel_size

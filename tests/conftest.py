@@ -43,3 +43,28 @@ def ulp_diff(a, b):
     ia = torch.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
     ib = torch.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
     return (ia - ib).abs()
+
+
+@pytest.fixture
+def tunables(monkeypatch):
+    """Set STM_* A/B switches for one test.  The library reads them once per process; stm_debug_reload_tunables() makes the
+    next launch read them again (and once more when the test's environment is restored)."""
+    from stmask_amd import _lib
+
+    def reload():
+        _lib.lib().stm_debug_reload_tunables()
+
+    class T:
+        def set(self, **env):
+            for k, v in env.items():
+                monkeypatch.setenv(k, str(v))
+            reload()
+
+        def clear(self, *names):
+            for k in names:
+                monkeypatch.delenv(k, raising=False)
+            reload()
+
+    yield T()
+    monkeypatch.undo()
+    reload()

@@ -184,7 +184,7 @@ def test_correlation_vs_oracle(B, C, H, W):
     assert (got2 - ref2).abs().max() < 2e-6
 
 
-def test_correlation_known_answers_and_generic_path(monkeypatch):
+def test_correlation_known_answers_and_generic_path(tunables):
     f1 = rnd(1, 16, 12, 20, seed=4)
     f2 = torch.roll(f1, shifts=(2, -3), dims=(2, 3))
     out = ops.corr_patch(f1.to(DEV), f2.to(DEV), 11, 1).cpu()
@@ -197,7 +197,7 @@ def test_correlation_known_answers_and_generic_path(monkeypatch):
         ref = oracle.corr_patch(f1, f2, P, dil)
         got = ops.corr_patch(f1.to(DEV), f2.to(DEV), P, dil).cpu()
         assert (got - ref).abs().max() < 1e-5
-    monkeypatch.setenv("STM_CORR_VARIANT", "1")
+    tunables.set(STM_CORR_VARIANT="1")
     got = ops.corr_patch(f1.to(DEV), f2.to(DEV), 11, 1).cpu()
     assert (got - out).abs().max() < 1e-5
 

@@ -234,17 +234,38 @@ def test_fp16_plane_graph_fails_loudly_out_of_range():
             pipe.step(frames, is_first=True)
 
 
-def test_fp16_backbone_option_config5():
-    """BASELINE config 5 flavour: fp16 autocast ResNet trunk (DCN, FPN, heads fp32).  fp16 trunk activations carry ~1e-3
-    relative error, so only closeness of the prototypes / box regression to the fp32 run is asserted."""
-    net = build("STMask_plus_resnet50_config")
-    x = synthetic.synthetic_clip(1, 128, 192, seed=4).cuda()
+@pytest.mark.parametrize("name,tag", [CASES[0], CASES[3]])
+def test_fp16x1_backbone_config5_flavour(name, tag):
+    """BASELINE config 5, "fp16 MFMA backbone convs": optimize_for_inference(planes="fp16x1") runs every convolution of the
+    ResNet backbone (bottleneck 1x1 / 3x3, projections, DCN offset convs, DCN GEMMs) on ONE fp16 plane -- hand-written
+    v_mfma_f32_16x16x32_f16, fp32 accumulation / bias / residual -- while FPN, proto-net, heads and TemporalNet stay in the
+    fp32-equivalent fp16x2 format.  Stated tolerance of the trunk outputs against the fp32 graph: 2e-2 of their range (fp16
+    activations through 50 / 101 layers; measured ~3e-3); detections: >= 85 % of the reference's instances found (IoU > 0.5,
+    same class) on every frame, their soft masks within 2e-2 RMS."""
+    from stmask_amd.fuse import optimize_for_inference
+    from test_gpu_parity import match_instances, soft_mask_delta
+    g = load_golden(f"model_{tag}.npz")
+    h, w = [int(v) for v in g["frames_hw"]]
+    ref_net = build(name)
+    opt_net = build(name)
+    optimize_for_inference(opt_net, planar=True, planes="fp16x1")
+    opt_net = opt_net.to(memory_format=torch.channels_last)
+    opt_net.TemporalNet = opt_net.TemporalNet.to(memory_format=torch.contiguous_format)
+    assert opt_net._planar_backbone.fmt == 2 and opt_net._planar.fmt == 1 and opt_net._planar_temporal.fmt == 1
+    assert all(e["c1"].fmt == 2 and e["c3"].fmt == 2 for blks in opt_net._planar_backbone.blocks for e in blks)
+    frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0)
+    x = frames[:1].cuda()
     with torch.no_grad():
-        _, a = net.forward_single(x)
-        net.backbone_fp16 = True
-        _, b = net.forward_single(x)
-    assert b["proto"].dtype == torch.float32
-    for k in ("proto", "loc", "mask_coeff"):
-        rel = (a[k] - b[k]).abs().max().item() / max(1e-6, a[k].abs().max().item())
-        assert rel < 3e-2, (k, rel)
-    net.backbone_fp16 = False
+        _, a = ref_net.forward_single(x)
+        _, b = opt_net.forward_single(x.contiguous(memory_format=torch.channels_last))
+    errs = {}
+    for k in ("proto", "loc", "mask_coeff", "conf"):
+        errs[k] = (a[k] - b[k]).abs().max().item() / max(1e-6, a[k].abs().max().item())
+        assert 1e-6 < errs[k] < 2e-2, (k, errs[k])       # fp16-level, and really not the fp32-equivalent path
+    outs = run_clip(opt_net, frames.contiguous(memory_format=torch.channels_last), "cuda")
+    for t, det in enumerate(outs):
+        ref_box, ref_cls = g[f"t{t}_box"], g[f"t{t}_class"]
+        gi, ri = match_instances(det["box"].cpu(), det["class"].cpu(), ref_box, ref_cls)
+        assert len(gi) >= 0.85 * ref_box.shape[0], (t, len(gi), ref_box.shape[0])
+        rms, _, _ = soft_mask_delta(det["mask"].cpu()[gi], g[f"t{t}_mask"][ri])
+        assert rms.max().item() < 2e-2, (t, rms.max().item())
