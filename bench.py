@@ -70,7 +70,10 @@ def parse_args(argv=None):
     ap.add_argument("--layer-table", action="store_true", help="per-layer-shape timing table of the planar convolution on stderr")
     ap.add_argument("--no-planar", dest="planar", action="store_false",
                     help="dense convolutions through MIOpen instead of the planar matrix-core kernel")
-    ap.add_argument("--no-graph", dest="graph", action="store_false", help="do not capture the trunk in a HIP graph")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="replay the trunk from captured HIP graphs (stmask_amd/pipeline.py _trunk).  auto = up to 8 clips per GPU, "
+                         "where the ~110 Python-driven launches of the trunk cost more host time than GPU time; at 32 clips the step is "
+                         "GPU-bound and the eager launches keep the per-kernel HIP-event timing of the roofline inside the timed region")
     ap.add_argument("--pipeline", default="batched", choices=["batched", "per-clip"],
                     help="batched: all clips' post-processing in concatenated tensors; per-clip: reference-shaped layer API")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" is RCCL on ROCm; gloo for the CPU launch test')
@@ -225,7 +228,8 @@ class Runner:
         self.pipe = BatchedClipPipeline(self.net, clips) if self.batched else ClipPipeline(self.net, clips)
         if self.batched:
             self.pipe.prefetch_early = args.overlap == "early"
-            self.pipe.use_graph = bool(getattr(args, "graph", True)) and args.fuse and args.planar and args.channels_last
+            gm = getattr(args, "graph", "auto")
+            self.pipe.use_graph = (gm == "on" or (gm == "auto" and clips <= 8)) and args.fuse and args.planar and args.channels_last
         self.tracked_sum = 0.0
         self.tracked_steps = 0
 
@@ -387,7 +391,14 @@ def main():
     run = Runner(args, dev, rank, world, args.clips)
     net = run.net
     cfg = net.cfg
-    elapsed, out, timing, conv_t = run.timed(args.warmup, args.steps, use_dist, collect=True)
+    graphed = run.batched and run.pipe.use_graph
+    elapsed, out, timing, conv_t = run.timed(args.warmup, args.steps, use_dist, collect=not graphed)
+    if graphed:
+        # a graph replay cannot be bracketed kernel by kernel: the per-kernel HIP-event timing of the roofline objects comes from
+        # a second, eager pass of the same K steps right after the timed region (same kernels, same shapes, same process)
+        run.pipe.use_graph = False
+        _, _, timing, conv_t = run.timed(1, args.steps, use_dist, collect=True)
+        run.pipe.use_graph = True
     if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -463,7 +474,8 @@ def main():
                                "mfma_tflops_issued": round(c_mfma / (c_ms * 1e-3) / 1e12, 1) if c_ms > 0 else 0.0,
                                "launches": len(conv_t), "avg_launch_us": round(c_ms * 1e3 / len(conv_t), 2),
                                "ms_per_step": round(c_ms / args.steps, 3),
-                               "algorithmic_gflop_per_launch": round(c_fl / len(conv_t) / 1e9, 2)}
+                               "algorithmic_gflop_per_launch": round(c_fl / len(conv_t) / 1e9, 2),
+                               "timed_in": "the timed region" if not graphed else "an eager pass of the same steps right after the timed region (which replays HIP graphs)"}
             res["roofline_im2col"] = im2col_roof
             if args.layer_table:
                 # per-layer-shape table of the dominant kernel (stderr; the JSON line stays alone on stdout)

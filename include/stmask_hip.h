@@ -316,6 +316,43 @@ int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed_weight, co
                              const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu,
                              void* workspace, size_t workspace_bytes, stm_stream_t stream);
 
+/* ---- tracker bookkeeping of the batched clip pipeline (rows a11, a15, a16 for many clips at once) ----------------------------
+ * The reference keeps one Track_TF per video and spends ~140 tiny torch launches and 4 host syncs per frame on row gathers,
+ * concatenations and score arithmetic (track_TF.py:50-181, TF_utils.py:12-51,99-120, detection_TF.py:120-134).  With the
+ * state of all clips concatenated (rows sorted by clip) each of those chains is one launch here; fp32 arithmetic in the
+ * reference's operand order, bit-equal to the torch chains (tests/test_gpu_tracker.py).
+ *
+ * stm_gather_detections_f32: the Fast-NMS survivors of stm_detect_cc_f32 (idx / cls / score / box [B,top_k(,4)], count [B] on
+ *   the device) -> concatenated detection rows: box, class, score, mask_coeff[idx], track[idx], centerness[idx], clip id.  D =
+ *   sum(count) as the host read it (rows past D are not written).
+ * stm_shift_rois_f32: RoIs of CandidateShift: (clip, sanitize_coordinates(box) in feature-map pixels) (box_utils.py:320-337).
+ * stm_shift_apply_f32 (in place): box = decode(loc_shift, center_size(box)), coeff += coeff_shift, score *= decay
+ *   (TF_utils.py:40-48; box_utils.py:25-35,238-283).
+ * stm_match_scores_f32: compute_comp_scores + argmax (TF_utils.py:99-120, track_TF.py:104-129) over [dummy | prev rows of the
+ *   same clip]: cos [D,Pn] raw embedding dot products, mask_iou [D,Pn]; box IoU and class equality are computed here;
+ *   coeff4 = cfg.match_coeff (host floats); match[d] = 0 (new) or 1 + prev row.  prev_offsets [B+1]: clip row ranges.
+ * stm_gather_rows2: out_t[r] = plan[r] < n_a ? a_t[plan[r]] : b_t[plan[r] - n_a] for up to 8 row tensors in one launch (the
+ *   tracker update cat(prev, det).index_select(plan), track_TF.py:132-156); row_bytes multiples of 4.
+ * stm_pack_tracked_f32: keep rule (tracked <= max_age, more than one mask pixel > 0.5, score > thr: track_TF.py:158-165) and
+ *   the fixed-shape output [B, top_k, cols] = (box 4, score, class, object id, valid, mask_coeff ...), zero padded.
+ *   keep_ws: n_rows ints of scratch. */
+int stm_gather_detections_f32(const int64_t* idx, const int64_t* cls, const float* score, const float* box, const int* count,
+                              const float* mask_coeff, const float* track, const float* centerness, int B, int top_k, int N,
+                              int mask_dim, int embed_dim, int D, float* out_box, int64_t* out_cls, float* out_score,
+                              float* out_coeff, float* out_track, float* out_centerness, int* out_clip, stm_stream_t stream);
+int stm_shift_rois_f32(const float* box, const int* clip, float* rois, int n, int feat_h, int feat_w, stm_stream_t stream);
+int stm_shift_apply_f32(const float* loc_shift, const float* coeff_shift, float* box, float* coeff, float* score, int n,
+                        int mask_dim, float score_decay, stm_stream_t stream);
+int stm_match_scores_f32(const float* cos, const float* mask_iou, const float* det_box, const float* prev_box,
+                         const float* det_score, const int64_t* det_cls, const int64_t* prev_cls, const int* det_clip,
+                         const int* prev_offsets, int D, int Pn, const float* coeff4, float dummy_iou, int* match,
+                         stm_stream_t stream);
+int stm_gather_rows2(const void* const* a_rows, const void* const* b_rows, void* const* out_rows, const int* row_bytes,
+                     int n_tensors, const int* plan, int n_rows, int n_a, stm_stream_t stream);
+int stm_pack_tracked_f32(const float* mask, const float* score, const int* tracked, const int* offsets, const float* box,
+                         const int64_t* cls, const float* mask_coeff, int n_rows, int hw, int B, int top_k, int cols,
+                         int mask_dim, int max_age, float score_thr, int* keep_ws, float* out, stm_stream_t stream);
+
 /* ---- frame pre-processing on the device (row f3) ------------------------------------------------------------------
  * Replaces the host chain of eval.py:703-717 (evaluate_single): mmcv.imresize(im, (w, h)) [cv2.resize INTER_LINEAR on
  * the uint8 HWC image] -> (im - MEANS) / STD [numpy float64] -> mmcv.impad_to_multiple(im, 32) -> permute(2,0,1).float().

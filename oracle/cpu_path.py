@@ -100,6 +100,61 @@ def _mask_iou(m1, m2, thr=0.5, group1=None, group2=None):
     return iou
 
 
+# ---- tracker bookkeeping (stmask_amd/csrc/tracker.hip): the torch chains those kernels replace -------------------------
+def _gather_detections(idx, cls, score, box, cnt, mask_coeff, track, centerness, D):
+    B, top_k = idx.shape
+    N = mask_coeff.shape[1]
+    valid = torch.arange(top_k)[None, :] < cnt[:, None]
+    flat = (idx + torch.arange(B, dtype=torch.int64)[:, None] * N)[valid]
+    return {"box": box[valid], "class": cls[valid], "score": score[valid],
+            "mask_coeff": mask_coeff.reshape(B * N, -1).index_select(0, flat), "track": track.reshape(B * N, -1).index_select(0, flat),
+            "centerness": centerness.reshape(B * N).index_select(0, flat),
+            "clip": torch.repeat_interleave(torch.arange(B, dtype=torch.int32), cnt.long())}
+
+
+def _shift_rois(box, clip, feat_h, feat_w):
+    from stmask_amd.layers.box_utils import sanitize_coordinates_hw
+    return torch.cat([clip.float().unsqueeze(1), sanitize_coordinates_hw(box, feat_h, feat_w)], dim=1)
+
+
+def _shift_apply_(loc_shift, coeff_shift, box, mask_coeff, score, decay=0.95):
+    from stmask_amd.layers.box_utils import center_size
+    box.copy_(orc.decode(loc_shift.contiguous(), center_size(box)))
+    mask_coeff.add_(coeff_shift)
+    score.mul_(decay)
+
+
+def _match_scores(cos, miou, det_box, prev_box, det_score, det_cls, prev_cls, det_clip, prev_offsets, match_coeff, dummy_iou=0.3):
+    D = det_box.shape[0]
+    c = match_coeff
+    prev_clip = torch.repeat_interleave(torch.arange(prev_offsets.numel() - 1, dtype=torch.int32), (prev_offsets[1:] - prev_offsets[:-1]).long())
+    cosf = (torch.cat([cos.new_zeros(D, 1), cos], dim=1) + 1) / 2
+    dummy = torch.full((D, 1), dummy_iou)
+    comp = cosf + c[0] * det_score.view(-1, 1) + c[1] * torch.cat([dummy, miou], 1) + c[2] * torch.cat([dummy, orc.jaccard(det_box, prev_box)], 1) \
+        + c[3] * torch.cat([torch.ones_like(dummy), (prev_cls[None, :] == det_cls[:, None]).float()], 1)
+    same = torch.cat([torch.ones(D, 1, dtype=torch.bool), det_clip[:, None] == prev_clip[None, :]], dim=1)
+    return torch.where(same, comp, torch.full_like(comp, float("-inf"))).argmax(dim=1).to(torch.int32)
+
+
+def _gather_rows2(a_rows, b_rows, plan, n_a):
+    return [torch.cat([a, b], dim=0).index_select(0, plan.long()) for a, b in zip(a_rows, b_rows)]
+
+
+def _pack_tracked(mask, score, tracked, offsets, box, cls, mask_coeff, B, top_k, cols, max_age=10, score_thr=0.05):
+    out = torch.zeros(B, top_k, cols)
+    if box.shape[0] == 0:
+        return out
+    keep = (tracked <= max_age) & (mask.gt(0.5).sum([1, 2]) > 1) & (score > score_thr)
+    off = offsets.tolist()
+    for b in range(B):
+        rows = torch.nonzero(keep[off[b]:off[b + 1]]).view(-1)[:top_k]
+        g = rows + off[b]
+        n = rows.numel()
+        out[b, :n, 0:4], out[b, :n, 4], out[b, :n, 5], out[b, :n, 6], out[b, :n, 7] = box[g], score[g], cls[g].float(), rows.float(), 1.0
+        out[b, :n, 8:8 + mask_coeff.shape[1]] = mask_coeff[g]
+    return out
+
+
 _PATCH = {
     "bias_act_": _bias_act_,
     "deform_conv": _deform_conv,
@@ -119,6 +174,12 @@ _PATCH = {
     "jaccard": orc.jaccard,
     "lincomb_sigmoid_crop": _lincomb,
     "mask_iou": _mask_iou,
+    "gather_detections": _gather_detections,
+    "shift_rois": _shift_rois,
+    "shift_apply_": _shift_apply_,
+    "match_scores": _match_scores,
+    "gather_rows2": _gather_rows2,
+    "pack_tracked": _pack_tracked,
 }
 
 

@@ -520,17 +520,112 @@ def check_planar_range():
         raise StmError(RANGE_MESSAGE)
 
 
-def counts_to_host(cnt):
+def counts_to_host(cnt, extra=None):
     """cnt.tolist() for an integer device tensor -- the host read every detection step does -- with the fp16 range flag
-    of the device (if a fp16x2 graph registered one) riding in the same copy.  Raises StmError when the flag is set."""
+    of the device (if a fp16 planar graph registered one) riding in the same copy.  Raises StmError when the flag is set.
+    extra: an fp32 tensor that travels in the same copy (the Fast-NMS scores the tracker's host logic needs); returns
+    (counts, extra as a flat numpy array) then."""
     flag = _range_flags.get(cnt.device.index) if cnt.is_cuda else None
-    if flag is None:
+    if flag is None and extra is None:
         return cnt.tolist()
-    host = torch.cat([cnt.reshape(-1), flag.to(cnt.dtype)]).tolist()
-    if host[-1]:
+    parts = [cnt.reshape(-1).to(torch.int32)]
+    if flag is not None:
+        parts.append(flag)
+    if extra is not None:
+        parts.append(extra.reshape(-1).view(torch.int32))
+    host = torch.cat(parts).cpu()
+    n = cnt.numel()
+    if flag is not None and int(host[n]):
         flag.zero_()
         raise StmError(RANGE_MESSAGE)
-    return host[:-1]
+    counts = host[:n].tolist()
+    if extra is None:
+        return counts
+    return counts, host[n + (1 if flag is not None else 0):].view(torch.float32).numpy()
+
+
+# ---- tracker bookkeeping of the batched pipeline (csrc/tracker.hip) -----------------------------------------------------
+def gather_detections(idx, cls, score, box, cnt, mask_coeff, track, centerness, D):
+    """Fast-NMS survivors of detect_cc ([B,top_k] slots, device counts) -> concatenated detection rows (dict of [D, ...]
+    tensors: box, class, score, mask_coeff, track, centerness, clip).  D = sum of the counts as read by the host."""
+    _dev(idx, cls, score, box, cnt, mask_coeff, track, centerness)
+    B, top_k = idx.shape
+    N, mdim, edim = mask_coeff.shape[1], mask_coeff.shape[2], track.shape[2]
+    dev = idx.device
+    out = {"box": torch.empty(D, 4, device=dev), "class": torch.empty(D, dtype=torch.int64, device=dev), "score": torch.empty(D, device=dev),
+           "mask_coeff": torch.empty(D, mdim, device=dev), "track": torch.empty(D, edim, device=dev), "centerness": torch.empty(D, device=dev),
+           "clip": torch.empty(D, dtype=torch.int32, device=dev)}
+    cen = _f32c(centerness.reshape(B, N)) if centerness is not None else None
+    check(_lib.lib().stm_gather_detections_f32(_p(idx), _p(cls), _p(_f32c(score)), _p(_f32c(box)), _p(cnt), _p(_f32c(mask_coeff)), _p(_f32c(track)),
+                                               _p(cen), c_i(B), c_i(top_k), c_i(N), c_i(mdim), c_i(edim), c_i(D), _p(out["box"]), _p(out["class"]),
+                                               _p(out["score"]), _p(out["mask_coeff"]), _p(out["track"]), _p(out["centerness"]), _p(out["clip"]),
+                                               _stream()), "stm_gather_detections_f32")
+    return out
+
+
+def shift_rois(box, clip, feat_h, feat_w):
+    """CandidateShift's RoIs: [n, 5] = (clip, x1, y1, x2, y2 in feature-map pixels, order-fixed and clamped)."""
+    _dev(box, clip)
+    n = box.shape[0]
+    rois = torch.empty(n, 5, device=box.device)
+    check(_lib.lib().stm_shift_rois_f32(_p(_f32c(box)), _p(clip), _p(rois), c_i(n), c_i(feat_h), c_i(feat_w), _stream()), "stm_shift_rois_f32")
+    return rois
+
+
+def shift_apply_(loc_shift, coeff_shift, box, mask_coeff, score, decay=0.95):
+    """In place: box = decode(loc_shift, center_size(box)); mask_coeff += coeff_shift; score *= decay (TF_utils.py:40-48)."""
+    _dev(loc_shift, coeff_shift, box, mask_coeff, score)
+    for t in (box, mask_coeff, score):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise StmError("shift_apply_: box / mask_coeff / score must be contiguous fp32 (modified in place)")
+    check(_lib.lib().stm_shift_apply_f32(_p(_f32c(loc_shift)), _p(_f32c(coeff_shift)), _p(box), _p(mask_coeff), _p(score), c_i(box.shape[0]),
+                                         c_i(mask_coeff.shape[1]), c_f(decay), _stream()), "stm_shift_apply_f32")
+
+
+def match_scores(cos, miou, det_box, prev_box, det_score, det_cls, prev_cls, det_clip, prev_offsets, match_coeff, dummy_iou=0.3):
+    """compute_comp_scores + argmax over [dummy | prev rows of the same clip] -> int32 [D]: 0 = new instance, 1 + prev row."""
+    _dev(cos, miou, det_box, prev_box, det_score, det_cls, prev_cls, det_clip, prev_offsets)
+    D, Pn = det_box.shape[0], prev_box.shape[0]
+    match = torch.empty(D, dtype=torch.int32, device=det_box.device)
+    c4 = (ctypes.c_float * 4)(*[float(v) for v in match_coeff])
+    check(_lib.lib().stm_match_scores_f32(_p(_f32c(cos)), _p(_f32c(miou)), _p(_f32c(det_box)), _p(_f32c(prev_box)), _p(_f32c(det_score)),
+                                          _p(det_cls), _p(prev_cls), _p(det_clip), _p(prev_offsets), c_i(D), c_i(Pn), c4, c_f(dummy_iou),
+                                          _p(match), _stream()), "stm_match_scores_f32")
+    return match
+
+
+def gather_rows2(a_rows, b_rows, plan, n_a):
+    """out_t[r] = plan[r] < n_a ? a_t[plan[r]] : b_t[plan[r] - n_a] for lists of row tensors (<= 8 per launch); plan int32."""
+    _dev(plan, *a_rows, *b_rows)
+    if plan.dtype != torch.int32:
+        raise StmError("gather_rows2: plan must be int32")
+    R = plan.shape[0]
+    outs = []
+    for i in range(0, len(a_rows), 8):
+        aa, bb = [t.contiguous() for t in a_rows[i:i + 8]], [t.contiguous() for t in b_rows[i:i + 8]]
+        oo = [torch.empty((R,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in aa]
+        n = len(aa)
+        rb = [t[0].numel() * t.element_size() if t.shape[0] else (bb[k][0].numel() * bb[k].element_size()) for k, t in enumerate(aa)]
+        pa = (ctypes.c_void_p * n)(*[t.data_ptr() for t in aa])
+        pb = (ctypes.c_void_p * n)(*[t.data_ptr() for t in bb])
+        po = (ctypes.c_void_p * n)(*[t.data_ptr() for t in oo])
+        prb = (ctypes.c_int * n)(*rb)
+        check(_lib.lib().stm_gather_rows2(pa, pb, po, prb, c_i(n), _p(plan), c_i(R), c_i(n_a), _stream()), "stm_gather_rows2")
+        outs += oo
+    return outs
+
+
+def pack_tracked(mask, score, tracked, offsets, box, cls, mask_coeff, B, top_k, cols, max_age=10, score_thr=0.05):
+    """Keep rule of track_TF.py:158-165 + scatter into the fixed-shape [B, top_k, cols] detection rows (stmask_amd.dist layout)."""
+    _dev(mask, score, tracked, offsets, box, cls, mask_coeff)
+    n = box.shape[0]
+    out = torch.empty(B, top_k, cols, device=offsets.device, dtype=torch.float32)
+    keep = torch.empty(max(n, 1), dtype=torch.int32, device=offsets.device)
+    hw = mask[0].numel() if n else 1
+    check(_lib.lib().stm_pack_tracked_f32(_p(_f32c(mask)) if n else c_p(0), _p(score), _p(tracked), _p(offsets), _p(box), _p(cls), _p(mask_coeff),
+                                          c_i(n), c_i(hw), c_i(B), c_i(top_k), c_i(cols), c_i(mask_coeff.shape[1] if n else cols - 8), c_i(max_age),
+                                          c_f(score_thr), _p(keep), _p(out), _stream()), "stm_pack_tracked_f32")
+    return out
 
 
 def resize_bilinear_planes(x_nhwc, size, fmt=0):

@@ -94,8 +94,12 @@ class BatchedClipPipeline:
         self._pending = None        # (frames, (fpn_outs, pred), event): trunk of the NEXT frame, running on the side stream
         self._side = None
         self.prefetch_early = False  # True: start the next trunk at the beginning of step() instead of after the TF convolutions
-        self.use_graph = False       # capture the trunk in a HIP graph (one graph per input buffer; see _trunk)
+        self.use_graph = False       # replay the trunk (forward_single) from captured HIP graphs: see _trunk
         self.graph_active = False
+        self._graphs = []            # round-robin slots: (static input, graph, outputs)
+        self._graph_next = 0
+        self._graph_pool = None
+        self._graph_warm = 0
 
     # -- stage helpers ------------------------------------------------------------------------------------------------
     def _shift_prev(self, P4, T2S, proto, dev):
@@ -108,7 +112,7 @@ class BatchedClipPipeline:
         corr = corr.view(P4.shape[0], P * P, P4.shape[2], P4.shape[3])
         fh, fw = P4.shape[2:]
         box_ref = prev["box"]
-        rois = torch.cat([clip_of_row.float().unsqueeze(1), sanitize_coordinates_hw(box_ref, fh, fw)], dim=1)
+        rois = ops.shift_rois(box_ref, clip_of_row, fh, fw)          # (clip, sanitised box in feature-map pixels)
         ptn = getattr(net, "_planar_temporal", None)
         a_prev, a_cur = T2S_prev.permute(0, 2, 3, 1), T2S.permute(0, 2, 3, 1)
         fused = (ptn is not None and ptn.ncorr == P * P and a_prev.is_contiguous() and a_cur.is_contiguous()
@@ -143,15 +147,53 @@ class BatchedClipPipeline:
             loc_shift = torch.cat([o[0] for o in outs], 0)[:n]
             coeff_shift = torch.cat([o[1] for o in outs], 0)[:n]
         self.timer.toc("tf_temporalnet")
-        box_shift = ops.decode(loc_shift.contiguous(), center_size(box_ref))
-        coeff = prev["mask_coeff"] + coeff_shift
-        prev["box"] = box_shift
-        prev["score"] = prev["score"] * 0.95
-        prev["mask_coeff"] = coeff
-        prev["mask"] = ops.lincomb_sigmoid_crop(proto, coeff, box_shift, apply_tanh=True, row_proto=clip_of_row)
+        # decode(loc_shift, center_size(box)) / coeff += shift / score *= 0.95 in one launch, in place on the tracked rows
+        ops.shift_apply_(loc_shift, coeff_shift, prev["box"], prev["mask_coeff"], prev["score"], 0.95)
+        prev["mask"] = ops.lincomb_sigmoid_crop(proto, prev["mask_coeff"], prev["box"], apply_tanh=True, row_proto=clip_of_row)
         self.timer.toc("tf_masks")
         for b in range(self.B):
             self.tracked[b] = [v + 1 for v in self.tracked[b]]
+
+    # -- trunk, eager or from HIP graphs ---------------------------------------------------------------------------------
+    N_GRAPH_SLOTS = 3   # outputs of frame t-1 (previous-frame features of the temporal fusion) and t are live while t+1 is produced
+
+    def _trunk(self, frames):
+        """forward_single(frames).  With use_graph the ~110 launches of the trunk (every one a Python -> ctypes call: ~25 us of
+        host time each, i.e. more than the GPU needs for them at 1-8 clips) are captured once per slot into a HIP graph and
+        replayed: one copy of the frames into the slot's static input + one graph launch per step.  Three slots in round-robin,
+        because a step still reads the previous frame's P4 / T2S while the next frame's trunk is already running on the side
+        stream; a slot's outputs stay valid until it is replayed again, three steps later.  The graphs share one memory pool
+        (they are replayed in capture order and never concurrently)."""
+        net = self.net
+        if not (self.use_graph and getattr(net, "_planar", None) is not None and not self.timer.on and ops._conv_timing is None
+                and ops._im2col_timing is None):
+            return net.forward_single(frames)
+        if self._graph_warm < 2:
+            # eager first: packs the weights, sizes the workspaces, fills the prior cache, reserves the kernels' LDS
+            self._graph_warm += 1
+            return net.forward_single(frames)
+        if len(self._graphs) < self.N_GRAPH_SLOTS:
+            static_in = frames.clone(memory_format=torch.preserve_format)
+            graph = torch.cuda.CUDAGraph()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            cur = torch.cuda.current_stream()
+            cap = torch.cuda.Stream(device=frames.device)
+            cap.wait_stream(cur)
+            with torch.cuda.stream(cap):
+                net.forward_single(static_in)                 # once more on the capture stream (its own workspace slots)
+            with torch.cuda.graph(graph, pool=self._graph_pool, stream=cap):
+                out = net.forward_single(static_in)
+            cur.wait_stream(cap)
+            self._graphs.append((static_in, graph, out))
+            self.graph_active = True
+        static_in, graph, out = self._graphs[self._graph_next]
+        self._graph_next = (self._graph_next + 1) % self.N_GRAPH_SLOTS
+        if static_in.shape != frames.shape:
+            raise ops.StmError("BatchedClipPipeline: the frame batch changed shape under a captured trunk graph")
+        static_in.copy_(frames)
+        graph.replay()
+        return out
 
     def _prefetch_trunk(self, next_frames):
         """Enqueue the trunk of the next frame on a second stream.  The trunk does not depend on the tracker, and the rest
@@ -165,7 +207,7 @@ class BatchedClipPipeline:
             self._side = torch.cuda.Stream(device=next_frames.device)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            out = self.net.forward_single(next_frames)
+            out = self._trunk(next_frames)
             ev = torch.cuda.Event()
             ev.record()
         self._pending = (next_frames, out, ev)
@@ -189,16 +231,17 @@ class BatchedClipPipeline:
         if pend is not None and pend[0] is frames:
             fpn_outs, pred = pend[1]
             torch.cuda.current_stream().wait_event(pend[2])
-            for t_ in list(pred.values()) + list(fpn_outs):      # allocated on the side stream, consumed on this one
-                if torch.is_tensor(t_):
-                    t_.record_stream(torch.cuda.current_stream())
-            t2s_ = pred["T2S_feat"][net.correlation_selected_layer]
-            if torch.is_tensor(t2s_):
-                t2s_.record_stream(torch.cuda.current_stream())
+            if not self.graph_active:                            # (graph outputs live in the graphs' own pool)
+                for t_ in list(pred.values()) + list(fpn_outs):  # allocated on the side stream, consumed on this one
+                    if torch.is_tensor(t_):
+                        t_.record_stream(torch.cuda.current_stream())
+                t2s_ = pred["T2S_feat"][net.correlation_selected_layer]
+                if torch.is_tensor(t2s_):
+                    t2s_.record_stream(torch.cuda.current_stream())
         else:
             if pend is not None:
                 torch.cuda.current_stream().wait_event(pend[2])   # a trunk nobody asked for: let it finish, drop it
-            fpn_outs, pred = net.forward_single(frames)
+            fpn_outs, pred = self._trunk(frames)
         tmr.toc("trunk")
         if self.prefetch_early:
             # start the next trunk right away: it then also shares the GPU with this step's temporal-fusion convolutions
@@ -221,51 +264,33 @@ class BatchedClipPipeline:
         priors = pred["priors"].squeeze(0)
         idx, cls, score, box, cnt = ops.detect_cc(pred["loc"], priors, conf, pred["centerness"], cfg.eval_conf_thresh,
                                                   cfg.nms_thresh, cfg.nms_top_k)
-        counts = ops.counts_to_host(cnt)  # host read 1 (B ints, + the fp16 range flag of a fp16x2 graph)
+        counts, host_scores = ops.counts_to_host(cnt, extra=score)  # host read 1: B counts + the fp16 range flag + the NMS scores
         tmr.toc("detect")
         D = sum(counts)
         top_k = cfg.nms_top_k
-        # ---- detections of all clips, concatenated (rows sorted by clip) ------------------------------------------
-        valid = torch.arange(top_k, device=dev)[None, :] < cnt[:, None]
-        offs = torch.arange(B, device=dev, dtype=torch.int64)[:, None] * N
-        flat = (idx + offs)[valid]
-        det = {
-            "box": box[valid], "class": cls[valid], "score": score[valid],
-            "mask_coeff": pred["mask_coeff"].reshape(B * N, -1).index_select(0, flat),
-            "track": pred["track"].reshape(B * N, -1).index_select(0, flat),
-            "centerness": pred["centerness"].reshape(B * N).index_select(0, flat),
-            "clip": torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32),
-                                            torch.tensor(counts, device=dev), output_size=D),
-        }
-        det["mask"] = (ops.lincomb_sigmoid_crop(proto, det["mask_coeff"], det["box"], apply_tanh=True,
-                                                row_proto=det["clip"])
+        # ---- detections of all clips, concatenated (rows sorted by clip): one gather kernel ------------------------------
+        det = ops.gather_detections(idx, cls, score, box, cnt, pred["mask_coeff"], pred["track"], pred["centerness"], D)
+        det["mask"] = (ops.lincomb_sigmoid_crop(proto, det["mask_coeff"], det["box"], apply_tanh=True, row_proto=det["clip"])
                        if D else proto.new_zeros(0, proto.shape[1], proto.shape[2]))
         tmr.toc("det_gather_masks")
+        det_scores = [float(host_scores[b * top_k + j]) for b in range(B) for j in range(counts[b])]   # row order of det
 
         if self.prev is None:
             # first frame of every clip (track_TF.py:88-93): the detections become the tracked set
             self.prev = det
             self.prev_n = list(counts)
             self.tracked = [[0] * k for k in counts]
+            self._upload_meta(dev, None)
         else:
             prev = self.prev
             if D and Pn:
                 # matching scores for all clips at once; pairs from different clips can never match
                 cos = det["track"] @ prev["track"].t()
-                cos = (torch.cat([cos.new_zeros(D, 1), cos], dim=1) + 1) / 2
-                biou = ops.jaccard(det["box"], prev["box"])
                 miou = ops.mask_iou(det["mask"], prev["mask"], group1=det["clip"], group2=prev["clip"])   # same-clip pairs only
-                dummy = torch.full((D, 1), 0.3, device=dev)
-                c = cfg.match_coeff
-                comp = cos + c[0] * det["score"].view(-1, 1) + c[1] * torch.cat([dummy, miou], 1) \
-                    + c[2] * torch.cat([dummy, biou], 1) \
-                    + c[3] * torch.cat([torch.ones_like(dummy), (prev["class"][None, :] == det["class"][:, None]).float()], 1)
-                same = torch.cat([torch.ones(D, 1, dtype=torch.bool, device=dev),
-                                  det["clip"][:, None] == prev["clip"][None, :]], dim=1)
-                comp = torch.where(same, comp, torch.full_like(comp, float("-inf")))
-                match = comp.argmax(dim=1)
-                host = torch.stack([match.float(), det["score"]]).cpu()  # host read 2
-                ids, scores = host[0].long().tolist(), host[1].tolist()
+                match = ops.match_scores(cos, miou, det["box"], prev["box"], det["score"], det["class"], prev["class"], det["clip"],
+                                         self._off_dev, cfg.match_coeff, 0.3)
+                ids = match.tolist()  # host read 2
+                scores = det_scores
                 tmr.toc("match_scores")
             else:
                 ids, scores = [0] * D, [0.0] * D
@@ -293,11 +318,13 @@ class BatchedClipPipeline:
                 new_tracked.append(tm)
                 p0 += pn
                 d0 += dn
-            if D:
-                plan_t = torch.tensor(plan, device=dev, dtype=torch.int64)
-                for k in _ROW_KEYS + ("clip",):
-                    prev[k] = torch.cat([prev[k], det[k]], dim=0).index_select(0, plan_t)
             self.prev_n, self.tracked = new_n, new_tracked
+            plan_dev = self._upload_meta(dev, plan if D else None)
+            if D:
+                keys = _ROW_KEYS + ("clip",)
+                rows = ops.gather_rows2([prev[k] for k in keys], [det[k] for k in keys], plan_dev, Pn)
+                for k, t in zip(keys, rows):
+                    prev[k] = t
             tmr.toc("tracker_update")
         self.prev_feat = (P4, T2S)
         self.t += 1
@@ -305,35 +332,25 @@ class BatchedClipPipeline:
         tmr.toc("pack")
         return out
 
+    def _upload_meta(self, dev, plan):
+        """One host -> device copy per step: [clip row offsets (B + 1) | frames-since-last-match counters | gather plan]."""
+        off = [0]
+        for n in self.prev_n:
+            off.append(off[-1] + n)
+        tm = [v for t in self.tracked for v in t]
+        meta = torch.tensor(off + tm + (plan or []), dtype=torch.int32).to(dev, non_blocking=True)
+        nb = len(off)
+        self._off_dev, self._tm_dev = meta[:nb], meta[nb:nb + len(tm)]
+        return meta[nb + len(tm):]
+
     def _pack_outputs(self, dev):
-        """keep rule of track_TF.py:158-165 on device, scattered into [B, top_k, 40] without a host sync."""
+        """keep rule of track_TF.py:158-165 on device, scattered into [B, top_k, 40] without a host sync (two launches)."""
         from .dist import DET_COLS
         cfg, B, prev = self.cfg, self.B, self.prev
-        top_k = cfg.nms_top_k
-        Pn = sum(self.prev_n)
-        if Pn == 0:
-            return torch.zeros(B, top_k, DET_COLS, device=dev)
-        tm = torch.tensor([v for t in self.tracked for v in t], device=dev)
-        keep = (tm <= 10) & (prev["mask"].gt(0.5).sum([1, 2]) > 1) & (prev["score"] > cfg.eval_conf_thresh)
-        starts, ids, s = [], [], 0
-        for n in self.prev_n:
-            starts += [s] * n
-            ids += list(range(n))
-            s += n
-        starts = torch.tensor(starts, device=dev)
-        obj_id = torch.tensor(ids, device=dev)
-        csum = torch.cumsum(keep.long(), 0)
-        before = csum - keep.long()
-        pos = before - before.index_select(0, starts)  # rank among the kept rows of the same clip
-        ok = keep & (pos < top_k)
-        rows = torch.cat([prev["box"], prev["score"][:, None], prev["class"][:, None].float(), obj_id[:, None].float(),
-                          torch.ones(Pn, 1, device=dev), prev["mask_coeff"]], dim=1)
-        tgt = prev["clip"].long() * top_k + torch.where(ok, pos, torch.zeros_like(pos))
-        # rows that are not kept are routed to a scratch row past the end (no data-dependent shapes, no sync)
-        scratch = torch.zeros(B * top_k + 1, DET_COLS, device=dev)
-        tgt = torch.where(ok, tgt, torch.full_like(tgt, B * top_k))
-        scratch.index_copy_(0, tgt, rows)
-        return scratch[: B * top_k].view(B, top_k, DET_COLS)
+        if prev is None or sum(self.prev_n) == 0:
+            return torch.zeros(B, cfg.nms_top_k, DET_COLS, device=dev)
+        return ops.pack_tracked(prev["mask"], prev["score"], self._tm_dev, self._off_dev, prev["box"], prev["class"], prev["mask_coeff"], B,
+                                cfg.nms_top_k, DET_COLS, 10, cfg.eval_conf_thresh)
 
     def detections(self):
         """Reference-shaped per-clip detection dicts of the last step (host sync; for tests and users who want them)."""
