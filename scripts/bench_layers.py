@@ -34,12 +34,22 @@ MFMA = [("proto 256->256 3x3 @96x160", 96, 160, 256, 256, 3, 1, False, "planes")
         ("temporal conv3 512->1024 3x3 (2900 rois)", 7, 7 * 91, 512, 1024, 3, 1, False, "f32")]
 
 
-def run(name, B, H, W, C, O, k, s, has_res, out, fmt, reps=20, nbuf=4):
+EXP = [("64->256 +res planes (baseline)", 96, 160, 64, 256, 1, 1, True, "planes"),
+       ("64->256 no res", 96, 160, 64, 256, 1, 1, False, "planes"),
+       ("64->256 +res f32 out", 96, 160, 64, 256, 1, 1, True, "f32"),
+       ("64->64 1x1 (one n-tile)", 96, 160, 64, 64, 1, 1, False, "planes"),
+       ("256->256 1x1", 96, 160, 256, 256, 1, 1, False, "planes"),
+       ("64->256 +res tile128", 96, 160, 64, 256, 1, 1, True, "planes", 128),
+       ("128->512 +res tile128", 48, 80, 128, 512, 1, 1, True, "planes", 128),
+       ("256->1024 +res tile128", 24, 40, 256, 1024, 1, 1, True, "planes", 128)]
+
+
+def run(name, B, H, W, C, O, k, s, has_res, out, tile_n=None, fmt=1, reps=20, nbuf=4):
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     w = torch.randn(O, C, k, k, device=dev, generator=g) * (C * k * k) ** -0.5
     b = torch.randn(O, device=dev, generator=g)
-    conv = PlanarConv(w, b, s, k // 2, relu=True, fmt=fmt)
+    conv = PlanarConv(w, b, s, k // 2, relu=True, fmt=fmt, tile_n=tile_n)
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
     M = B * Ho * Wo
     xs = [ops.split_planes(torch.randn(B, H, W, C, device=dev, generator=g), fmt) for _ in range(nbuf)]
@@ -74,6 +84,6 @@ if __name__ == "__main__":
     planar.set_format(a.fmt if a.fmt != 2 else 1, backbone_fmt=2 if a.fmt == 2 else None)
     print(torch.cuda.get_device_name(0), "fmt", a.fmt, "batch", a.batch, flush=True)
     tot = 0.0
-    for name, *shape in (HBM if a.set in ("hbm", "all") else []) + (MFMA if a.set in ("mfma", "all") else []):
+    for name, *shape in (HBM if a.set in ("hbm", "all") else []) + (MFMA if a.set in ("mfma", "all") else []) + (EXP if a.set == "exp" else []):
         tot += run(name, a.batch, *shape, fmt=a.fmt)
     print(f"sum {tot:.0f} us")

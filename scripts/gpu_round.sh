@@ -18,7 +18,7 @@ bench)
   timeout 900 python bench.py --steps 20 --warmup 4 > $OUT/bench.log 2> $OUT/bench.err; echo "bench exit $?"; tail -2 $OUT/bench.log; tail -3 $OUT/bench.err ;;
 prof)
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/prof.log 2>&1
   echo "prof exit $?"; cd $R
   f=$(ls $OUT/prof/*/*kernel_stats.csv $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1); echo "stats: $f"; head -25 "$f"
   # the raw per-dispatch trace is large: keep only the stats
@@ -29,8 +29,6 @@ trunk)
   grep -E "first pass|steady" $OUT/trunk.log ;;
 kernels)
   timeout 1200 python scripts/bench_kernels.py --batch 8 > $OUT/kernels.log 2>&1; echo "kernels exit $?"; grep -E "TOTAL|gemm|corr|lincomb|nms|detect|roi|deform_conv" $OUT/kernels.log | head -70 ;;
-sweep)
-  timeout 1500 python scripts/bench_kernels.py --batch 8 --env-sweep > $OUT/sweep.log 2>&1; echo "sweep exit $?"; grep BEST $OUT/sweep.log ;;
 pmcim2col)
   cd /tmp
   i=0
@@ -42,8 +40,9 @@ pmcim2col)
   find $OUT/pmc_im2col -name '*.csv' -size +5M -delete ;;
 pmc)
   cd /tmp
-  timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
-  timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?"
+  rm -rf $OUT/pmc_fetch $OUT/pmc_write
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?"
   cd $R; python scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt ;;
 esac
 done

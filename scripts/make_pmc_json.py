@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/r01_pmc_traffic.json from the two PMC passes of `scripts/gpu_round.sh pmc` (gpurun_out/pmc_fetch, pmc_write).
-Keeps the top-level deform_im2col_lds entry of the existing file (it comes from an earlier --no-planar pass).
-usage: python scripts/make_pmc_json.py gpurun_out profiles/r01_pmc_traffic.json"""
+"""profiles/r0N_pmc_traffic.json from the two PMC passes of `scripts/gpu_round.sh pmc` (gpurun_out/pmc_fetch, pmc_write).
+usage: python scripts/make_pmc_json.py gpurun_out profiles/r02_pmc_traffic.json"""
 import json
 import os
 import sys
@@ -33,6 +32,9 @@ def main():
     g = group("dcn_sample_planar_kernel")
     if g:
         doc["dcn_sample_planar"] = {"kernel": "dcn_sample_planar_kernel (7 DCN layers of R50 at batch 32)", **g}
+    g = group("corr_patch_tiled")
+    if g:
+        doc["corr_patch"] = {"kernel": "corr_patch_tiled<11> (P4 24x40, 256 channels, batch 32: inputs 62.9 MB, output 14.9 MB)", **g}
     g = group("conv_planar_kernel")
     if g:
         doc["conv_planar"] = {"kernel": "conv_planar_kernel<*> (all launches of bench.py at batch 32, fp16x2 plane format)", **g}
@@ -40,7 +42,7 @@ def main():
                      "counters are KiB; FETCH_SIZE doubled per the gfx950 correction (MI355X guide, HBM section); WRITE_SIZE exact for 16-byte streaming stores")
     per = {}
     for k in sorted(set(fetch) | set(write)):
-        if not any(t in k for t in ("anonymous namespace", "stm_", "conv_planar", "dcn_", "corr_", "lincomb", "nms", "head_assemble", "roi_align", "mask_")):
+        if not any(t in k for t in ("anonymous namespace", "stm_", "conv_planar", "dcn_", "corr_", "lincomb", "nms", "head_assemble", "roi_align", "mask_", "gather_", "match_", "pack_", "keep_", "shift_")):
             continue
         nf, nw = max(fetch[k][1], 1), max(write[k][1], 1)
         name = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")

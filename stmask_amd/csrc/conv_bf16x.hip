@@ -275,7 +275,7 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
 
 template <int NJ>
 __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_t* smem, int wave, int lane, int m0, int n0g, int grp,
-                                                     int wm, int wn, bool early = false, const f16x8* e0 = nullptr, const f16x8* e1 = nullptr)
+                                                     int wm, int wn)
 {
     constexpr int EP_LD = 32 * NJ + 4;                 // floats per parked pixel row (+ 4 pad)
     constexpr int LPR = 4 * NJ;                        // lanes per pixel row (8 channels each)
@@ -294,10 +294,7 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
     // (64-channel tiles only: with LPR = 8 the 64 extra registers push the 256 x 128 kernel into scratch -- 380 -> 1065 us)
     const bool pre = NJ == 1 && a.vec_epilogue && a.res_pl != nullptr && a.fmt >= 1;
     f16x8 r0[LPR], r1[LPR];
-    if (pre && early) {                                // loaded before the K loop (conv_planar_kernel<..., RE = 1>)
-#pragma unroll
-        for (int pass = 0; pass < LPR; ++pass) { r0[pass] = e0[pass]; r1[pass] = e1[pass]; }
-    } else if (pre) {
+    if (pre) {
 #pragma unroll
         for (int pass = 0; pass < LPR; ++pass) {
             const int m = min(m0 + wm * 64 + pass * (64 / LPR) + prow, a.M - 1);
@@ -344,10 +341,11 @@ __global__ __launch_bounds__(256) void planar_splitk_finish_kernel(const PlanarA
 // 593 vs 656 us on the 145-GF proto layer); ST = 3: three-buffer LDS ring with fragment prefetch (fp16 formats), 2: two buffers.
 // ABL (builds with -DSTM_ABLATE only): timing ablations of the ring loop, RESULTS ARE WRONG -- 1 no DMA, 2 no barrier, 4 no
 // fragment reads, 8 no wait for the DMAs.
-// RE = 1 (64-channel tiles, fp16 formats, residual planes): the residual of the tile is loaded BEFORE the K loop -- its addresses
-// are known from the start -- so that the HBM-bound expanding 1x1 convolutions of the bottlenecks do not pay a second memory
-// round trip in the epilogue (32 more registers live across the loop).
-template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0, int RE = 0>
+// (Tried and removed, round 2: loading the residual planes of a 64-channel tile BEFORE the K loop -- no change on the HBM-bound
+// expanding 1x1 convolutions, 337 vs 345 us, for 32 more live registers and one wave per SIMD less; and resident workgroups
+// walking the tiles instead of one workgroup per tile -- 404 -> 451 us.  Neither the epilogue's second memory round trip nor
+// workgroup launch overhead is what holds these layers at 3.3 TB/s.)
+template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
@@ -443,21 +441,6 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         }
     };
 
-    // early residual loads (RE): the epilogue tail's (pass, pixel row, 8-channel segment) mapping of this lane
-    f16x8 er0[RE ? 4 * NJ : 1], er1[RE ? 4 * NJ : 1];
-    if constexpr (RE == 1) {
-        constexpr int LPR = 4 * NJ;
-        const int seg = lane % LPR, prow = lane / LPR;
-        const int co = grp * a.cout_g + n0g + wn * (32 * NJ) + seg * 8;
-        const int coc = min(co, a.Cout - 8);                            // (segments past Cout are never stored)
-#pragma unroll
-        for (int pass = 0; pass < LPR; ++pass) {
-            const int m = min(m0 + wm * 64 + pass * (64 / LPR) + prow, a.M - 1);
-            const size_t ri = (((size_t)(coc >> 5) * a.res_np + m) * 32 + (coc & 31)) * 2;
-            er0[pass] = *reinterpret_cast<const f16x8*>(a.res_pl + ri);
-            er1[pass] = a.fmt == 1 ? *reinterpret_cast<const f16x8*>(a.res_pl + ri + a.res_pstride) : er0[pass];
-        }
-    }
     f32x4 acc16[4][2 * NJ], accl16[4][2 * NJ];   // main products / plane-correction products (v_mfma_f32_16x16x32 C layout)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -727,8 +710,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
             *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
         }
     } else {
-        if constexpr (RE == 1) planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn, true, er0, er1);
-        else planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
+        planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
     }
 #endif
 }
@@ -1002,23 +984,6 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
     }
 }
 
-template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0, int RE = 0>
-int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
-{
-    size_t lds = (size_t)ST * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
-    const size_t park = (size_t)4 * MG * 64 * (32 * NJ + 4) * sizeof(float);   // the epilogue parks one 64 x 32NJ tile per wave
-    if (lds < park) lds = park;
-    static bool lds_reserved = false;   // per instantiation; the attribute is sticky, setting it again each launch only costs host time
-    if (!lds_reserved) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL, RE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
-        lds_reserved = true;
-    }
-    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL, RE>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
-    STM_CHECK_LAUNCH("conv_planar_kernel");
-    return STM_OK;
-}
-
 // Launch tunables: read from the environment ONCE (first launch), never per launch.  Defaults are the measured best (DESIGN.md
 // section 9); the variables exist for A/B runs.  stm_debug_reload_tunables() (capi.hip) makes the next launch re-read them.
 struct ConvTunables {
@@ -1029,7 +994,6 @@ struct ConvTunables {
     int mg = 0;            // STM_CONV_MG: force 128 (1) or 256 (2) pixel tiles
     long long nt_mb = 0;   // STM_CONV_NT: nontemporal plane stores for outputs of at least this many MB (0 = off; no gain measured)
     int scalar_epilogue = 0;   // STM_CONV_SCALAR_EPILOGUE: element-wise epilogue stores (tests)
-    int res_early = 1;         // STM_CONV_RES_EARLY: residual planes loaded before the K loop on the 64-wide tiles (0 = in the epilogue)
     int abl = 0;           // STM_CONV_ABL (builds with -DSTM_ABLATE only)
 };
 ConvTunables read_tunables()
@@ -1043,7 +1007,6 @@ ConvTunables read_tunables()
     t.mg = (int)geti("STM_CONV_MG", 0);
     t.nt_mb = geti("STM_CONV_NT", 0);
     t.scalar_epilogue = (int)geti("STM_CONV_SCALAR_EPILOGUE", 0);
-    t.res_early = (int)geti("STM_CONV_RES_EARLY", t.res_early);
     t.abl = (int)geti("STM_CONV_ABL", 0);
     return t;
 }
@@ -1054,6 +1017,23 @@ const ConvTunables& tunables()
     const int g = stm_env_generation();
     if (gen != g) { t = read_tunables(); gen = g; }
     return t;
+}
+
+template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0>
+int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
+{
+    size_t lds = (size_t)ST * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
+    const size_t park = (size_t)4 * MG * 64 * (32 * NJ + 4) * sizeof(float);   // the epilogue parks one 64 x 32NJ tile per wave
+    if (lds < park) lds = park;
+    static bool lds_reserved = false;   // per instantiation; the attribute is sticky, setting it again each launch only costs host time
+    if (!lds_reserved) {
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
+        lds_reserved = true;
+    }
+    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
+    STM_CHECK_LAUNCH("conv_planar_kernel");
+    return STM_OK;
 }
 
 bool geom_ok(const stm_conv_geom* g, const char* who)
@@ -1352,11 +1332,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         // the split-K ones (100 -> 114 us at 72 slabs), where two resident two-buffer workgroups already cover each other;
         // under 12 slabs the layer is HBM-bound and the two-buffer loop's 48 KB (three workgroups per CU) wins: 302 vs 389 us
         const bool ring = full && (tn.ring64 == 3 ? (a.splitk == 1 && a.slabs >= 12 && a.slabs <= 40) : tn.ring64 == 4);
-        // residual planes of an unsplit vector-epilogue launch: loaded before the K loop (RE = 1)
-        const bool re = tn.res_early && residual_planes && a.vec_epilogue && a.splitk == 1 && a.fmt >= 1 && cout_g % 8 == 0 && g->Cout >= 8;
-        if (a.fmt == 2 && re) rc = ring ? launch_planar<1, 1, 1, 1, 3, 0, 1>(a, tiles, stream) : launch_planar<1, 1, 1, 1, 2, 0, 1>(a, tiles, stream);
-        else if (a.fmt == 1 && re) rc = ring ? launch_planar<2, 1, 1, 1, 3, 0, 1>(a, tiles, stream) : launch_planar<2, 1, 1, 1, 2, 0, 1>(a, tiles, stream);
-        else if (a.fmt == 2) rc = ring ? launch_planar<1, 1, 1, 1, 3>(a, tiles, stream) : launch_planar<1, 1, 1, 1>(a, tiles, stream);
+        if (a.fmt == 2) rc = ring ? launch_planar<1, 1, 1, 1, 3>(a, tiles, stream) : launch_planar<1, 1, 1, 1>(a, tiles, stream);
         else if (a.fmt == 1) rc = ring ? launch_planar<2, 1, 1, 1, 3>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
         else rc = g->planes == 3 ? launch_planar<3, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1>(a, tiles, stream);
         return rc != STM_OK ? rc : finish_splitk();

@@ -21,7 +21,7 @@ constexpr int CORR_CCK = 16;  // channels staged per chunk (8 per half-wave)
 template <int P>
 __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict__ f1, const float* __restrict__ f2,
                                                         float* __restrict__ out, int C, int H, int W, float scale,
-                                                        float slope)
+                                                        float slope, int B)
 {
     constexpr int R = P / 2;
     constexpr int WIN = 4 + P - 1;          // f2 values per item per channel (14 for P = 11)
@@ -32,7 +32,13 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
     float* f1s = smem;                      // [CCK][W]
     float* f2s = smem + CORR_CCK * W;       // [CCK][P][LW2], index x + R
 
-    const int y = blockIdx.x, b = blockIdx.y;
+    // One workgroup per output row; the 11 workgroups whose windows share an f2 row must meet in ONE L2: workgroup ids are
+    // dealt round-robin to the 8 XCDs, so the (image, row) list is cut into 8 contiguous runs, one per XCD (stm_xcd_block).
+    // With plain (row, image) grid order every XCD's L2 fetched every row: 297 MB from HBM for 62.9 MB of inputs at batch 32
+    // (rocprofv3 FETCH_SIZE, round 1).
+    const int64_t blk = stm_xcd_block((int64_t)H * B);
+    if (blk < 0) return;
+    const int y = (int)(blk % H), b = (int)(blk / H);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int half = lane >> 5;             // channel half handled by this lane
     const int slot = wave * 32 + (lane & 31);  // 128 item slots per pass
@@ -249,8 +255,8 @@ extern "C" int stm_corr_patch_f32(const float* f1, const float* f2, float* out, 
         int LW2 = ((W + 10 + 3) / 4) * 4;
         size_t lds = (size_t)(CORR_CCK * W + CORR_CCK * 11 * LW2) * sizeof(float);
         if (lds <= 64 * 1024) {
-            hipLaunchKernelGGL(corr_patch_tiled<11>, dim3(H, B), dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W,
-                               scale, leaky_slope);
+            hipLaunchKernelGGL(corr_patch_tiled<11>, dim3(stm_xcd_grid((int64_t)H * B)), dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W,
+                               scale, leaky_slope, B);
             STM_CHECK_LAUNCH("corr_patch_tiled");
             return STM_OK;
         }

@@ -171,7 +171,8 @@ def test_gemm_is_exact_fmaf_chain_on_integers():
 
 
 # ------------------------------------------------------------------------------------------ temporal
-@pytest.mark.parametrize("B,C,H,W", [(1, 256, 24, 40), (2, 32, 12, 20), (1, 20, 7, 9), (1, 8, 3, 5), (3, 20, 6, 8), (2, 40, 30, 44)])
+@pytest.mark.parametrize("B,C,H,W", [(1, 256, 24, 40), (2, 32, 12, 20), (1, 20, 7, 9), (1, 8, 3, 5), (3, 20, 6, 8), (2, 40, 30, 44),
+                                     (2, 256, 46, 80), (1, 24, 13, 40), (2, 12, 9, 16), (1, 9, 5, 72)])
 def test_correlation_vs_oracle(B, C, H, W):
     f1, f2 = rnd(B, C, H, W, seed=1), rnd(B, C, H, W, seed=2)
     ref = oracle.corr_patch(f1, f2, 11, 1)
