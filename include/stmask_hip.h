@@ -353,6 +353,23 @@ int stm_pack_tracked_f32(const float* mask, const float* score, const int* track
                          const int64_t* cls, const float* mask_coeff, int n_rows, int hw, int B, int top_k, int cols,
                          int mask_dim, int max_age, float score_thr, int* keep_ws, float* out, stm_stream_t stream);
 
+/* ---- `_f16` entry points: the genuine-fp16 convolution path of BASELINE config 5 ("fp16 MFMA backbone convs") -----------------
+ * Replaces, for the ResNet backbone of a half-precision deployment, the same reference layers as the fp32-equivalent entries
+ * above (backbone.py:38-58 Bottleneck 1x1 / 3x3 / downsample, backbone.py:20-26,45 DCN).  One fp16 plane per tensor
+ * ([1][C/32][pixels][32] _Float16: plane format 2), weights as one fp16 plane scaled by the power of two `wscale`, ONE
+ * v_mfma_f32_16x16x32_f16 product per reference product, fp32 accumulation, fp32 bias / residual / ReLU in the epilogue.
+ * Stated tolerance: |y - y_fp64| <= 1e-3 * sum |x w| (each operand rounded to 11 bits).  g->fmt / g->planes are ignored (forced
+ * to 2 / 1); g->out_fmt_plus1 = 2 makes the layer write BOTH planes of the fp16x2 format (hand-over to a fp32-equivalent
+ * consumer).  Range guard as for fmt 1 (stm_planar_set_range_flag). */
+int stm_split_planes_f16(const float* x, void* planes, int64_t n_pixels, int C, stm_stream_t stream);
+int stm_conv_pack_weights_f16(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int tile_n, float wscale,
+                              stm_stream_t stream);
+int stm_conv2d_planar_f16(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
+                          const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu,
+                          void* workspace, size_t workspace_bytes, stm_stream_t stream);
+int stm_dcn_sample_planar_f16(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
+                              long long out_plane_stride, const stm_deform_geom* g, stm_stream_t stream);
+
 /* ---- frame pre-processing on the device (row f3) ------------------------------------------------------------------
  * Replaces the host chain of eval.py:703-717 (evaluate_single): mmcv.imresize(im, (w, h)) [cv2.resize INTER_LINEAR on
  * the uint8 HWC image] -> (im - MEANS) / STD [numpy float64] -> mmcv.impad_to_multiple(im, 32) -> permute(2,0,1).float().

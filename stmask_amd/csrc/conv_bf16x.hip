@@ -1375,3 +1375,29 @@ extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_we
     return stm_conv2d_planar_ws_f32(x_planes, packed_weight, bias, residual_f32, residual_planes, out_f32, out_planes, g, relu, nullptr,
                                     0, stream);
 }
+
+// ---- `_f16` entry points ("fp16 variants _f16 for config 5") ------------------------------------------
+// The genuine-fp16 convolution path of BASELINE config 5 under its own names: one fp16 plane per tensor (plane format 2), one
+// v_mfma_f32_16x16x32_f16 product, fp32 accumulation / bias / residual / ReLU.  Thin forms of the format-aware entries above.
+extern "C" int stm_split_planes_f16(const float* x, void* planes, int64_t n_pixels, int C, stm_stream_t stream)
+{
+    return stm_split_planes_fmt_f32(x, planes, n_pixels, C, 2, stream);
+}
+
+extern "C" int stm_conv_pack_weights_f16(const float* weight, void* packed, int Cout, int Cin, int kh, int kw, int tile_n, float wscale,
+                                         stm_stream_t stream)
+{
+    return stm_conv_pack_weights_fmt_f32(weight, packed, Cout, Cin, kh, kw, tile_n, 2, wscale, stream);
+}
+
+extern "C" int stm_conv2d_planar_f16(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
+                                     const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu,
+                                     void* workspace, size_t workspace_bytes, stm_stream_t stream)
+{
+    STM_REQUIRE(g, STM_ENULL, "stm_conv2d_planar_f16: geometry is NULL");
+    stm_conv_geom h = *g;
+    h.fmt = 2;
+    h.planes = 1;
+    return stm_conv2d_planar_ws_f32(x_planes, packed_weight, bias, residual_f32, residual_planes, out_f32, out_planes, &h, relu, workspace,
+                                    workspace_bytes, stream);
+}

@@ -899,3 +899,10 @@ extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const floa
     STM_CHECK_LAUNCH("dcn_sample_planar_kernel");
     return STM_OK;
 }
+
+// `_f16` form of the planar sampler (BASELINE config 5): columns as ONE fp16 plane
+extern "C" int stm_dcn_sample_planar_f16(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np, long long out_plane_stride,
+                                         const stm_deform_geom* g, stm_stream_t stream)
+{
+    return stm_dcn_sample_planar_fmt_f32(x, offset_mask, om_ld, planes, out_np, out_plane_stride, g, 2, stream);
+}

@@ -494,3 +494,37 @@ def test_stem_row_patches_plus_planar_conv_equals_7x7_stride2(fmt):
             assert ((y - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
     finally:
         planar.set_format(1)
+
+
+def test_f16_entry_points_are_plane_format_2():
+    """The `_f16`-named C entries of BASELINE config 5 (stm_split_planes_f16 / stm_conv_pack_weights_f16 / stm_conv2d_planar_f16 /
+    stm_dcn_sample_planar_f16) called through ctypes give the bits of the format-aware entries with fmt = 2."""
+    import ctypes
+    from stmask_amd import _lib
+    from stmask_amd._lib import c_f, c_i, c_l, c_p, c_sz
+    lib = _lib.lib()
+    stream = c_p(torch.cuda.current_stream().cuda_stream)
+    B, H, W, C, O = 2, 12, 20, 64, 96
+    x, w, b = rnd(B, H, W, C, seed=1).to(DEV), (rnd(O, C, 3, 3, seed=2) * 0.04).to(DEV), rnd(O, seed=3).to(DEV)
+    xp = torch.empty(1, C // 32, B * H * W, 32, device=DEV, dtype=torch.float16)
+    _lib.check(lib.stm_split_planes_f16(c_p(x.data_ptr()), c_p(xp.data_ptr()), c_l(B * H * W), c_i(C), stream), "stm_split_planes_f16")
+    assert torch.equal(xp, ops.split_planes(x, fmt=2))
+    pk_ref, oscale = ops.conv_pack_weights(w, tile_n=128, fmt=2)
+    pk = torch.empty_like(pk_ref)
+    _lib.check(lib.stm_conv_pack_weights_f16(c_p(w.data_ptr()), c_p(pk.data_ptr()), c_i(O), c_i(C), c_i(3), c_i(3), c_i(128), c_f(1.0 / oscale), stream),
+               "stm_conv_pack_weights_f16")
+    assert torch.equal(pk, pk_ref)
+    y_ref = ops.conv2d_planar(xp, pk, (O, C, 3, 3), (B, H, W), b, None, padding=1, relu=True, out="f32", fmt=2, out_scale=oscale)
+    g = _lib.ConvGeom(B, H, W, C, H, W, O, 3, 3, 1, 1, 1, 1, 0, 0, 0, 3)      # planes / fmt left at other values: the entry forces them
+    g.out_scale, g.tile_n = oscale, 128
+    y = torch.empty(B * H * W, O, device=DEV)
+    _lib.check(lib.stm_conv2d_planar_f16(c_p(xp.data_ptr()), c_p(pk.data_ptr()), c_p(b.data_ptr()), c_p(0), c_p(0), c_p(y.data_ptr()), c_p(0),
+                                         ctypes.byref(g), c_i(1), c_p(0), c_sz(0), stream), "stm_conv2d_planar_f16")
+    assert torch.equal(y, y_ref)
+    xs, om = rnd(1, 8, 10, 128, seed=4).to(DEV), (rnd(80, 27, seed=5) * 0.8).to(DEV)
+    cols_ref = ops.dcn_sample_planar(xs, om, 1, 1, 1, fmt=2)
+    cols = torch.empty_like(cols_ref)
+    dg = _lib.DeformGeom(1, 128, 8, 10, 3, 3, 1, 1, 1, 1, 1, 1, 1, 8, 10)
+    _lib.check(lib.stm_dcn_sample_planar_f16(c_p(xs.data_ptr()), c_p(om.data_ptr()), c_i(27), c_p(cols.data_ptr()), c_i(80), c_l(0), ctypes.byref(dg),
+                                             stream), "stm_dcn_sample_planar_f16")
+    assert cols.shape[0] == 1 and torch.equal(cols, cols_ref)
