@@ -1,24 +1,22 @@
-// conv_bf16x.hip -- dense 2-D convolution (NHWC, fp32 in / fp32 out) as an implicit GEMM on the bf16 matrix cores,
-// with every fp32 operand carried as THREE bf16 planes (x = p0 + p1 + p2, each plane round-to-nearest of the running
-// residual) and six plane products per fp32 product:
-//      x*w ~= x0 w0 + x0 w1 + x1 w0 + x1 w1 + x0 w2 + x2 w0          (dropped terms <= 2^-24 |x w|)
-// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The result carries fp32-level error (measured: 2e-7 relative to the
-// fp64 oracle, the same as an fp32 FMA chain) while the six bf16 MFMAs cost 6/16 of the one fp32 MFMA they replace
-// (fp32 matrix peak 157 TFLOP/s, bf16 2.5 PFLOP/s).  `planes == 2` keeps only x0 w0 + x0 w1 + x1 w0 (error 2^-16, three
-// MFMAs) for callers that state a looser tolerance.
+// conv_bf16x.hip -- dense 2-D convolution as an implicit GEMM on the 16-bit matrix cores with fp32-equivalent accuracy: every
+// fp32 operand travels as PLANES whose sum is the value --
+//   format 0: three bf16 planes (x = p0 + p1 + p2, each the round-to-nearest of the running residual), six plane products
+//             x*w ~= x0 w0 + x0 w1 + x1 w0 + x1 w1 + x0 w2 + x2 w0 (dropped terms <= 2^-24 |x w|), any fp32 range;
+//   format 1: two fp16 planes, x = h + l / 2048 (22 significand bits for 6.1e-5 <= |x| <= 65504), three products
+//             h h + (h l + l h) / 2048 -- half the matrix work at the same tested error (2e-6 of sum |x w| against fp64);
+//   format 2: ONE fp16 plane, one product: genuine fp16 convolution with fp32 accumulation (BASELINE config 5; 1e-3 of sum |x w|)
+// -- accumulated in fp32 by v_mfma_f32_16x16x32_{bf16,f16}.  The fp32 matrix peak of the chip is 157 TFLOP/s, the 16-bit peak 2.5 P.
 //
-// This is the reference's nn.Conv2d on the hot path -- Bottleneck 1x1/3x3 (backbone.py:38-58), FPN (FPN.py:68-108),
-// proto-net (make_net.py:5-59) and the PredictionModule_FC tower (prediction_head_FC.py:146-195), SURVEY.md section 8
-// rows a2-a5 / f4 -- with the eval-mode BatchNorm folded into the weights, and bias, residual add and ReLU fused into
-// the epilogue.
+// This is the reference's nn.Conv2d on the hot path -- Bottleneck 1x1/3x3 (backbone.py:38-58), the GEMM of dcn_v2.DCN
+// (backbone.py:20-26,45), FPN (FPN.py:68-108), proto-net (make_net.py:5-59), the PredictionModule_FC tower
+// (prediction_head_FC.py:146-195) and TemporalNet (track_to_segment_head.py:10-37), SURVEY.md section 8 rows a1-a5 / a10 / f4 --
+// with the eval-mode BatchNorm folded into the weights, and bias, residual add and ReLU fused into the epilogue.
 //
-// Tiling: one 256-thread workgroup (4 waves as 2x2) produces 128 output pixels x 128 output channels; K runs over
-// (tap, 32 input channels).  Per K-slab the activation tile (128 pixels x 32 channels fp32, one 128-B line per pixel in
-// NHWC, fetched with buffer loads whose out-of-range offsets return 0 = the zero padding) is split into planes in
-// registers and written to LDS; the weight tile arrives pre-split and pre-tiled (stm_conv_pack_weights_f32) so it is a
-// linear 24 KB copy.  LDS rows are 64 B (32 bf16) with the 16-B chunk index XORed by (row>>2)&3, which makes the
-// ds_read_b128 fragment reads of both operands conflict-free without padding.  48 KB LDS and < 256 VGPRs per thread:
-// two workgroups per CU, so one workgroup's split/stage phase runs under the other's MFMA phase.
+// Activations stay split BETWEEN layers ([planes][C/32][pixels][32], include/stmask_hip.h): each element is split once, by its
+// producer's epilogue, and staging a K-slab (one tap, 32 channels) is pure LDS-DMA.  Tiles: 128*MG pixels x 64*NJ channels, 4*MG
+// waves; LDS rows of 64 B with the 16-B chunk index XORed by f((row >> 2) & 3), conflict-free for the 16x16x32 fragment reads;
+// two LDS buffers, or a three-buffer ring with fragment prefetch (fp16 formats); split-K for grids that would idle the chip.
+// DESIGN.md section 4 has the history of this kernel and what bounds it.
 #include "stm_common.h"
 #include <algorithm>
 #include <mutex>

@@ -13,27 +13,25 @@ import numpy as np
 
 
 def bbox2result_with_id(preds, img_meta, classes):
-    """layers/eval_utils.py:15-50.  preds: dict with 'box' [n,4], 'class' [n] (or None), 'score' [n], 'segm' (list of RLE
-    dicts), 'box_ids' [n] -- tensors on any device."""
-    video_id, frame_id = img_meta["video_id"], img_meta["frame_id"]
-    results = {"video_id": video_id, "frame_id": frame_id}
-    if preds["box"].shape[0] == 0:
-        return results
-    bboxes = preds["box"].cpu().numpy()
-    labels = preds["class"].cpu().numpy() if preds["class"] is not None else None
-    scores = preds["score"].cpu().numpy()
-    segms = preds["segm"]
-    obj_ids = preds["box_ids"].cpu().numpy()
-    if labels is not None:
-        for bbox, label, score, segm, obj_id in zip(bboxes, labels, scores, segms, obj_ids):
-            if obj_id >= 0:
-                results[obj_id] = {"bbox": bbox, "label": label, "score": score, "segm": segm,
-                                   "category": classes[label - 1]}
-    else:
-        for bbox, score, segm, obj_id in zip(bboxes, scores, segms, obj_ids):
-            if obj_id >= 0:
-                results[obj_id] = {"bbox": bbox, "score": score, "segm": segm}
-    return results
+    """One frame of tracked detections -> the per-frame record `results2json_videoseg` consumes (output contract of
+    layers/eval_utils.py:15-50): `{"video_id": v, "frame_id": f, <object id>: {"bbox", "score", "segm"[, "label", "category"]}}`,
+    one entry per instance whose tracker id is >= 0 (`remove_false_inst` marks dropped instances with -1).  `preds`: 'box' [n,4],
+    'score' [n], 'box_ids' [n], 'class' [n] or None, 'segm' = n RLE dicts; tensors on any device.  Values are numpy scalars /
+    rows, exactly as the reference hands them on (numpy float32 scores matter: the per-video mean is taken in float32)."""
+    record = {"video_id": img_meta["video_id"], "frame_id": img_meta["frame_id"]}
+    n = int(preds["box"].shape[0])
+    if n == 0:
+        return record
+    to_np = lambda t: t.detach().cpu().numpy()
+    ids, boxes, scores = to_np(preds["box_ids"]), to_np(preds["box"]), to_np(preds["score"])
+    labels = to_np(preds["class"]) if preds["class"] is not None else None
+    for row in np.flatnonzero(ids >= 0):
+        entry = {"bbox": boxes[row], "score": scores[row], "segm": preds["segm"][row]}
+        if labels is not None:
+            entry["label"] = labels[row]
+            entry["category"] = classes[labels[row] - 1]
+        record[ids[row]] = entry
+    return record
 
 
 def video_records(results):
