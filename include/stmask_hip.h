@@ -214,6 +214,14 @@ int stm_mask_iou_f32(const float* m1, int n1, const float* m2, int n2, int hw, f
  * matches a detection only against the tracked instances of its own clip). */
 int stm_mask_iou_grouped_f32(const float* m1, int n1, const float* m2, int n2, int hw, float thr, float* out, const int* group1,
                              const int* group2, void* workspace, size_t workspace_bytes, stm_stream_t stream);
+/* The same two kernels without the re-read of the soft masks: stm_lincomb_sigmoid_crop_bits_f32 also writes the binarised mask
+ * (value > bits_thr) as 64-pixel words [n][ceil(h*w / 64)] (bit k of word j = pixel 64 j + k), stm_mask_iou_bits_f32 takes two
+ * such tables (mask_utils.py:111-128 + box_utils.py:435-447 on m.gt(0.5): the matching of track_TF.py:104-110). */
+int stm_lincomb_sigmoid_crop_bits_f32(const float* proto, const float* coeff, const float* boxes, float* out, int h, int w, int m,
+                                      int n, int apply_tanh, const int* n_dev, const int* row_proto, uint64_t* bits, float bits_thr,
+                                      stm_stream_t stream);
+int stm_mask_iou_bits_f32(const uint64_t* bits1, int n1, const uint64_t* bits2, int n2, int hw, float* out, const int* group1,
+                          const int* group2, stm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Fused dense-conv epilogue, in place: y = act(y + bias[c] (+ residual)).

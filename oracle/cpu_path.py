@@ -155,6 +155,16 @@ def _pack_tracked(mask, score, tracked, offsets, box, cls, mask_coeff, B, top_k,
     return out
 
 
+def _lincomb_bits(proto, coeff, boxes, row_proto, thr=0.5, apply_tanh=True):
+    """CPU stand-in: the soft masks plus a 'bit table' that simply is the binarised mask (only _mask_iou_bits reads it)."""
+    out = _lincomb(proto, coeff, boxes, apply_tanh, None, row_proto)
+    return out, out.gt(thr).reshape(out.shape[0], -1)
+
+
+def _mask_iou_bits(bits1, bits2, hw, group1=None, group2=None):
+    return _mask_iou(bits1.float().reshape(bits1.shape[0], 1, -1), bits2.float().reshape(bits2.shape[0], 1, -1), 0.5, group1, group2)
+
+
 _PATCH = {
     "bias_act_": _bias_act_,
     "deform_conv": _deform_conv,
@@ -174,6 +184,8 @@ _PATCH = {
     "jaccard": orc.jaccard,
     "lincomb_sigmoid_crop": _lincomb,
     "mask_iou": _mask_iou,
+    "lincomb_sigmoid_crop_bits": _lincomb_bits,
+    "mask_iou_bits": _mask_iou_bits,
     "gather_detections": _gather_detections,
     "shift_rois": _shift_rois,
     "shift_apply_": _shift_apply_,

@@ -151,6 +151,8 @@ struct PlanarArgs {
     int group_real[8];                               // output channels per group that are not zero padding (MFMA tiles past them are skipped)
     int n_levels;                                    // > 0: pixels are the concatenation of n_levels images sizes
     int lvl_start[9], lvl_h[8], lvl_w[8];
+    int pointwise;            // 1x1 / stride 1 / no padding / one image size: input pixel == output pixel, no coordinate arithmetic
+    float inv_hw, inv_w;      // 1 / (Ho * Wo), 1 / Wo for the pixel -> (image, row, column) split of single-size launches
     int fmt;                  // input / residual planes: 0 three bf16 planes (six products), 1 two fp16 planes (three), 2 one fp16 plane (one)
     int out_fmt;              // format of out_pl (normally fmt; a fmt-2 layer may write fmt 1 for a consumer that wants both planes)
     float out_scale;          // 1 / (power-of-two weight scale of the packed image)
@@ -184,14 +186,21 @@ __device__ __forceinline__ void park16(f32x4 (&acc)[4][2 * NJ], f32x4 (&accl)[4]
 }
 
 // bias + residual + ReLU + stores of one 8-channel segment (pixel m, channels co .. co+7, nvalid of them real); v = raw sums
+// SCALE_BIAS false: the caller has applied out_scale and the bias already.  FMT >= 0: the plane format is known at compile time (the
+// convolution kernels: it follows from their template parameters) and the branches on it fold away; -1: read it from the arguments.
+template <bool SCALE_BIAS = true, int FMT = -1>
 __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int co, int nvalid, float (&v)[8], bool have_pre = false,
                                                 f16x8 pre0 = f16x8{}, f16x8 pre1 = f16x8{})   // pre0 / pre1: this segment's fp16 residual planes, already loaded
 {
+    const int fmt = FMT >= 0 ? FMT : a.fmt;
+    const int ofmt = (FMT == 0 || FMT == 1) ? FMT : a.out_fmt;      // only a format-2 layer may write another format (1)
     const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
     // element index of (pixel m, channel co) in a slab-major planar buffer with np pixels per slab
     auto pidx = [](int m_, int co_, int np) { return ((size_t)(co_ >> 5) * np + m_) * 32 + (co_ & 31); };
+    if constexpr (SCALE_BIAS) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * a.out_scale + ((a.bias && e < nvalid) ? a.bias[co + e] : 0.0f);
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * a.out_scale + ((a.bias && e < nvalid) ? a.bias[co + e] : 0.0f);
+    }
     if (a.vec_epilogue) {                              // implies nvalid == 8
         if (a.res_f32) {
             const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.res_f32 + (size_t)m * a.res_ld + co);
@@ -200,11 +209,11 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         }
         if (a.res_pl) {
             const size_t ri = pidx(m, co, a.res_np) * 2;
-            if (a.fmt == 2) {
+            if (fmt == 2) {
                 const f16x8 p0 = have_pre ? pre0 : *reinterpret_cast<const f16x8*>(a.res_pl + ri);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)p0[e];
-            } else if (a.fmt == 1) {
+            } else if (fmt == 1) {
                 const f16x8 p0 = have_pre ? pre0 : *reinterpret_cast<const f16x8*>(a.res_pl + ri);
                 const f16x8 p1 = have_pre ? pre1 : *reinterpret_cast<const f16x8*>(a.res_pl + ri + rpl * 2);
 #pragma unroll
@@ -228,7 +237,7 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         }
         if (a.out_pl) {
             uint8_t* o = a.out_pl + pidx(m, co, a.out_np) * 2;
-            store_planes8(o, opl * 2, v, a.out_fmt, a.range_flag, a.nt_out != 0);
+            store_planes8(o, opl * 2, v, ofmt, a.range_flag, a.nt_out != 0);
         }
         return;
     }
@@ -241,10 +250,10 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         if (a.res_f32) x += a.res_f32[(size_t)m * a.res_ld + co + e];
         if (resp) {
             const size_t ri = pidx(m, co + e, a.res_np);
-            if (a.fmt >= 1) {
+            if (fmt >= 1) {
                 const _Float16* rh = reinterpret_cast<const _Float16*>(a.res_pl);
                 x += (float)rh[ri];
-                if (a.fmt == 1) x += (float)rh[ri + rpl] * (1.0f / STM_F16_LOW_SCALE);
+                if (fmt == 1) x += (float)rh[ri + rpl] * (1.0f / STM_F16_LOW_SCALE);
             } else {
                 x += ((float)resp[ri] + (float)resp[ri + rpl]) + (float)resp[ri + 2 * rpl];
             }
@@ -253,11 +262,11 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co + e] = x;
         if (outp) {
             const size_t oi = pidx(m, co + e, a.out_np);
-            if (a.out_fmt >= 1) {
+            if (ofmt >= 1) {
                 _Float16* oh = reinterpret_cast<_Float16*>(a.out_pl);
                 const _Float16 h = (_Float16)x;
                 oh[oi] = h;
-                if (a.out_fmt == 1) oh[oi + opl] = (_Float16)((x - (float)h) * STM_F16_LOW_SCALE);
+                if (ofmt == 1) oh[oi + opl] = (_Float16)((x - (float)h) * STM_F16_LOW_SCALE);
                 if (!(fabsf(x) <= 65504.0f) && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
             } else {
                 const __bf16 h = (__bf16)x;
@@ -271,10 +280,11 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
     }
 }
 
-template <int NJ>
+template <int NJ, int FMT = -1>
 __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_t* smem, int wave, int lane, int m0, int n0g, int grp,
                                                      int wm, int wn)
 {
+    const int fmt = FMT >= 0 ? FMT : a.fmt;
     constexpr int EP_LD = 32 * NJ + 4;                 // floats per parked pixel row (+ 4 pad)
     constexpr int LPR = 4 * NJ;                        // lanes per pixel row (8 channels each)
     const float* park = park_base<NJ>(smem, wave);
@@ -290,7 +300,21 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
     // (expanding 1x1 convolutions of the bottlenecks) then run at the latency of four dependent round trips.  The fragment
     // and accumulator registers are dead here, so the 8 * LPR registers cost nothing.
     // (64-channel tiles only: with LPR = 8 the 64 extra registers push the 256 x 128 kernel into scratch -- 380 -> 1065 us)
-    const bool pre = NJ == 1 && a.vec_epilogue && a.res_pl != nullptr && a.fmt >= 1;
+    // bias of this lane's 8 channels: loaded once, not once per pass and element
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.0f;
+    if (a.bias) {
+        if (nvalid == 8 && a.vec_epilogue) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co), b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
+            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < nvalid) bias8[e] = a.bias[co + e];
+        }
+    }
+    const bool pre = NJ == 1 && a.vec_epilogue && a.res_pl != nullptr && fmt >= 1;
     f16x8 r0[LPR], r1[LPR];
     if (pre) {
 #pragma unroll
@@ -298,7 +322,7 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
             const int m = min(m0 + wm * 64 + pass * (64 / LPR) + prow, a.M - 1);
             const size_t ri = (((size_t)(co >> 5) * a.res_np + m) * 32 + (co & 31)) * 2;
             r0[pass] = *reinterpret_cast<const f16x8*>(a.res_pl + ri);
-            r1[pass] = a.fmt == 1 ? *reinterpret_cast<const f16x8*>(a.res_pl + ri + a.res_pstride) : r0[pass];   // fmt 2: one plane
+            r1[pass] = fmt == 1 ? *reinterpret_cast<const f16x8*>(a.res_pl + ri + a.res_pstride) : r0[pass];   // fmt 2: one plane
         }
     }
 #pragma unroll
@@ -309,8 +333,10 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        if (pre) epilogue_store8(a, m, co, nvalid, v, true, r0[pass], r1[pass]);
-        else epilogue_store8(a, m, co, nvalid, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * a.out_scale + bias8[e];
+        if (pre) epilogue_store8<false, FMT>(a, m, co, nvalid, v, true, r0[pass], r1[pass]);
+        else epilogue_store8<false, FMT>(a, m, co, nvalid, v);
     }
 }
 
@@ -338,7 +364,8 @@ __global__ __launch_bounds__(256) void planar_splitk_finish_kernel(const PlanarA
 // (v_mfma_f32_16x16x32_bf16 -- the 16x16x32 shape spends less energy per flop than 32x32x16 and the chip is power-limited here:
 // 593 vs 656 us on the 145-GF proto layer); ST = 3: three-buffer LDS ring with fragment prefetch (fp16 formats), 2: two buffers.
 // ABL (builds with -DSTM_ABLATE only): timing ablations of the ring loop, RESULTS ARE WRONG -- 1 no DMA, 2 no barrier, 4 no
-// fragment reads, 8 no wait for the DMAs.
+// fragment reads, 8 no wait for the DMAs, 16 activation DMA on every third slab only (the traffic of a kx-reuse staging), 32 no
+// activation DMA, 64 no weight DMA.
 // (Tried and removed, round 2: loading the residual planes of a 64-channel tile BEFORE the K loop -- no change on the HBM-bound
 // expanding 1x1 convolutions, 337 vs 345 us, for 32 more live registers and one wave per SIMD less; and resident workgroups
 // walking the tiles instead of one workgroup per tile -- 404 -> 451 us.  Neither the epilogue's second memory round trip nor
@@ -361,10 +388,12 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     const int per_xcd = (tiles + 7) >> 3;
     const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (logical >= tiles) return;
-    const int ksp = logical % a.splitk;                  // split-K part (the parts of one tile sit on one XCD)
-    const int tile = logical / a.splitk;
-    const int nt = tile % a.n_tiles;
-    const int mt = tile / a.n_tiles;
+    // (integer divisions cost ~40 instructions each on this ISA and a short-K tile is only a few hundred MFMA cycles long: the
+    // common cases -- no split-K, one n-tile, one group -- take none)
+    const int ksp = a.splitk == 1 ? 0 : logical % a.splitk;      // split-K part (the parts of one tile sit on one XCD)
+    const int tile = a.splitk == 1 ? logical : logical / a.splitk;
+    const int mt = a.n_tiles == 1 ? tile : (a.n_tiles == 2 ? tile >> 1 : (a.n_tiles == 4 ? tile >> 2 : tile / a.n_tiles));
+    const int nt = tile - mt * a.n_tiles;
     const int m0 = mt * BM;
     const int s_begin = ksp * a.kslabs, s_end = min(a.slabs, s_begin + a.kslabs);
 
@@ -373,7 +402,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     const int wm = wave % (2 * MG), wn = wave / (2 * MG);
 
     // grouped convolution: n-tile -> group; the group reads its own C input channels and writes its own cout_g outputs
-    const int grp = nt / a.ntpg;
+    const int grp = a.groups == 1 ? 0 : nt / a.ntpg;
     const int n0g = (nt - grp * a.ntpg) * BN;           // first output channel of this tile within its group
     const int creal = a.group_real[grp & 7];            // real (not zero-padding) output channels of the group
     // DMA duties of this lane: activation row groups 2*wave and 2*wave+1 (16 rows x 64 B each, all planes)
@@ -385,6 +414,14 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         const int m = m0 + r;
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
+        if (a.pointwise) {
+            // 1x1 convolution without stride or padding: the pixel is its own 1 x 1 image at offset m
+            iy0[i] = ok ? 0 : -(1 << 20);
+            ix0[i] = 0;
+            hl[i] = 1; wl[i] = 1;
+            pbase[i] = mm * 64 + ((slot ^ swz(r)) << 4);
+            continue;
+        }
         int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, first = 0, local = mm;
         if (a.n_levels > 0) {
             // the pixel axis concatenates several image sizes (the FPN levels a shared head runs over): find this
@@ -394,9 +431,22 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                 if (l < a.n_levels && mm >= a.lvl_start[l]) { first = a.lvl_start[l]; H = a.lvl_h[l]; W = a.lvl_w[l]; }
             Ho = H; Wo = W; local = mm - first;
         }
-        const int b = local / (Ho * Wo);
-        const int rem = local - b * (Ho * Wo);
-        const int oy = rem / Wo, ox = rem - oy * Wo;
+        int b, rem, oy, ox;
+        if (a.n_levels > 0) {
+            b = local / (Ho * Wo);
+            rem = local - b * (Ho * Wo);
+            oy = rem / Wo;
+        } else {
+            // reciprocal multiply + one correction step instead of two integer divisions (exact: pixel counts < 2^24)
+            const int hw = Ho * Wo;
+            b = (int)((float)local * a.inv_hw);
+            rem = local - b * hw;
+            if (rem < 0) { --b; rem += hw; } else if (rem >= hw) { ++b; rem -= hw; }
+            oy = (int)((float)rem * a.inv_w);
+            int t = rem - oy * Wo;
+            if (t < 0) --oy; else if (t >= Wo) ++oy;
+        }
+        ox = rem - oy * Wo;
         iy0[i] = ok ? oy * a.sh - a.ph : -(1 << 20);
         ix0[i] = ox * a.sw - a.pw;
         hl[i] = H; wl[i] = W;
@@ -412,10 +462,17 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
 
-    int s_tap = s_begin % (a.kh * a.kw), s_c = s_begin / (a.kh * a.kw);
-    auto dma_x = [&](int buf) {
+    // K-slab -> (channel slab, ky, kx), kept as counters: a division per slab would cost more than the slab's DMA issue
+    int s_c = 0, s_ky = 0, s_kx = 0;
+    if (s_begin != 0) {
+        const int s_tap = s_begin % taps;
+        s_c = s_begin / taps;
+        s_ky = s_tap / a.kw;
+        s_kx = s_tap - s_ky * a.kw;
+    }
+    auto dma_x = [&](int buf, bool issue = true) {
         uint8_t* xb = smem + buf * BUF;
-        const int ky = s_tap / a.kw, kx = s_tap - ky * a.kw;
+        const int ky = s_ky, kx = s_kx;
         const int slab_off = (grp * cslabs + s_c) * (a.x_np * 64);     // uniform: this K-slab's channel slab
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -425,9 +482,12 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
             const unsigned off = (unsigned)(pbase[i] + (iy * wl[i] + ix) * 64 + slab_off) | (oob << 31);
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(xb + p * (BM * 64) + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
+                if (issue) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(xb + p * (BM * 64) + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
         }
-        if (++s_tap == taps) { s_tap = 0; ++s_c; }
+        if (++s_kx == a.kw) {
+            s_kx = 0;
+            if (++s_ky == a.kh) { s_ky = 0; ++s_c; }
+        }
     };
     auto dma_w = [&](int slab, int buf) {
         uint8_t* wb = smem + buf * BUF + XBUF;
@@ -490,8 +550,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
                 _Pragma("unroll") for (int p = 0; p < NPL; ++p)                                                                 \
                     if (!(ABL & 4)) af1[i][p] = *reinterpret_cast<const bf16x8*>(xs + xoff[2 + i] + p * (BM * 64));            \
             if (DMA_ && !(ABL & 1)) {                                                                                           \
-                dma_x(dmb);                                                                                                     \
-                dma_w(min((S_) + 2, s_end - 1), dmb);                                                                           \
+                dma_x(dmb, !(ABL & 32) && (!(ABL & 16) || ((S_) + 2) % 3 == 0));                                                \
+                if (!(ABL & 64)) dma_w(min((S_) + 2, s_end - 1), dmb);                                                          \
             }                                                                                                                   \
             _Pragma("unroll") for (int j = 0; j < 2 * NJ; ++j) {                                                                \
                 if constexpr (NPL == 2) {                                                                                       \
@@ -523,8 +583,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         {                                                                                                                       \
             const uint8_t* xn = smem + nxt * BUF;                                                                               \
             if (DMA_ && !(ABL & 1)) {                                                                                           \
-                dma_x(dmb);                                                                                                     \
-                dma_w(min((S_) + 2, s_end - 1), dmb);                                                                           \
+                dma_x(dmb, !(ABL & 32) && (!(ABL & 16) || ((S_) + 2) % 3 == 0));                                                \
+                if (!(ABL & 64)) dma_w(min((S_) + 2, s_end - 1), dmb);                                                          \
             }                                                                                                                   \
             if (PRE_ && !(ABL & 4)) {                                                                                           \
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                   \
@@ -569,6 +629,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
             // slab s+1 (issued one slab ago) has landed for this wave, then for every wave; slab s+2's DMAs stay in flight
             if constexpr (ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // no wait for the DMAs to land
             else if constexpr (ABL & 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+            else if constexpr ((ABL & 48) != 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WDMA) : "memory");   // fewer A DMAs in flight
+            else if constexpr ((ABL & 64) != 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NPL) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA) : "memory");
             RING_HALF1(true, s, false);
             cur = nxt; nxt = dmb; dmb = dmb == 2 ? 0 : dmb + 1;
@@ -708,7 +770,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
             *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
         }
     } else {
-        planar_epilogue_tail<NJ>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
+        planar_epilogue_tail<NJ, DT == 1 ? (NPL == 2 ? 1 : 2) : 0>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
     }
 #endif
 }
@@ -1276,6 +1338,10 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     a.vec_epilogue = (cout_g % 8 == 0) && (!out_f32 || out_ld % 4 == 0) && (!residual_f32 || res_ld % 4 == 0) && ((uintptr_t)out_f32 % 16 == 0) &&
                      ((uintptr_t)out_planes % 16 == 0) && ((uintptr_t)residual_f32 % 16 == 0) && ((uintptr_t)residual_planes % 16 == 0) &&
                      (ops % 8 == 0) && (rps % 8 == 0) && !tn.scalar_epilogue;
+    a.pointwise = (g->n_levels <= 0 && g->kh == 1 && g->kw == 1 && g->sh == 1 && g->sw == 1 && g->ph == 0 && g->pw == 0) ? 1 : 0;
+    a.inv_hw = g->n_levels > 0 ? 0.0f : 1.0f / (float)((int64_t)g->Ho * g->Wo);
+    a.inv_w = g->n_levels > 0 ? 0.0f : 1.0f / (float)g->Wo;
+    STM_REQUIRE(g->n_levels > 0 || M < ((int64_t)1 << 24), STM_EUNSUPPORTED, "%s: more than 2^24 output pixels in one launch", who);
     a.fmt = (g->fmt >= 0 && g->fmt <= 2) ? g->fmt : 0;
     a.out_fmt = g->out_fmt_plus1 > 0 ? g->out_fmt_plus1 - 1 : a.fmt;
     STM_REQUIRE(a.out_fmt >= 0 && a.out_fmt <= 2 && (a.out_fmt == a.fmt || (a.fmt == 2 && a.out_fmt == 1)), STM_EINVAL,
@@ -1350,7 +1416,8 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         const int abl = tn.abl;
         rc = abl == 1 ? launch_planar<2, 2, 2, 1, 3, 1>(a, tiles, stream) : abl == 2 ? launch_planar<2, 2, 2, 1, 3, 2>(a, tiles, stream)
            : abl == 3 ? launch_planar<2, 2, 2, 1, 3, 3>(a, tiles, stream) : abl == 5 ? launch_planar<2, 2, 2, 1, 3, 5>(a, tiles, stream)
-           : abl == 8 ? launch_planar<2, 2, 2, 1, 3, 8>(a, tiles, stream)
+           : abl == 8 ? launch_planar<2, 2, 2, 1, 3, 8>(a, tiles, stream) : abl == 16 ? launch_planar<2, 2, 2, 1, 3, 16>(a, tiles, stream)
+           : abl == 32 ? launch_planar<2, 2, 2, 1, 3, 32>(a, tiles, stream) : abl == 64 ? launch_planar<2, 2, 2, 1, 3, 64>(a, tiles, stream)
                       : launch_planar<2, 2, 2, 1, 3, 7>(a, tiles, stream);
         return rc != STM_OK ? rc : finish_splitk();
     }

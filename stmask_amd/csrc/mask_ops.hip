@@ -20,7 +20,8 @@ template <int M>
 __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ proto, const float* __restrict__ coeff,
                                                       const float* __restrict__ boxes, float* __restrict__ out, int h,
                                                       int w, int n, int apply_tanh, const int* __restrict__ n_dev,
-                                                      const int* __restrict__ row_proto)
+                                                      const int* __restrict__ row_proto, unsigned long long* __restrict__ bits,
+                                                      float bits_thr)
 {
     __shared__ float sc[LC_DCHUNK * M];
     __shared__ float sb[LC_DCHUNK * 4];  // x1, x2, y1, y2 (float bounds, padding 1)
@@ -47,7 +48,13 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ 
         sb[threadIdx.x * 4 + 3] = y2;
     }
     __syncthreads();
-    if (pix >= hw) return;
+    // bits != null: also the binarised mask (v > bits_thr) as 64-pixel words [n][ceil(hw / 64)] -- what mask IoU consumes
+    // (box_utils.py:435-447 on m.gt(0.5)); a wave is 64 consecutive pixels, so the word is one ballot.  Waves that lie
+    // entirely past the last pixel leave; lanes past it inside the last wave stay for the ballot and vote 0.
+    const bool live = pix < hw;
+    if (!bits && !live) return;
+    if (bits && ((pix & ~63) >= hw)) return;
+    const int words = (hw + 63) >> 6;
 
     float p[M];
     int cur = -1;  // prototype set currently held in registers (rows of several frames may share one launch)
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ 
     const float fx = (float)x, fy = (float)y;
     for (int d = 0; d < nd; ++d) {
         const int want = row_proto ? row_proto[d0 + d] : 0;  // wave-uniform
-        if (want != cur) {
+        if (want != cur && live) {
             cur = want;
             const float4* pr = reinterpret_cast<const float4*>(proto + ((int64_t)cur * hw + pix) * M);
 #pragma unroll
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ 
             }
         }
         float v = 0.0f;
-        const bool inside = (d0 + d < n_valid) && fx >= sb[d * 4] && fx < sb[d * 4 + 1] && fy >= sb[d * 4 + 2] &&
+        const bool inside = live && (d0 + d < n_valid) && fx >= sb[d * 4] && fx < sb[d * 4 + 1] && fy >= sb[d * 4 + 2] &&
                             fy < sb[d * 4 + 3];
         if (inside) {
             float acc = 0.0f;
@@ -73,7 +80,11 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ 
             for (int k = 0; k < M; ++k) acc = fmaf(p[k], sc[d * M + k], acc);
             v = 1.0f / (1.0f + expf(-acc));
         }
-        out[(int64_t)(d0 + d) * hw + pix] = v;
+        if (live) out[(int64_t)(d0 + d) * hw + pix] = v;
+        if (bits) {
+            const unsigned long long bal = __ballot(v > bits_thr);
+            if ((threadIdx.x & 63) == 0) bits[(int64_t)(d0 + d) * words + (pix >> 6)] = bal;
+        }
     }
 }
 
@@ -131,10 +142,21 @@ __global__ __launch_bounds__(256) void mask_iou_pairs_kernel(const unsigned long
 
 }  // namespace
 
+extern "C" int stm_lincomb_sigmoid_crop_bits_f32(const float* proto, const float* coeff, const float* boxes, float* out, int h, int w, int m,
+                                                 int n, int apply_tanh, const int* n_dev, const int* row_proto, uint64_t* bits, float bits_thr,
+                                                 stm_stream_t stream);
 extern "C" int stm_lincomb_sigmoid_crop_f32(const float* proto, const float* coeff, const float* boxes, float* out, int h,
                                             int w, int m, int n, int apply_tanh, const int* n_dev, const int* row_proto,
                                             stm_stream_t stream)
 {
+    return stm_lincomb_sigmoid_crop_bits_f32(proto, coeff, boxes, out, h, w, m, n, apply_tanh, n_dev, row_proto, nullptr, 0.5f, stream);
+}
+
+extern "C" int stm_lincomb_sigmoid_crop_bits_f32(const float* proto, const float* coeff, const float* boxes, float* out, int h, int w, int m,
+                                                 int n, int apply_tanh, const int* n_dev, const int* row_proto, uint64_t* bits_out, float bits_thr,
+                                                 stm_stream_t stream)
+{
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(bits_out);
     STM_REQUIRE(n >= 0, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: n=%d", n);
     if (n == 0) return STM_OK;
     STM_REQUIRE(proto && coeff && out, STM_ENULL, "stm_lincomb_sigmoid_crop_f32: proto/coeff/out must be non-NULL");
@@ -144,13 +166,13 @@ extern "C" int stm_lincomb_sigmoid_crop_f32(const float* proto, const float* coe
     STM_REQUIRE(grid.y <= 65535, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: n=%d too large", n);
     if (m == 32) {
         hipLaunchKernelGGL(lincomb_kernel<32>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
-                           apply_tanh, n_dev, row_proto);
+                           apply_tanh, n_dev, row_proto, bits, bits_thr);
     } else if (m == 8) {
         hipLaunchKernelGGL(lincomb_kernel<8>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
-                           apply_tanh, n_dev, row_proto);
+                           apply_tanh, n_dev, row_proto, bits, bits_thr);
     } else if (m == 64) {
         hipLaunchKernelGGL(lincomb_kernel<64>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
-                           apply_tanh, n_dev, row_proto);
+                           apply_tanh, n_dev, row_proto, bits, bits_thr);
     } else {
         STM_REQUIRE(false, STM_EUNSUPPORTED, "stm_lincomb_sigmoid_crop_f32: mask_dim %d not in {8,32,64}", m);
     }
@@ -190,6 +212,23 @@ extern "C" int stm_mask_iou_grouped_f32(const float* m1, int n1, const float* m2
     STM_CHECK_LAUNCH("mask_pack_kernel");
     hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n2, 256), n1), dim3(256), (size_t)words * 8, stm_hs(stream), b1,
                        b2, n2, words, out, group1, group2);
+    STM_CHECK_LAUNCH("mask_iou_pairs_kernel");
+    return STM_OK;
+}
+
+// mask IoU of masks that are already bit-packed (stm_lincomb_sigmoid_crop_bits_f32): the pairs kernel alone
+extern "C" int stm_mask_iou_bits_f32(const uint64_t* bits1, int n1, const uint64_t* bits2, int n2, int hw, float* out, const int* group1,
+                                     const int* group2, stm_stream_t stream)
+{
+    STM_REQUIRE((group1 == nullptr) == (group2 == nullptr), STM_EINVAL, "stm_mask_iou_bits_f32: give both group arrays or neither");
+    STM_REQUIRE(n1 >= 0 && n2 >= 0 && hw > 0, STM_EINVAL, "stm_mask_iou_bits_f32: bad sizes");
+    if (n1 == 0 || n2 == 0) return STM_OK;
+    STM_REQUIRE(bits1 && bits2 && out, STM_ENULL, "stm_mask_iou_bits_f32: bits1/bits2/out must be non-NULL");
+    STM_REQUIRE(n1 <= 65535 && n2 <= 65535, STM_EINVAL, "stm_mask_iou_bits_f32: too many masks");
+    const int words = (hw + 63) / 64;
+    hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n2, 256), n1), dim3(256), (size_t)words * 8, stm_hs(stream),
+                       reinterpret_cast<const unsigned long long*>(bits1), reinterpret_cast<const unsigned long long*>(bits2), n2, words, out, group1,
+                       group2);
     STM_CHECK_LAUNCH("mask_iou_pairs_kernel");
     return STM_OK;
 }

@@ -354,6 +354,37 @@ def jaccard(a, b):
     return out
 
 
+def lincomb_sigmoid_crop_bits(proto, coeff, boxes, row_proto, thr=0.5, apply_tanh=True):
+    """lincomb_sigmoid_crop that also returns the binarised masks (value > thr) bit-packed, [n, ceil(h*w/64)] int64 words -- the
+    form mask_iou_bits consumes, produced in the pass that writes the soft masks instead of a second read of them."""
+    _dev(proto, coeff, boxes, row_proto)
+    proto, coeff = _f32c(proto), _f32c(coeff)
+    assert proto.dim() == 4 and row_proto.dtype == torch.int32 and row_proto.numel() == coeff.shape[0]
+    h, w, m = proto.shape[1:]
+    n = coeff.shape[0]
+    out = torch.empty(n, h, w, dtype=torch.float32, device=proto.device)
+    bits = torch.empty(n, (h * w + 63) // 64, dtype=torch.int64, device=proto.device)
+    check(_lib.lib().stm_lincomb_sigmoid_crop_bits_f32(_p(proto), _p(coeff), _p(_f32c(boxes)), _p(out), c_i(h), c_i(w), c_i(m), c_i(n),
+                                                       c_i(1 if apply_tanh else 0), c_p(0), _p(row_proto), _p(bits), c_f(thr), _stream()),
+          "stm_lincomb_sigmoid_crop_bits_f32")
+    return out, bits
+
+
+def mask_iou_bits(bits1, bits2, hw, group1=None, group2=None):
+    """box_utils.py:435-447 on bit-packed binary masks (lincomb_sigmoid_crop_bits) -> [n1, n2]; groups as in mask_iou."""
+    _dev(bits1, bits2, group1, group2)
+    n1, n2 = bits1.shape[0], bits2.shape[0]
+    out = torch.zeros(n1, n2, dtype=torch.float32, device=bits1.device)
+    if n1 == 0 or n2 == 0:
+        return out
+    if bits1.dtype != torch.int64 or bits2.dtype != torch.int64 or bits1.shape[1] != (hw + 63) // 64 or bits2.shape[1] != bits1.shape[1]:
+        raise StmError("mask_iou_bits: bit tables must be int64 [n, ceil(hw / 64)]")
+    check(_lib.lib().stm_mask_iou_bits_f32(_p(bits1.contiguous()), c_i(n1), _p(bits2.contiguous()), c_i(n2), c_i(hw), _p(out),
+                                           _p(group1.contiguous()) if group1 is not None else c_p(0),
+                                           _p(group2.contiguous()) if group2 is not None else c_p(0), _stream()), "stm_mask_iou_bits_f32")
+    return out
+
+
 def lincomb_sigmoid_crop(proto, coeff, boxes=None, apply_tanh=True, n_dev=None, row_proto=None):
     """generate_mask (mask_utils.py:111-128) + crop.  proto [h,w,m], coeff [n,m], boxes [n,4] -> [n,h,w].
     With row_proto (int32 [n]) proto is [P,h,w,m] and row i uses proto[row_proto[i]] (rows of many clips, one launch)."""

@@ -149,7 +149,8 @@ class BatchedClipPipeline:
         self.timer.toc("tf_temporalnet")
         # decode(loc_shift, center_size(box)) / coeff += shift / score *= 0.95 in one launch, in place on the tracked rows
         ops.shift_apply_(loc_shift, coeff_shift, prev["box"], prev["mask_coeff"], prev["score"], 0.95)
-        prev["mask"] = ops.lincomb_sigmoid_crop(proto, prev["mask_coeff"], prev["box"], apply_tanh=True, row_proto=clip_of_row)
+        # masks of the shifted instances on the CURRENT prototypes, and their > 0.5 bits for this step's mask IoU (one pass)
+        prev["mask"], self._prev_bits = ops.lincomb_sigmoid_crop_bits(proto, prev["mask_coeff"], prev["box"], clip_of_row)
         self.timer.toc("tf_masks")
         for b in range(self.B):
             self.tracked[b] = [v + 1 for v in self.tracked[b]]
@@ -270,8 +271,10 @@ class BatchedClipPipeline:
         top_k = cfg.nms_top_k
         # ---- detections of all clips, concatenated (rows sorted by clip): one gather kernel ------------------------------
         det = ops.gather_detections(idx, cls, score, box, cnt, pred["mask_coeff"], pred["track"], pred["centerness"], D)
-        det["mask"] = (ops.lincomb_sigmoid_crop(proto, det["mask_coeff"], det["box"], apply_tanh=True, row_proto=det["clip"])
-                       if D else proto.new_zeros(0, proto.shape[1], proto.shape[2]))
+        if D:
+            det["mask"], det_bits = ops.lincomb_sigmoid_crop_bits(proto, det["mask_coeff"], det["box"], det["clip"])
+        else:
+            det["mask"], det_bits = proto.new_zeros(0, proto.shape[1], proto.shape[2]), None
         tmr.toc("det_gather_masks")
         det_scores = [float(host_scores[b * top_k + j]) for b in range(B) for j in range(counts[b])]   # row order of det
 
@@ -286,7 +289,8 @@ class BatchedClipPipeline:
             if D and Pn:
                 # matching scores for all clips at once; pairs from different clips can never match
                 cos = det["track"] @ prev["track"].t()
-                miou = ops.mask_iou(det["mask"], prev["mask"], group1=det["clip"], group2=prev["clip"])   # same-clip pairs only
+                miou = ops.mask_iou_bits(det_bits, self._prev_bits, proto.shape[1] * proto.shape[2], group1=det["clip"],
+                                         group2=prev["clip"])                               # same-clip pairs only
                 match = ops.match_scores(cos, miou, det["box"], prev["box"], det["score"], det["class"], prev["class"], det["clip"],
                                          self._off_dev, cfg.match_coeff, 0.3)
                 ids = match.tolist()  # host read 2

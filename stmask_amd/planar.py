@@ -321,11 +321,16 @@ class PlanarGraph:
                 h, w = sizes[j]
                 res = None
                 if x is not None:
-                    up = F.interpolate(x, size=(h, w), mode=fpn.interpolation_mode, align_corners=False)
-                    res = _nhwc(up).view(-1, conv.O)
-                if j > 0:                                  # a finer level follows: it upsamples this one in fp32
+                    if fpn.interpolation_mode == "bilinear":
+                        # the upsampled coarser level goes straight to planes (the residual form the epilogue reads fastest):
+                        # no fp32 upsampled tensor, no layout copy
+                        res = ops.resize_bilinear_planes(x, (h, w), self.fmt)
+                    else:
+                        up = F.interpolate(x.permute(0, 3, 1, 2), size=(h, w), mode=fpn.interpolation_mode)
+                        res = _nhwc(up).view(-1, conv.O)
+                if j > 0:                                  # a finer level follows: it upsamples this one (fp32 NHWC)
                     y32, latp[j] = conv(planes[j][0], ("img", B, h, w), out="both", residual=res)
-                    x = y32.view(B, h, w, conv.O).permute(0, 3, 1, 2)
+                    x = y32.view(B, h, w, conv.O)
                 else:
                     latp[j] = conv(planes[j][0], ("img", B, h, w), out="planes", residual=res)
         else:

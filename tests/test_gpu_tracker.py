@@ -132,3 +132,32 @@ def test_pack_tracked_equals_keep_rule_and_scatter():
                            10, 0.05).cpu()
     assert torch.equal(got, want)
     assert int((got[1, :, 7] > 0).sum()) == 20 and int((got[2, :, 7] > 0).sum()) == 0
+
+
+def test_lincomb_bits_and_mask_iou_bits_equal_the_two_pass_form():
+    """stm_lincomb_sigmoid_crop_bits_f32 writes the soft masks AND their (> 0.5) bits in one pass; stm_mask_iou_bits_f32 on those
+    bits equals stm_mask_iou_grouped_f32 on the soft masks (which packs them itself), for a pixel count that is not a multiple of
+    64 or 256 as well."""
+    for (h, w) in [(24, 40), (13, 11), (96, 160)]:
+        g = torch.Generator().manual_seed(h)
+        protos = torch.relu(torch.randn(3, h, w, 32, generator=g))
+        n1, n2 = 19, 33
+        c1, c2 = torch.randn(n1, 32, generator=g), torch.randn(n2, 32, generator=g)
+        mk = lambda n: torch.cat([torch.rand(n, 2, generator=g) * 0.5, torch.rand(n, 2, generator=g) * 0.5 + 0.5], 1)
+        b1, b2 = mk(n1), mk(n2)
+        r1 = torch.sort(torch.randint(0, 3, (n1,), generator=g)).values.to(torch.int32)
+        r2 = torch.sort(torch.randint(0, 3, (n2,), generator=g)).values.to(torch.int32)
+        m1, bits1 = ops.lincomb_sigmoid_crop_bits(_d(protos), _d(c1), _d(b1), _d(r1))
+        m2, bits2 = ops.lincomb_sigmoid_crop_bits(_d(protos), _d(c2), _d(b2), _d(r2))
+        ref1 = ops.lincomb_sigmoid_crop(_d(protos), _d(c1), _d(b1), apply_tanh=True, row_proto=_d(r1))
+        assert torch.equal(m1, ref1)
+        # the words: bit k of word j = pixel 64 j + k
+        flat = (m1.reshape(n1, -1) > 0.5).cpu()
+        words = bits1.cpu()
+        for row in (0, n1 - 1):
+            got = torch.tensor([(int(words[row, p // 64]) >> (p % 64)) & 1 for p in range(h * w)], dtype=torch.bool)
+            assert torch.equal(got, flat[row])
+        want = ops.mask_iou(m1, m2, group1=_d(r1), group2=_d(r2))
+        got = ops.mask_iou_bits(bits1, bits2, h * w, group1=_d(r1), group2=_d(r2))
+        assert torch.equal(got, want)
+        assert torch.equal(ops.mask_iou_bits(bits1, bits2, h * w), ops.mask_iou(m1, m2))
