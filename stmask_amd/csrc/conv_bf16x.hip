@@ -199,7 +199,7 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
     auto pidx = [](int m_, int co_, int np) { return ((size_t)(co_ >> 5) * np + m_) * 32 + (co_ & 31); };
     if constexpr (SCALE_BIAS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * a.out_scale + ((a.bias && e < nvalid) ? a.bias[co + e] : 0.0f);
+        for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], a.out_scale, (a.bias && e < nvalid) ? a.bias[co + e] : 0.0f);
     }
     if (a.vec_epilogue) {                              // implies nvalid == 8
         if (a.res_f32) {
@@ -216,8 +216,9 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
             } else if (fmt == 1) {
                 const f16x8 p0 = have_pre ? pre0 : *reinterpret_cast<const f16x8*>(a.res_pl + ri);
                 const f16x8 p1 = have_pre ? pre1 : *reinterpret_cast<const f16x8*>(a.res_pl + ri + rpl * 2);
+                // l / 2048 is exact, so fma(l, 1/2048, h) is the same single rounding as h + l * (1/2048) (v_fma_mix_f32: no converts)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)p0[e] + (float)p1[e] * (1.0f / STM_F16_LOW_SCALE);
+                for (int e = 0; e < 8; ++e) v[e] += __builtin_fmaf((float)p1[e], 1.0f / STM_F16_LOW_SCALE, (float)p0[e]);
             } else {
                 const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri);
                 const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a.res_pl + ri + rpl * 2);
@@ -228,7 +229,7 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
         }
         if (a.relu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+            for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaxf(v[e], 0.0f);   // (nan -> 0 and -0 -> +0, as `v > 0 ? v : 0` gives)
         }
         if (a.out_f32) {
             float* o = a.out_f32 + (size_t)m * a.out_ld + co;
@@ -333,8 +334,10 @@ __device__ __forceinline__ void planar_epilogue_tail(const PlanarArgs& a, uint8_
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(park + pr * EP_LD + seg * 8 + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        // out_scale is a power of two: v * out_scale is exact, so the fused form rounds exactly like multiply-then-add (one
+        // instruction per element instead of two under -ffp-contract=off)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * a.out_scale + bias8[e];
+        for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], a.out_scale, bias8[e]);
         if (pre) epilogue_store8<false, FMT>(a, m, co, nvalid, v, true, r0[pass], r1[pass]);
         else epilogue_store8<false, FMT>(a, m, co, nvalid, v);
     }
@@ -405,8 +408,13 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     const int grp = a.groups == 1 ? 0 : nt / a.ntpg;
     const int n0g = (nt - grp * a.ntpg) * BN;           // first output channel of this tile within its group
     const int creal = a.group_real[grp & 7];            // real (not zero-padding) output channels of the group
-    // DMA duties of this lane: activation row groups 2*wave and 2*wave+1 (16 rows x 64 B each, all planes)
-    int iy0[2], ix0[2], pbase[2], hl[2], wl[2];
+    // DMA duties of this lane: activation row groups 2*wave and 2*wave+1 (16 rows x 64 B each, all planes).  Per row, computed
+    // once: the byte offset of tap (0, 0) within a channel slab (`base`, may be negative), the row pitch in bytes (`wl64`), and
+    // one validity bit per tap (`vmask`: the tap's source pixel lies inside the image -- zero padding otherwise).  A K-slab's
+    // address is then base + ky * wl64 + kx * 64 + slab offset and its out-of-range flag one bit extract: ~5 VALU per row and
+    // slab instead of the coordinate arithmetic (this loop is instruction-bound on the 64-channel tiles and on short K).
+    int base[2], wl64[2];
+    unsigned vmask[2];
     const int slot = lane & 3;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -414,12 +422,12 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         const int m = m0 + r;
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
+        const int swz16 = (slot ^ swz(r)) << 4;
         if (a.pointwise) {
-            // 1x1 convolution without stride or padding: the pixel is its own 1 x 1 image at offset m
-            iy0[i] = ok ? 0 : -(1 << 20);
-            ix0[i] = 0;
-            hl[i] = 1; wl[i] = 1;
-            pbase[i] = mm * 64 + ((slot ^ swz(r)) << 4);
+            // 1x1 convolution without stride or padding: input pixel == output pixel, one tap, always inside
+            base[i] = mm * 64 + swz16;
+            wl64[i] = 0;
+            vmask[i] = ok ? 1u : 0u;
             continue;
         }
         int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo, first = 0, local = mm;
@@ -447,11 +455,15 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
             if (t < 0) --oy; else if (t >= Wo) ++oy;
         }
         ox = rem - oy * Wo;
-        iy0[i] = ok ? oy * a.sh - a.ph : -(1 << 20);
-        ix0[i] = ox * a.sw - a.pw;
-        hl[i] = H; wl[i] = W;
-        // byte offset of (image origin, logical chunk) within one channel slab of a plane
-        pbase[i] = (first + b * H * W) * 64 + ((slot ^ swz(r)) << 4);
+        const int iy0 = oy * a.sh - a.ph, ix0 = ox * a.sw - a.pw;
+        unsigned xbits = 0, vm = 0;
+        for (int kx = 0; kx < a.kw; ++kx) xbits |= ((unsigned)(ix0 + kx) < (unsigned)W ? 1u : 0u) << kx;
+        for (int ky = 0; ky < a.kh; ++ky)
+            if ((unsigned)(iy0 + ky) < (unsigned)H) vm |= xbits << (ky * a.kw);
+        vmask[i] = ok ? vm : 0u;
+        wl64[i] = W * 64;
+        // byte offset of (image origin + tap (0, 0), logical chunk) within one channel slab of a plane
+        base[i] = (first + b * H * W + iy0 * W + ix0) * 64 + swz16;
     }
     __amdgpu_buffer_rsrc_t xr[NPL];
 #pragma unroll
@@ -470,23 +482,23 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         s_ky = s_tap / a.kw;
         s_kx = s_tap - s_ky * a.kw;
     }
+    int s_t = s_ky * a.kw + s_kx;                                      // tap index of the next slab to stage
     auto dma_x = [&](int buf, bool issue = true) {
         uint8_t* xb = smem + buf * BUF;
-        const int ky = s_ky, kx = s_kx;
-        const int slab_off = (grp * cslabs + s_c) * (a.x_np * 64);     // uniform: this K-slab's channel slab
+        const int uni = (grp * cslabs + s_c) * (a.x_np * 64) + s_kx * 64;  // uniform: this K-slab's channel slab + the tap's column
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
             // branch-free (a select the compiler turns into an exec-masked branch would split the MFMA block)
-            const unsigned oob = ((unsigned)iy >= (unsigned)hl[i]) | ((unsigned)ix >= (unsigned)wl[i]);
-            const unsigned off = (unsigned)(pbase[i] + (iy * wl[i] + ix) * 64 + slab_off) | (oob << 31);
+            const unsigned oob = ((vmask[i] >> s_t) & 1u) ^ 1u;
+            const unsigned off = (unsigned)(base[i] + s_ky * wl64[i] + uni) | (oob << 31);
 #pragma unroll
             for (int p = 0; p < NPL; ++p)
                 if (issue) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(xb + p * (BM * 64) + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
         }
+        ++s_t;
         if (++s_kx == a.kw) {
             s_kx = 0;
-            if (++s_ky == a.kh) { s_ky = 0; ++s_c; }
+            if (++s_ky == a.kh) { s_ky = 0; s_t = 0; ++s_c; }
         }
     };
     auto dma_w = [&](int slab, int buf) {
@@ -1338,6 +1350,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     a.vec_epilogue = (cout_g % 8 == 0) && (!out_f32 || out_ld % 4 == 0) && (!residual_f32 || res_ld % 4 == 0) && ((uintptr_t)out_f32 % 16 == 0) &&
                      ((uintptr_t)out_planes % 16 == 0) && ((uintptr_t)residual_f32 % 16 == 0) && ((uintptr_t)residual_planes % 16 == 0) &&
                      (ops % 8 == 0) && (rps % 8 == 0) && !tn.scalar_epilogue;
+    STM_REQUIRE(g->kh * g->kw <= 32, STM_EUNSUPPORTED, "%s: more than 32 taps", who);
     a.pointwise = (g->n_levels <= 0 && g->kh == 1 && g->kw == 1 && g->sh == 1 && g->sw == 1 && g->ph == 0 && g->pw == 0) ? 1 : 0;
     a.inv_hw = g->n_levels > 0 ? 0.0f : 1.0f / (float)((int64_t)g->Ho * g->Wo);
     a.inv_w = g->n_levels > 0 ? 0.0f : 1.0f / (float)g->Wo;
