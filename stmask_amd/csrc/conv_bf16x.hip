@@ -507,6 +507,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 #pragma unroll
         for (int j = 0; j < WDMA; ++j) {
             const int wi = wave + NWAVES * j;
+            // (default cache policy: the nontemporal hint on this stream, which every CU re-reads from L2, measured -1.5 %)
             __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + wi * 1024 + lane * 16), (lds_ptr)(wb + wi * 1024), 16, 0, 0);
         }
     };
