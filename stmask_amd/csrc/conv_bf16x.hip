@@ -1418,7 +1418,15 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     // 256-pixel tiles once there are enough of them, else 128-pixel tiles.  (A cost model of rounds x tile time x measured
     // efficiency was tried for this choice and for the 64-channel tile: 478-483 frames/s against 502-509 with these plain
     // thresholds in the same session -- rejected.  So was a kx-reuse kernel that stages each activation row once per kernel
-    // row: 1.8x fewer DMA bytes, no gain -- 654 vs 670 us on the 145-GF proto layer -- removed.)
+    // row: 1.8x fewer DMA bytes, no gain -- 654 vs 670 us on the 145-GF proto layer -- removed.  Round 2 rebuilt it on the
+    // three-buffer ring -- one staged copy of BM + 2 pixels per (channel slab, ky) serving kx = 0, 1, 2 at LDS row r + kx, an
+    // all-zero LDS row for the padding columns, stage parts spread over the three K-slabs, bit-identical results: half the
+    // activation DMA instructions, 1/2.8 of their L2 reads, and 1.5-2.5 % SLOWER on every 3x3 layer (proto 1465 vs 1440 us,
+    // tower 1850 vs 1807, TemporalNet conv3 2993 vs 2953).  Its own ablations: no stage DMA at all 1406 -> 1188 us, no
+    // per-tap register rotation 1379, never waiting for a stage to land 1378.  The cost of the activation staging follows
+    // the number of DMA instructions issued (~30 clocks of a wave's issue each), not the bytes they fetch or their latency,
+    // and the bookkeeping of the reuse eats what the fewer instructions give back -- removed again.  The three-slab body
+    // unrolled (compile-time taps, no rotation) made the register allocator migrate the accumulators: 53 quads, 54 spills.)
     const int64_t t2 = (int64_t)stm_cdiv(M, 2 * CV_BM) * a.n_tiles;
     const int mg = tn.mg ? tn.mg : (t2 >= 192 ? 2 : 1);
     a.m_tiles = stm_cdiv(M, CV_BM * mg);
