@@ -21,7 +21,7 @@ def t(fn, reps=20):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-us = t(lambda i: torch.relu(bufs[i % 3][0], out=bufs[i % 3][1]))
+us = t(lambda i: torch.clamp_min(bufs[i % 3][0], 0.0, out=bufs[i % 3][1]))
 print(f"relu copy  {2 * n * 2 / 1e6:.0f} MB in {us:.1f} us = {2 * n * 2 / us / 1e6:.2f} TB/s")
 us = t(lambda i: bufs[i % 3][1].copy_(bufs[i % 3][0]))
 print(f"copy_      {2 * n * 2 / 1e6:.0f} MB in {us:.1f} us = {2 * n * 2 / us / 1e6:.2f} TB/s")

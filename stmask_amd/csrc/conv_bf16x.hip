@@ -1061,6 +1061,7 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
 // section 9); the variables exist for A/B runs.  stm_debug_reload_tunables() (capi.hip) makes the next launch re-read them.
 struct ConvTunables {
     int ring = 3;          // STM_CONV_RING: 2 = two-buffer loop on the 128-wide tiles, 3 = three-buffer ring (fp16 formats)
+    int ring64_small = 512; // STM_CONV_RING64_SMALL: grids up to this many workgroups take the ring on 128 x 64 tiles whatever K
     int ring64 = 3;        // STM_CONV_RING64: 2 never / 4 always the ring on 128 x 64 tiles, 3 = by K length (rule below)
     int splitk = 0;        // STM_CONV_SPLITK: force this many K parts (0 = rule)
     int sk_target = 768;   // STM_CONV_SK_TARGET: workgroups the split-K rule of the 64-wide tiles aims at
@@ -1075,6 +1076,7 @@ ConvTunables read_tunables()
     auto geti = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
     t.ring = (int)geti("STM_CONV_RING", t.ring);
     t.ring64 = (int)geti("STM_CONV_RING64", t.ring64);
+    t.ring64_small = (int)geti("STM_CONV_RING64_SMALL", t.ring64_small);
     t.splitk = (int)geti("STM_CONV_SPLITK", 0);
     t.sk_target = (int)geti("STM_CONV_SK_TARGET", t.sk_target);
     t.mg = (int)geti("STM_CONV_MG", 0);
@@ -1369,8 +1371,12 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     a.splitk = 1; a.kslabs = a.slabs; a.partial = nullptr; a.ldp = a.n_tiles * bn;
     // split-K for grids that would leave most CUs idle over a long K (small feature maps: ResNet stages 3/4, P5-P7):
     // parts write fp32 partial sums into the caller's workspace, planar_splitk_finish_kernel adds them and runs the epilogue.
-    // (A fused reduction -- the part drawing a tile's last ticket adds the parts -- was built and measured: its device-scope
-    // fences cost an L2 write-back / invalidate per workgroup, 665 vs 919 frames/s; removed.)
+    // (A fused reduction -- the part drawing a tile's last ticket adds the parts -- was built and measured twice.  Round 1 with
+    // device-scope fences: an L2 write-back / invalidate per workgroup, 665 vs 919 frames/s.  Round 2 without any fence -- the
+    // parts' sums written and read as agent-scope relaxed atomics (sc1 accesses), store -> vmcnt(0) -> ticket ... ticket -> load
+    // -- to save the 47 finishing launches of a single-stream step (12 % of its GPU time): 359 vs 461 frames/s at 1 clip, 965 vs
+    // 1047 at 8, 1201 vs 1214 at 32.  One workgroup adding a tile's parts at the end of the kernel is a longer tail than the
+    // finishing kernel's few thousand threads after it; removed again.)
     auto plan_splitk = [&](int tiles) {
         int sk = tn.splitk;
         if (sk <= 0) {
@@ -1409,7 +1415,12 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         // 46 -> 36 us, 45 -> 37 us), where its two-slab head start hides the first DMA latency, and loses on the long and
         // the split-K ones (100 -> 114 us at 72 slabs), where two resident two-buffer workgroups already cover each other;
         // under 12 slabs the layer is HBM-bound and the two-buffer loop's 48 KB (three workgroups per CU) wins: 302 vs 389 us
-        const bool ring = full && (tn.ring64 == 3 ? (a.splitk == 1 && a.slabs >= 12 && a.slabs <= 40) : tn.ring64 == 4);
+        // grids of at most two workgroups per CU (single-stream / small batches: every layer; layer4 at 8 clips) have no further
+        // resident workgroup to cover a workgroup's staging gaps: the ring whatever K.  Swept 0 / 128 / 256 / 512 / 1024 on one
+        // box (scripts/sweep_ring64_small.sh): 1 clip 399 / 421 / 436 / 456 / 452 frames/s, 2 clips 628 .. 662, 4 clips 836 ..
+        // 880, 8 clips flat (1053), 32 clips 1219 .. 1226.
+        const bool small_grid = tiles <= tn.ring64_small;
+        const bool ring = full && (tn.ring64 == 3 ? (small_grid || (a.splitk == 1 && a.slabs >= 12 && a.slabs <= 40)) : tn.ring64 == 4);
         if (a.fmt == 2) rc = ring ? launch_planar<1, 1, 1, 1, 3>(a, tiles, stream) : launch_planar<1, 1, 1, 1>(a, tiles, stream);
         else if (a.fmt == 1) rc = ring ? launch_planar<2, 1, 1, 1, 3>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
         else rc = g->planes == 3 ? launch_planar<3, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1>(a, tiles, stream);
