@@ -209,9 +209,9 @@ int stm_lincomb_sigmoid_crop_f32(const float* proto, const float* coeff, const f
 size_t stm_mask_iou_workspace_bytes(int n1, int n2, int hw);
 int stm_mask_iou_f32(const float* m1, int n1, const float* m2, int n2, int hw, float thr, float* out,
                      void* workspace, size_t workspace_bytes, stm_stream_t stream);
-/* Batched-clip form: group1 [n1], group2 [n2] (int32, group2 non-decreasing -- the clip of each mask, rows sorted by clip
- * as stmask_amd.pipeline keeps them): out[i][j] = IoU if group1[i] == group2[j], else 0 without reading the pair (track_TF
- * matches a detection only against the tracked instances of its own clip). */
+/* Batched-clip form: group1 [n1], group2 [n2] (int32 -- the clip of each mask; any order is correct, rows sorted by clip as
+ * stmask_amd.pipeline keeps them let whole workgroups skip): out[i][j] = IoU if group1[i] == group2[j], else 0 without reading
+ * the pair (track_TF matches a detection only against the tracked instances of its own clip). */
 int stm_mask_iou_grouped_f32(const float* m1, int n1, const float* m2, int n2, int hw, float thr, float* out, const int* group1,
                              const int* group2, void* workspace, size_t workspace_bytes, stm_stream_t stream);
 /* The same two kernels without the re-read of the soft masks: stm_lincomb_sigmoid_crop_bits_f32 also writes the binarised mask

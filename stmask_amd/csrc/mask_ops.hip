@@ -112,13 +112,13 @@ __global__ __launch_bounds__(256) void mask_iou_pairs_kernel(const unsigned long
     extern __shared__ unsigned long long arow[];
     const int i = blockIdx.y;
     // group ids (the clip a mask belongs to in the batched pipeline): pairs of different groups are never compared by the
-    // caller -- their IoU is left at 0 and their words are not read.  Rows of a group are contiguous, so a workgroup whose
-    // 256 columns all belong to other groups leaves at once.
+    // caller -- their IoU is left at 0 and their words are not read.  A workgroup none of whose 256 columns belongs to row i's
+    // group leaves at once (rows sorted by group, as the pipeline keeps them, make that the common case; any order is correct).
     const int gi = g1 ? g1[i] : 0;
     if (g2) {
-        const int j0 = blockIdx.x * 256, j1 = min(j0 + 255, n2 - 1);
-        if (g2[j0] > gi || g2[j1] < gi) {                  // sorted group ids: no column of this block can match
-            const int j = j0 + threadIdx.x;
+        const int j = blockIdx.x * 256 + threadIdx.x;
+        const bool mine = j < n2 && g2[j] == gi;
+        if (!__syncthreads_or(mine ? 1 : 0)) {
             if (j < n2) out[(int64_t)i * n2 + j] = 0.0f;
             return;
         }

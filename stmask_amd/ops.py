@@ -405,8 +405,8 @@ def lincomb_sigmoid_crop(proto, coeff, boxes=None, apply_tanh=True, n_dev=None, 
 
 
 def mask_iou(m1, m2, thr=0.5, group1=None, group2=None):
-    """box_utils.py:435-447 on (m > thr).  m1 [n1,h,w], m2 [n2,h,w] soft masks -> [n1,n2].  group1 / group2 (int32, group2
-    sorted): only pairs of the same group are computed, the others stay 0 (stm_mask_iou_grouped_f32)."""
+    """box_utils.py:435-447 on (m > thr).  m1 [n1,h,w], m2 [n2,h,w] soft masks -> [n1,n2].  group1 / group2 (int32, any
+    order; sorted rows skip whole workgroups): only pairs of the same group are computed, the others stay 0 (stm_mask_iou_grouped_f32)."""
     _dev(m1, m2, group1, group2)
     m1, m2 = _f32c(m1), _f32c(m2)
     n1, n2 = m1.shape[0], m2.shape[0]

@@ -622,3 +622,7 @@ def test_mask_iou_grouped_equals_full_masked_by_group():
     same = g1[:, None] == g2[None, :]
     assert torch.equal(got, torch.where(same, full, torch.zeros_like(full)))
     assert same.any() and (~same).any()
+    # the C entry promises nothing about the order of the groups: shuffled columns give the same pairs
+    perm = torch.randperm(n2, generator=g)
+    got_p = ops.mask_iou(m1.to(DEV), m2[perm].to(DEV), group1=g1.to(DEV), group2=g2[perm].to(DEV)).cpu()
+    assert torch.equal(got_p, got[:, perm])
