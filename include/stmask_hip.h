@@ -339,6 +339,8 @@ int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed_weight, co
  * stm_match_scores_f32: compute_comp_scores + argmax (TF_utils.py:99-120, track_TF.py:104-129) over [dummy | prev rows of the
  *   same clip]: cos [D,Pn] raw embedding dot products, mask_iou [D,Pn]; box IoU and class equality are computed here;
  *   coeff4 = cfg.match_coeff (host floats); match[d] = 0 (new) or 1 + prev row.  prev_offsets [B+1]: clip row ranges.
+ *   stm_match_scores_embed_f32: the same from the embedding tables det_track [D,E] / prev_track [Pn,E] (track_TF.py:99-101's
+ *   matrix product restricted to the same-clip pairs, one fmaf chain over E per pair) instead of a precomputed cos.
  * stm_gather_rows2: out_t[r] = plan[r] < n_a ? a_t[plan[r]] : b_t[plan[r] - n_a] for up to 8 row tensors in one launch (the
  *   tracker update cat(prev, det).index_select(plan), track_TF.py:132-156); row_bytes multiples of 4.
  * stm_pack_tracked_f32: keep rule (tracked <= max_age, more than one mask pixel > 0.5, score > thr: track_TF.py:158-165) and
@@ -355,6 +357,10 @@ int stm_match_scores_f32(const float* cos, const float* mask_iou, const float* d
                          const float* det_score, const int64_t* det_cls, const int64_t* prev_cls, const int* det_clip,
                          const int* prev_offsets, int D, int Pn, const float* coeff4, float dummy_iou, int* match,
                          stm_stream_t stream);
+int stm_match_scores_embed_f32(const float* det_track, const float* prev_track, int embed_dim, const float* mask_iou,
+                               const float* det_box, const float* prev_box, const float* det_score, const int64_t* det_cls,
+                               const int64_t* prev_cls, const int* det_clip, const int* prev_offsets, int D, int Pn,
+                               const float* coeff4, float dummy_iou, int* match, stm_stream_t stream);
 int stm_gather_rows2(const void* const* a_rows, const void* const* b_rows, void* const* out_rows, const int* row_bytes,
                      int n_tensors, const int* plan, int n_rows, int n_a, stm_stream_t stream);
 int stm_pack_tracked_f32(const float* mask, const float* score, const int* tracked, const int* offsets, const float* box,

@@ -136,6 +136,10 @@ def _match_scores(cos, miou, det_box, prev_box, det_score, det_cls, prev_cls, de
     return torch.where(same, comp, torch.full_like(comp, float("-inf"))).argmax(dim=1).to(torch.int32)
 
 
+def _match_scores_embed(det_track, prev_track, miou, *rest, **kw):
+    return _match_scores(det_track @ prev_track.t(), miou, *rest, **kw)     # track_TF.py:99-101
+
+
 def _gather_rows2(a_rows, b_rows, plan, n_a):
     return [torch.cat([a, b], dim=0).index_select(0, plan.long()) for a, b in zip(a_rows, b_rows)]
 
@@ -190,6 +194,7 @@ _PATCH = {
     "shift_rois": _shift_rois,
     "shift_apply_": _shift_apply_,
     "match_scores": _match_scores,
+    "match_scores_embed": _match_scores_embed,
     "gather_rows2": _gather_rows2,
     "pack_tracked": _pack_tracked,
 }

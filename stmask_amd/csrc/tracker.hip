@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256) void shift_apply_kernel(const float* __restric
 // in exactly this association (TF_utils.py:117-120 evaluates left to right); argmax with the lowest column on ties.
 // match[d] = 0 (new instance) or 1 + global prev row.
 struct MatchArgs {
-    const float* cos;        // [D, Pn] raw dot products of the track embeddings
+    const float* cos;        // [D, Pn] raw dot products of the track embeddings, or null: computed here from the two tables below
+    const float* det_track;  // [D, E]
+    const float* prev_track; // [Pn, E]
+    int E;
     const float* miou;       // [D, Pn] (pairs of different clips are 0 and never read)
     const float* det_box;    // [D, 4]
     const float* prev_box;   // [Pn, 4]
@@ -130,7 +133,27 @@ __global__ __launch_bounds__(256) void match_scores_kernel(const MatchArgs a)
         arg = 0;
     }
     for (int p = p0 + lane; p < p1; p += 64) {
-        const float cs = (a.cos[(int64_t)d * a.Pn + p] + 1.0f) / 2.0f;
+        float dot;
+        if (a.cos) {
+            dot = a.cos[(int64_t)d * a.Pn + p];
+        } else {
+            // the detection's embedding is uniform over the wave, the lane walks its own prev row (E is 128: the all-pairs matrix
+            // product this replaces spent 120 us in a library GEMM on a [164 x 128] x [128 x 3584] problem of which one pair
+            // in 32 -- the same-clip ones -- is ever read)
+            const float* x = a.det_track + (int64_t)d * a.E;
+            const float* y = a.prev_track + (int64_t)p * a.E;
+            dot = 0.0f;
+            if ((a.E & 3) == 0) {
+                for (int e = 0; e < a.E; e += 4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(x + e), yv = *reinterpret_cast<const float4*>(y + e);
+                    dot = __builtin_fmaf(xv.x, yv.x, dot); dot = __builtin_fmaf(xv.y, yv.y, dot);
+                    dot = __builtin_fmaf(xv.z, yv.z, dot); dot = __builtin_fmaf(xv.w, yv.w, dot);
+                }
+            } else {
+                for (int e = 0; e < a.E; ++e) dot = __builtin_fmaf(x[e], y[e], dot);
+            }
+        }
+        const float cs = (dot + 1.0f) / 2.0f;
         const float bi = stm_iou(db, reinterpret_cast<const float4*>(a.prev_box)[p]);
         float t = cs + a.c0 * s;
         t = t + a.c1 * a.miou[(int64_t)d * a.Pn + p];
@@ -301,23 +324,55 @@ extern "C" int stm_shift_apply_f32(const float* loc_shift, const float* coeff_sh
     return STM_OK;
 }
 
+namespace {
+int launch_match_scores(const char* who, const float* cos, const float* det_track, const float* prev_track, int E, const float* mask_iou,
+                        const float* det_box, const float* prev_box, const float* det_score, const int64_t* det_cls, const int64_t* prev_cls,
+                        const int* det_clip, const int* prev_offsets, int D, int Pn, const float* coeff4, float dummy_iou, int* match,
+                        stm_stream_t stream);
+}
+
 extern "C" int stm_match_scores_f32(const float* cos, const float* mask_iou, const float* det_box, const float* prev_box, const float* det_score,
                                     const int64_t* det_cls, const int64_t* prev_cls, const int* det_clip, const int* prev_offsets, int D, int Pn,
                                     const float* coeff4, float dummy_iou, int* match, stm_stream_t stream)
 {
-    STM_REQUIRE(D >= 0 && Pn >= 0, STM_EINVAL, "stm_match_scores_f32: bad sizes");
+    STM_REQUIRE(D <= 0 || Pn <= 0 || cos, STM_ENULL, "stm_match_scores_f32: cos is NULL");
+    return launch_match_scores("stm_match_scores_f32", cos, nullptr, nullptr, 0, mask_iou, det_box, prev_box, det_score, det_cls, prev_cls, det_clip,
+                               prev_offsets, D, Pn, coeff4, dummy_iou, match, stream);
+}
+
+extern "C" int stm_match_scores_embed_f32(const float* det_track, const float* prev_track, int embed_dim, const float* mask_iou,
+                                          const float* det_box, const float* prev_box, const float* det_score, const int64_t* det_cls,
+                                          const int64_t* prev_cls, const int* det_clip, const int* prev_offsets, int D, int Pn,
+                                          const float* coeff4, float dummy_iou, int* match, stm_stream_t stream)
+{
+    STM_REQUIRE(embed_dim > 0, STM_EINVAL, "stm_match_scores_embed_f32: embed_dim must be positive");
+    STM_REQUIRE(D <= 0 || Pn <= 0 || (det_track && prev_track), STM_ENULL, "stm_match_scores_embed_f32: NULL embedding table");
+    STM_REQUIRE(embed_dim % 4 != 0 || ((uintptr_t)det_track % 16 == 0 && (uintptr_t)prev_track % 16 == 0), STM_EINVAL,
+                "stm_match_scores_embed_f32: embedding tables must be 16-byte aligned");
+    return launch_match_scores("stm_match_scores_embed_f32", nullptr, det_track, prev_track, embed_dim, mask_iou, det_box, prev_box, det_score,
+                               det_cls, prev_cls, det_clip, prev_offsets, D, Pn, coeff4, dummy_iou, match, stream);
+}
+
+namespace {
+int launch_match_scores(const char* who, const float* cos, const float* det_track, const float* prev_track, int E, const float* mask_iou,
+                        const float* det_box, const float* prev_box, const float* det_score, const int64_t* det_cls, const int64_t* prev_cls,
+                        const int* det_clip, const int* prev_offsets, int D, int Pn, const float* coeff4, float dummy_iou, int* match,
+                        stm_stream_t stream)
+{
+    STM_REQUIRE(D >= 0 && Pn >= 0, STM_EINVAL, "%s: bad sizes", who);
     if (D == 0) return STM_OK;
-    STM_REQUIRE(det_box && det_score && det_cls && det_clip && prev_offsets && coeff4 && match, STM_ENULL, "stm_match_scores_f32: NULL argument");
-    STM_REQUIRE(Pn == 0 || (cos && mask_iou && prev_box && prev_cls), STM_ENULL, "stm_match_scores_f32: NULL prev argument");
-    STM_REQUIRE((uintptr_t)det_box % 16 == 0 && (uintptr_t)prev_box % 16 == 0, STM_EINVAL, "stm_match_scores_f32: boxes must be 16-byte aligned");
+    STM_REQUIRE(det_box && det_score && det_cls && det_clip && prev_offsets && coeff4 && match, STM_ENULL, "%s: NULL argument", who);
+    STM_REQUIRE(Pn == 0 || (mask_iou && prev_box && prev_cls), STM_ENULL, "%s: NULL prev argument", who);
+    STM_REQUIRE((uintptr_t)det_box % 16 == 0 && (uintptr_t)prev_box % 16 == 0, STM_EINVAL, "%s: boxes must be 16-byte aligned", who);
     MatchArgs a;
-    a.cos = cos; a.miou = mask_iou; a.det_box = det_box; a.prev_box = prev_box; a.det_score = det_score; a.det_cls = det_cls; a.prev_cls = prev_cls;
+    a.cos = cos; a.det_track = det_track; a.prev_track = prev_track; a.E = E; a.miou = mask_iou; a.det_box = det_box; a.prev_box = prev_box; a.det_score = det_score; a.det_cls = det_cls; a.prev_cls = prev_cls;
     a.det_clip = det_clip; a.prev_off = prev_offsets; a.match = match; a.D = D; a.Pn = Pn;
     a.c0 = coeff4[0]; a.c1 = coeff4[1]; a.c2 = coeff4[2]; a.c3 = coeff4[3]; a.dummy = dummy_iou;
     hipLaunchKernelGGL(match_scores_kernel, dim3(stm_cdiv(D, 4)), dim3(256), 0, stm_hs(stream), a);
     STM_CHECK_LAUNCH("match_scores_kernel");
     return STM_OK;
 }
+}  // namespace
 
 extern "C" int stm_gather_rows2(const void* const* a_rows, const void* const* b_rows, void* const* out_rows, const int* row_bytes, int n_tensors,
                                 const int* plan, int n_rows, int n_a, stm_stream_t stream)

@@ -625,6 +625,21 @@ def match_scores(cos, miou, det_box, prev_box, det_score, det_cls, prev_cls, det
     return match
 
 
+def match_scores_embed(det_track, prev_track, miou, det_box, prev_box, det_score, det_cls, prev_cls, det_clip, prev_offsets, match_coeff,
+                       dummy_iou=0.3):
+    """match_scores with the cosine term computed in the kernel from the track embeddings (same-clip pairs only): no [D, Pn]
+    matrix product in front of it."""
+    _dev(det_track, prev_track, miou, det_box, prev_box, det_score, det_cls, prev_cls, det_clip, prev_offsets)
+    D, Pn = det_box.shape[0], prev_box.shape[0]
+    match = torch.empty(D, dtype=torch.int32, device=det_box.device)
+    c4 = (ctypes.c_float * 4)(*[float(v) for v in match_coeff])
+    check(_lib.lib().stm_match_scores_embed_f32(_p(_f32c(det_track)), _p(_f32c(prev_track)), c_i(det_track.shape[1]), _p(_f32c(miou)),
+                                                _p(_f32c(det_box)), _p(_f32c(prev_box)), _p(_f32c(det_score)), _p(det_cls), _p(prev_cls),
+                                                _p(det_clip), _p(prev_offsets), c_i(D), c_i(Pn), c4, c_f(dummy_iou), _p(match), _stream()),
+          "stm_match_scores_embed_f32")
+    return match
+
+
 def gather_rows2(a_rows, b_rows, plan, n_a):
     """out_t[r] = plan[r] < n_a ? a_t[plan[r]] : b_t[plan[r] - n_a] for lists of row tensors (<= 8 per launch); plan int32."""
     _dev(plan, *a_rows, *b_rows)

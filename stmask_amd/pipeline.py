@@ -288,11 +288,11 @@ class BatchedClipPipeline:
             prev = self.prev
             if D and Pn:
                 # matching scores for all clips at once; pairs from different clips can never match
-                cos = det["track"] @ prev["track"].t()
                 miou = ops.mask_iou_bits(det_bits, self._prev_bits, proto.shape[1] * proto.shape[2], group1=det["clip"],
                                          group2=prev["clip"])                               # same-clip pairs only
-                match = ops.match_scores(cos, miou, det["box"], prev["box"], det["score"], det["class"], prev["class"], det["clip"],
-                                         self._off_dev, cfg.match_coeff, 0.3)
+                # (the embedding dot products of the same-clip pairs are taken inside the kernel)
+                match = ops.match_scores_embed(det["track"], prev["track"], miou, det["box"], prev["box"], det["score"], det["class"],
+                                               prev["class"], det["clip"], self._off_dev, cfg.match_coeff, 0.3)
                 ids = match.tolist()  # host read 2
                 scores = det_scores
                 tmr.toc("match_scores")

@@ -92,6 +92,12 @@ def test_match_scores_equals_comp_scores_argmax(coeffs):
                            _d(t["off"]), coeffs, 0.3).cpu()
     assert torch.equal(got, want), (got.tolist(), want.tolist())
     assert int(got[0]) == 2 and int(got[1]) == 3               # the planted matches; the tie goes to the lower row
+    # the pipeline's form: the cosine term from the embedding tables inside the kernel (identical rows still tie exactly)
+    got_e = ops.match_scores_embed(_d(det["track"]), _d(p["track"]), _d(miou), _d(det["box"]), _d(p["box"]), _d(det["score"]), _d(det["class"]),
+                                   _d(p["class"]), _d(det["clip"]), _d(t["off"]), coeffs, 0.3).cpu()
+    assert torch.equal(got_e, want), (got_e.tolist(), want.tolist())
+    assert torch.equal(ref._match_scores_embed(det["track"], p["track"], miou, det["box"], p["box"], det["score"], det["class"], p["class"],
+                                               det["clip"], t["off"], coeffs, 0.3), want)
     assert (got[t["cnt"][0]:t["cnt"][0] + t["cnt"][2]] == 0).all()   # clip 2 has no tracked rows: every detection is new
 
 
