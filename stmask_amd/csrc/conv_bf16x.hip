@@ -1079,7 +1079,8 @@ struct ConvTunables {
     int ring64_small = 512; // STM_CONV_RING64_SMALL: grids up to this many workgroups take the ring on 128 x 64 tiles whatever K
     int ring64 = 3;        // STM_CONV_RING64: 2 never / 4 always the ring on 128 x 64 tiles, 3 = by K length (rule below)
     int splitk = 0;        // STM_CONV_SPLITK: force this many K parts (0 = rule)
-    int sk_target = 768;   // STM_CONV_SK_TARGET: workgroups the split-K rule of the 64-wide tiles aims at
+    int sk_rule = 0;       // STM_CONV_SK_RULE: 1 = round 1's split-K rule of the 64-wide tiles for every layer (A/B runs)
+    int sk_target = 256;   // STM_CONV_SK_TARGET: workgroups the split-K rule of the 64-wide tiles aims at (one per CU)
     int mg = 0;            // STM_CONV_MG: force 128 (1) or 256 (2) pixel tiles
     long long nt_mb = 0;   // STM_CONV_NT: nontemporal plane stores for outputs of at least this many MB (0 = off; no gain measured)
     int scalar_epilogue = 0;   // STM_CONV_SCALAR_EPILOGUE: element-wise epilogue stores (tests)
@@ -1094,6 +1095,7 @@ ConvTunables read_tunables()
     t.ring64_small = (int)geti("STM_CONV_RING64_SMALL", t.ring64_small);
     t.splitk = (int)geti("STM_CONV_SPLITK", 0);
     t.sk_target = (int)geti("STM_CONV_SK_TARGET", t.sk_target);
+    t.sk_rule = (int)geti("STM_CONV_SK_RULE", t.sk_rule);
     t.mg = (int)geti("STM_CONV_MG", 0);
     t.nt_mb = geti("STM_CONV_NT", 0);
     t.scalar_epilogue = (int)geti("STM_CONV_SCALAR_EPILOGUE", 0);
@@ -1392,14 +1394,26 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     // -- to save the 47 finishing launches of a single-stream step (12 % of its GPU time): 359 vs 461 frames/s at 1 clip, 965 vs
     // 1047 at 8, 1201 vs 1214 at 32.  One workgroup adding a tile's parts at the end of the kernel is a longer tail than the
     // finishing kernel's few thousand threads after it; removed again.)
+    // (128 x 64 tiles) every group fills its 64-channel tiles: the layer can take the ring loop; the narrow ones (output layers
+    // with 41 / 5 / 32 real channels of 64, offset convolutions) keep the two-buffer loop with its skip of all-padding column tiles
+    bool full = cout_g % 64 == 0;
+    for (int gi = 0; gi < groups && gi < 8; ++gi) full = full && a.group_real[gi] == cout_g;
     auto plan_splitk = [&](int tiles) {
         int sk = tn.splitk;
         if (sk <= 0) {
             sk = 1;
             if (bn == 64) {
-                // 128 x 64 tiles run two workgroups per CU; a grid of at most one workgroup per CU spends its time in
-                // the staging latency of each K-slab, so split K until ~3 workgroups per CU are resident or queued
-                if (tiles <= 256 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, tn.sk_target / tiles), a.slabs / 10);
+                // 128 x 64 tiles: grids of at most half a workgroup per CU are split until about one workgroup per CU exists,
+                // with at least 16 K-slabs per part (10 on the tiniest grids).  Re-measured in round 2 with every configuration
+                // replayed from a HIP graph (scripts/sweep_small_m.py; round 1's rule -- up to 256 tiles, three workgroups per
+                // CU, 10 slabs per part -- dated from before the ring loop took the small grids): 240 tiles x 32 slabs 31.9 us
+                // split in 3 vs 20.2 unsplit, 240 x 72 slabs 49.5 vs 39.8, 120 tiles x 64 slabs 29.8 (6 parts) vs 24.4 (2),
+                // 64 x 64 19.4 (6) vs 17.3 (4), 240 x 36 (layer2's 3x3 at 4 clips) 34.3 vs 20.0.
+                // The narrow layers (two-buffer loop) keep round 1's rule: 120 tiles x 72 slabs 36.8 us in 6 parts, 55.2 in 2.
+                if (tn.sk_rule == 1 || !full) {
+                    if (tiles <= 256 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, 768 / tiles), a.slabs / 10);
+                } else if (tiles <= 128 && a.slabs >= 24)
+                    sk = (int)std::min<int64_t>(std::min<int64_t>(8, tn.sk_target / tiles), a.slabs / (tiles <= 40 ? 10 : 16));
             } else if (tiles < 128 && a.slabs >= 24) sk = (int)std::min<int64_t>(std::min<int64_t>(8, 256 / tiles), a.slabs / 12);
         }
         if (sk < 2) return;
@@ -1422,10 +1436,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         a.m_tiles = stm_cdiv(M, CV_BM);
         plan_splitk(a.m_tiles * a.n_tiles);
         const int tiles = a.m_tiles * a.n_tiles * a.splitk;
-        // the three-buffer ring (72 KB: still two workgroups per CU) has no skip of zero-padded column tiles: layers whose
-        // every group fills its 64-channel tile take it, the narrow ones keep the guarded two-buffer loop
-        bool full = cout_g % 64 == 0;
-        for (int gi = 0; gi < groups && gi < 8; ++gi) full = full && a.group_real[gi] == cout_g;
+        // the three-buffer ring (72 KB: still two workgroups per CU) has no skip of zero-padded column tiles: `full` layers only
         // measured in the graph (bench.py --layer-table): the ring wins on the short K loops (<= 36 slabs: 35 -> 30 us,
         // 46 -> 36 us, 45 -> 37 us), where its two-slab head start hides the first DMA latency, and loses on the long and
         // the split-K ones (100 -> 114 us at 72 slabs), where two resident two-buffer workgroups already cover each other;
