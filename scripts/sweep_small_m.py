@@ -28,7 +28,13 @@ SHAPES = [("l3 conv1 1024->256", 24, 40, 1024, 256, 1, False, "both"),
           ("proto 256->256 3x3 @48x80", 48, 80, 256, 256, 3, False, "planes"),
           ("l2 conv2 128->128 3x3 @48x80", 48, 80, 128, 128, 3, False, "planes"),
           ("l1 conv2 64->64 3x3 @96x160", 96, 160, 64, 64, 3, False, "planes"),
-          ("l1 conv1 256->64 @96x160", 96, 160, 256, 64, 1, False, "planes")]
+          ("l1 conv1 256->64 @96x160", 96, 160, 256, 64, 1, False, "planes"),
+          ("l1 conv3 64->256 +res @96x160", 96, 160, 64, 256, 1, True, "planes"),
+          ("l2 conv3 128->512 +res @48x80", 48, 80, 128, 512, 1, True, "planes"),
+          ("l2 dcn gemm 1152->128 @48x80", 48, 80, 1152, 128, 1, False, "planes"),
+          ("proto 256->256 3x3 @96x160", 96, 160, 256, 256, 3, False, "planes"),
+          ("tower 256->1024 3x3 (levels proxy 55x93)", 55, 93, 256, 1024, 3, False, "planes"),
+          ("l4 conv3 512->2048 +res", 12, 20, 512, 2048, 1, True, "planes")]
 
 
 def set_env(env):

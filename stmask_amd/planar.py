@@ -99,12 +99,14 @@ class PlanarConv:
         if cg <= 64 or (cg % 128 != 0 and cg % 128 <= 64 and cg < 256):
             return 64
         tiles128 = -(-M // 128) * -(-self.O // 128)
-        if tiles128 < 400:
+        slabs = self.C * self.kh * self.kw // 32
+        # (long K on a grid of about one 128 x 128 workgroup per CU -- layer4 at 32 clips -- is better off on the wide tiles:
+        # 2048 -> 512 at M = 7 680: 58.4 -> 53.5 us, the 4608 -> 512 DCN product 118.1 -> 104.9; scripts/sweep_small_m.py)
+        if tiles128 < 400 and not (tiles128 >= 192 and slabs >= 64):
             return 64
         # short K, wide output (the bottlenecks' expanding 1x1 convs with their residual): HBM-bound, and three resident
         # 128 x 64 workgroups per CU (48 KB each) keep more loads and stores in flight than one 256 x 128 workgroup:
         # 393 -> 302 us (64 -> 256 channels at 96x160, batch 32), 213 -> 175 us, 123 -> 112 us (scripts/ab_shortk.py)
-        slabs = self.C * self.kh * self.kw // 32
         if slabs <= TILE64_MAX_SLABS:
             return 64
         return 128
