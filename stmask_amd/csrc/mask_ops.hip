@@ -14,21 +14,22 @@
 
 namespace {
 
-constexpr int LC_DCHUNK = 8;   // detections per workgroup
+constexpr int LC_DCHUNK = 32;  // most detections per workgroup (it holds the prototypes of its 256 pixels in registers and walks its rows:
+                               // every chunk re-reads them, 128 B per pixel -- 880 MB per launch at 8 rows per chunk and 3 600 rows)
 
 template <int M>
 __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ proto, const float* __restrict__ coeff,
                                                       const float* __restrict__ boxes, float* __restrict__ out, int h,
                                                       int w, int n, int apply_tanh, const int* __restrict__ n_dev,
                                                       const int* __restrict__ row_proto, unsigned long long* __restrict__ bits,
-                                                      float bits_thr)
+                                                      float bits_thr, int dchunk)
 {
     __shared__ float sc[LC_DCHUNK * M];
     __shared__ float sb[LC_DCHUNK * 4];  // x1, x2, y1, y2 (float bounds, padding 1)
     const int hw = h * w;
     const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int d0 = blockIdx.y * LC_DCHUNK;
-    const int nd = min(LC_DCHUNK, n - d0);
+    const int d0 = blockIdx.y * dchunk;
+    const int nd = min(dchunk, n - d0);
     const int n_valid = n_dev ? min(max(*n_dev, 0), n) : n;
 
     for (int idx = threadIdx.x; idx < nd * M; idx += 256) {
@@ -162,17 +163,19 @@ extern "C" int stm_lincomb_sigmoid_crop_bits_f32(const float* proto, const float
     STM_REQUIRE(proto && coeff && out, STM_ENULL, "stm_lincomb_sigmoid_crop_f32: proto/coeff/out must be non-NULL");
     STM_REQUIRE(h > 0 && w > 0, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: bad mask size %dx%d", h, w);
     STM_REQUIRE((uintptr_t)proto % 16 == 0, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: proto must be 16-byte aligned");
-    dim3 grid(stm_cdiv((int64_t)h * w, 256), stm_cdiv(n, LC_DCHUNK));
+    // rows per workgroup: 8 while that still gives every CU several workgroups, 32 on the big tracked sets (less prototype re-reading)
+    const int dchunk = (int64_t)stm_cdiv((int64_t)h * w, 256) * stm_cdiv(n, 32) >= 2048 ? 32 : 8;
+    dim3 grid(stm_cdiv((int64_t)h * w, 256), stm_cdiv(n, dchunk));
     STM_REQUIRE(grid.y <= 65535, STM_EINVAL, "stm_lincomb_sigmoid_crop_f32: n=%d too large", n);
     if (m == 32) {
         hipLaunchKernelGGL(lincomb_kernel<32>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
-                           apply_tanh, n_dev, row_proto, bits, bits_thr);
+                           apply_tanh, n_dev, row_proto, bits, bits_thr, dchunk);
     } else if (m == 8) {
         hipLaunchKernelGGL(lincomb_kernel<8>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
-                           apply_tanh, n_dev, row_proto, bits, bits_thr);
+                           apply_tanh, n_dev, row_proto, bits, bits_thr, dchunk);
     } else if (m == 64) {
         hipLaunchKernelGGL(lincomb_kernel<64>, grid, dim3(256), 0, stm_hs(stream), proto, coeff, boxes, out, h, w, n,
-                           apply_tanh, n_dev, row_proto, bits, bits_thr);
+                           apply_tanh, n_dev, row_proto, bits, bits_thr, dchunk);
     } else {
         STM_REQUIRE(false, STM_EUNSUPPORTED, "stm_lincomb_sigmoid_crop_f32: mask_dim %d not in {8,32,64}", m);
     }

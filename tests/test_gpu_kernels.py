@@ -518,6 +518,28 @@ def test_generate_mask_rows_of_several_clips_in_one_launch():
         assert (got[sel] - ref).abs().max() < 5e-6
 
 
+def test_generate_mask_big_tracked_set_takes_32_row_chunks():
+    """Past ~1 100 rows at 96x160 the launch walks 32 rows per workgroup instead of 8 (the prototypes of a pixel block are read
+    once per chunk): same values bit for bit as the 8-row launches of the same rows, rows of several clips in one chunk, the
+    bit words included; spot-checked against the oracle."""
+    gen = torch.Generator().manual_seed(9)
+    n, P = 1150, 5
+    protos = torch.relu(torch.randn(P, 96, 160, 32, generator=gen))
+    coeff = torch.randn(n, 32, generator=gen)
+    c = torch.rand(n, 2, generator=gen)
+    wh = torch.rand(n, 2, generator=gen) * 0.5
+    box = torch.cat([c - wh / 2, c + wh / 2], 1)
+    rp = torch.sort(torch.randint(0, P, (n,), generator=gen)).values.to(torch.int32)
+    big, big_bits = ops.lincomb_sigmoid_crop_bits(protos.to(DEV), coeff.to(DEV), box.to(DEV), rp.to(DEV))
+    for lo in range(0, n, 500):                       # 500 rows per launch: 8-row chunks
+        hi = min(n, lo + 500)
+        part, part_bits = ops.lincomb_sigmoid_crop_bits(protos.to(DEV), coeff[lo:hi].to(DEV), box[lo:hi].to(DEV), rp[lo:hi].to(DEV))
+        assert torch.equal(part, big[lo:hi]) and torch.equal(part_bits, big_bits[lo:hi])
+    for r in (0, 31, 32, 577, n - 1):
+        ref = oracle.generate_mask(protos[int(rp[r])], coeff[r:r + 1], box[r:r + 1])
+        assert (big[r].cpu() - ref[0]).abs().max() < 5e-6
+
+
 @pytest.mark.parametrize("p", CASES)
 def test_mask_iou_bit_exact(golden_postproc, p):
     m = golden_postproc[p + "masks"]
