@@ -111,6 +111,10 @@ int stm_fcb_ali_offsets_f32(const float* loc, float* offset, int B, int H, int W
  * ------------------------------------------------------------------------------------------------- */
 int stm_corr_patch_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P,
                        int dil, float scale, float leaky_slope, stm_stream_t stream);
+/* the same values channels-last: out[b,y,x,i*P+j], [B,H,W,out_ld] with out_ld >= P*P (channels past P*P are not written) -- the
+ * layout stm_roi_align_planes_nhwc_f32 gathers from */
+int stm_corr_patch_nhwc_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P, int dil,
+                            float scale, float leaky_slope, int out_ld, stm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * RoIAlign, average pooling.
@@ -437,6 +441,11 @@ int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bias, void* pl
  * stm_roi_align_avg_f32 on the concatenated map. */
 int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s, const float* corr, const float* rois, void* planes, int B,
                              int H, int W, int C1, int Cc, int n, int PH, int PW, int fmt, stm_stream_t stream);
+/* the same with the correlation volume channels-last, [B][H][W][corr_ld] as stm_corr_patch_nhwc_f32 writes it (corr_ld a multiple
+ * of 4, >= Cc rounded up to 8; 0 = the NCHW form above): a sample's Cc displacement channels are then 4 cache lines instead of Cc */
+int stm_roi_align_planes_nhwc_f32(const float* t2s_prev, const float* t2s, const float* corr, int corr_ld, const float* rois,
+                                  void* planes, int B, int H, int W, int C1, int Cc, int n, int PH, int PW, int fmt,
+                                  stm_stream_t stream);
 
 /* Stem entry (backbone.py:73 / resnet conv1: kh x kw convolution, stride s, on a Cin-channel frame with kw * Cin <= 32): x fp32
  * NHWC [B][H][W][Cin] -> planes R [P][1][B*H*Wo][32], Wo = (W + 2 pw - kw) / sw + 1, R[b][y][ox][j] = x[b][y][sw*ox - pw + j / Cin]

@@ -15,14 +15,14 @@ c_i, c_l, c_f, c_p, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.
 # every symbol include/stmask_hip.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
     "stm_version", "stm_last_error_string", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
-    "stm_deform_conv_fwd_f32", "stm_gemm_bias_f32", "stm_gemm_workspace_bytes", "stm_gemm_bias_ws_f32", "stm_fcb_ali_offsets_f32", "stm_corr_patch_f32",
+    "stm_deform_conv_fwd_f32", "stm_gemm_bias_f32", "stm_gemm_workspace_bytes", "stm_gemm_bias_ws_f32", "stm_fcb_ali_offsets_f32", "stm_corr_patch_f32", "stm_corr_patch_nhwc_f32",
     "stm_roi_align_avg_f32", "stm_decode_boxes_f32", "stm_generate_candidates_f32", "stm_cc_fast_nms_f32",
     "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
     "stm_jaccard_f32", "stm_lincomb_sigmoid_crop_f32", "stm_mask_iou_workspace_bytes", "stm_mask_iou_f32",
     "stm_bias_act_f32", "stm_mask_rle_workspace_bytes", "stm_mask_resize_rle_f32",
     "stm_conv_packed_weight_bytes", "stm_conv_pack_weights_f32",
     "stm_split_bf16_planes_f32", "stm_conv2d_planar_f32", "stm_conv_packed_weight_bytes_tiled",
-    "stm_conv_pack_weights_tiled_f32", "stm_preprocess_u8_f32", "stm_head_assemble_f32", "stm_conv2d_planar_ws_f32", "stm_dcn_sample_planar_f32", "stm_conv_pack_weights_fmt_f32", "stm_split_planes_fmt_f32", "stm_dcn_sample_planar_fmt_f32", "stm_planar_set_range_flag", "stm_resize_bilinear_planes_f32", "stm_bias_relu_maxpool_planes_f32", "stm_roi_align_planes_f32", "stm_deform_sample_planar_f32", "stm_stem_rows_planes_f32", "stm_mask_iou_grouped_f32", "stm_cc_fast_nms_workspace_bytes", "stm_cc_fast_nms_ws_f32",
+    "stm_conv_pack_weights_tiled_f32", "stm_preprocess_u8_f32", "stm_head_assemble_f32", "stm_conv2d_planar_ws_f32", "stm_dcn_sample_planar_f32", "stm_conv_pack_weights_fmt_f32", "stm_split_planes_fmt_f32", "stm_dcn_sample_planar_fmt_f32", "stm_planar_set_range_flag", "stm_resize_bilinear_planes_f32", "stm_bias_relu_maxpool_planes_f32", "stm_roi_align_planes_f32", "stm_roi_align_planes_nhwc_f32", "stm_deform_sample_planar_f32", "stm_stem_rows_planes_f32", "stm_mask_iou_grouped_f32", "stm_cc_fast_nms_workspace_bytes", "stm_cc_fast_nms_ws_f32",
     "stm_gather_detections_f32", "stm_shift_rois_f32", "stm_shift_apply_f32", "stm_match_scores_f32", "stm_match_scores_embed_f32", "stm_gather_rows2", "stm_pack_tracked_f32",
     "stm_lincomb_sigmoid_crop_bits_f32", "stm_mask_iou_bits_f32", "stm_split_planes_f16", "stm_conv_pack_weights_f16", "stm_conv2d_planar_f16", "stm_dcn_sample_planar_f16",
 ]

@@ -925,7 +925,8 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_planes_kernel(const flo
 struct RoiPlanesArgs {
     const float* t2s_prev;   // [B][H][W][C1]
     const float* t2s;        // [B][H][W][C1]
-    const float* corr;       // [B][Cc][H][W]
+    const float* corr;       // [B][Cc][H][W], or channels-last [B][H][W][corr_ld] when corr_ld > 0
+    int corr_ld;
     const float* rois;       // [n][5] = (image, x1, y1, x2, y2) in feature-map pixels
     uint8_t* planes;         // [P][Cpad/32][n*PH*PW][32]
     int n, H, W, C1, Cc, Cpad, PH, PW, fmt;
@@ -959,6 +960,7 @@ __global__ __launch_bounds__(256) void roi_align_planes_kernel(const RoiPlanesAr
                                   : a.t2s + (size_t)b * a.H * a.W * a.C1 + (c0 - a.C1);
     const int cc0 = c0 - 2 * a.C1;                                 // first correlation channel of the lane (NCHW source)
     const float* nchw = a.corr + ((size_t)b * a.Cc + (cc0 > 0 ? cc0 : 0)) * a.H * a.W;
+    const float* cl = a.corr + (size_t)b * a.H * a.W * a.corr_ld + (cc0 > 0 ? cc0 : 0);        // channels-last source of the lane's 8 channels
     const int HW = a.H * a.W;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int iy = 0; iy < gh; ++iy) {
@@ -985,6 +987,21 @@ __global__ __launch_bounds__(256) void roi_align_planes_kernel(const RoiPlanesAr
                     const f32x4 q4 = *reinterpret_cast<const f32x4*>(nhwc + (size_t)o4 * a.C1 + 4 * h);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v1[4 * h + e] = q1[e]; v2[4 * h + e] = q2[e]; v3[4 * h + e] = q3[e]; v4[4 * h + e] = q4[e]; }
+                }
+            } else if (a.corr_ld > 0) {
+                // (channels past Cc of the padded row are whatever the buffer holds: masked, never used)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(cl + (size_t)o1 * a.corr_ld + 4 * h);
+                    const f32x4 q2 = *reinterpret_cast<const f32x4*>(cl + (size_t)o2 * a.corr_ld + 4 * h);
+                    const f32x4 q3 = *reinterpret_cast<const f32x4*>(cl + (size_t)o3 * a.corr_ld + 4 * h);
+                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(cl + (size_t)o4 * a.corr_ld + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool real = cc0 + 4 * h + e < a.Cc;
+                        v1[4 * h + e] = real ? q1[e] : 0.0f; v2[4 * h + e] = real ? q2[e] : 0.0f;
+                        v3[4 * h + e] = real ? q3[e] : 0.0f; v4[4 * h + e] = real ? q4[e] : 0.0f;
+                    }
                 }
             } else {
 #pragma unroll
@@ -1266,9 +1283,19 @@ extern "C" int stm_bias_relu_maxpool_planes_f32(const float* x, const float* bia
     return STM_OK;
 }
 
+extern "C" int stm_roi_align_planes_nhwc_f32(const float* t2s_prev, const float* t2s, const float* corr, int corr_ld, const float* rois,
+                                             void* planes, int B, int H, int W, int C1, int Cc, int n, int PH, int PW, int fmt, stm_stream_t stream);
 extern "C" int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s, const float* corr, const float* rois, void* planes, int B,
                                         int H, int W, int C1, int Cc, int n, int PH, int PW, int fmt, stm_stream_t stream)
 {
+    return stm_roi_align_planes_nhwc_f32(t2s_prev, t2s, corr, 0, rois, planes, B, H, W, C1, Cc, n, PH, PW, fmt, stream);
+}
+
+extern "C" int stm_roi_align_planes_nhwc_f32(const float* t2s_prev, const float* t2s, const float* corr, int corr_ld, const float* rois,
+                                             void* planes, int B, int H, int W, int C1, int Cc, int n, int PH, int PW, int fmt, stm_stream_t stream)
+{
+    STM_REQUIRE(corr_ld == 0 || (corr_ld >= (Cc + 7) / 8 * 8 && corr_ld % 4 == 0 && (uintptr_t)corr % 16 == 0), STM_EINVAL,
+                "stm_roi_align_planes_nhwc_f32: corr_ld must be 0 (NCHW) or a multiple of 4 >= Cc rounded up to 8, corr 16-byte aligned");
     STM_REQUIRE(fmt >= 0 && fmt <= 2, STM_EINVAL, "stm_roi_align_planes_f32: fmt must be 0, 1 or 2");
     STM_REQUIRE(t2s_prev && t2s && corr && rois && planes, STM_ENULL, "stm_roi_align_planes_f32: NULL argument");
     STM_REQUIRE(B > 0 && H > 0 && W > 0 && C1 > 0 && C1 % 8 == 0 && Cc > 0 && n > 0 && PH > 0 && PW > 0, STM_EINVAL,
@@ -1276,7 +1303,7 @@ extern "C" int stm_roi_align_planes_f32(const float* t2s_prev, const float* t2s,
     STM_REQUIRE((uintptr_t)t2s_prev % 16 == 0 && (uintptr_t)t2s % 16 == 0 && (uintptr_t)planes % 16 == 0, STM_EINVAL,
                 "stm_roi_align_planes_f32: 16-byte alignment required");
     RoiPlanesArgs a;
-    a.t2s_prev = t2s_prev; a.t2s = t2s; a.corr = corr; a.rois = rois; a.planes = static_cast<uint8_t*>(planes);
+    a.t2s_prev = t2s_prev; a.t2s = t2s; a.corr = corr; a.corr_ld = corr_ld; a.rois = rois; a.planes = static_cast<uint8_t*>(planes);
     a.n = n; a.H = H; a.W = W; a.C1 = C1; a.Cc = Cc; a.Cpad = (2 * C1 + Cc + 31) / 32 * 32; a.PH = PH; a.PW = PW; a.fmt = fmt;
     a.range_flag = current_range_flag();
     const int64_t threads = (int64_t)n * PH * PW * (a.Cpad / 8);

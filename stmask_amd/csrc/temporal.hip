@@ -21,7 +21,7 @@ constexpr int CORR_CCK = 16;  // channels staged per chunk (8 per half-wave)
 template <int P>
 __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict__ f1, const float* __restrict__ f2,
                                                         float* __restrict__ out, int C, int H, int W, float scale,
-                                                        float slope, int B)
+                                                        float slope, int B, int out_ld)
 {
     constexpr int R = P / 2;
     constexpr int WIN = 4 + P - 1;          // f2 values per item per channel (14 for P = 11)
@@ -152,8 +152,16 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
                     float v = acc[p][j] * scale;
                     o[p] = v < 0.0f ? v * slope : v;
                 }
-                float* op = out + ((((int64_t)b * P + i) * P + j) * H + y) * W + x0;
-                *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+                if (out_ld == 0) {
+                    float* op = out + ((((int64_t)b * P + i) * P + j) * H + y) * W + x0;
+                    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    // channels-last [B][H][W][out_ld], channel i * P + j: what the RoI kernel of the temporal fusion gathers (a
+                    // pixel's 121 displacements in 4 cache lines instead of 121)
+                    float* op = out + (((int64_t)b * H + y) * W + x0) * out_ld + i * P + j;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) op[(int64_t)p * out_ld] = o[p];
+                }
             }
         }
     }
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
 
 // Generic fallback (any patch size / patch dilation): one thread per output, channel loop from global.
 __global__ void corr_patch_generic(const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out,
-                                   int B, int C, int H, int W, int P, int dil, float scale, float slope)
+                                   int B, int C, int H, int W, int P, int dil, float scale, float slope, int out_ld)
 {
     int64_t total = (int64_t)B * P * P * H * W;
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,7 +189,9 @@ __global__ void corr_patch_generic(const float* __restrict__ f1, const float* __
         for (int c = 0; c < C; ++c) acc = fmaf(p1[c * HW], p2[c * HW], acc);
     }
     acc *= scale;
-    out[t] = acc < 0.0f ? acc * slope : acc;
+    const float v = acc < 0.0f ? acc * slope : acc;
+    if (out_ld == 0) out[t] = v;
+    else out[(((int64_t)b * H + y) * W + x) * out_ld + i * P + j] = v;
 }
 
 // ---------------------------------------------------------------------------------------- RoIAlign
@@ -240,8 +250,9 @@ __global__ void roi_align_avg_kernel(const float* __restrict__ feat, const float
 
 }  // namespace
 
-extern "C" int stm_corr_patch_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P,
-                                  int dil, float scale, float leaky_slope, stm_stream_t stream)
+namespace {
+int corr_patch_launch(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P, int dil, float scale, float leaky_slope,
+                      int out_ld, stm_stream_t stream)
 {
     STM_REQUIRE(f1 && f2 && out, STM_ENULL, "stm_corr_patch_f32: f1/f2/out must be non-NULL");
     STM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, STM_EINVAL, "stm_corr_patch_f32: empty input");
@@ -256,16 +267,30 @@ extern "C" int stm_corr_patch_f32(const float* f1, const float* f2, float* out, 
         size_t lds = (size_t)(CORR_CCK * W + CORR_CCK * 11 * LW2) * sizeof(float);
         if (lds <= 64 * 1024) {
             hipLaunchKernelGGL(corr_patch_tiled<11>, dim3(stm_xcd_grid((int64_t)H * B)), dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W,
-                               scale, leaky_slope, B);
+                               scale, leaky_slope, B, out_ld);
             STM_CHECK_LAUNCH("corr_patch_tiled");
             return STM_OK;
         }
     }
     int64_t total = (int64_t)B * P * P * H * W;
     hipLaunchKernelGGL(corr_patch_generic, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), f1, f2, out, B, C, H,
-                       W, P, dil, scale, leaky_slope);
+                       W, P, dil, scale, leaky_slope, out_ld);
     STM_CHECK_LAUNCH("corr_patch_generic");
     return STM_OK;
+}
+}  // namespace
+
+extern "C" int stm_corr_patch_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P,
+                                  int dil, float scale, float leaky_slope, stm_stream_t stream)
+{
+    return corr_patch_launch(f1, f2, out, B, C, H, W, P, dil, scale, leaky_slope, 0, stream);
+}
+
+extern "C" int stm_corr_patch_nhwc_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P, int dil, float scale,
+                                       float leaky_slope, int out_ld, stm_stream_t stream)
+{
+    STM_REQUIRE(out_ld >= P * P, STM_EINVAL, "stm_corr_patch_nhwc_f32: out_ld (%d) must hold the %d displacement channels", out_ld, P * P);
+    return corr_patch_launch(f1, f2, out, B, C, H, W, P, dil, scale, leaky_slope, out_ld, stream);
 }
 
 extern "C" int stm_roi_align_avg_f32(const float* feat, const float* rois, float* out, int B, int C, int H, int W, int n,

@@ -228,6 +228,21 @@ def corr_patch(f1, f2, patch_size=11, dilation_patch=1, scale=1.0, leaky_slope=1
     return out
 
 
+def corr_patch_nhwc(f1, f2, patch_size=11, scale=1.0, leaky_slope=1.0, ld=None):
+    """corr_patch with the displacement channels last: [B, H, W, ld] (ld >= P*P, default P*P rounded up to 8; channels past P*P are
+    not written) -- the layout roi_align_planes(corr_nhwc=...) gathers from."""
+    _dev(f1, f2)
+    f1, f2 = _f32c(f1), _f32c(f2)
+    if f1.shape != f2.shape:
+        raise StmError(f"correlation inputs differ in shape: {tuple(f1.shape)} vs {tuple(f2.shape)}")
+    B, C, H, W = f1.shape
+    ld = ld or -(-patch_size * patch_size // 8) * 8
+    out = torch.empty(B, H, W, ld, device=f1.device, dtype=torch.float32)
+    check(_lib.lib().stm_corr_patch_nhwc_f32(_p(f1), _p(f2), _p(out), c_i(B), c_i(C), c_i(H), c_i(W), c_i(patch_size), c_i(1), c_f(scale),
+                                             c_f(leaky_slope), c_i(ld), _stream()), "stm_corr_patch_nhwc_f32")
+    return out
+
+
 def roi_align(feat, rois, output_size, spatial_scale=1.0, sampling_ratio=0, aligned=True):
     _dev(feat, rois)
     feat, rois = _f32c(feat), _f32c(rois)
@@ -704,21 +719,24 @@ def bias_relu_maxpool_planes(x_nhwc, bias, fmt=0):
     return planes, (Ho, Wo)
 
 
-def roi_align_planes(t2s_prev_nhwc, t2s_nhwc, corr_nchw, rois, output_size=7, fmt=0):
+def roi_align_planes(t2s_prev_nhwc, t2s_nhwc, corr, rois, output_size=7, fmt=0, corr_nhwc=0):
     """relu(cat([corr, T2S_prev, T2S], 1)) -> roi_align(output_size, aligned, adaptive grid) as planes
-    [P, Cpad/32, n*ph*pw, 32] with channel order [T2S_prev | T2S | corr | zero padding] (stm_roi_align_planes_f32)."""
-    _dev(t2s_prev_nhwc, t2s_nhwc, corr_nchw, rois)
-    a, b, c, rois = _f32c(t2s_prev_nhwc), _f32c(t2s_nhwc), _f32c(corr_nchw), _f32c(rois)
+    [P, Cpad/32, n*ph*pw, 32] with channel order [T2S_prev | T2S | corr | zero padding] (stm_roi_align_planes_f32).  corr is
+    [B, Cc, H, W], or with corr_nhwc = Cc the channels-last [B, H, W, ld] of corr_patch_nhwc."""
+    _dev(t2s_prev_nhwc, t2s_nhwc, corr, rois)
+    a, b, c, rois = _f32c(t2s_prev_nhwc), _f32c(t2s_nhwc), _f32c(corr), _f32c(rois)
     B, H, W, C1 = a.shape
-    if tuple(b.shape) != (B, H, W, C1) or c.shape[0] != B or tuple(c.shape[2:]) != (H, W):
+    ok = (tuple(c.shape[:3]) == (B, H, W) and c.shape[3] >= corr_nhwc) if corr_nhwc else (c.shape[0] == B and tuple(c.shape[2:]) == (H, W))
+    if tuple(b.shape) != (B, H, W, C1) or not ok:
         raise StmError(f"roi_align_planes: shapes {tuple(a.shape)}, {tuple(b.shape)}, {tuple(c.shape)} do not match")
-    Cc, n = c.shape[1], rois.shape[0]
+    Cc, n = (corr_nhwc or c.shape[1]), rois.shape[0]
     ph, pw = _pair(output_size)
     cpad = -(-(2 * C1 + Cc) // 32) * 32
     planes = _empty_planes(fmt, cpad // 32, n * ph * pw, a.device)
     if n:
-        check(_lib.lib().stm_roi_align_planes_f32(_p(a), _p(b), _p(c), _p(rois), _p(planes), c_i(B), c_i(H), c_i(W), c_i(C1), c_i(Cc), c_i(n),
-                                                  c_i(ph), c_i(pw), c_i(fmt), _stream()), "stm_roi_align_planes_f32")
+        check(_lib.lib().stm_roi_align_planes_nhwc_f32(_p(a), _p(b), _p(c), c_i(c.shape[3] if corr_nhwc else 0), _p(rois), _p(planes), c_i(B),
+                                                       c_i(H), c_i(W), c_i(C1), c_i(Cc), c_i(n), c_i(ph), c_i(pw), c_i(fmt), _stream()),
+              "stm_roi_align_planes_f32")
     return planes
 
 

@@ -108,8 +108,6 @@ class BatchedClipPipeline:
         clip_of_row = prev["clip"]
         P4_prev, T2S_prev = self.prev_feat
         P = cfg.correlation_patch_size
-        corr = ops.corr_patch(P4_prev, P4, P, 1, scale=1.0 / P4.shape[1], leaky_slope=0.1)
-        corr = corr.view(P4.shape[0], P * P, P4.shape[2], P4.shape[3])
         fh, fw = P4.shape[2:]
         box_ref = prev["box"]
         rois = ops.shift_rois(box_ref, clip_of_row, fh, fw)          # (clip, sanitised box in feature-map pixels)
@@ -119,12 +117,16 @@ class BatchedClipPipeline:
                  and 2 * T2S.shape[1] + P * P == ptn.cin)
         if fused:
             # ReLU + concatenation + RoIAlign + channel padding + split in one kernel: the RoI features leave as the planes
-            # TemporalNet's first convolution reads (the feature maps are channels_last views of the head's fp32 output)
+            # TemporalNet's first convolution reads (the feature maps are channels_last views of the head's fp32 output; the
+            # correlation volume is written channels-last too, so a sample's 121 displacements are 4 cache lines, not 121)
             n = rois.shape[0]
-            xp = ops.roi_align_planes(a_prev, a_cur, corr, rois, 7, fmt=ptn.fmt)
+            corr = ops.corr_patch_nhwc(P4_prev, P4, P, scale=1.0 / P4.shape[1], leaky_slope=0.1)
+            xp = ops.roi_align_planes(a_prev, a_cur, corr, rois, 7, fmt=ptn.fmt, corr_nhwc=P * P)
             self.timer.toc("tf_corr_roi")
             loc_shift, coeff_shift = ptn.forward_planes(xp, n)
         else:
+            corr = ops.corr_patch(P4_prev, P4, P, 1, scale=1.0 / P4.shape[1], leaky_slope=0.1)
+            corr = corr.view(P4.shape[0], P * P, P4.shape[2], P4.shape[3])
             feats = F.relu(torch.cat([corr, T2S_prev, T2S], dim=1))
             roi_feats = ops.roi_align(feats, rois, 7)
             self.timer.toc("tf_corr_roi")

@@ -464,6 +464,11 @@ def test_roi_align_planes_equals_cat_relu_roialign_split(fmt):
     cpad = pl.shape[1] * 32
     ref = torch.nn.functional.pad(ref, (0, cpad - ref.shape[-1])).contiguous()
     assert torch.equal(pl.cpu(), ops.split_planes(ref, fmt=fmt).cpu().view_as(pl.cpu()))
+    # the correlation volume channels-last in a padded row (16 floats, the spare ones poisoned): same planes
+    cl = torch.full((B, H, W, 16), float("nan"))
+    cl[..., :Cc] = corr.permute(0, 2, 3, 1)
+    pl2 = ops.roi_align_planes(prev.to(DEV), cur.to(DEV), cl.to(DEV), rois.to(DEV), 7, fmt=fmt, corr_nhwc=Cc)
+    assert torch.equal(pl2.cpu(), pl.cpu())
 
 
 @pytest.mark.parametrize("fmt", [1, 0])

@@ -183,6 +183,10 @@ def test_correlation_vs_oracle(B, C, H, W):
     ref2 = oracle.correlate(f1, f2, 11)
     got2 = ops.corr_patch(f1.to(DEV), f2.to(DEV), 11, 1, scale=1.0 / C, leaky_slope=0.1).view(B, 121, H, W).cpu()
     assert (got2 - ref2).abs().max() < 2e-6
+    # channels-last form (what the temporal fusion's RoI kernel gathers from): the same values, bit for bit, in [B, H, W, 128];
+    # the 7 spare channels are not written (both the tiled and the generic kernel: W % 4 != 0 takes the latter)
+    nhwc = ops.corr_patch_nhwc(f1.to(DEV), f2.to(DEV), 11, scale=1.0 / C, leaky_slope=0.1).cpu()
+    assert nhwc.shape == (B, H, W, 128) and torch.equal(nhwc[..., :121], got2.permute(0, 2, 3, 1))
 
 
 def test_correlation_known_answers_and_generic_path(tunables):
