@@ -112,9 +112,10 @@ int stm_fcb_ali_offsets_f32(const float* loc, float* offset, int B, int H, int W
 int stm_corr_patch_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P,
                        int dil, float scale, float leaky_slope, stm_stream_t stream);
 /* the same values channels-last: out[b,y,x,i*P+j], [B,H,W,out_ld] with out_ld >= P*P (channels past P*P are not written) -- the
- * layout stm_roi_align_planes_nhwc_f32 gathers from */
+ * layout stm_roi_align_planes_nhwc_f32 gathers from.  in_nhwc != 0: f1 / f2 are channels-last too, [B,H,W,C] (what the trunk's
+ * fp32 outputs are; same arithmetic, same bits) */
 int stm_corr_patch_nhwc_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P, int dil,
-                            float scale, float leaky_slope, int out_ld, stm_stream_t stream);
+                            float scale, float leaky_slope, int out_ld, int in_nhwc, stm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * RoIAlign, average pooling.

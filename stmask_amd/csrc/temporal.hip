@@ -18,7 +18,9 @@ namespace {
 
 constexpr int CORR_CCK = 16;  // channels staged per chunk (8 per half-wave)
 
-template <int P>
+// IN_NHWC: f1 / f2 are channels-last [B][H][W][C] (C % 4 == 0) -- the layout the trunk's fp32 outputs have; a staging unit is then
+// (f2 row, x, 4 channels) instead of (channel, f2 row, 4 x): same LDS image, same arithmetic, no NCHW copy of the feature maps.
+template <int P, bool IN_NHWC>
 __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict__ f1, const float* __restrict__ f2,
                                                         float* __restrict__ out, int C, int H, int W, float scale,
                                                         float slope, int B, int out_ld)
@@ -46,6 +48,7 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
     const int64_t HW = (int64_t)H * W;
     const float* f1b = f1 + (int64_t)b * C * HW;
     const float* f2b = f2 + (int64_t)b * C * HW;
+    constexpr int CQ = CORR_CCK / 4;        // channel quads per chunk (channels-last staging)
 
     // ---- staging plan, computed ONCE: unit u = (channel c, f2 row rr, x quad) -> one float4 global load + 4 LDS words.
     //      Only in-image rows are ever loaded; halo columns and out-of-image rows are zeroed once and never touched again.
@@ -57,17 +60,30 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
         g_off[u] = -1;
         l_off[u] = 0;
         if (id < units) {
-            int c = id / (P * Wq), rem = id - c * (P * Wq);
-            int rr = rem / Wq, xq = rem - rr * Wq;
-            int yy = y + rr - R;
-            if (yy >= 0 && yy < H) {
-                g_off[u] = c * (int)HW + yy * W + xq * 4;
-                l_off[u] = (c * P + rr) * LW2 + R + xq * 4;
+            if constexpr (IN_NHWC) {
+                // unit = (f2 row rr, x, channel quad): 16 bytes of 4 channels at one pixel; the quad is the fastest index, so the
+                // CQ lanes of a pixel read 64 contiguous bytes
+                const int cq = id % CQ, rem = id / CQ;
+                const int rr = rem / W, x = rem - rr * W;
+                const int yy = y + rr - R;
+                if (yy >= 0 && yy < H) {
+                    g_off[u] = (yy * W + x) * C + cq * 4;
+                    l_off[u] = (cq * 4 * P + rr) * LW2 + R + x;
+                }
+            } else {
+                int c = id / (P * Wq), rem = id - c * (P * Wq);
+                int rr = rem / Wq, xq = rem - rr * Wq;
+                int yy = y + rr - R;
+                if (yy >= 0 && yy < H) {
+                    g_off[u] = c * (int)HW + yy * W + xq * 4;
+                    l_off[u] = (c * P + rr) * LW2 + R + xq * 4;
+                }
             }
         }
     }
-    const bool f1_unit = tid < CORR_CCK * Wq;
-    const int f1_c = tid / Wq, f1_xq = tid - f1_c * Wq;
+    const bool f1_unit = IN_NHWC ? tid < CQ * W : tid < CORR_CCK * Wq;
+    const int f1_c = IN_NHWC ? (tid % CQ) * 4 : tid / Wq;            // first channel of the unit
+    const int f1_xq = IN_NHWC ? tid / CQ : tid - f1_c * Wq;          // its x (channels-last) / x quad
     for (int idx = tid; idx < CORR_CCK * P * LW2; idx += 256) f2s[idx] = 0.0f;
 
     float4 pf[MAXU], pf1;
@@ -76,22 +92,38 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
         for (int u = 0; u < MAXU; ++u) {
             pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g_off[u] >= 0) {
-                int c = (tid + u * 256) / (P * Wq);
-                if (c0 + c < C) pf[u] = *reinterpret_cast<const float4*>(f2b + (int64_t)c0 * HW + g_off[u]);
+                if constexpr (IN_NHWC) {
+                    const int c = ((tid + u * 256) % CQ) * 4;     // C % 4 == 0: a quad is inside or outside as a whole
+                    if (c0 + c < C) pf[u] = *reinterpret_cast<const float4*>(f2b + g_off[u] + c0);
+                } else {
+                    int c = (tid + u * 256) / (P * Wq);
+                    if (c0 + c < C) pf[u] = *reinterpret_cast<const float4*>(f2b + (int64_t)c0 * HW + g_off[u]);
+                }
             }
         }
         pf1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f1_unit && c0 + f1_c < C)
-            pf1 = *reinterpret_cast<const float4*>(f1b + (int64_t)(c0 + f1_c) * HW + (int64_t)y * W + f1_xq * 4);
+        if (f1_unit && c0 + f1_c < C) {
+            if constexpr (IN_NHWC) pf1 = *reinterpret_cast<const float4*>(f1b + ((int64_t)y * W + f1_xq) * C + c0 + f1_c);
+            else pf1 = *reinterpret_cast<const float4*>(f1b + (int64_t)(c0 + f1_c) * HW + (int64_t)y * W + f1_xq * 4);
+        }
     };
     auto commit = [&]() {
 #pragma unroll
         for (int u = 0; u < MAXU; ++u)
             if (g_off[u] >= 0) {
                 float* d = f2s + l_off[u];
-                d[0] = pf[u].x; d[1] = pf[u].y; d[2] = pf[u].z; d[3] = pf[u].w;
+                constexpr int ST = IN_NHWC ? 0 : 1;              // word stride between the unit's 4 values: channels (P * LW2) or x (1)
+                const int st = ST ? 1 : P * LW2;
+                d[0] = pf[u].x; d[st] = pf[u].y; d[2 * st] = pf[u].z; d[3 * st] = pf[u].w;
             }
-        if (f1_unit) *reinterpret_cast<float4*>(f1s + f1_c * W + f1_xq * 4) = pf1;
+        if (f1_unit) {
+            if constexpr (IN_NHWC) {
+                float* d = f1s + f1_c * W + f1_xq;
+                d[0] = pf1.x; d[W] = pf1.y; d[2 * W] = pf1.z; d[3 * W] = pf1.w;
+            } else {
+                *reinterpret_cast<float4*>(f1s + f1_c * W + f1_xq * 4) = pf1;
+            }
+        }
     };
 
     for (int pass0 = 0; pass0 < items; pass0 += 128) {
@@ -169,7 +201,7 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
 
 // Generic fallback (any patch size / patch dilation): one thread per output, channel loop from global.
 __global__ void corr_patch_generic(const float* __restrict__ f1, const float* __restrict__ f2, float* __restrict__ out,
-                                   int B, int C, int H, int W, int P, int dil, float scale, float slope, int out_ld)
+                                   int B, int C, int H, int W, int P, int dil, float scale, float slope, int out_ld, int in_nhwc)
 {
     int64_t total = (int64_t)B * P * P * H * W;
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,9 +216,10 @@ __global__ void corr_patch_generic(const float* __restrict__ f1, const float* __
     float acc = 0.0f;
     if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) {
         const int64_t HW = (int64_t)H * W;
-        const float* p1 = f1 + (int64_t)b * C * HW + (int64_t)y * W + x;
-        const float* p2 = f2 + (int64_t)b * C * HW + (int64_t)y2 * W + x2;
-        for (int c = 0; c < C; ++c) acc = fmaf(p1[c * HW], p2[c * HW], acc);
+        const int64_t cs = in_nhwc ? 1 : HW, ps = in_nhwc ? C : 1;     // channel / pixel strides of the inputs
+        const float* p1 = f1 + (int64_t)b * C * HW + ((int64_t)y * W + x) * ps;
+        const float* p2 = f2 + (int64_t)b * C * HW + ((int64_t)y2 * W + x2) * ps;
+        for (int c = 0; c < C; ++c) acc = fmaf(p1[c * cs], p2[c * cs], acc);
     }
     acc *= scale;
     const float v = acc < 0.0f ? acc * slope : acc;
@@ -252,7 +285,7 @@ __global__ void roi_align_avg_kernel(const float* __restrict__ feat, const float
 
 namespace {
 int corr_patch_launch(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P, int dil, float scale, float leaky_slope,
-                      int out_ld, stm_stream_t stream)
+                      int out_ld, int in_nhwc, stm_stream_t stream)
 {
     STM_REQUIRE(f1 && f2 && out, STM_ENULL, "stm_corr_patch_f32: f1/f2/out must be non-NULL");
     STM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, STM_EINVAL, "stm_corr_patch_f32: empty input");
@@ -261,20 +294,24 @@ int corr_patch_launch(const float* f1, const float* f2, float* out, int B, int C
     // tiled kernel: P = 11, rows of whole float4 quads, staging plan of <= 8 units per thread (W <= 44)
     bool tiled = (P == 11 && dil == 1 && H <= 65535 && B <= 65535 && W % 4 == 0 && CORR_CCK * 11 * (W / 4) <= 8 * 256 &&
                   ((uintptr_t)out % 16 == 0) && ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f2 % 16 == 0));
-    if (force == 1) tiled = false;
+    if (force == 1 || (in_nhwc && C % 4 != 0)) tiled = false;
     if (tiled) {
         int LW2 = ((W + 10 + 3) / 4) * 4;
         size_t lds = (size_t)(CORR_CCK * W + CORR_CCK * 11 * LW2) * sizeof(float);
         if (lds <= 64 * 1024) {
-            hipLaunchKernelGGL(corr_patch_tiled<11>, dim3(stm_xcd_grid((int64_t)H * B)), dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W,
-                               scale, leaky_slope, B, out_ld);
+            if (in_nhwc)
+                hipLaunchKernelGGL((corr_patch_tiled<11, true>), dim3(stm_xcd_grid((int64_t)H * B)), dim3(256), lds, stm_hs(stream), f1, f2, out, C,
+                                   H, W, scale, leaky_slope, B, out_ld);
+            else
+                hipLaunchKernelGGL((corr_patch_tiled<11, false>), dim3(stm_xcd_grid((int64_t)H * B)), dim3(256), lds, stm_hs(stream), f1, f2, out, C,
+                                   H, W, scale, leaky_slope, B, out_ld);
             STM_CHECK_LAUNCH("corr_patch_tiled");
             return STM_OK;
         }
     }
     int64_t total = (int64_t)B * P * P * H * W;
     hipLaunchKernelGGL(corr_patch_generic, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), f1, f2, out, B, C, H,
-                       W, P, dil, scale, leaky_slope, out_ld);
+                       W, P, dil, scale, leaky_slope, out_ld, in_nhwc);
     STM_CHECK_LAUNCH("corr_patch_generic");
     return STM_OK;
 }
@@ -283,14 +320,14 @@ int corr_patch_launch(const float* f1, const float* f2, float* out, int B, int C
 extern "C" int stm_corr_patch_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P,
                                   int dil, float scale, float leaky_slope, stm_stream_t stream)
 {
-    return corr_patch_launch(f1, f2, out, B, C, H, W, P, dil, scale, leaky_slope, 0, stream);
+    return corr_patch_launch(f1, f2, out, B, C, H, W, P, dil, scale, leaky_slope, 0, 0, stream);
 }
 
 extern "C" int stm_corr_patch_nhwc_f32(const float* f1, const float* f2, float* out, int B, int C, int H, int W, int P, int dil, float scale,
-                                       float leaky_slope, int out_ld, stm_stream_t stream)
+                                       float leaky_slope, int out_ld, int in_nhwc, stm_stream_t stream)
 {
     STM_REQUIRE(out_ld >= P * P, STM_EINVAL, "stm_corr_patch_nhwc_f32: out_ld (%d) must hold the %d displacement channels", out_ld, P * P);
-    return corr_patch_launch(f1, f2, out, B, C, H, W, P, dil, scale, leaky_slope, out_ld, stream);
+    return corr_patch_launch(f1, f2, out, B, C, H, W, P, dil, scale, leaky_slope, out_ld, in_nhwc ? 1 : 0, stream);
 }
 
 extern "C" int stm_roi_align_avg_f32(const float* feat, const float* rois, float* out, int B, int C, int H, int W, int n,

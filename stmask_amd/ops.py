@@ -230,16 +230,20 @@ def corr_patch(f1, f2, patch_size=11, dilation_patch=1, scale=1.0, leaky_slope=1
 
 def corr_patch_nhwc(f1, f2, patch_size=11, scale=1.0, leaky_slope=1.0, ld=None):
     """corr_patch with the displacement channels last: [B, H, W, ld] (ld >= P*P, default P*P rounded up to 8; channels past P*P are
-    not written) -- the layout roi_align_planes(corr_nhwc=...) gathers from."""
+    not written) -- the layout roi_align_planes(corr_nhwc=...) gathers from.  f1 / f2 are [B, C, H, W] tensors in either memory
+    format: channels_last ones (the trunk's outputs) are read in place."""
     _dev(f1, f2)
-    f1, f2 = _f32c(f1), _f32c(f2)
     if f1.shape != f2.shape:
         raise StmError(f"correlation inputs differ in shape: {tuple(f1.shape)} vs {tuple(f2.shape)}")
     B, C, H, W = f1.shape
+    cl = (f1.dtype == f2.dtype == torch.float32 and C > 1 and f1.is_contiguous(memory_format=torch.channels_last)
+          and f2.is_contiguous(memory_format=torch.channels_last) and not f1.is_contiguous())
+    if not cl:
+        f1, f2 = _f32c(f1), _f32c(f2)
     ld = ld or -(-patch_size * patch_size // 8) * 8
     out = torch.empty(B, H, W, ld, device=f1.device, dtype=torch.float32)
     check(_lib.lib().stm_corr_patch_nhwc_f32(_p(f1), _p(f2), _p(out), c_i(B), c_i(C), c_i(H), c_i(W), c_i(patch_size), c_i(1), c_f(scale),
-                                             c_f(leaky_slope), c_i(ld), _stream()), "stm_corr_patch_nhwc_f32")
+                                             c_f(leaky_slope), c_i(ld), c_i(1 if cl else 0), _stream()), "stm_corr_patch_nhwc_f32")
     return out
 
 

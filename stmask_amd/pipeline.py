@@ -120,8 +120,7 @@ class BatchedClipPipeline:
             # TemporalNet's first convolution reads (the feature maps are channels_last views of the head's fp32 output; the
             # correlation volume is written channels-last too, so a sample's 121 displacements are 4 cache lines, not 121)
             n = rois.shape[0]
-            # (the correlation kernel reads NCHW; the copy of this frame's P4 is kept: it is the next step's P4_prev)
-            P4 = self._p4_nchw = P4.contiguous()
+            # (P4 is a channels_last view of the FPN's fp32 output: the correlation kernel reads it in place)
             corr = ops.corr_patch_nhwc(P4_prev, P4, P, scale=1.0 / P4.shape[1], leaky_slope=0.1)
             xp = ops.roi_align_planes(a_prev, a_cur, corr, rois, 7, fmt=ptn.fmt, corr_nhwc=P * P)
             self.timer.toc("tf_corr_roi")
@@ -334,9 +333,7 @@ class BatchedClipPipeline:
                 for k, t in zip(keys, rows):
                     prev[k] = t
             tmr.toc("tracker_update")
-        p4c = getattr(self, "_p4_nchw", None)
-        self.prev_feat = (p4c if p4c is not None else P4, T2S)
-        self._p4_nchw = None
+        self.prev_feat = (P4, T2S)
         self.t += 1
         out = self._pack_outputs(dev)
         tmr.toc("pack")

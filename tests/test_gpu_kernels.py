@@ -187,6 +187,12 @@ def test_correlation_vs_oracle(B, C, H, W):
     # the 7 spare channels are not written (both the tiled and the generic kernel: W % 4 != 0 takes the latter)
     nhwc = ops.corr_patch_nhwc(f1.to(DEV), f2.to(DEV), 11, scale=1.0 / C, leaky_slope=0.1).cpu()
     assert nhwc.shape == (B, H, W, 128) and torch.equal(nhwc[..., :121], got2.permute(0, 2, 3, 1))
+    # channels_last inputs (the trunk's fp32 outputs) are read in place: a staging unit is (row, x, 4 channels) instead of
+    # (channel, row, 4 x), the LDS image and the arithmetic are the same -> the same bits (C % 4 != 0 takes the generic kernel)
+    cl1, cl2 = (t.to(DEV).contiguous(memory_format=torch.channels_last) for t in (f1, f2))
+    assert not cl1.is_contiguous() or C == 1
+    nhwc_cl = ops.corr_patch_nhwc(cl1, cl2, 11, scale=1.0 / C, leaky_slope=0.1).cpu()
+    assert torch.equal(nhwc_cl[..., :121], nhwc[..., :121])
 
 
 def test_correlation_known_answers_and_generic_path(tunables):
