@@ -371,6 +371,12 @@ int stm_gather_rows2(const void* const* a_rows, const void* const* b_rows, void*
 int stm_pack_tracked_f32(const float* mask, const float* score, const int* tracked, const int* offsets, const float* box,
                          const int64_t* cls, const float* mask_coeff, int n_rows, int hw, int B, int top_k, int cols,
                          int mask_dim, int max_age, float score_thr, int* keep_ws, float* out, stm_stream_t stream);
+/* the same with the keep rule's pixel count taken from the masks' bit words (stm_lincomb_sigmoid_crop_bits_f32: [n_rows][words],
+ * bit = value > 0.5): the soft masks are not read */
+int stm_pack_tracked_bits_f32(const uint64_t* mask_bits, int words, const float* score, const int* tracked, const int* offsets,
+                              const float* box, const int64_t* cls, const float* mask_coeff, int n_rows, int B, int top_k,
+                              int cols, int mask_dim, int max_age, float score_thr, int* keep_ws, float* out,
+                              stm_stream_t stream);
 
 /* ---- `_f16` entry points: the genuine-fp16 convolution path of BASELINE config 5 ("fp16 MFMA backbone convs") -----------------
  * Replaces, for the ResNet backbone of a half-precision deployment, the same reference layers as the fp32-equivalent entries

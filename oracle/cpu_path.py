@@ -169,6 +169,12 @@ def _mask_iou_bits(bits1, bits2, hw, group1=None, group2=None):
     return _mask_iou(bits1.float().reshape(bits1.shape[0], 1, -1), bits2.float().reshape(bits2.shape[0], 1, -1), 0.5, group1, group2)
 
 
+def _pack_tracked_bits(bits, score, tracked, offsets, box, cls, mask_coeff, B, top_k, cols, max_age=10, score_thr=0.05):
+    # (the CPU stand-in of the bit table is the binarised mask itself: see _lincomb_bits)
+    return _pack_tracked(bits.reshape(bits.shape[0], 1, -1).float(), score, tracked, offsets, box, cls, mask_coeff, B, top_k, cols, max_age,
+                         score_thr)
+
+
 _PATCH = {
     "bias_act_": _bias_act_,
     "deform_conv": _deform_conv,
@@ -197,6 +203,7 @@ _PATCH = {
     "match_scores_embed": _match_scores_embed,
     "gather_rows2": _gather_rows2,
     "pack_tracked": _pack_tracked,
+    "pack_tracked_bits": _pack_tracked_bits,
 }
 
 

@@ -233,6 +233,24 @@ __global__ __launch_bounds__(256) void keep_flags_kernel(const float* __restrict
     if (threadIdx.x == 0) keep[r] = (other && cnt > 1) ? 1 : 0;
 }
 
+// the same rule from the masks' bit words (stm_lincomb_sigmoid_crop_bits_f32: bit = value > 0.5): one wave per row, popcounts
+__global__ __launch_bounds__(256) void keep_flags_bits_kernel(const unsigned long long* __restrict__ bits, const float* __restrict__ score,
+                                                              const int* __restrict__ tracked, int* __restrict__ keep, int n_rows, int words,
+                                                              int max_age, float thr)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_rows) return;
+    const bool other = tracked[r] <= max_age && score[r] > thr;   // wave-uniform
+    int c = 0;
+    if (other) {
+        const unsigned long long* w = bits + (int64_t)r * words;
+        for (int i = lane; i < words; i += 64) c += __popcll(w[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, STM_WAVE);
+    }
+    if (lane == 0) keep[r] = (other && c > 1) ? 1 : 0;
+}
+
 // one block per clip: kept rows of the clip, in row order, become rows 0.. of out[clip]: (box 4, score, class, object id =
 // row index within the clip, 1, mask coefficients); rows past the kept count (and past top_k) are zero
 __global__ __launch_bounds__(256) void pack_tracked_kernel(const int* __restrict__ keep, const int* __restrict__ off, const float* __restrict__ box,
@@ -406,6 +424,25 @@ extern "C" int stm_pack_tracked_f32(const float* mask, const float* score, const
     if (n_rows > 0) {
         hipLaunchKernelGGL(keep_flags_kernel, dim3(n_rows), dim3(256), 0, stm_hs(stream), mask, score, tracked, keep_ws, hw, max_age, score_thr);
         STM_CHECK_LAUNCH("keep_flags_kernel");
+    }
+    hipLaunchKernelGGL(pack_tracked_kernel, dim3(B), dim3(256), 0, stm_hs(stream), keep_ws, offsets, box, score, cls, mask_coeff, out, top_k, cols,
+                       mask_dim);
+    STM_CHECK_LAUNCH("pack_tracked_kernel");
+    return STM_OK;
+}
+
+extern "C" int stm_pack_tracked_bits_f32(const uint64_t* mask_bits, int words, const float* score, const int* tracked, const int* offsets,
+                                         const float* box, const int64_t* cls, const float* mask_coeff, int n_rows, int B, int top_k, int cols,
+                                         int mask_dim, int max_age, float score_thr, int* keep_ws, float* out, stm_stream_t stream)
+{
+    STM_REQUIRE(n_rows >= 0 && words > 0 && B > 0 && top_k > 0 && mask_dim > 0 && cols >= 8 + mask_dim, STM_EINVAL, "stm_pack_tracked_bits_f32: bad sizes");
+    STM_REQUIRE(offsets && out, STM_ENULL, "stm_pack_tracked_bits_f32: NULL argument");
+    STM_REQUIRE(n_rows == 0 || (mask_bits && score && tracked && box && cls && mask_coeff && keep_ws), STM_ENULL, "stm_pack_tracked_bits_f32: NULL row argument");
+    STM_REQUIRE((uintptr_t)box % 16 == 0, STM_EINVAL, "stm_pack_tracked_bits_f32: boxes must be 16-byte aligned");
+    if (n_rows > 0) {
+        hipLaunchKernelGGL(keep_flags_bits_kernel, dim3(stm_cdiv(n_rows, 4)), dim3(256), 0, stm_hs(stream),
+                           reinterpret_cast<const unsigned long long*>(mask_bits), score, tracked, keep_ws, n_rows, words, max_age, score_thr);
+        STM_CHECK_LAUNCH("keep_flags_bits_kernel");
     }
     hipLaunchKernelGGL(pack_tracked_kernel, dim3(B), dim3(256), 0, stm_hs(stream), keep_ws, offsets, box, score, cls, mask_coeff, out, top_k, cols,
                        mask_dim);

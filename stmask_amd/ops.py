@@ -693,6 +693,21 @@ def pack_tracked(mask, score, tracked, offsets, box, cls, mask_coeff, B, top_k, 
     return out
 
 
+def pack_tracked_bits(bits, score, tracked, offsets, box, cls, mask_coeff, B, top_k, cols, max_age=10, score_thr=0.05):
+    """pack_tracked with the keep rule's pixel count taken from the masks' bit words [n, words] (lincomb_sigmoid_crop_bits)."""
+    _dev(bits, score, tracked, offsets, box, cls, mask_coeff)
+    n = box.shape[0]
+    out = torch.empty(B, top_k, cols, device=offsets.device, dtype=torch.float32)
+    keep = torch.empty(max(n, 1), dtype=torch.int32, device=offsets.device)
+    if n and (bits.dtype != torch.int64 or bits.shape[0] != n or not bits.is_contiguous()):
+        raise StmError("pack_tracked_bits: bits must be contiguous int64 words [n, words]")
+    check(_lib.lib().stm_pack_tracked_bits_f32(_p(bits) if n else c_p(0), c_i(bits.shape[1] if n else 1), _p(score), _p(tracked), _p(offsets), _p(box),
+                                               _p(cls), _p(mask_coeff), c_i(n), c_i(B), c_i(top_k), c_i(cols),
+                                               c_i(mask_coeff.shape[1] if n else cols - 8), c_i(max_age), c_f(score_thr), _p(keep), _p(out), _stream()),
+          "stm_pack_tracked_bits_f32")
+    return out
+
+
 def resize_bilinear_planes(x_nhwc, size, fmt=0):
     """F.interpolate(x, size=size, mode="bilinear", align_corners=False) of an fp32 NHWC tensor [B,H,W,C], returned as planes
     [P, C/32, B*Ho*Wo, 32] (split_planes' format) without the fp32 intermediate."""

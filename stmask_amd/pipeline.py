@@ -77,6 +77,31 @@ class ClipPipeline:
 _ROW_KEYS = ("box", "mask_coeff", "track", "class", "score", "centerness", "mask")
 
 
+class _TrackedRows(dict):
+    """The tracked set's row tensors.  After a tracker update the soft masks of the merged set are not gathered (61 KB per row,
+    rewritten from the prototypes at the next step anyway; the keep rule reads their bit words): `rows["mask"]` gathers them on
+    first use from the two sources and the gather plan of that update."""
+
+    def defer_mask(self, prev_mask, det_mask, plan, n_prev):
+        self._deferred = (prev_mask, det_mask, plan, n_prev)
+        dict.pop(self, "mask", None)
+
+    def __getitem__(self, key):
+        if key == "mask" and not dict.__contains__(self, "mask") and getattr(self, "_deferred", None) is not None:
+            a, b, plan, n_prev = self._deferred
+            dict.__setitem__(self, "mask", ops.gather_rows2([a], [b], plan, n_prev)[0])
+            self._deferred = None
+        return dict.__getitem__(self, key)
+
+    def __setitem__(self, key, value):
+        if key == "mask":
+            self._deferred = None
+        dict.__setitem__(self, key, value)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (key == "mask" and getattr(self, "_deferred", None) is not None)
+
+
 class BatchedClipPipeline:
     """All clips' tracker state concatenated (rows sorted by clip); per-clip row ranges are host integers."""
 
@@ -283,7 +308,7 @@ class BatchedClipPipeline:
 
         if self.prev is None:
             # first frame of every clip (track_TF.py:88-93): the detections become the tracked set
-            self.prev = det
+            self.prev, self._bits = det, det_bits
             self.prev_n = list(counts)
             self.tracked = [[0] * k for k in counts]
             self._upload_meta(dev, None)
@@ -328,10 +353,18 @@ class BatchedClipPipeline:
             self.prev_n, self.tracked = new_n, new_tracked
             plan_dev = self._upload_meta(dev, plan if D else None)
             if D:
-                keys = _ROW_KEYS + ("clip",)
-                rows = ops.gather_rows2([prev[k] for k in keys], [det[k] for k in keys], plan_dev, Pn)
-                for k, t in zip(keys, rows):
-                    prev[k] = t
+                # prev <- cat(prev, det)[plan] for every row tensor but the soft masks (see _TrackedRows); the masks' bit words ride
+                # along instead: the keep rule of _pack_outputs counts pixels on them
+                keys = tuple(k for k in _ROW_KEYS if k != "mask") + ("clip",)
+                pbits = self._prev_bits if Pn else det_bits[:0]
+                rows = ops.gather_rows2([prev[k] for k in keys] + [pbits], [det[k] for k in keys] + [det_bits], plan_dev, Pn)
+                merged = _TrackedRows()
+                for k, t in zip(keys, rows[:-1]):
+                    merged[k] = t
+                merged.defer_mask(prev["mask"], det["mask"], plan_dev, Pn)
+                self.prev, self._bits = merged, rows[-1]
+            else:
+                self._bits = self._prev_bits if Pn else None
             tmr.toc("tracker_update")
         self.prev_feat = (P4, T2S)
         self.t += 1
@@ -356,8 +389,8 @@ class BatchedClipPipeline:
         cfg, B, prev = self.cfg, self.B, self.prev
         if prev is None or sum(self.prev_n) == 0:
             return torch.zeros(B, cfg.nms_top_k, DET_COLS, device=dev)
-        return ops.pack_tracked(prev["mask"], prev["score"], self._tm_dev, self._off_dev, prev["box"], prev["class"], prev["mask_coeff"], B,
-                                cfg.nms_top_k, DET_COLS, 10, cfg.eval_conf_thresh)
+        return ops.pack_tracked_bits(self._bits, prev["score"], self._tm_dev, self._off_dev, prev["box"], prev["class"], prev["mask_coeff"], B,
+                                     cfg.nms_top_k, DET_COLS, 10, cfg.eval_conf_thresh)
 
     def detections(self):
         """Reference-shaped per-clip detection dicts of the last step (host sync; for tests and users who want them)."""

@@ -138,6 +138,17 @@ def test_pack_tracked_equals_keep_rule_and_scatter():
                            10, 0.05).cpu()
     assert torch.equal(got, want)
     assert int((got[1, :, 7] > 0).sum()) == 20 and int((got[2, :, 7] > 0).sum()) == 0
+    # the pipeline's form: the pixel count of the keep rule from the masks' bit words (hw = 24 * 40 = 15 words, the last one
+    # partly filled), the soft masks are not read
+    hw = p["mask"][0].numel()
+    words = (hw + 63) // 64
+    bits = torch.zeros(t["Pn"], words * 64, dtype=torch.bool)
+    bits[:, :hw] = p["mask"].reshape(t["Pn"], -1) > 0.5
+    weights = (2 ** torch.arange(63, dtype=torch.int64)).tolist() + [-(2 ** 63)]
+    packed = (bits.view(t["Pn"], words, 64).to(torch.int64) * torch.tensor(weights, dtype=torch.int64)).sum(-1)
+    got_b = ops.pack_tracked_bits(_d(packed), _d(p["score"]), _d(tm), _d(t["off"]), _d(p["box"]), _d(p["class"]), _d(p["mask_coeff"]), t["B"],
+                                  20, 40, 10, 0.05).cpu()
+    assert torch.equal(got_b, want)
 
 
 def test_lincomb_bits_and_mask_iou_bits_equal_the_two_pass_form():
