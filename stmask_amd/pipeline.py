@@ -86,12 +86,35 @@ class _TrackedRows(dict):
         self._deferred = (prev_mask, det_mask, plan, n_prev)
         dict.pop(self, "mask", None)
 
-    def __getitem__(self, key):
-        if key == "mask" and not dict.__contains__(self, "mask") and getattr(self, "_deferred", None) is not None:
+    def _materialize(self):
+        if not dict.__contains__(self, "mask") and getattr(self, "_deferred", None) is not None:
             a, b, plan, n_prev = self._deferred
             dict.__setitem__(self, "mask", ops.gather_rows2([a], [b], plan, n_prev)[0])
             self._deferred = None
+
+    def __getitem__(self, key):
+        if key == "mask":
+            self._materialize()
         return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        self._materialize()
+        return dict.keys(self)
+
+    def values(self):
+        self._materialize()
+        return dict.values(self)
+
+    def items(self):
+        self._materialize()
+        return dict.items(self)
+
+    def __iter__(self):
+        self._materialize()
+        return dict.__iter__(self)
 
     def __setitem__(self, key, value):
         if key == "mask":
