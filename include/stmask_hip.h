@@ -17,7 +17,15 @@
  *     memory (`*_count`) so the caller decides when to read them;
  *   - return value: STM_OK (0) or a negative STM_E* code; stm_last_error_string() (thread-local) explains it.
  *     Nothing throws, nothing aborts;
- *   - re-entrant: no global mutable state except the thread-local error string.
+ *   - process-wide state, all of it listed here: the thread-local error string; one fp16-range flag POINTER per device
+ *     (stm_planar_set_range_flag: kernels launched on device d raise the flag registered on d); a once-read cache of the
+ *     STM_* environment switches (stm_debug_reload_tunables makes the next call read them again); the
+ *     per-device "dynamic LDS size reserved" marks of the convolution kernels.  Nothing else: no allocation, no stream, no
+ *     tensor is retained.  Calls from different host threads are safe as long as they do not race on the same output memory;
+ *     the error string is per thread.
+ *   - STM_ABI_VERSION changes whenever a struct of this header changes size or an entry point changes signature or disappears
+ *     (2: stm_conv_geom gained out_fmt_plus1, stm_conv2d_nhwc_f32 was removed, stm_struct_bytes and
+ *     stm_debug_reload_tunables are declared).  stm_struct_bytes(which) lets a client check its struct layout against the library.
  */
 #ifndef STMASK_HIP_H_
 #define STMASK_HIP_H_
@@ -29,7 +37,7 @@
 extern "C" {
 #endif
 
-#define STM_ABI_VERSION 1
+#define STM_ABI_VERSION 2
 
 enum stm_status {
     STM_OK = 0,
@@ -44,6 +52,11 @@ typedef void* stm_stream_t; /* hipStream_t */
 
 int stm_version(void);
 const char* stm_last_error_string(void);
+/* sizeof of the library's own view of a header struct: which = 0 stm_deform_geom, 1 stm_conv_geom; 0 for anything else */
+size_t stm_struct_bytes(int which);
+/* Diagnostics: the STM_* environment switches are read once per process; this makes the next call read them again (tests, A/B
+ * scripts).  Not needed in production. */
+void stm_debug_reload_tunables(void);
 
 /* ---------------------------------------------------------------------------------------------------
  * Deformable convolution.

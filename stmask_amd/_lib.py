@@ -13,8 +13,9 @@ _lib = None
 c_i, c_l, c_f, c_p, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
 # every symbol include/stmask_hip.h declares (tests/test_abi.py checks the library exports all of them)
+ABI_VERSION = 2   # include/stmask_hip.h STM_ABI_VERSION
 ABI_SYMBOLS = [
-    "stm_version", "stm_last_error_string", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
+    "stm_version", "stm_last_error_string", "stm_struct_bytes", "stm_debug_reload_tunables", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
     "stm_deform_conv_fwd_f32", "stm_gemm_bias_f32", "stm_gemm_workspace_bytes", "stm_gemm_bias_ws_f32", "stm_fcb_ali_offsets_f32", "stm_corr_patch_f32", "stm_corr_patch_nhwc_f32",
     "stm_roi_align_avg_f32", "stm_decode_boxes_f32", "stm_generate_candidates_f32", "stm_cc_fast_nms_f32",
     "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
@@ -70,6 +71,15 @@ def lib():
         for name in ("stm_deform_conv_workspace_bytes", "stm_gemm_workspace_bytes", "stm_mask_rle_workspace_bytes", "stm_detect_cc_workspace_bytes", "stm_fast_nms_workspace_bytes",
                      "stm_mask_iou_workspace_bytes", "stm_conv_packed_weight_bytes", "stm_conv_packed_weight_bytes_tiled", "stm_cc_fast_nms_workspace_bytes"):
             getattr(_lib, name).restype = c_sz
+        _lib.stm_struct_bytes.restype = c_sz
+        _lib.stm_debug_reload_tunables.restype = None
+        # this binding and the library must describe the same structs (a stale .so would read garbage past a shorter struct)
+        if _lib.stm_version() != ABI_VERSION or _lib.stm_struct_bytes(0) != ctypes.sizeof(DeformGeom) or \
+                _lib.stm_struct_bytes(1) != ctypes.sizeof(ConvGeom):
+            v = _lib.stm_version()
+            _lib = None
+            raise StmError(f"{LIB_PATH} has ABI version {v}, this binding was written for {ABI_VERSION} (or a struct size "
+                           "differs): rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
     return _lib
 
 

@@ -18,6 +18,10 @@ void stm_set_error(const char* fmt, ...)
 
 extern "C" int stm_version(void) { return STM_ABI_VERSION; }
 extern "C" const char* stm_last_error_string(void) { return g_err; }
+extern "C" size_t stm_struct_bytes(int which)
+{
+    return which == 0 ? sizeof(stm_deform_geom) : (which == 1 ? sizeof(stm_conv_geom) : 0);
+}
 
 static std::atomic<int> g_env_gen{0};
 int stm_env_generation() { return g_env_gen.load(std::memory_order_relaxed); }
@@ -26,5 +30,5 @@ int stm_env_int_uncached(const char* name, int dflt)
     const char* s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
 }
-// test / A-B aid (not in include/stmask_hip.h): re-read every STM_* switch at its next use
+// test / A-B aid: re-read every STM_* switch at its next use
 extern "C" void stm_debug_reload_tunables() { g_env_gen.fetch_add(1, std::memory_order_relaxed); }

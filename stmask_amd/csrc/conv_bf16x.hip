@@ -19,6 +19,7 @@
 // DESIGN.md section 4 has the history of this kernel and what bounds it.
 #include "stm_common.h"
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -992,10 +993,13 @@ __global__ __launch_bounds__(256) void roi_align_planes_kernel(const RoiPlanesAr
                 // (channels past Cc of the padded row are whatever the buffer holds: masked, never used)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(cl + (size_t)o1 * a.corr_ld + 4 * h);
-                    const f32x4 q2 = *reinterpret_cast<const f32x4*>(cl + (size_t)o2 * a.corr_ld + 4 * h);
-                    const f32x4 q3 = *reinterpret_cast<const f32x4*>(cl + (size_t)o3 * a.corr_ld + 4 * h);
-                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(cl + (size_t)o4 * a.corr_ld + 4 * h);
+                    // a 4-channel group that lies wholly in the zero padding past Cc is not loaded at all: its address may be
+                    // beyond the padded row (Cpad rounds 2*C1 + Cc up to 32, corr_ld only Cc up to 8) or, on the last pixel, the buffer
+                    const int hofs = cc0 + 4 * h < a.Cc ? 4 * h : -cc0;          // all-padding group: re-read channel 0 (masked below)
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(cl + (size_t)o1 * a.corr_ld + hofs);
+                    const f32x4 q2 = *reinterpret_cast<const f32x4*>(cl + (size_t)o2 * a.corr_ld + hofs);
+                    const f32x4 q3 = *reinterpret_cast<const f32x4*>(cl + (size_t)o3 * a.corr_ld + hofs);
+                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(cl + (size_t)o4 * a.corr_ld + hofs);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const bool real = cc0 + 4 * h + e < a.Cc;
@@ -1134,11 +1138,15 @@ int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
     size_t lds = (size_t)ST * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
     const size_t park = (size_t)4 * MG * 64 * (32 * NJ + 4) * sizeof(float);   // the epilogue parks one 64 x 32NJ tile per wave
     if (lds < park) lds = park;
-    static bool lds_reserved = false;   // per instantiation; the attribute is sticky, setting it again each launch only costs host time
-    if (!lds_reserved) {
+    // per instantiation AND per device (the attribute belongs to the device's copy of the function); it is sticky, so it is set once --
+    // setting it at each launch only costs host time.  Relaxed atomics: two host threads racing here both set the same value.
+    static std::atomic<bool> lds_reserved[STM_MAX_DEVICES];
+    int dev = 0;
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STM_MAX_DEVICES;
+    if (!have_dev || !lds_reserved[dev].load(std::memory_order_relaxed)) {
         STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
-        lds_reserved = true;
+        if (have_dev) lds_reserved[dev].store(true, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kernel");

@@ -29,7 +29,7 @@ void stm_set_error(const char* fmt, ...);
     } while (0)
 
 // A/B switches (STM_* environment variables) are read ONCE per process, at first use -- never per launch.
-// stm_debug_reload_tunables() (tests, A/B scripts; not part of the ABI header) bumps the generation so they are read again.
+// stm_debug_reload_tunables() (tests, A/B scripts) bumps the generation so they are read again.
 int stm_env_generation();
 int stm_env_int_uncached(const char* name, int dflt);
 #define STM_ENV_INT(name, dflt)                                                          \

@@ -6,6 +6,7 @@ YouTube-VIS records: per object the mean score over its frames (float32 mean, as
 scalars gives), the majority-vote category (`np.bincount(...).argmax()`), and the per-frame RLE list with None for frames
 the object is absent from.  Host-side bookkeeping on the all-gathered detections; no device work.
 """
+import itertools
 import json
 import os
 
@@ -34,38 +35,47 @@ def bbox2result_with_id(preds, img_meta, classes):
     return record
 
 
+_META_KEYS = ("video_id", "frame_id")
+
+
+class _ObjectTrack:
+    """One tracked object of one video: what the YouTube-VIS record needs from its per-frame entries."""
+
+    __slots__ = ("scores", "labels", "rle_by_frame")
+
+    def __init__(self):
+        self.scores, self.labels, self.rle_by_frame = [], [], {}
+
+    def add(self, frame_id, entry):
+        rle = entry["segm"]
+        if isinstance(rle["counts"], bytes):          # pycocotools hands the counts out as bytes; JSON wants str
+            rle["counts"] = rle["counts"].decode()
+        self.scores.append(entry["score"])
+        self.labels.append(entry["label"])
+        self.rle_by_frame[frame_id] = rle
+
+    def record(self, video_id, n_frames):
+        return {"video_id": video_id,
+                "score": np.array(self.scores).mean().item(),                       # float32 mean of float32 scalars
+                "category_id": np.bincount(np.array(self.labels)).argmax().item(),  # majority vote, lowest id wins a tie
+                "segmentations": [self.rle_by_frame.get(f) for f in range(n_frames)]}
+
+
 def video_records(results):
-    """The list `results2json_videoseg` (layers/eval_utils.py:53-101) dumps: `results` is the frame-ordered list of
-    bbox2result_with_id dicts of one or more videos.  RLE counts given as bytes are decoded to str, as the reference does."""
-    json_results = []
-    vid_objs = {}
-    size = len(results)
-    for idx in range(size):
-        vid_id, frame_id = results[idx]["video_id"], results[idx]["frame_id"]
-        is_last = idx == size - 1 or results[idx + 1]["video_id"] != vid_id
-        det = results[idx]
-        for obj_id in det:
-            if obj_id in ("video_id", "frame_id"):
-                continue
-            obj = det[obj_id]
-            segm = obj["segm"]
-            if obj_id not in vid_objs:
-                vid_objs[obj_id] = {"scores": [], "cats": [], "segms": {}}
-            vid_objs[obj_id]["scores"].append(obj["score"])
-            vid_objs[obj_id]["cats"].append(obj["label"])
-            if isinstance(segm["counts"], bytes):
-                segm["counts"] = segm["counts"].decode()
-            vid_objs[obj_id]["segms"][frame_id] = segm
-        if is_last:
-            for obj_id, obj in vid_objs.items():
-                data = {"video_id": vid_id,
-                        "score": np.array(obj["scores"]).mean().item(),
-                        # majority voting for the sequence category (eval_utils.py:91)
-                        "category_id": np.bincount(np.array(obj["cats"])).argmax().item()}
-                data["segmentations"] = [obj["segms"].get(fid) for fid in range(frame_id + 1)]
-                json_results.append(data)
-            vid_objs = {}
-    return json_results
+    """Output contract of `results2json_videoseg` (layers/eval_utils.py:53-101): `results` is the frame-ordered list of
+    bbox2result_with_id dicts of one or more videos (a video = a run of consecutive entries with one video_id); the return
+    value is one record per (video, object), videos in order of appearance and objects in order of first appearance, each
+    with the object's mean score, its majority category and one RLE (or None) per frame up to the video's last frame id."""
+    records = []
+    for video_id, run in itertools.groupby(results, key=lambda r: r["video_id"]):
+        tracks, last_frame = {}, -1
+        for frame in run:
+            last_frame = frame["frame_id"]
+            for obj_id, entry in frame.items():
+                if obj_id not in _META_KEYS:
+                    tracks.setdefault(obj_id, _ObjectTrack()).add(last_frame, entry)
+        records.extend(t.record(video_id, last_frame + 1) for t in tracks.values())
+    return records
 
 
 def results2json_videoseg(results, out_file):

@@ -85,10 +85,43 @@ def deform_im2col(x, offset, mask, kernel_size, stride=1, padding=0, dilation=1,
 
 
 _ws_cache = {}
+_ws_scope = None   # a dict owned by a pipeline while it captures HIP graphs (workspace_scope)
+
+
+class workspace_scope:
+    """`with workspace_scope(store):` -- every _workspace() request inside comes from `store` (keyed by device and tag, not by
+    stream) and the owner of `store` keeps the buffers alive.  BatchedClipPipeline captures its trunk graphs under one: the
+    scratch pointers baked into a graph (split-K partial sums, column buffers) then belong to the pipeline, not to the
+    throw-away capture stream's slot of the global cache -- PyTorch recycles stream handles from a pool of 32, so a later
+    pipeline could otherwise be handed the same (device, stream) key, outgrow the buffer and free it under a live graph.
+    A buffer that must grow inside a scope is retired into the store, never freed."""
+
+    def __init__(self, store):
+        self.store = store
+
+    def __enter__(self):
+        global _ws_scope
+        self.saved, _ws_scope = _ws_scope, self.store
+        return self.store
+
+    def __exit__(self, *exc):
+        global _ws_scope
+        _ws_scope = self.saved
+        return False
 
 
 def _workspace(nbytes, device, tag="ws"):
-    """Grow-only per-(device, stream, tag) scratch buffer (cols buffers are GBs at large batch: never per call)."""
+    """Grow-only scratch buffer per (device, stream, tag) -- or per (device, tag) of the active workspace_scope
+    (cols buffers are GBs at large batch: never allocated per call)."""
+    if _ws_scope is not None:
+        key = (device.index, tag)
+        buf = _ws_scope.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                _ws_scope.setdefault("retired", []).append(buf)     # a captured graph may still write into it
+            buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+            _ws_scope[key] = buf
+        return buf
     key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -148,6 +148,7 @@ class BatchedClipPipeline:
         self._graph_next = 0
         self._graph_pool = None
         self._graph_warm = 0
+        self._graph_ws = {}          # workspaces the captured graphs write into (kept alive here)
 
     # -- stage helpers ------------------------------------------------------------------------------------------------
     def _shift_prev(self, P4, T2S, proto, dev):
@@ -232,10 +233,13 @@ class BatchedClipPipeline:
             cur = torch.cuda.current_stream()
             cap = torch.cuda.Stream(device=frames.device)
             cap.wait_stream(cur)
-            with torch.cuda.stream(cap):
-                net.forward_single(static_in)                 # once more on the capture stream (its own workspace slots)
-            with torch.cuda.graph(graph, pool=self._graph_pool, stream=cap):
-                out = net.forward_single(static_in)
+            # scratch buffers whose addresses the graph bakes in are owned by this pipeline (ops.workspace_scope), not by the
+            # capture stream's slot of the global cache
+            with ops.workspace_scope(self._graph_ws):
+                with torch.cuda.stream(cap):
+                    net.forward_single(static_in)             # once more on the capture stream: sizes this scope's workspaces
+                with torch.cuda.graph(graph, pool=self._graph_pool, stream=cap):
+                    out = net.forward_single(static_in)
             cur.wait_stream(cap)
             self._graphs.append((static_in, graph, out))
             self.graph_active = True
@@ -295,7 +299,11 @@ class BatchedClipPipeline:
                 torch.cuda.current_stream().wait_event(pend[2])   # a trunk nobody asked for: let it finish, drop it
             fpn_outs, pred = self._trunk(frames)
         tmr.toc("trunk")
-        if self.prefetch_early:
+        # A dropped prefetch under graph replay leaves the round-robin one slot ahead: the slot the NEXT replay overwrites is then
+        # the one holding the previous frame's P4 / T2S, which CandidateShift below still reads -- so in that step the next trunk
+        # must not start before _shift_prev is enqueued (the late position), whatever prefetch_early says.
+        dropped = pend is not None and pend[0] is not frames
+        if self.prefetch_early and not (dropped and self.graph_active):
             # start the next trunk right away: it then also shares the GPU with this step's temporal-fusion convolutions
             # (more throughput, but kernels of the two streams stretch each other: per-kernel timings stop being clean)
             self._prefetch_trunk(next_frames)

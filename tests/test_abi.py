@@ -27,7 +27,20 @@ def test_library_loads_and_exports_every_symbol():
     for name in _header_symbols():
         assert hasattr(lib, name), f"{name} declared in include/stmask_hip.h but not exported"
     lib.stm_version.restype = ctypes.c_int
-    assert lib.stm_version() == 1
+    assert lib.stm_version() == _lib.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "stmask_hip.h")).read()
+    assert int(re.search(r"#define STM_ABI_VERSION (\d+)", header).group(1)) == _lib.ABI_VERSION
+
+
+def test_struct_layouts_of_binding_and_library_agree():
+    """A client built against another header revision passes a struct of another size: stm_struct_bytes lets it find out
+    (stm_conv_geom grew a trailing field in round 2 while the version stayed 1)."""
+    _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.stm_struct_bytes.restype = ctypes.c_size_t
+    assert lib.stm_struct_bytes(0) == ctypes.sizeof(_lib.DeformGeom)
+    assert lib.stm_struct_bytes(1) == ctypes.sizeof(_lib.ConvGeom)
+    assert lib.stm_struct_bytes(7) == 0
 
 
 def test_library_targets_gfx950():
