@@ -1,0 +1,458 @@
+// conv_kxr.hip -- stride-1 kh x kw convolution (kw >= 3) with FEW output channels per group (<= 64) on the 16-bit matrix cores, in
+// the planar operand formats of conv_bf16x.hip (format 1: two fp16 planes / three products, fp32-equivalent; format 2: one fp16
+// plane), for the layers whose time is set by the L2 -> LDS staging rate rather than by the matrix pipe:
+//   * the shared head's output layers (prediction_head_FC.py:146-195: conf 41 / centerness + bbox 5 / mask 32 channels, three
+//     kernel shapes 3x3, 3x5, 5x3, each group reading its own 256-channel tower) -- SURVEY.md section 8 rows a5 / f4;
+//   * the DCN layers' 27-channel offset / mask convolutions at stride 1 (backbone.py:20-26), the 64 -> 64 3x3 convolutions of layer1
+//     (backbone.py:38-58) -- rows a1 / a2.
+// On conv_planar_kernel's 128 x 64 tiles these layers stage 24 KB per K-slab and workgroup for at most 48 matrix instructions per
+// wave and run at the rate the CUs can pull rows from L2 into LDS (17 TB/s chip-wide: 8.8 GB per launch of the 3x3 / 3x5 output
+// layers at batch 32, 510 us).  This kernel moves 3-4x fewer bytes:
+//   * kx-reuse: per (channel slab, ky) the BM + kw - 1 consecutive input pixels of a FLAT run of BM = 256 output pixels are
+//     staged ONCE and serve all kw taps -- tap kx of output pixel m is staged row (m - m0) + kx.  Where that neighbour lies in
+//     another image row (x + kx - pw outside [0, W)) the lane reads an always-zero LDS row instead; rows of the ky-shifted run that
+//     fall outside the image are zero-filled by the DMA's range check.  No masking instruction in the loop;
+//   * weight tiles as wide as the group's real channels (16 * NC, NC = 1..4) instead of 64, and 256 pixels per tile;
+//   * every wave multiplies: the four waves split the PIXELS (64 each) and take all NC channel tiles, computed transposed --
+//     D[channel][pixel] = W x X^T, weights as the A operand -- so a lane ends with 4 consecutive channels of one pixel and the
+//     epilogue stores 16-byte fp32 vectors (or 8-byte plane pieces) straight from registers, no LDS round trip.
+// Groups with different NC share one launch (job table; the heavy groups' tiles are dealt first).
+// Same arithmetic as conv_planar_kernel: per K-slab acc += w_h x_h, accl += w_h x_l then w_l x_h, K order (channel slab, ky, kx),
+// fp32 accumulation, acc + accl / 2048, power-of-two weight scale taken out in the epilogue.  tests/test_gpu_conv.py holds both
+// kernels to the same bound against the fp64 oracle.
+#include "planar_common.h"
+
+#include <atomic>
+
+namespace {
+
+constexpr int KX_BM = 256;        // flat output pixels per workgroup: 4 waves x 64
+constexpr int KX_XROWS = 272;     // staged pixel rows per plane (17 DMA row groups of 16); rows >= BM + kw - 1 are always zero
+constexpr int KX_MAX_JOBS = 4;
+constexpr int KX_MAX_DEVICES = 32;
+
+struct KxrJob {
+    const uint8_t* wp;     // packed weights of this group: [stage = (channel slab, ky)][kx][plane][16 * nc rows][64 B, chunk-swizzled]
+    const float* bias;     // bias of the group's channel 0 (bias_n entries) or null
+    int bias_n;
+    int x_slab0;           // first input channel slab of the group
+    int out_ch0;           // first output channel of the group in the output tensors
+    int nc;                // 16-channel tiles
+};
+
+struct KxrArgs {
+    const uint8_t* xp;     // [NPL][slabs][x_np][32] fp16 planes
+    float* out_f32;        // [M][out_ld] or null
+    uint8_t* out_pl;       // [planes][Cout/32][out_np][32] or null
+    KxrJob job[KX_MAX_JOBS];
+    int n_jobs, tiles;     // tiles per job (all levels)
+    int cslabs, kh, ph, pw;
+    int x_np, out_ld, out_np;
+    long long x_pstride, out_pstride;     // bytes between planes
+    unsigned plane_bytes;
+    int relu, out_fmt;
+    float out_scale;
+    int* range_flag;
+    int n_lvl;
+    int lvl_start[9], lvl_h[8], lvl_w[8], lvl_tile0[9];
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+#define KX_MM(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c_, 0, 0, 0)
+
+template <int KW, int NPL, int NC>
+__device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int tile, uint8_t* smem)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int HALO = KW - 1;
+    constexpr int XPL = KX_XROWS * 64;          // bytes of one plane of the staged rows
+    constexpr int XBUF = NPL * XPL;
+    constexpr int WT = NC * 16 * 64;            // bytes of one (kx, plane) weight tile
+    constexpr int WBUF = KW * NPL * WT;
+    constexpr int BUF = XBUF + WBUF;
+    constexpr int NRG = KX_XROWS / 16;          // DMA row groups per plane (1 KB each)
+    constexpr int RGW = (NRG + 3) / 4;          // ... per wave
+    constexpr int NWD = KW * NPL * NC;          // weight DMA instructions per stage (1 KB each)
+    constexpr int WDW = (NWD + 3) / 4;
+    static_assert(KX_BM + HALO <= KX_XROWS - 1, "the always-zero row must exist");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < 8; ++l)
+        if (l < a.n_lvl && tile >= a.lvl_tile0[l]) lvl = l;
+    const int H = a.lvl_h[lvl], W = a.lvl_w[lvl], lstart = a.lvl_start[lvl], lend = a.lvl_start[lvl + 1];
+    const int m0 = lstart + (tile - a.lvl_tile0[lvl]) * KX_BM;
+    const int HW = H * W;
+
+    // ---- DMA duties of this lane: row groups wave, wave + 4, ...; per row the byte offset of (ky = 0) within a channel slab and one
+    // validity bit per ky (the ky-shifted source pixel lies in the same image)
+    int dbase[RGW];
+    unsigned dmask[RGW];
+#pragma unroll
+    for (int i = 0; i < RGW; ++i) {
+        const int rg = wave + 4 * i;
+        const int j = rg * 16 + (lane >> 2);
+        const int q = m0 - a.pw + j;
+        const bool okq = rg < NRG && j < KX_BM + HALO && q >= lstart && q < lend;
+        const int local = okq ? q - lstart : 0;
+        const int y = (local % HW) / W;
+        unsigned vm = 0;
+        for (int ky = 0; ky < a.kh; ++ky)
+            if ((unsigned)(y + ky - a.ph) < (unsigned)H) vm |= 1u << ky;
+        dmask[i] = okq ? vm : 0u;
+        dbase[i] = (q - a.ph * W) * 64 + (((lane & 3) ^ swz(j)) << 4);
+    }
+    __amdgpu_buffer_rsrc_t xr[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+        xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
+
+    auto dma_stage = [&](int cs, int ky, int s, int buf) {
+        uint8_t* xb = smem + buf * BUF;
+        const int uni = (jb.x_slab0 + cs) * (a.x_np * 64) + ky * (W * 64);
+#pragma unroll
+        for (int i = 0; i < RGW; ++i) {
+            const int rg = wave + 4 * i;
+            if (rg < NRG) {
+                const unsigned oob = ((dmask[i] >> ky) & 1u) ^ 1u;
+                const unsigned off = (unsigned)(dbase[i] + uni) | (oob << 31);
+#pragma unroll
+                for (int p = 0; p < NPL; ++p)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(xb + p * XPL + rg * 1024), 16, off, 0, 0, 0);
+            }
+        }
+        uint8_t* wb = xb + XBUF;
+        const uint8_t* wsrc = jb.wp + (size_t)s * WBUF;
+#pragma unroll
+        for (int k = 0; k < WDW; ++k) {
+            const int idx = wave + 4 * k;
+            if (idx < NWD) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(wb + idx * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses.  B operand (activations): lane (pixel r16 of pixel tile t, chunk kc), tap kx -> staged row + kx, or the
+    // always-zero row where the tap leaves the image row.  A operand (weights): lane (channel r16 of tile c, chunk kc).
+    const int r16 = lane & 15, kc = lane >> 4;
+    int boff[4][KW];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row0 = 64 * wave + 16 * t + r16;
+        const int m = m0 + row0;
+        const bool okm = m < lend;
+        const int x = okm ? (m - lstart) % W : 0;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const bool v = okm && (unsigned)(x + kx - a.pw) < (unsigned)W;
+            boff[t][kx] = lds_off(v ? row0 + kx : KX_BM + HALO, kc);
+        }
+    }
+    const int aoff = XBUF + lds_off(r16, kc);
+
+    f32x4 acc[NC][4], accl[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[c][t][r] = 0.0f; accl[c][t][r] = 0.0f; }
+
+    const int S = a.cslabs * a.kh;
+    int n_cs = 0, n_ky = 0;                                // (channel slab, ky) of the next stage to bring in
+    dma_stage(0, 0, 0, 0);
+    if (++n_ky == a.kh) { n_ky = 0; ++n_cs; }
+    for (int s = 0; s < S; ++s) {
+        // stage s has landed for this wave, then for every wave; nobody reads buffer (s + 1) & 1 any more
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const uint8_t* xs = smem + (s & 1) * BUF;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            f16x8 bh[4], bl[4], ah[NC], al[NC];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bh[t] = *reinterpret_cast<const f16x8*>(xs + boff[t][kx]);
+                if constexpr (NPL == 2) bl[t] = *reinterpret_cast<const f16x8*>(xs + XPL + boff[t][kx]);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                ah[c] = *reinterpret_cast<const f16x8*>(xs + aoff + ((kx * NPL) * NC + c) * 1024);
+                if constexpr (NPL == 2) al[c] = *reinterpret_cast<const f16x8*>(xs + aoff + ((kx * NPL + 1) * NC + c) * 1024);
+            }
+            if (kx == 0 && s + 1 < S) {
+                // the next stage starts on its way in behind this stage's first fragment reads (an LDS-DMA is an LDS store to the
+                // compiler: reads cannot move above it)
+                dma_stage(n_cs, n_ky, s + 1, (s + 1) & 1);
+                if (++n_ky == a.kh) { n_ky = 0; ++n_cs; }
+            }
+            if constexpr (NPL == 2) {
+                f32x4 tmp[NC][4];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) tmp[c][t] = KX_MM(ah[c], bl[t], accl[c][t]);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[c][t] = KX_MM(ah[c], bh[t], acc[c][t]);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accl[c][t] = KX_MM(al[c], bh[t], tmp[c][t]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[c][t] = KX_MM(ah[c], bh[t], acc[c][t]);
+            }
+        }
+    }
+
+    // ---- epilogue, straight from the accumulators: lane holds channels 16 c + 4 kc .. + 3 of pixel m0 + 64 wave + 16 t + r16
+    const float ls = NPL == 2 ? 1.0f / STM_F16_LOW_SCALE : 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = 16 * c + 4 * kc;                    // channel within the group
+        float b4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (jb.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ch + r < jb.bias_n) b4[r] = jb.bias[ch + r];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = m0 + 64 * wave + 16 * t + r16;
+            if (m >= lend) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sum = NPL == 2 ? acc[c][t][r] + accl[c][t][r] * ls : acc[c][t][r];
+                v[r] = __builtin_fmaf(sum, a.out_scale, b4[r]);
+                if (a.relu) v[r] = __builtin_fmaxf(v[r], 0.0f);
+            }
+            const int oc = jb.out_ch0 + ch;
+            if (a.out_f32) *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * a.out_ld + oc) = f32x4{v[0], v[1], v[2], v[3]};
+            if (a.out_pl) {
+                unsigned m4 = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m4 = max(m4, __builtin_bit_cast(unsigned, v[r]) & 0x7fffffffu);
+                if (m4 > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
+                unsigned h0, h1, l0, l1;
+                split2_f16(f32x2{v[0], v[1]}, h0, l0);
+                split2_f16(f32x2{v[2], v[3]}, h1, l1);
+                uint8_t* o = a.out_pl + (((size_t)(oc >> 5) * a.out_np + m) * 32 + (oc & 31)) * 2;
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2*>(o) = u32x2{h0, h1};
+                if (a.out_fmt == 1) *reinterpret_cast<u32x2*>(o + a.out_pstride) = u32x2{l0, l1};
+            }
+        }
+    }
+#endif
+}
+
+template <int KW, int NPL>
+__global__ __launch_bounds__(256, 1) void conv_kxr_kernel(const KxrArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int total = a.tiles * a.n_jobs;
+    const int per_xcd = (total + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= total) return;
+    // jobs are interleaved tile by tile (tile-major): the groups of one pixel tile run side by side on one XCD
+    const int tile = logical / a.n_jobs, j = logical - tile * a.n_jobs;
+    const KxrJob& jb = a.job[j];
+    switch (jb.nc) {
+        case 1: kxr_body<KW, NPL, 1>(a, jb, tile, smem); break;
+        case 2: kxr_body<KW, NPL, 2>(a, jb, tile, smem); break;
+        case 3: kxr_body<KW, NPL, 3>(a, jb, tile, smem); break;
+        default: kxr_body<KW, NPL, 4>(a, jb, tile, smem); break;
+    }
+#endif
+}
+
+// weights [Cout][C][kh][kw] fp32 (grouped: group g = rows [g * cout_g, ...)) -> the blob of one job:
+// [cs][ky][kx][plane][row 0 .. 16 nc)[chunk ^ swz(row)][8 fp16]; rows past the group's real channels are zero.
+__global__ __launch_bounds__(256) void kxr_pack_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp, int row0, int creal, int nc, int C,
+                                                       int kh, int kw, int npl, float wscale)
+{
+    const int rows = nc * 16;
+    const int64_t total = (int64_t)(C / 32) * kh * kw * rows * 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int chunk = (int)(idx & 3), row = (int)((idx >> 2) % rows);
+    const int tap = (int)((idx / (rows * 4)) % (kh * kw)), cs = (int)(idx / ((int64_t)rows * 4 * kh * kw));
+    const int ky = tap / kw, kx = tap - ky * kw;
+    unsigned pl[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f32x2 v = {0.0f, 0.0f};
+        if (row < creal) {
+            const size_t b = ((size_t)(row0 + row) * C + cs * 32 + chunk * 8 + 2 * e) * (kh * kw) + tap;
+            v.x = w[b];
+            v.y = w[b + (size_t)kh * kw];
+        }
+        split2_f16(v * wscale, pl[0][e], pl[1][e]);
+    }
+    const size_t stage = (size_t)cs * kh + ky;
+    const size_t wt = (size_t)rows * 64;
+    uint8_t* dst = wp + ((stage * kw + kx) * npl) * wt + lds_off(row, chunk);
+    for (int p = 0; p < npl; ++p) *reinterpret_cast<u32x4*>(dst + p * wt) = u32x4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
+}
+
+struct KxrPlan {
+    int n_jobs, nc[KX_MAX_JOBS], creal[KX_MAX_JOBS], cout_g, npl, slabs_kh;   // slabs_kh = (C / 32) * kh stages
+    size_t woff[KX_MAX_JOBS + 1];
+};
+
+// Which layers the kernel takes, and how its weights are laid out.  Returns false with the error string set otherwise.
+bool kxr_plan(const stm_conv_geom* g, KxrPlan* pl, const char* who)
+{
+    if (!g) { stm_set_error("%s: geometry is NULL", who); return false; }
+    const int groups = g->groups > 0 ? g->groups : 1;
+    if (g->C <= 0 || g->C % 32 || g->Cout <= 0 || g->Cout % groups || groups > KX_MAX_JOBS) {
+        stm_set_error("%s: C (%d) must be a multiple of 32, Cout (%d) a multiple of groups (%d <= %d)", who, g->C, g->Cout, groups, KX_MAX_JOBS);
+        return false;
+    }
+    if (!(g->kw == 3 || g->kw == 5) || g->kh < 1 || g->kh > 8 || g->sh != 1 || g->sw != 1 || g->ph < 0 || g->pw < 0 || g->pw >= g->kw || g->ph >= g->kh) {
+        stm_set_error("%s: stride 1, kw = 3 or 5, kh <= 8, padding smaller than the kernel", who);
+        return false;
+    }
+    if (g->fmt != 1 && g->fmt != 2) { stm_set_error("%s: fp16 plane formats (1, 2) only", who); return false; }
+    pl->n_jobs = groups;
+    pl->cout_g = g->Cout / groups;
+    pl->npl = g->fmt == 1 ? 2 : 1;
+    pl->slabs_kh = (g->C / 32) * g->kh;
+    pl->woff[0] = 0;
+    for (int i = 0; i < groups; ++i) {
+        const int real = (g->group_cout[i] > 0 && g->group_cout[i] < pl->cout_g) ? g->group_cout[i] : pl->cout_g;
+        if (real > 64) { stm_set_error("%s: at most 64 output channels per group (group %d has %d)", who, i, real); return false; }
+        pl->creal[i] = real;
+        pl->nc[i] = (real + 15) / 16;
+        pl->woff[i + 1] = pl->woff[i] + (size_t)pl->slabs_kh * g->kw * pl->npl * pl->nc[i] * 1024;
+    }
+    return true;
+}
+
+template <int KW, int NPL>
+int kxr_launch(const KxrArgs& a, int nc_max, stm_stream_t stream)
+{
+    const size_t lds = 2 * ((size_t)NPL * KX_XROWS * 64 + (size_t)KW * NPL * nc_max * 1024);
+    static std::atomic<int> reserved[KX_MAX_DEVICES];      // bytes reserved so far, per device
+    int dev = 0;
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < KX_MAX_DEVICES;
+    if (!have_dev || reserved[dev].load(std::memory_order_relaxed) < (int)lds) {
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kxr_kernel<KW, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_kxr_f32: cannot reserve %zu bytes of LDS", lds);
+        if (have_dev) reserved[dev].store((int)lds, std::memory_order_relaxed);
+    }
+    const int total = a.tiles * a.n_jobs;
+    hipLaunchKernelGGL((conv_kxr_kernel<KW, NPL>), dim3(8 * stm_cdiv(total, 8)), dim3(256), lds, stm_hs(stream), a);
+    STM_CHECK_LAUNCH("conv_kxr_kernel");
+    return STM_OK;
+}
+
+}  // namespace
+
+extern "C" size_t stm_conv_kxr_packed_bytes(const stm_conv_geom* g)
+{
+    KxrPlan pl;
+    return kxr_plan(g, &pl, "stm_conv_kxr_packed_bytes") ? pl.woff[pl.n_jobs] : 0;
+}
+
+extern "C" int stm_conv_pack_weights_kxr_f32(const float* weight, void* packed, const stm_conv_geom* g, float wscale, stm_stream_t stream)
+{
+    const char* who = "stm_conv_pack_weights_kxr_f32";
+    STM_REQUIRE(weight && packed, STM_ENULL, "%s: weight/packed must be non-NULL", who);
+    KxrPlan pl;
+    if (!kxr_plan(g, &pl, who)) return STM_EINVAL;
+    STM_REQUIRE((uintptr_t)packed % 16 == 0, STM_EINVAL, "%s: packed buffer must be 16-byte aligned", who);
+    STM_REQUIRE(wscale > 0.0f && wscale < 3.0e38f, STM_EINVAL, "%s: bad weight scale", who);
+    for (int i = 0; i < pl.n_jobs; ++i) {
+        const int64_t total = (int64_t)(g->C / 32) * g->kh * g->kw * pl.nc[i] * 16 * 4;
+        hipLaunchKernelGGL(kxr_pack_kernel, dim3(stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream), weight, static_cast<uint8_t*>(packed) + pl.woff[i],
+                           i * pl.cout_g, pl.creal[i], pl.nc[i], g->C, g->kh, g->kw, pl.npl, wscale);
+        STM_CHECK_LAUNCH("kxr_pack_kernel");
+    }
+    return STM_OK;
+}
+
+extern "C" int stm_conv2d_planar_kxr_f32(const void* x_planes, const void* packed_weight, const float* bias, float* out_f32, void* out_planes,
+                                         const stm_conv_geom* g, int relu, stm_stream_t stream)
+{
+    const char* who = "stm_conv2d_planar_kxr_f32";
+    STM_REQUIRE(x_planes && packed_weight && (out_f32 || out_planes), STM_ENULL, "%s: x_planes/packed_weight and at least one output must be non-NULL", who);
+    KxrPlan pl;
+    if (!kxr_plan(g, &pl, who)) return STM_EINVAL;
+    KxrArgs a;
+    memset(&a, 0, sizeof(a));
+    int64_t M;
+    if (g->n_levels > 0) {
+        STM_REQUIRE(g->n_levels <= 8 && g->lvl_start[0] == 0, STM_EINVAL, "%s: at most 8 levels, lvl_start[0] = 0", who);
+        a.n_lvl = g->n_levels;
+        for (int l = 0; l < g->n_levels; ++l) {
+            const int n = g->lvl_start[l + 1] - g->lvl_start[l];
+            STM_REQUIRE(g->lvl_h[l] > 0 && g->lvl_w[l] > 0 && n > 0 && n % (g->lvl_h[l] * g->lvl_w[l]) == 0, STM_EINVAL,
+                        "%s: level %d: %d pixels is not a whole number of %dx%d images", who, l, n, g->lvl_h[l], g->lvl_w[l]);
+            a.lvl_start[l] = g->lvl_start[l]; a.lvl_h[l] = g->lvl_h[l]; a.lvl_w[l] = g->lvl_w[l];
+        }
+        a.lvl_start[g->n_levels] = g->lvl_start[g->n_levels];
+        M = g->lvl_start[g->n_levels];
+    } else {
+        STM_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0, STM_EINVAL, "%s: bad image batch", who);
+        STM_REQUIRE(g->Ho == g->H + 2 * g->ph - g->kh + 1 && g->Wo == g->W + 2 * g->pw - g->kw + 1 && g->Ho == g->H && g->Wo == g->W, STM_EUNSUPPORTED,
+                    "%s: the kernel keeps the image size (padding (k - 1) / 2)", who);
+        a.n_lvl = 1;
+        M = (int64_t)g->B * g->H * g->W;
+        a.lvl_start[0] = 0; a.lvl_start[1] = (int)M; a.lvl_h[0] = g->H; a.lvl_w[0] = g->W;
+    }
+    STM_REQUIRE(2 * g->ph == g->kh - 1 && 2 * g->pw == g->kw - 1, STM_EUNSUPPORTED, "%s: same padding only", who);
+    STM_REQUIRE(M < ((int64_t)1 << 30), STM_EUNSUPPORTED, "%s: too many pixels", who);
+    int t0 = 0;
+    for (int l = 0; l < a.n_lvl; ++l) { a.lvl_tile0[l] = t0; t0 += stm_cdiv(a.lvl_start[l + 1] - a.lvl_start[l], KX_BM); }
+    a.lvl_tile0[a.n_lvl] = t0;
+    a.tiles = t0;
+    const int groups = pl.n_jobs;
+    const int64_t x_np = g->x_np ? g->x_np : M, out_np = g->out_np ? g->out_np : M;
+    STM_REQUIRE(x_np >= M && out_np >= M, STM_EINVAL, "%s: x_np / out_np smaller than the pixel count", who);
+    const int64_t x_slabs = (int64_t)groups * (g->C / 32);
+    const int64_t plane_bytes = x_slabs * x_np * 64;
+    STM_REQUIRE(plane_bytes < ((int64_t)1 << 31), STM_EUNSUPPORTED, "%s: plane larger than 2 GiB", who);
+    const int64_t xps = g->x_plane_stride ? g->x_plane_stride : x_slabs * x_np * 32;
+    const int64_t ops = g->out_plane_stride ? g->out_plane_stride : (int64_t)stm_cdiv(g->Cout, 32) * out_np * 32;
+    const int out_ld = g->out_ld ? g->out_ld : g->Cout;
+    STM_REQUIRE((uintptr_t)x_planes % 16 == 0 && (uintptr_t)packed_weight % 16 == 0 && xps % 8 == 0, STM_EINVAL, "%s: 16-byte alignment required", who);
+    STM_REQUIRE(!out_f32 || ((uintptr_t)out_f32 % 16 == 0 && out_ld % 4 == 0), STM_EINVAL, "%s: out_f32 must be 16-byte aligned with out_ld a multiple of 4", who);
+    STM_REQUIRE(!out_planes || ((uintptr_t)out_planes % 16 == 0 && ops % 8 == 0), STM_EINVAL, "%s: out_planes must be 16-byte aligned", who);
+    a.xp = static_cast<const uint8_t*>(x_planes); a.out_f32 = out_f32; a.out_pl = static_cast<uint8_t*>(out_planes);
+    a.n_jobs = groups;
+    int nc_max = 1;
+    for (int i = 0; i < groups; ++i) {
+        KxrJob& j = a.job[i];
+        j.wp = static_cast<const uint8_t*>(packed_weight) + pl.woff[i];
+        j.bias = bias ? bias + (size_t)i * pl.cout_g : nullptr;
+        j.bias_n = pl.cout_g;
+        j.x_slab0 = i * (g->C / 32);
+        j.out_ch0 = i * pl.cout_g;
+        j.nc = pl.nc[i];
+        nc_max = std::max(nc_max, j.nc);
+        // every 16-channel tile is written whole: the output row must hold it
+        STM_REQUIRE(j.out_ch0 + 16 * j.nc <= (out_f32 ? out_ld : g->Cout) || !out_f32, STM_EINVAL,
+                    "%s: group %d writes channels [%d, %d) but an output row has %d", who, i, j.out_ch0, j.out_ch0 + 16 * j.nc, out_ld);
+        STM_REQUIRE(!out_planes || j.out_ch0 + 16 * j.nc <= stm_cdiv(g->Cout, 32) * 32, STM_EINVAL, "%s: group %d leaves the output planes", who, i);
+    }
+    a.cslabs = g->C / 32; a.kh = g->kh; a.ph = g->ph; a.pw = g->pw;
+    a.x_np = (int)x_np; a.out_ld = out_ld; a.out_np = (int)out_np;
+    a.x_pstride = xps * 2; a.out_pstride = ops * 2;
+    a.plane_bytes = (unsigned)plane_bytes;
+    a.relu = relu;
+    a.out_fmt = g->out_fmt_plus1 > 0 ? g->out_fmt_plus1 - 1 : g->fmt;
+    STM_REQUIRE(a.out_fmt == g->fmt || (g->fmt == 2 && a.out_fmt == 1), STM_EINVAL, "%s: output format %d cannot be produced by a format-%d layer", who,
+                a.out_fmt, g->fmt);
+    a.out_scale = g->out_scale > 0.0f ? g->out_scale : 1.0f;
+    a.range_flag = stm_internal_range_flag();
+    if (g->fmt == 1) return g->kw == 3 ? kxr_launch<3, 2>(a, nc_max, stream) : kxr_launch<5, 2>(a, nc_max, stream);
+    return g->kw == 3 ? kxr_launch<3, 1>(a, nc_max, stream) : kxr_launch<5, 1>(a, nc_max, stream);
+}

@@ -42,13 +42,57 @@ def unpack_detections(packed):
 
 def all_gather_detections(packed):
     """[local_clips, top_k, DET_COLS] on every rank -> [world * local_clips, top_k, DET_COLS] (rank-major).
-    Every rank must pass the same local_clips (pad the last shard)."""
+    Every rank must pass the same local_clips (pad the last shard).  Blocking form (the current stream waits for the
+    collective); the benchmark's steady state uses DetectionGatherer, which keeps the collective off the compute streams."""
     if not (dist.is_available() and dist.is_initialized()):
         return packed
     world = dist.get_world_size()
+    if packed.is_cuda and dist.get_backend() == "gloo":
+        # gloo moves host memory: stage through the host (the two-ranks-on-one-GPU check of bench.py, CPU tests)
+        host = packed.contiguous().cpu()
+        out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host)
+        return out.to(packed.device, non_blocking=True)
     out = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(out, packed.contiguous())
     return out
+
+
+class DetectionGatherer:
+    """The per-step all-gather of SURVEY.md section 8(e), kept off the compute streams: the packed detections of step t are
+    gathered on a communication stream of their own (it waits for the stream that produced them; RCCL's collective then
+    synchronises with THAT stream), while the main stream goes straight on to step t + 1 and the side stream keeps running the
+    next trunk.  Nothing on the device consumes the gathered rows (they feed the host-side result aggregation), so no compute
+    stream ever waits for the 32 KB-per-clip exchange.  `gather()` returns the gathered tensor; it is complete once `wait()`
+    (or a device synchronisation) has returned."""
+
+    def __init__(self, device=None):
+        self.device = device
+        self._comm = None
+        self._events = []
+
+    def gather(self, packed):
+        if not (dist.is_available() and dist.is_initialized()):
+            return packed
+        if not packed.is_cuda or dist.get_backend() == "gloo":
+            return all_gather_detections(packed)
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=packed.device)
+        main = torch.cuda.current_stream()
+        self._comm.wait_stream(main)
+        with torch.cuda.stream(self._comm):
+            packed.record_stream(self._comm)
+            out = all_gather_detections(packed)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._events = [ev]
+        return out
+
+    def wait(self):
+        """Host-side: the last gather() has completed."""
+        for ev in self._events:
+            ev.synchronize()
+        self._events = []
 
 
 def global_clip_order(n_clips, world):

@@ -149,6 +149,11 @@ class BatchedClipPipeline:
         self._graph_pool = None
         self._graph_warm = 0
         self._graph_ws = {}          # workspaces the captured graphs write into (kept alive here)
+        # Workload knob of the benchmark ("a max_instances cap to study n ~ 5-10, the realistic regime"), NOT
+        # a reference semantic: the reference's tracker never prunes (track_TF.py:132-165).  n > 0: at most n detections per frame
+        # (the best-scoring ones: Fast NMS returns them sorted) and at most n tracked instances per clip (an unmatched detection
+        # opens a new track only while the clip holds fewer).  0 = the reference's behaviour.
+        self.max_instances = 0
 
     # -- stage helpers ------------------------------------------------------------------------------------------------
     def _shift_prev(self, P4, T2S, proto, dev):
@@ -324,6 +329,8 @@ class BatchedClipPipeline:
         priors = pred["priors"].squeeze(0)
         idx, cls, score, box, cnt = ops.detect_cc(pred["loc"], priors, conf, pred["centerness"], cfg.eval_conf_thresh,
                                                   cfg.nms_thresh, cfg.nms_top_k)
+        if self.max_instances > 0:
+            cnt = torch.clamp(cnt, max=self.max_instances)
         counts, host_scores = ops.counts_to_host(cnt, extra=score)  # host read 1: B counts + the fp16 range flag + the NMS scores
         tmr.toc("detect")
         D = sum(counts)
@@ -360,6 +367,7 @@ class BatchedClipPipeline:
             # greedy resolution (track_TF.py:132-156) per clip on host scalars -> one gather plan for all clips
             plan, new_n, new_tracked = [], [], []
             p0 = d0 = 0
+            cap = self.max_instances
             for b in range(B):
                 pn, dn = self.prev_n[b], counts[b]
                 src = list(range(p0, p0 + pn))
@@ -368,6 +376,8 @@ class BatchedClipPipeline:
                 for j in range(dn):
                     mid = ids[d0 + j]
                     if mid == 0:
+                        if cap and len(src) >= cap:
+                            continue                     # benchmark-only cap on the tracked set (see max_instances)
                         src.append(Pn + d0 + j)
                         tm.append(0)
                     else:

@@ -76,6 +76,7 @@ class PlanarConv:
         self.relu, self.groups, self.planes, self.tile_n = relu, groups, (planes if self.fmt == 0 else ops.plane_layout(self.fmt)[0]), tile_n
         self._packed = {}
         self.out_scale = 1.0
+        self.role = "trunk"          # "temporal" for TemporalNet's layers: bench.py reports the trunk-only roofline beside the overall one
         self.bias = bias.detach().float().contiguous() if bias is not None else None
 
     def packed(self, tile_n):
@@ -199,9 +200,19 @@ class PlanarConv:
         if timing is not None:
             e1.record()
             # (start, end, algorithmic flops, layer key, MFMA products per product of the reference: 6 bf16x3 / 3 fp16x2 / 1 fp16x1)
+            # algorithmic HBM bytes of the launch: every input / residual / output element and every weight once, in the
+            # formats they are stored in (planes 2 B per plane and element, fp32 4 B)
+            in_px = M if shape[0] == "levels" else shape[1] * shape[2] * shape[3]
+            nbytes = in_px * self.groups * self.C * 2 * NP + self.weight.numel() * 2 * NP
+            if out_planes is not None:
+                nbytes += M * self.O * 2 * NPo
+            if out_f32 is not None:
+                nbytes += M * self.O * 4
+            if residual is not None:
+                nbytes += M * self.O * (2 * NP if residual.dtype == dt else 4)
             timing.append((e0, e1, 2.0 * M * self.O * self.C * self.kh * self.kw * self.algo_frac,
                            (M, self.C, self.O, self.kh, self.sh, self.groups, g.tile_n),
-                           {0: 6 if self.planes == 3 else 3, 1: 3, 2: 1}[self.fmt]))
+                           {0: 6 if self.planes == 3 else 3, 1: 3, 2: 1}[self.fmt], self.role, float(nbytes)))
         if out == "both":
             return out_f32, out_planes
         return out_f32 if out == "f32" else out_planes
@@ -555,6 +566,8 @@ class PlanarTemporalNet:
         self.c3 = PlanarConv(tn.conv3.weight, tn.conv3.bias, 1, tn.conv3.padding, relu=True)
         self.fc, self.fc_coeff = tn.fc, tn.fc_coeff
         self.fmt = FMT
+        for c in (self.c1, self.c2, self.c3):
+            c.role = "temporal"
 
     def __call__(self, roi_feats):
         """roi_feats [n, 633, 7, 7] fp32 -> (loc shift [n, 4], coeff shift [n, 32])."""

@@ -77,7 +77,7 @@ def test_batched_pipeline_equals_per_clip_driver_on_gpu():
             assert torch.equal(d[b]["box_ids"], r[b]["box_ids"]), (t, b)
             assert torch.equal(d[b]["class"], r[b]["class"])
             assert (d[b]["box"] - r[b]["box"]).abs().max() < 1e-4
-            assert (d[b]["mask"] - r[b]["mask"]).abs().max() < 1e-3
+            assert (d[b]["mask"] - r[b]["mask"]).abs().max() < 2e-5      # same kernels on the same boxes / coefficients (measured <= 2e-6)
             un = unpack_detections(packed[b])
             assert torch.equal(un["box_ids"], r[b]["box_ids"][:200])
 
