@@ -306,6 +306,23 @@ typedef struct stm_conv_geom {
                              supported (the last fp16 layer of a ResNet stage hands both planes to the fp32-equivalent FPN) */
 } stm_conv_geom;
 
+/* ---- narrow-output stride-1 convolution with kx-reuse (csrc/conv_kxr.hip) ------------------------------------------------------
+ * The same convolution for the layers with FEW output channels per group (<= 64 real ones, <= 4 groups), stride 1, "same" padding,
+ * kw = 3 or 5, plane formats 1 / 2: the shared head's output layers (prediction_head_FC.py:146-195: conf / centerness + bbox / mask
+ * groups of 41 / 5 / 32 channels over three kernel shapes), the DCN offset / mask convolutions at stride 1 (backbone.py:20-26), the
+ * 64 -> 64 3x3 convolutions of ResNet layer1 (backbone.py:38-58).  On stm_conv2d_planar_f32's 128 x 64 tiles these layers run at the
+ * L2 -> LDS staging rate; here each run of 256 flat pixels is staged once per (channel slab, ky) and serves all kw taps, the weight
+ * tiles are as wide as the group's real channels (rounded up to 16), and results are stored straight from the accumulators.
+ * Geometry: stm_conv_geom with C = input channels PER GROUP, Cout = groups * (output row stride of a group), group_cout[i] = real
+ * channels of group i (0 = all), n_levels / lvl_* or B, H, W as for stm_conv2d_planar_f32, fmt, out_scale, x_np / x_plane_stride /
+ * out_ld / out_np / out_plane_stride; tile_n, res_* and planes are ignored.  Every 16-channel tile of a group is written whole:
+ * channels [group_cout[i], 16 * ceil(group_cout[i] / 16)) of a group receive bias-only values.  No residual input.
+ * Weights: stm_conv_pack_weights_kxr_f32 of the OIHW tensor [Cout, C, kh, kw] (its own layout; wscale as stm_conv_pack_weights_fmt_f32). */
+size_t stm_conv_kxr_packed_bytes(const struct stm_conv_geom* g);
+int stm_conv_pack_weights_kxr_f32(const float* weight, void* packed, const struct stm_conv_geom* g, float wscale, stm_stream_t stream);
+int stm_conv2d_planar_kxr_f32(const void* x_planes, const void* packed_weight, const float* bias, float* out_f32, void* out_planes,
+                              const struct stm_conv_geom* g, int relu, stm_stream_t stream);
+
 /* bytes of the packed (pre-split, pre-tiled) weight image; 0 on bad arguments */
 size_t stm_conv_packed_weight_bytes(int Cout, int Cin, int kh, int kw, int planes);
 /* weight [Cout, Cin, kh, kw] fp32 (torch OIHW, contiguous) -> packed image; done once per layer */
@@ -473,6 +490,17 @@ int stm_roi_align_planes_nhwc_f32(const float* t2s_prev, const float* t2s, const
  * padding (ph, 0) planar convolution over R with weights w'[o][j][ky][0] = w[o][j % Cin][ky][j / Cin]. */
 int stm_stem_rows_planes_f32(const float* x, void* planes, int B, int H, int W, int Cin, int kw, int sw, int pw, int fmt,
                              stm_stream_t stream);
+
+/* The whole ResNet stem in one kernel (backbone.py:61-75: conv1 7x7 / stride 2 / padding 3 on a 3-channel frame, eval BatchNorm
+ * folded into weight and bias, ReLU, MaxPool2d(3, 2, 1)): x fp32 NHWC [B][H][W][3] -> planes [P][Cout/32][B*Hp*Wp][32] in format
+ * out_fmt, Hp = ((H - 1) / 2) / 2 + 1 (conv then pool, floor mode).  Cout = 64, fmt 1 or 2 (fmt 2 may write out_fmt 1).  No
+ * intermediate tensor: the input patch of a tile of pooled pixels is split into fp16 planes in LDS, the conv positions under the
+ * pool windows are computed on the matrix cores (three products per reference product in fmt 1) and pooled from LDS.
+ * Weights: stm_stem_pack_weights_f32 of the OIHW tensor [64, 3, 7, 7] * wscale (a power of two); out_scale = 1 / wscale. */
+size_t stm_stem_packed_weight_bytes(int Cout, int fmt);
+int stm_stem_pack_weights_f32(const float* weight, void* packed, int Cout, int fmt, float wscale, stm_stream_t stream);
+int stm_stem_fused_f32(const float* x, const void* packed_weight, const float* bias, void* out_planes, int B, int H, int W, int Cout,
+                       int fmt, int out_fmt, float out_scale, stm_stream_t stream);
 
 /* fp16 plane formats (fmt 1, fmt 2) range guard.  A value with |x| > 65504 (or inf / nan) has no fp16 plane representation and
  * would poison the following layers silently (inf - inf = nan, and a ReLU epilogue maps nan to 0).  Every producer of

@@ -22,14 +22,32 @@
 // kernels to the same bound against the fp64 oracle.
 #include "planar_common.h"
 
+#include <algorithm>
 #include <atomic>
 
 namespace {
 
-constexpr int KX_BM = 256;        // flat output pixels per workgroup: 4 waves x 64
-constexpr int KX_XROWS = 272;     // staged pixel rows per plane (17 DMA row groups of 16); rows >= BM + kw - 1 are always zero
+constexpr int KX_CONSUMERS = 4, KX_PRODUCERS = 2, KX_THREADS = 64 * (KX_CONSUMERS + KX_PRODUCERS);
 constexpr int KX_MAX_JOBS = 4;
 constexpr int KX_MAX_DEVICES = 32;
+constexpr int KX_LDS_MAX = 160 * 1024;
+
+// Tile shape of a (kw, planes, channel tiles) combination: each of the 4 consumer waves takes PT pixel tiles of 16 (workgroup tile
+// BM = 64 PT flat pixels), the LDS holds a ring of D stages.  A stage (one (channel slab, ky): BM + 16 staged pixel rows per plane and
+// the kw weight tiles) must be fetched two stages ahead of its use -- the first touch of the activations comes from HBM, and a stage
+// is what a CU has to keep in flight to cover that latency at the L2 -> LDS rate -- so D >= 3 decides PT: the widest tile whose ring fits.
+constexpr int kx_stage_bytes(int kw, int npl, int nc, int pt) { return npl * (64 * pt + 16) * 64 + kw * npl * nc * 1024; }
+constexpr int kx_pt(int kw, int npl, int nc)
+{
+    for (int pt = 4; pt > 2; --pt)
+        if (3 * kx_stage_bytes(kw, npl, nc, pt) <= KX_LDS_MAX) return pt;
+    return 2;
+}
+constexpr int kx_depth(int kw, int npl, int nc)
+{
+    const int d = KX_LDS_MAX / kx_stage_bytes(kw, npl, nc, kx_pt(kw, npl, nc));
+    return d > 4 ? 4 : d;
+}
 
 struct KxrJob {
     const uint8_t* wp;     // packed weights of this group: [stage = (channel slab, ky)][kx][plane][16 * nc rows][64 B, chunk-swizzled]
@@ -38,6 +56,8 @@ struct KxrJob {
     int x_slab0;           // first input channel slab of the group
     int out_ch0;           // first output channel of the group in the output tensors
     int nc;                // 16-channel tiles
+    int tile0;             // first workgroup of this job
+    int lvl_tile0[9];      // first tile of each level, in this job's tile size
 };
 
 struct KxrArgs {
@@ -45,7 +65,7 @@ struct KxrArgs {
     float* out_f32;        // [M][out_ld] or null
     uint8_t* out_pl;       // [planes][Cout/32][out_np][32] or null
     KxrJob job[KX_MAX_JOBS];
-    int n_jobs, tiles;     // tiles per job (all levels)
+    int n_jobs, total;     // workgroups of all jobs
     int cslabs, kh, ph, pw;
     int x_np, out_ld, out_np;
     long long x_pstride, out_pstride;     // bytes between planes
@@ -54,163 +74,216 @@ struct KxrArgs {
     float out_scale;
     int* range_flag;
     int n_lvl;
-    int lvl_start[9], lvl_h[8], lvl_w[8], lvl_tile0[9];
+    int lvl_start[9], lvl_h[8], lvl_w[8];
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* glb_ptr;
 
 #define KX_MM(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c_, 0, 0, 0)
+#ifndef KX_ABL
+#define KX_ABL 0      // diagnostic builds (make EXTRA=-DKX_ABL=n, RESULTS ARE WRONG): 1 no DMA, 2 no fragment reads / MFMAs, 4 no activation DMA, 8 no weight DMA
+#endif
 
+// Workgroup = 4 consumer waves (16 PT pixels each, all NC channel tiles: LDS fragment reads and MFMAs, nothing else in their loop) + 2
+// producer waves that issue every LDS-DMA of the workgroup.  With one consumer wave per SIMD an LDS-DMA issued from the MFMA stream
+// stalls that SIMD's matrix pipe for the ~60 cycles the instruction takes to issue (15 of them per stage and wave: a third of the
+// stage); a wave that does nothing else issues one every ~25 cycles.  Ring of D stage buffers, one barrier per stage:
+//   producers:  DMA(stage s) -> wait until stage s - (D - 2) has landed (the later ones stay in flight) -> barrier s - (D - 2)
+//   consumers:  barrier k -> fragments + MFMAs of stage k
+// DMA(s) goes into the buffer of stage s - D, which every consumer left before it reached barrier s - D + 1 -- the last barrier the
+// producers passed before issuing it.
 template <int KW, int NPL, int NC>
 __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int tile, uint8_t* smem)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PT = kx_pt(KW, NPL, NC), D = kx_depth(KW, NPL, NC);
+    constexpr int BM = 64 * PT, XROWS = BM + 16, NRG = XROWS / 16;
     constexpr int HALO = KW - 1;
-    constexpr int XPL = KX_XROWS * 64;          // bytes of one plane of the staged rows
+    constexpr int XPL = XROWS * 64;             // bytes of one plane of the staged rows
     constexpr int XBUF = NPL * XPL;
     constexpr int WT = NC * 16 * 64;            // bytes of one (kx, plane) weight tile
     constexpr int WBUF = KW * NPL * WT;
     constexpr int BUF = XBUF + WBUF;
-    constexpr int NRG = KX_XROWS / 16;          // DMA row groups per plane (1 KB each)
-    constexpr int RGW = (NRG + 3) / 4;          // ... per wave
     constexpr int NWD = KW * NPL * NC;          // weight DMA instructions per stage (1 KB each)
-    constexpr int WDW = (NWD + 3) / 4;
-    static_assert(KX_BM + HALO <= KX_XROWS - 1, "the always-zero row must exist");
+    constexpr int NXD = NRG * NPL;              // activation DMA instructions per stage
+    constexpr int XDW = (NXD + KX_PRODUCERS - 1) / KX_PRODUCERS, WDW = (NWD + KX_PRODUCERS - 1) / KX_PRODUCERS;
+    constexpr int NPD = XDW + WDW;              // DMA instructions per producer wave and stage
+    static_assert(BM + HALO <= XROWS - 1, "the always-zero row must exist");
+    static_assert(D >= 2 && D * BUF <= KX_LDS_MAX && (D - 2) * NPD <= 63, "ring does not fit");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lvl = 0;
 #pragma unroll
     for (int l = 1; l < 8; ++l)
-        if (l < a.n_lvl && tile >= a.lvl_tile0[l]) lvl = l;
+        if (l < a.n_lvl && tile >= jb.lvl_tile0[l]) lvl = l;
     const int H = a.lvl_h[lvl], W = a.lvl_w[lvl], lstart = a.lvl_start[lvl], lend = a.lvl_start[lvl + 1];
-    const int m0 = lstart + (tile - a.lvl_tile0[lvl]) * KX_BM;
+    const int m0 = lstart + (tile - jb.lvl_tile0[lvl]) * BM;
     const int HW = H * W;
+    const int S = a.cslabs * a.kh;
 
-    // ---- DMA duties of this lane: row groups wave, wave + 4, ...; per row the byte offset of (ky = 0) within a channel slab and one
-    // validity bit per ky (the ky-shifted source pixel lies in the same image)
-    int dbase[RGW];
-    unsigned dmask[RGW];
+    if (wave >= KX_CONSUMERS) {
+        // ---------------------------------------------------------------------------------------------------------- producer
+        // activation pieces p * NRG + rg (plane p, row group rg) and weight pieces are dealt round-robin to the producers.  Staged row
+        // j = input pixel m0 - pw + j of the ky-shifted run; per row: byte offset of ky = 0 within a channel slab, one validity bit per
+        // ky (the shifted pixel lies in the same image; everything else, and rows >= BM + kw - 1, is zero-filled by the range check)
+        const int pw_ = wave - KX_CONSUMERS;
+        int dbase[XDW];
+        unsigned dmask[XDW];
 #pragma unroll
-    for (int i = 0; i < RGW; ++i) {
-        const int rg = wave + 4 * i;
-        const int j = rg * 16 + (lane >> 2);
-        const int q = m0 - a.pw + j;
-        const bool okq = rg < NRG && j < KX_BM + HALO && q >= lstart && q < lend;
-        const int local = okq ? q - lstart : 0;
-        const int y = (local % HW) / W;
-        unsigned vm = 0;
-        for (int ky = 0; ky < a.kh; ++ky)
-            if ((unsigned)(y + ky - a.ph) < (unsigned)H) vm |= 1u << ky;
-        dmask[i] = okq ? vm : 0u;
-        dbase[i] = (q - a.ph * W) * 64 + (((lane & 3) ^ swz(j)) << 4);
-    }
-    __amdgpu_buffer_rsrc_t xr[NPL];
+        for (int i = 0; i < XDW; ++i) {
+            const int piece = min(pw_ + KX_PRODUCERS * i, NXD - 1);
+            const int rg = piece % NRG;
+            const int j = rg * 16 + (lane >> 2);
+            const int q = m0 - a.pw + j;
+            const bool okq = j < BM + HALO && q >= lstart && q < lend;
+            const int local = okq ? q - lstart : 0;
+            const int y = (local % HW) / W;
+            unsigned vm = 0;
+            for (int ky = 0; ky < a.kh; ++ky)
+                if ((unsigned)(y + ky - a.ph) < (unsigned)H) vm |= 1u << ky;
+            dmask[i] = okq ? vm : 0u;
+            dbase[i] = (q - a.ph * W) * 64 + (((lane & 3) ^ swz(j)) << 4);
+        }
+        __amdgpu_buffer_rsrc_t xr[NPL];
 #pragma unroll
-    for (int p = 0; p < NPL; ++p)
-        xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
-
-    auto dma_stage = [&](int cs, int ky, int s, int buf) {
-        uint8_t* xb = smem + buf * BUF;
-        const int uni = (jb.x_slab0 + cs) * (a.x_np * 64) + ky * (W * 64);
+        for (int p = 0; p < NPL; ++p)
+            xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
+        int cs = 0, ky = 0, buf = 0;
+        auto issue = [&](int s) {
+            uint8_t* xb = smem + buf * BUF;
+            const int uni = (jb.x_slab0 + cs) * (a.x_np * 64) + ky * (W * 64);
 #pragma unroll
-        for (int i = 0; i < RGW; ++i) {
-            const int rg = wave + 4 * i;
-            if (rg < NRG) {
+            for (int i = 0; i < XDW; ++i) {
+                const int piece = min(pw_ + KX_PRODUCERS * i, NXD - 1);       // (an uneven split fetches its last piece twice)
+                const int p = piece / NRG, rg = piece - p * NRG;
                 const unsigned oob = ((dmask[i] >> ky) & 1u) ^ 1u;
                 const unsigned off = (unsigned)(dbase[i] + uni) | (oob << 31);
-#pragma unroll
-                for (int p = 0; p < NPL; ++p)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(xb + p * XPL + rg * 1024), 16, off, 0, 0, 0);
+                if (!(KX_ABL & 5)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[NPL == 2 ? (p & 1) : 0], (lds_ptr)(xb + p * XPL + rg * 1024), 16, off, 0, 0, 0);
             }
-        }
-        uint8_t* wb = xb + XBUF;
-        const uint8_t* wsrc = jb.wp + (size_t)s * WBUF;
+            uint8_t* wb = xb + XBUF;
+            const uint8_t* wsrc = jb.wp + (size_t)s * WBUF;
 #pragma unroll
-        for (int k = 0; k < WDW; ++k) {
-            const int idx = wave + 4 * k;
-            if (idx < NWD) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(wb + idx * 1024), 16, 0, 0);
+            for (int k = 0; k < WDW; ++k) {
+                const int idx = min(pw_ + KX_PRODUCERS * k, NWD - 1);
+                if (!(KX_ABL & 9)) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(wb + idx * 1024), 16, 0, 0);
+            }
+            if (++ky == a.kh) { ky = 0; ++cs; }
+            if (++buf == D) buf = 0;
+        };
+        // head: D - 2 stages go out before the first wait
+#pragma unroll
+        for (int s = 0; s < D - 2; ++s)
+            if (s < S) issue(s);
+        for (int s = D - 2; s < S; ++s) {
+            issue(s);
+            // stage s - (D - 2) has landed; the D - 2 stages behind it stay in flight across the barrier
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((D - 2) * NPD) : "memory");
         }
-    };
+        // tail: the last D - 2 stages (issued above, or all of them when S < D - 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int k = max(S - (D - 2), 0); k < S; ++k) asm volatile("s_barrier" ::: "memory");
+        return;
+    }
 
-    // ---- fragment addresses.  B operand (activations): lane (pixel r16 of pixel tile t, chunk kc), tap kx -> staged row + kx, or the
-    // always-zero row where the tap leaves the image row.  A operand (weights): lane (channel r16 of tile c, chunk kc).
+    // -------------------------------------------------------------------------------------------------------------- consumer
+    // B operand (activations): lane (pixel r16 of pixel tile t, chunk kc), tap kx -> staged row + kx, or the always-zero row where the
+    // tap leaves the image row.  A operand (weights): lane (channel r16 of tile c, chunk kc).
     const int r16 = lane & 15, kc = lane >> 4;
-    int boff[4][KW];
+    int boff[PT][KW];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int row0 = 64 * wave + 16 * t + r16;
+    for (int t = 0; t < PT; ++t) {
+        const int row0 = 16 * PT * wave + 16 * t + r16;
         const int m = m0 + row0;
         const bool okm = m < lend;
         const int x = okm ? (m - lstart) % W : 0;
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
             const bool v = okm && (unsigned)(x + kx - a.pw) < (unsigned)W;
-            boff[t][kx] = lds_off(v ? row0 + kx : KX_BM + HALO, kc);
+            boff[t][kx] = lds_off(v ? row0 + kx : BM + HALO, kc);
         }
     }
     const int aoff = XBUF + lds_off(r16, kc);
 
-    f32x4 acc[NC][4], accl[NC][4];
+    f32x4 acc[NC][PT], accl[NC][PT];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < PT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc[c][t][r] = 0.0f; accl[c][t][r] = 0.0f; }
 
-    const int S = a.cslabs * a.kh;
-    int n_cs = 0, n_ky = 0;                                // (channel slab, ky) of the next stage to bring in
-    dma_stage(0, 0, 0, 0);
-    if (++n_ky == a.kh) { n_ky = 0; ++n_cs; }
+    constexpr int NRD = (PT + NC) * NPL;        // fragment reads per tap
+    constexpr int NM = PT * NC * (NPL == 2 ? 3 : 1);   // MFMAs per tap
+    constexpr bool PF = NC <= 3;                // four channel tiles: the second fragment set does not fit beside the accumulators
+    constexpr int NS = PF ? 2 : 1;
+    f16x8 bh[NS][PT], bl[NS][PT], ah[NS][NC], al[NS][NC];
+    auto read_frags = [&](const uint8_t* xs, int kx, int set) {
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            bh[set][t] = *reinterpret_cast<const f16x8*>(xs + boff[t][kx]);
+            if constexpr (NPL == 2) bl[set][t] = *reinterpret_cast<const f16x8*>(xs + XPL + boff[t][kx]);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            ah[set][c] = *reinterpret_cast<const f16x8*>(xs + aoff + ((kx * NPL) * NC + c) * 1024);
+            if constexpr (NPL == 2) al[set][c] = *reinterpret_cast<const f16x8*>(xs + aoff + ((kx * NPL + 1) * NC + c) * 1024);
+        }
+    };
+    auto mfmas = [&](int set) {
+        if constexpr (NPL == 2) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) accl[c][t] = KX_MM(ah[set][c], bl[set][t], accl[c][t]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[c][t] = KX_MM(ah[set][c], bh[set][t], acc[c][t]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) accl[c][t] = KX_MM(al[set][c], bh[set][t], accl[c][t]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[c][t] = KX_MM(ah[set][c], bh[set][t], acc[c][t]);
+        }
+    };
+    int buf = 0;
     for (int s = 0; s < S; ++s) {
-        // stage s has landed for this wave, then for every wave; nobody reads buffer (s + 1) & 1 any more
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        const uint8_t* xs = smem + (s & 1) * BUF;
+        asm volatile("s_barrier" ::: "memory");             // barrier s: stage s is in LDS (and every consumer has left stage s - 1)
+        const uint8_t* xs = smem + buf * BUF;
+        if (++buf == D) buf = 0;
+        if constexpr ((KX_ABL & 2) != 0) continue;
+        if constexpr (PF) {
+            read_frags(xs, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-            f16x8 bh[4], bl[4], ah[NC], al[NC];
+            for (int kx = 0; kx < KW; ++kx) {
+                const int cur = kx & 1;
+                if (kx + 1 < KW) read_frags(xs, kx + 1, cur ^ 1);      // the next tap's fragments arrive under this tap's MFMAs
+                mfmas(cur);
+                // schedule: one fragment read of the next tap behind each of the first MFMAs
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                bh[t] = *reinterpret_cast<const f16x8*>(xs + boff[t][kx]);
-                if constexpr (NPL == 2) bl[t] = *reinterpret_cast<const f16x8*>(xs + XPL + boff[t][kx]);
+                for (int k = 0; k < NM; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (kx + 1 < KW && k < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                ah[c] = *reinterpret_cast<const f16x8*>(xs + aoff + ((kx * NPL) * NC + c) * 1024);
-                if constexpr (NPL == 2) al[c] = *reinterpret_cast<const f16x8*>(xs + aoff + ((kx * NPL + 1) * NC + c) * 1024);
-            }
-            if (kx == 0 && s + 1 < S) {
-                // the next stage starts on its way in behind this stage's first fragment reads (an LDS-DMA is an LDS store to the
-                // compiler: reads cannot move above it)
-                dma_stage(n_cs, n_ky, s + 1, (s + 1) & 1);
-                if (++n_ky == a.kh) { n_ky = 0; ++n_cs; }
-            }
-            if constexpr (NPL == 2) {
-                f32x4 tmp[NC][4];
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) tmp[c][t] = KX_MM(ah[c], bl[t], accl[c][t]);
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[c][t] = KX_MM(ah[c], bh[t], acc[c][t]);
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) accl[c][t] = KX_MM(al[c], bh[t], tmp[c][t]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[c][t] = KX_MM(ah[c], bh[t], acc[c][t]);
+            for (int kx = 0; kx < KW; ++kx) {
+                read_frags(xs, kx, 0);
+                mfmas(0);
             }
         }
     }
 
-    // ---- epilogue, straight from the accumulators: lane holds channels 16 c + 4 kc .. + 3 of pixel m0 + 64 wave + 16 t + r16
+    // ---- epilogue, straight from the accumulators: lane holds channels 16 c + 4 kc .. + 3 of pixel m0 + 16 PT wave + 16 t + r16
     const float ls = NPL == 2 ? 1.0f / STM_F16_LOW_SCALE : 0.0f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -222,8 +295,8 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
                 if (ch + r < jb.bias_n) b4[r] = jb.bias[ch + r];
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int m = m0 + 64 * wave + 16 * t + r16;
+        for (int t = 0; t < PT; ++t) {
+            const int m = m0 + 16 * PT * wave + 16 * t + r16;
             if (m >= lend) continue;
             float v[4];
 #pragma unroll
@@ -252,18 +325,23 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
 #endif
 }
 
+// One launch covers every group (job) of a layer, whatever its channel-tile count: the jobs are dealt widest first (their tiles take
+// longest), the body is selected per workgroup.  (Register budget 256: six waves per workgroup put two on two of the SIMDs.  With 512
+// the compiler splits the file into VGPRs and AGPRs and moves accumulators between them at every stage.)
 template <int KW, int NPL>
-__global__ __launch_bounds__(256, 1) void conv_kxr_kernel(const KxrArgs a)
+__global__ __launch_bounds__(KX_THREADS) void conv_kxr_kernel(const KxrArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __align__(16) uint8_t smem[];
-    const int total = a.tiles * a.n_jobs;
-    const int per_xcd = (total + 7) >> 3;
+    const int per_xcd = (a.total + 7) >> 3;
     const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (logical >= total) return;
-    // jobs are interleaved tile by tile (tile-major): the groups of one pixel tile run side by side on one XCD
-    const int tile = logical / a.n_jobs, j = logical - tile * a.n_jobs;
+    if (logical >= a.total) return;
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < KX_MAX_JOBS; ++i)
+        if (i < a.n_jobs && logical >= a.job[i].tile0) j = i;
     const KxrJob& jb = a.job[j];
+    const int tile = logical - jb.tile0;
     switch (jb.nc) {
         case 1: kxr_body<KW, NPL, 1>(a, jb, tile, smem); break;
         case 2: kxr_body<KW, NPL, 2>(a, jb, tile, smem); break;
@@ -307,6 +385,9 @@ struct KxrPlan {
     size_t woff[KX_MAX_JOBS + 1];
 };
 
+// can the kernel take kw / format / nc at all (a three-stage ring must fit)
+bool kxr_ring_fits(int kw, int npl, int nc) { return kx_depth(kw, npl, nc) >= 3; }
+
 // Which layers the kernel takes, and how its weights are laid out.  Returns false with the error string set otherwise.
 bool kxr_plan(const stm_conv_geom* g, KxrPlan* pl, const char* who)
 {
@@ -331,16 +412,34 @@ bool kxr_plan(const stm_conv_geom* g, KxrPlan* pl, const char* who)
         if (real > 64) { stm_set_error("%s: at most 64 output channels per group (group %d has %d)", who, i, real); return false; }
         pl->creal[i] = real;
         pl->nc[i] = (real + 15) / 16;
+        if (!kxr_ring_fits(g->kw, pl->npl, pl->nc[i])) {
+            stm_set_error("%s: %d output channels with kw = %d: no three-stage ring fits the LDS", who, real, g->kw);
+            return false;
+        }
         pl->woff[i + 1] = pl->woff[i] + (size_t)pl->slabs_kh * g->kw * pl->npl * pl->nc[i] * 1024;
     }
     return true;
 }
 
 template <int KW, int NPL>
-int kxr_launch(const KxrArgs& a, int nc_max, stm_stream_t stream)
+int kxr_launch(KxrArgs a, stm_stream_t stream)
 {
-    const size_t lds = 2 * ((size_t)NPL * KX_XROWS * 64 + (size_t)KW * NPL * nc_max * 1024);
-    static std::atomic<int> reserved[KX_MAX_DEVICES];      // bytes reserved so far, per device
+    std::stable_sort(a.job, a.job + a.n_jobs, [](const KxrJob& x, const KxrJob& y) { return x.nc > y.nc; });    // widest first
+    size_t lds = 0;
+    a.total = 0;
+    for (int i = 0; i < a.n_jobs; ++i) {
+        KxrJob& j = a.job[i];
+        const int nc = j.nc;
+        const int pt = kx_pt(KW, NPL, nc), d = kx_depth(KW, NPL, nc);
+        STM_REQUIRE(d >= 3, STM_EUNSUPPORTED, "stm_conv2d_planar_kxr_f32: %d channel tiles x kw = %d: no three-stage ring fits the LDS", nc, KW);
+        lds = std::max(lds, (size_t)d * kx_stage_bytes(KW, NPL, nc, pt));
+        j.tile0 = a.total;
+        int t0 = 0;
+        for (int l = 0; l < a.n_lvl; ++l) { j.lvl_tile0[l] = t0; t0 += stm_cdiv(a.lvl_start[l + 1] - a.lvl_start[l], 64 * pt); }
+        j.lvl_tile0[a.n_lvl] = t0;
+        a.total += t0;
+    }
+    static std::atomic<int> reserved[KX_MAX_DEVICES];      // bytes reserved so far, per instantiation and device
     int dev = 0;
     const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < KX_MAX_DEVICES;
     if (!have_dev || reserved[dev].load(std::memory_order_relaxed) < (int)lds) {
@@ -348,8 +447,7 @@ int kxr_launch(const KxrArgs& a, int nc_max, stm_stream_t stream)
                                         (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_kxr_f32: cannot reserve %zu bytes of LDS", lds);
         if (have_dev) reserved[dev].store((int)lds, std::memory_order_relaxed);
     }
-    const int total = a.tiles * a.n_jobs;
-    hipLaunchKernelGGL((conv_kxr_kernel<KW, NPL>), dim3(8 * stm_cdiv(total, 8)), dim3(256), lds, stm_hs(stream), a);
+    hipLaunchKernelGGL((conv_kxr_kernel<KW, NPL>), dim3(8 * stm_cdiv(a.total, 8)), dim3(KX_THREADS), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_kxr_kernel");
     return STM_OK;
 }
@@ -410,10 +508,6 @@ extern "C" int stm_conv2d_planar_kxr_f32(const void* x_planes, const void* packe
     }
     STM_REQUIRE(2 * g->ph == g->kh - 1 && 2 * g->pw == g->kw - 1, STM_EUNSUPPORTED, "%s: same padding only", who);
     STM_REQUIRE(M < ((int64_t)1 << 30), STM_EUNSUPPORTED, "%s: too many pixels", who);
-    int t0 = 0;
-    for (int l = 0; l < a.n_lvl; ++l) { a.lvl_tile0[l] = t0; t0 += stm_cdiv(a.lvl_start[l + 1] - a.lvl_start[l], KX_BM); }
-    a.lvl_tile0[a.n_lvl] = t0;
-    a.tiles = t0;
     const int groups = pl.n_jobs;
     const int64_t x_np = g->x_np ? g->x_np : M, out_np = g->out_np ? g->out_np : M;
     STM_REQUIRE(x_np >= M && out_np >= M, STM_EINVAL, "%s: x_np / out_np smaller than the pixel count", who);
@@ -453,6 +547,7 @@ extern "C" int stm_conv2d_planar_kxr_f32(const void* x_planes, const void* packe
                 a.out_fmt, g->fmt);
     a.out_scale = g->out_scale > 0.0f ? g->out_scale : 1.0f;
     a.range_flag = stm_internal_range_flag();
-    if (g->fmt == 1) return g->kw == 3 ? kxr_launch<3, 2>(a, nc_max, stream) : kxr_launch<5, 2>(a, nc_max, stream);
-    return g->kw == 3 ? kxr_launch<3, 1>(a, nc_max, stream) : kxr_launch<5, 1>(a, nc_max, stream);
+    (void)nc_max;
+    if (g->fmt == 1) return g->kw == 3 ? kxr_launch<3, 2>(a, stream) : kxr_launch<5, 2>(a, stream);
+    return g->kw == 3 ? kxr_launch<3, 1>(a, stream) : kxr_launch<5, 1>(a, stream);
 }

@@ -544,6 +544,45 @@ def conv_pack_weights(weight, planes=3, tile_n=128, fmt=0):
     return packed
 
 
+def conv_kxr_supported(O, C, kh, kw, stride, padding, groups, group_cout, fmt, max_tiles=4):
+    """Layers the kx-reuse narrow-output kernel (csrc/conv_kxr.hip, stm_conv2d_planar_kxr_f32) takes: stride 1, same padding,
+    kw = 3 or 5, fp16 plane formats, at most 16 * max_tiles real output channels per group, at most 4 groups, and a three-stage
+    LDS ring that fits (the library refuses the others)."""
+    (sh, sw), (ph, pw) = _pair(stride), _pair(padding)
+    if fmt not in (1, 2) or (sh, sw) != (1, 1) or kw not in (3, 5) or not (1 <= kh <= 8) or 2 * ph != kh - 1 or 2 * pw != kw - 1:
+        return False
+    if C % 32 or groups < 1 or groups > 4 or O % groups:
+        return False
+    cg = O // groups
+    real = [(group_cout[i] if group_cout and 0 < group_cout[i] < cg else cg) for i in range(groups)]
+    npl = 2 if fmt == 1 else 1
+    for r in real:
+        nc = -(-r // 16)
+        if nc > max_tiles or 16 * nc > cg or cg % 4:       # whole 16-channel tiles are written: they must fit the group's row stride
+            return False
+        # csrc/conv_kxr.hip kx_pt / kx_depth: some tile of 64 * pt pixels (pt = 4, 3, 2) must leave room for three stages
+        if 3 * (npl * (64 * 2 + 16) * 64 + kw * npl * nc * 1024) > 160 * 1024:
+            return False
+    return True
+
+
+def conv_pack_weights_kxr(weight, geom):
+    """OIHW fp32 weights (grouped layers: group g = rows [g * O / groups, ...)) -> the image stm_conv2d_planar_kxr_f32 streams;
+    geom: a ConvGeom with C (per group), Cout, kh, kw, groups, group_cout, fmt set.  Returns (packed, 1 / wscale)."""
+    _dev(weight)
+    weight = _f32c(weight)
+    nbytes = _lib.lib().stm_conv_kxr_packed_bytes(ctypes.byref(geom))
+    if nbytes == 0:
+        raise StmError("conv_pack_weights_kxr: " + _lib.lib().stm_last_error_string().decode(errors="replace"))
+    packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
+    import math
+    wmax = float(weight.abs().max())
+    wscale = 2.0 ** (10 - math.floor(math.log2(wmax))) if wmax > 0 else 1.0
+    check(_lib.lib().stm_conv_pack_weights_kxr_f32(_p(weight), _p(packed), ctypes.byref(geom), c_f(wscale), _stream()),
+          "stm_conv_pack_weights_kxr_f32")
+    return packed, 1.0 / wscale
+
+
 def plane_layout(fmt):
     """(number of planes, element type) of a planar format: 0 = bf16 x 3, 1 = fp16 x 2, 2 = fp16 x 1 (include/stmask_hip.h)."""
     if fmt == 0:
@@ -803,6 +842,39 @@ def stem_rows_planes(x_nhwc, kw, sw, pw, fmt=0):
     check(_lib.lib().stm_stem_rows_planes_f32(_p(x), _p(planes), c_i(B), c_i(H), c_i(W), c_i(Cin), c_i(kw), c_i(sw), c_i(pw), c_i(fmt),
                                               _stream()), "stm_stem_rows_planes_f32")
     return planes, Wo
+
+
+def stem_pack_weights(weight, fmt):
+    """conv1 weights [64, 3, 7, 7] -> the fragment image stm_stem_fused_f32 keeps in registers; returns (packed, 1 / wscale)."""
+    _dev(weight)
+    weight = _f32c(weight)
+    O = weight.shape[0]
+    nbytes = _lib.lib().stm_stem_packed_weight_bytes(c_i(O), c_i(fmt))
+    if nbytes == 0 or tuple(weight.shape[1:]) != (3, 7, 7):
+        raise StmError(f"stem_pack_weights: unsupported stem {tuple(weight.shape)} / format {fmt}")
+    import math
+    wmax = float(weight.abs().max())
+    wscale = 2.0 ** (10 - math.floor(math.log2(wmax))) if wmax > 0 else 1.0
+    packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
+    check(_lib.lib().stm_stem_pack_weights_f32(_p(weight), _p(packed), c_i(O), c_i(fmt), c_f(wscale), _stream()), "stm_stem_pack_weights_f32")
+    return packed, 1.0 / wscale
+
+
+def stem_fused(x_nhwc, packed, out_scale, bias, fmt, out_fmt=None):
+    """conv1 (7x7 / 2 / 3, BN folded) + ReLU + MaxPool2d(3, 2, 1) in one kernel: fp32 frame [B,H,W,3] -> (planes [P, 2, B*Hp*Wp, 32],
+    (Hp, Wp)).  stm_stem_fused_f32."""
+    _dev(x_nhwc, packed, bias)
+    x = _f32c(x_nhwc)
+    B, H, W, Cin = x.shape
+    if Cin != 3:
+        raise StmError(f"stem_fused: 3-channel frames only, got {Cin}")
+    out_fmt = fmt if out_fmt is None else out_fmt
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    planes = _empty_planes(out_fmt, 2, B * Hp * Wp, x.device)
+    check(_lib.lib().stm_stem_fused_f32(_p(x), _p(packed), _p(_f32c(bias)) if bias is not None else c_p(0), _p(planes), c_i(B), c_i(H), c_i(W),
+                                        c_i(64), c_i(fmt), c_i(out_fmt), c_f(out_scale), _stream()), "stm_stem_fused_f32")
+    return planes, (Hp, Wp)
 
 
 def planes_to_f32(planes):

@@ -40,6 +40,8 @@ BACKBONE_FMT = None
 TILE64_MAX_SLABS = int(os.environ.get("STM_TILE64_MAX_SLABS", "8"))
 FCB_PLANAR = os.environ.get("STM_FCB_PLANAR", "1") != "0"
 STEM_PLANAR = os.environ.get("STM_STEM_PLANAR", "1") != "0"
+STEM_FUSED = os.environ.get("STM_STEM_FUSED", "1") != "0"    # conv1 + ReLU + max-pool as one kernel (csrc/stem_fused.hip)
+CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 layers on the kx-reuse kernel (csrc/conv_kxr.hip)
 
 
 def set_format(fmt, backbone_fmt=None):
@@ -77,6 +79,11 @@ class PlanarConv:
         self._packed = {}
         self.out_scale = 1.0
         self.role = "trunk"          # "temporal" for TemporalNet's layers: bench.py reports the trunk-only roofline beside the overall one
+        # few output channels per group, stride 1, kw >= 3: the kx-reuse kernel (stm_conv2d_planar_kxr_f32) -- these layers run at the
+        # L2 -> LDS staging rate on the 128 x 64 tiles (head output layers, DCN offset convolutions, layer1's 3x3)
+        self.kxr = CONV_KXR and self.out_fmt == self.fmt and ops.conv_kxr_supported(self.O, self.C, self.kh, self.kw, (self.sh, self.sw), (self.ph, self.pw),
+                                                                                     self.groups, self.group_cout, self.fmt, max_tiles=3)
+        self.kxr_min_pixels = None   # None: the measured thresholds of __call__; tests set 0 to force the kernel on small inputs
         self.bias = bias.detach().float().contiguous() if bias is not None else None
 
     def packed(self, tile_n):
@@ -150,7 +157,12 @@ class PlanarConv:
             if x_off + B * H * W > N:
                 raise StmError("PlanarConv: input slice runs past the plane buffer")
         g.x_np, g.x_plane_stride = N, S * N * 32
-        g.tile_n = self.pick_tile(M)
+        # measured against the 128 x 64 tiles (scripts/bench_kxr.py, 1 / 4 / 8 / 32 clips): the head's grouped output layers win from
+        # ~20 000 pixels (x1.3-1.8), single-group layers of up to 48 channels from ~30 000 (x1.1-1.4); below that its 256-pixel tiles
+        # leave CUs idle, and four channel tiles (layer1's 64 -> 64) stay on the general kernel (x0.65)
+        use_kxr = (self.kxr and residual is None and (shape[0] == "levels" or (Ho, Wo) == (H, W))
+                   and M >= (self.kxr_min_pixels if self.kxr_min_pixels is not None else (20000 if self.groups > 1 else 30000)))
+        g.tile_n = 0 if use_kxr else self.pick_tile(M)
         dev = xp.device
         NPo, dto = _planes_dtype(self.out_fmt)
         if out in ("planes", "both") and out_planes is None:
@@ -187,6 +199,16 @@ class PlanarConv:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         x_ptr = xp.data_ptr() + ((x_ch_off // 32) * N + x_off) * 64
+        if use_kxr:
+            g.fmt = self.fmt
+            if "kxr" not in self._packed:
+                ops.planar_range_flag()
+                self._packed["kxr"] = ops.conv_pack_weights_kxr(self.weight, g)
+            packed, g.out_scale = self._packed["kxr"]
+            rc = _lib.lib().stm_conv2d_planar_kxr_f32(ctypes.c_void_p(x_ptr), ops._p(packed), ops._p(self.bias), ctypes.c_void_p(p_f32),
+                                                      ctypes.c_void_p(p_pl), ctypes.byref(g), c_i(1 if self.relu else 0), ops._stream())
+            check(rc, "stm_conv2d_planar_kxr_f32")
+            return self._finish(timing, e0 if timing is not None else None, M, shape, g, NP, NPo, dt, out, out_f32, out_planes, residual)
         packed = self.packed(g.tile_n)                     # (sets self.out_scale for the fp16 format)
         g.fmt, g.out_scale = self.fmt, self.out_scale
         g.out_fmt_plus1 = 0 if self.out_fmt == self.fmt else self.out_fmt + 1
@@ -197,9 +219,12 @@ class PlanarConv:
                                                  c_i(1 if self.relu else 0), ops._p(ws), ctypes.c_size_t(ws.numel()),
                                                  ops._stream())
         check(rc, "stm_conv2d_planar_f32")
+        return self._finish(timing, e0 if timing is not None else None, M, shape, g, NP, NPo, dt, out, out_f32, out_planes, residual)
+
+    def _finish(self, timing, e0, M, shape, g, NP, NPo, dt, out, out_f32, out_planes, residual):
         if timing is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            # (start, end, algorithmic flops, layer key, MFMA products per product of the reference: 6 bf16x3 / 3 fp16x2 / 1 fp16x1)
             # algorithmic HBM bytes of the launch: every input / residual / output element and every weight once, in the
             # formats they are stored in (planes 2 B per plane and element, fp32 4 B)
             in_px = M if shape[0] == "levels" else shape[1] * shape[2] * shape[3]
@@ -210,6 +235,8 @@ class PlanarConv:
                 nbytes += M * self.O * 4
             if residual is not None:
                 nbytes += M * self.O * (2 * NP if residual.dtype == dt else 4)
+            # (start, end, algorithmic flops, layer key [tile 0 = the kx-reuse kernel], MFMA products per product of the reference: 6 bf16x3 /
+            # 3 fp16x2 / 1 fp16x1, role, algorithmic bytes)
             timing.append((e0, e1, 2.0 * M * self.O * self.C * self.kh * self.kw * self.algo_frac,
                            (M, self.C, self.O, self.kh, self.sh, self.groups, g.tile_n),
                            {0: 6 if self.planes == 3 else 3, 1: 3, 2: 1}[self.fmt], self.role, float(nbytes)))
@@ -302,7 +329,13 @@ class PlanarGraph:
                 # deformable kernels (NCHW fp32), then its trailing conv on the planar kernel over all levels at once
                 fa = head.conf_layer[k]
                 entry.append(fa)
-                entry.append(PlanarConv(fa.conv.weight, fa.conv.bias, 1, fa.conv.padding, relu=False, tile_n=64))
+                # (41 class channels in rows of 48: whole 16-channel tiles for the kx-reuse kernel; the rows land in the 64-column
+                # class group of the output buffer)
+                n_c = fa.conv.weight.shape[0]
+                n_cp = -(-n_c // 16) * 16
+                assert n_cp <= P
+                entry.append(PlanarConv(F.pad(fa.conv.weight, (0, 0, 0, 0, 0, 0, 0, n_cp - n_c)), F.pad(fa.conv.bias, (0, n_cp - n_c)), 1, fa.conv.padding,
+                                        relu=False, tile_n=64, group_cout=[n_c], algo_frac=n_c / n_cp))
                 # FeatureAlign's DeformConv2d as planar sampler (columns [pixel][tap*C + c] for all levels) + planar 1x1
                 # convolution over kh*kw*C channels (+ ReLU); offsets as one [pixels, 4] x [4, 2K] product (ada)
                 ad = fa.conv_adaption
@@ -604,6 +637,7 @@ class PlanarBackbone:
         fmt = self.fmt
         self.planes_only = False    # fuse: the planar FPN takes the stage outputs as planes; their fp32 copies are not made
         self.out_planes = None      # [(planes, B, H, W)] of the last call, one entry per stage
+        self._stem_fused = None     # (packed conv1 weights, 1 / wscale) of the one-kernel stem
         # stem: w'[o][j][ky][0] = w[o][j % Cin][ky][j / Cin] over the row-patch tensor of stm_stem_rows_planes_f32
         c1 = bb.conv1
         O, Cin, kh, kw = c1.weight.shape
@@ -625,7 +659,13 @@ class PlanarBackbone:
                 if isinstance(c2, DCN):
                     e["dcn"] = c2
                     om = c2.conv_offset_mask
-                    e["om"] = PlanarConv(om.weight, om.bias, om.stride, om.padding, relu=False, fmt=fmt)
+                    # 27 offset / mask channels in rows of 32 (zero weights behind them): whole 16-channel tiles for the kx-reuse
+                    # kernel, 16-byte rows for everyone; the sampler reads the first 27 values of a row
+                    n_om = om.weight.shape[0]
+                    n_pad = -(-n_om // 16) * 16
+                    e["om"] = PlanarConv(F.pad(om.weight, (0, 0, 0, 0, 0, 0, 0, n_pad - n_om)), F.pad(om.bias, (0, n_pad - n_om)), om.stride, om.padding,
+                                         relu=False, fmt=fmt, group_cout=[n_om], algo_frac=n_om / n_pad)
+                    e["n_om"] = n_om
                     # the deformable conv's GEMM as a planar 1x1 convolution over the sampled columns [pixel][tap*C + c]
                     O, Cin = c2.weight.shape[:2]
                     e["dcn_planar"] = (c2.kernel_size == (3, 3) and c2.deformable_groups == 1 and Cin in (128, 256, 512))
@@ -646,6 +686,15 @@ class PlanarBackbone:
         c1, mp = bb.conv1, bb.maxpool
         if (isinstance(bb.bn1, torch.nn.Identity) and c1.out_channels % 32 == 0 and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1
                 and not mp.ceil_mode and mp.dilation == 1):
+            # the whole stem as one kernel: no row-patch tensor, no fp32 convolution output
+            if (STEM_FUSED and self.fmt in (1, 2) and tuple(c1.weight.shape) == (64, 3, 7, 7) and tuple(c1.stride) == (2, 2) and tuple(c1.padding) == (3, 3)
+                    and c1.groups == 1 and tuple(c1.dilation) == (1, 1)):
+                if self._stem_fused is None:
+                    ops.planar_range_flag()
+                    self._stem_fused = ops.stem_pack_weights(c1.weight.detach(), self.fmt)
+                xp, (H, W) = ops.stem_fused(_nhwc(x), self._stem_fused[0], self._stem_fused[1], c1.bias, self.fmt)
+                B, C = x.shape[0], c1.out_channels
+                return self._stages(xp, B, C, H, W)
             # stem tail in one pass: folded-BN bias + ReLU + 3x3/2 max-pool of the raw 7x7 convolution output, straight to planes
             if self.stem is not None and STEM_PLANAR:
                 # the 7x7 / stride-2 convolution itself as a (7 x 1) planar convolution over the row-patch tensor R
@@ -664,6 +713,9 @@ class PlanarBackbone:
             x = bb.maxpool(bb.relu(bb.bn1(bb.conv1(x))))        # conv1 carries the folded BN + ReLU after fuse
             B, C, H, W = x.shape
             xp = _split(_nhwc(x), self.fmt)
+        return self._stages(xp, B, C, H, W)
+
+    def _stages(self, xp, B, C, H, W):
         outs, self.out_planes = [], []
         for blks in self.blocks:
             y32 = None
@@ -685,7 +737,7 @@ class PlanarBackbone:
                         mid = e["dcn_conv"](cols, ("img", B, Ho, Wo))
                     elif B * Ho * Wo >= self.OM_PLANAR_MIN_PIXELS:
                         t32, tpl = e["c1"](xp, shape, out="both")
-                        om = e["om"](tpl, shape, out="f32").view(B, Ho, Wo, -1).permute(0, 3, 1, 2).contiguous()
+                        om = e["om"](tpl, shape, out="f32")[:, :e["n_om"]].reshape(B, Ho, Wo, -1).permute(0, 3, 1, 2).contiguous()
                     else:
                         # alternative for tiny maps: the dense-conv library's small-tile kernel (not taken by default)
                         t32 = e["c1"](xp, shape, out="f32")

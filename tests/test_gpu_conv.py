@@ -533,3 +533,150 @@ def test_f16_entry_points_are_plane_format_2():
     _lib.check(lib.stm_dcn_sample_planar_f16(c_p(xs.data_ptr()), c_p(om.data_ptr()), c_i(27), c_p(cols.data_ptr()), c_i(80), c_l(0), ctypes.byref(dg),
                                              stream), "stm_dcn_sample_planar_f16")
     assert cols.shape[0] == 1 and torch.equal(cols, cols_ref)
+
+
+# ---------------------------------------------------------------------------------------------- narrow layers: the kx-reuse kernel
+def _planar_conv_vs_oracle(conv, xs, sizes, B, wts, bias, pad, relu, C, groups, cg, real, fmt, tol):
+    """Run `conv` over the concatenated levels and compare every (level, group) with the fp64 oracle."""
+    starts = [0]
+    for h, w in sizes:
+        starts.append(starts[-1] + B * h * w)
+    flat = torch.cat([x.reshape(-1, x.shape[-1]) for x in xs], 0)
+    xp = ops.split_planes(flat.to(DEV), fmt)
+    shape = ("levels", B, sizes) if len(sizes) > 1 else ("img", B, *sizes[0])
+    y32, ypl = conv(xp, shape, out="both")
+    y32, ypl = y32.cpu(), ypl.cpu()
+    worst = 0.0
+    for l, (h, w) in enumerate(sizes):
+        for g in range(groups):
+            xg = xs[l][..., g * C:(g + 1) * C].contiguous()
+            wg, bg = wts[g * cg:g * cg + real[g]], (bias[g * cg:g * cg + real[g]] if bias is not None else None)
+            ref = oracle.conv2d_nhwc(xg, wg, bg, None, padding=pad, relu=relu)
+            mag = oracle.conv2d_nhwc(xg.abs(), wg.abs(), bg.abs() if bg is not None else None, None, padding=pad)
+            out = y32[starts[l]:starts[l + 1], g * cg:g * cg + real[g]].view(B, h, w, real[g])
+            worst = max(worst, ((out - ref).abs() / mag.clamp_min(1e-6)).max().item())
+    assert worst < tol, worst
+    return y32, ypl, worst
+
+
+KXR_CASES = [
+    # kh, kw, groups, channels per group (row stride), real channels per group, sizes, B, relu
+    (3, 3, 3, 64, (41, 5, 32), [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)], 3, False),     # head output layers, five levels
+    (3, 5, 3, 64, (41, 5, 32), [(12, 20), (6, 10), (3, 5)], 2, False),
+    (5, 3, 3, 64, (41, 5, 32), [(12, 20), (6, 10), (3, 5)], 2, False),
+    (3, 3, 1, 64, (64,), [(24, 40)], 2, True),                                           # layer1's 64 -> 64 3x3 (+ ReLU)
+    (3, 3, 1, 32, (27,), [(13, 17)], 3, False),                                          # DCN offset / mask convolution, odd sizes
+    (5, 3, 2, 64, (64, 16), [(9, 7), (4, 5)], 1, True),
+]
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("case", KXR_CASES)
+def test_conv_kxr_vs_oracle(case, fmt):
+    """stm_conv2d_planar_kxr_f32 (csrc/conv_kxr.hip: kx-reuse staging, channel tiles of 16, transposed product, stores from the
+    accumulators) against the fp64 oracle at the bound of the general planar kernel -- 2e-6 of sum |x w| with two fp16 planes, 1e-3
+    with one -- over multi-level pixel axes whose tiles straddle image rows, images and (for the last tile) the level's end, grouped
+    layers with different real channel counts, and both output forms."""
+    from stmask_amd.planar import PlanarConv
+    kh, kw, G, cg, real, sizes, B, relu = case
+    C = 64
+    xs = [rnd(B, h, w, G * C, seed=40 + i) for i, (h, w) in enumerate(sizes)]
+    wts = rnd(G * cg, C, kh, kw, seed=50, scale=(C * kh * kw) ** -0.5)
+    for g in range(G):
+        wts[g * cg + real[g]:(g + 1) * cg] = 0.0                     # zero-padded groups, as planar.py builds them
+    bias = rnd(G * cg, seed=51)
+    pad = ((kh - 1) // 2, (kw - 1) // 2)
+    conv = PlanarConv(wts.to(DEV), bias.to(DEV), 1, pad, relu=relu, groups=G, group_cout=list(real), tile_n=64, fmt=fmt)
+    conv.kxr = ops.conv_kxr_supported(G * cg, C, kh, kw, 1, pad, G, list(real), fmt)     # (the graph leaves four-tile groups to the general kernel)
+    conv.kxr_min_pixels = 0
+    assert conv.kxr
+    tol = 2e-6 if fmt == 1 else 1e-3
+    y32, ypl, worst = _planar_conv_vs_oracle(conv, xs, sizes, B, wts, bias, pad, relu, C, G, cg, real, fmt, tol)
+    # the planes ARE the fp32 output (channels of whole 16-tiles; the rest of a slab is never written)
+    back = planes_to_f32(ypl)
+    for g in range(G):
+        sl = slice(g * cg, g * cg + real[g])
+        assert (back[:, sl] - y32[:, sl]).abs().max().item() <= 2.0 ** (-21 if fmt == 1 else -10) * max(1.0, y32[:, sl].abs().max().item())
+    # ... and the general kernel gives the same values to fp32 rounding (different MFMA operand roles, same products in the same order)
+    ref_conv = PlanarConv(wts.to(DEV), bias.to(DEV), 1, pad, relu=relu, groups=G, group_cout=list(real), tile_n=64, fmt=fmt)
+    ref_conv.kxr = False
+    flat = torch.cat([x.reshape(-1, x.shape[-1]) for x in xs], 0)
+    shape = ("levels", B, sizes) if len(sizes) > 1 else ("img", B, *sizes[0])
+    y_old = ref_conv(ops.split_planes(flat.to(DEV), fmt), shape, out="f32").cpu()
+    for g in range(G):
+        sl = slice(g * cg, g * cg + real[g])
+        assert (y_old[:, sl] - y32[:, sl]).abs().max().item() < (2e-5 if fmt == 1 else 2e-2)
+
+
+def test_conv_kxr_known_answers():
+    """One-hot taps shift the image with zero padding -- across image rows, images and levels (the cases the always-zero LDS row
+    and the DMA's range check exist for): exact."""
+    from stmask_amd.planar import PlanarConv
+    C, B, sizes = 32, 2, [(7, 9), (5, 33), (3, 4)]
+    xs = [rnd(B, h, w, C, seed=60 + i) for i, (h, w) in enumerate(sizes)]
+    flat = torch.cat([x.reshape(-1, C) for x in xs], 0)
+    starts = [0]
+    for h, w in sizes:
+        starts.append(starts[-1] + B * h * w)
+    for (ky, kx) in [(0, 0), (0, 4), (2, 2), (1, 3), (2, 0)]:
+        w5 = torch.zeros(C, C, 3, 5)
+        w5[:, :, ky, kx] = torch.eye(C)                      # y[oy, ox] = x[oy + ky - 1, ox + kx - 2]
+        conv = PlanarConv(w5.to(DEV), None, 1, (1, 2), relu=False, fmt=1)
+        conv.kxr_min_pixels = 0
+        assert conv.kxr
+        y = conv(ops.split_planes(flat.to(DEV), 1), ("levels", B, sizes), out="f32").cpu()
+        for l, (h, w) in enumerate(sizes):
+            exp = torch.zeros(B, h, w, C)
+            dy, dx = ky - 1, kx - 2
+            ys, xs_ = slice(max(0, -dy), min(h, h - dy)), slice(max(0, -dx), min(w, w - dx))
+            yd, xd = slice(max(0, dy), min(h, h + dy)), slice(max(0, dx), min(w, w + dx))
+            exp[:, ys, xs_] = xs[l][:, yd, xd]
+            got = y[starts[l]:starts[l + 1]].view(B, h, w, C)
+            assert (got - exp).abs().max().item() <= 2.0 ** -21 * xs[l].abs().max().item(), (ky, kx, l)
+
+
+# ---------------------------------------------------------------------------------------------- the stem as one kernel
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("hw", [(64, 96), (37, 53), (384, 640)])
+def test_stem_fused_vs_fp64(hw, fmt):
+    """stm_stem_fused_f32 (conv1 7x7 / 2 / 3 + folded-BN bias + ReLU + MaxPool2d(3, 2, 1) in one kernel, csrc/stem_fused.hip)
+    against the same chain in float64: 2e-6 of sum |x w| with two fp16 planes (the bound of the planar convolutions), 1e-3 with one;
+    odd sizes exercise partial tiles, pool windows and conv windows that leave the frame on every side."""
+    H, W = hw
+    B = 2 if H < 300 else 1
+    x = rnd(B, H, W, 3, seed=70)
+    w = rnd(64, 3, 7, 7, seed=71, scale=147 ** -0.5)
+    b = rnd(64, seed=72)
+    xd, wd = x.permute(0, 3, 1, 2).double(), w.double()
+    ref = F.max_pool2d(F.relu(F.conv2d(xd, wd, b.double(), stride=2, padding=3)), 3, 2, 1).permute(0, 2, 3, 1)
+    mag = F.max_pool2d(F.conv2d(xd.abs(), wd.abs(), b.abs().double(), stride=2, padding=3), 3, 2, 1).permute(0, 2, 3, 1)
+    packed, osc = ops.stem_pack_weights(w.to(DEV), fmt)
+    planes, (Hp, Wp) = ops.stem_fused(x.to(DEV), packed, osc, b.to(DEV), fmt)
+    assert (Hp, Wp) == tuple(ref.shape[1:3]) and planes.shape == ((2 if fmt == 1 else 1), 2, B * Hp * Wp, 32)
+    y = planes_to_f32(planes.cpu()).view(B, Hp, Wp, 64).double()
+    tol = 2e-6 if fmt == 1 else 1e-3
+    # (the pooled maximum may come from a neighbouring position whose value is within the bound: compare values, bound by the
+    # window's largest magnitude)
+    assert ((y - ref).abs() / mag.clamp_min(1e-6)).max().item() < tol + (2.0 ** -21 if fmt == 1 else 2.0 ** -10)
+    torch.cuda.synchronize()
+    assert int(ops.planar_range_flag().item()) == 0
+
+
+def test_stem_fused_equals_three_kernel_stem():
+    """The one-kernel stem against round 2's three launches (row patches -> (7 x 1) planar convolution -> bias + ReLU + max-pool):
+    same products, same fp32 accumulation per kernel row; the K order inside a slab differs (pixel-major 4-channel groups instead of
+    21 interleaved values), so the results agree to fp32 rounding of the sums, not bit for bit."""
+    import stmask_amd.planar as pl
+    from stmask_amd.backbone import ResNetBackbone
+    torch.manual_seed(0)
+    x = rnd(2, 96, 160, 3, seed=80).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last).to(DEV)
+    w, b = rnd(64, 3, 7, 7, seed=81, scale=147 ** -0.5).to(DEV), rnd(64, seed=82).to(DEV)
+    packed, osc = ops.stem_pack_weights(w, 1)
+    fused, (Hp, Wp) = ops.stem_fused(x.permute(0, 2, 3, 1), packed, osc, b, 1)
+    wr = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(64, 7, 21), (0, 11)).permute(0, 2, 1).reshape(64, 32, 7, 1).contiguous()
+    conv = pl.PlanarConv(wr, None, (2, 1), (3, 0), relu=False, fmt=1)
+    rp, Wo = ops.stem_rows_planes(x.permute(0, 2, 3, 1), 7, 2, 3, 1)
+    y = conv(rp, ("img", 2, 96, Wo), out="f32").view(2, 48, Wo, 64)
+    old, _ = ops.bias_relu_maxpool_planes(y, b, 1)
+    a, c = planes_to_f32(fused.cpu()), planes_to_f32(old.cpu())
+    assert a.shape == c.shape and (a - c).abs().max().item() < 2e-6 * max(1.0, c.abs().max().item())
