@@ -13,9 +13,11 @@
 //      (kx = 7 and channel 3 carry zero weights).  No im2col / row-patch tensor exists anywhere;
 //   2. the conv outputs of the (2 PH + 1) x (2 PW + 1) positions the pool windows cover are computed transposed, D[channel][position]
 //      = W x X^T: wave w keeps the weight fragments of channels 16 w .. 16 w + 15 for all 7 kernel rows in registers (56 VGPRs, loaded
-//      once), reads activation fragments from LDS, and parks fp32 results in LDS;
-//   3. 3x3 / stride-2 max over the parked values (positions outside the conv output are skipped: -inf padding), + bias, ReLU -- bias and
-//      ReLU are monotone and per channel, so they commute with the max exactly -- split, 16-byte plane stores.
+//      once) and reads activation fragments from LDS;
+//   3. the 3x3 / stride-2 max runs on the accumulators: across positions with wavefront shuffles inside the 16-lane groups,
+//      across conv rows as running maxima in registers (positions outside the conv output are -inf: MaxPool2d's padding); then
+//      + bias, ReLU -- monotone and per channel, so they commute with the max exactly -- split, plane stores.  (A first version parked
+//      the conv tile in LDS for the pool: 155 KB of LDS, one workgroup per CU, every phase's latency exposed: 400 us at batch 32.)
 // Arithmetic: fp32-equivalent like the planar convolutions (three MFMA products per reference product: w_h x_h + (w_h x_l + w_l x_h) /
 // 2048, fp32 accumulation, power-of-two weight scale removed after the sum); format 2 keeps one plane / one product.
 #include "planar_common.h"
@@ -32,7 +34,6 @@ constexpr int ST_IR = 2 * ST_CR + 5;                 // input rows of the patch 
 constexpr int ST_IS = 2 * ST_CC + 6;                 // input pixel slots per patch row (102): slot s = input column ix0 + s
 constexpr int ST_ROWB = ST_IS * 8;                   // bytes per patch row and plane
 constexpr int ST_XPL = ST_IR * ST_ROWB;              // bytes per plane of the patch
-constexpr int ST_OLD = 68;                           // floats per parked conv position (64 channels + 4: 16-byte rows, banks spread)
 constexpr int ST_MAX_DEVICES = 32;
 
 struct StemArgs {
@@ -54,7 +55,6 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* xin = smem;                                         // [NPL][IR][IS][4] fp16
-    float* park = reinterpret_cast<float*>(smem + NPL * ST_XPL); // [CR][CC][OLD] fp32
     const int64_t nblk = (int64_t)a.B * a.tiles_y * a.tiles_x;
     const int64_t blk = stm_xcd_block(nblk);
     if (blk < 0) return;
@@ -101,9 +101,29 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
     // ---- 2. conv positions, one conv row (3 column tiles) at a time.  B fragment of lane (position r16 of tile ct, chunk kc), kernel
     // row ky: 8 fp16 = pixels 2 kc, 2 kc + 1 of the 7-pixel window of conv column 16 ct + r16, i.e. patch slots 2 (16 ct + r16) + 2 kc ..:
     // byte offset 16 (16 ct + r16 + kc) -- always 16-byte aligned because the patch starts at an odd input column.
+    // ---- 3. the pool runs on the accumulators, no parked tile: a lane holds 4 channels (16 wave + 4 kc ..) of conv position (row cr,
+    // column 16 ct + r16).  Horizontally, pooled column pc = 8 ct + r16 / 2 (even r16) covers r16, r16 + 1, r16 + 2 of the same register
+    // -- lanes r16 + 1, r16 + 2 of the 16-lane group, or lanes 0 / 1 of the NEXT tile's register for r16 = 14 -- fetched with wavefront
+    // shuffles; vertically, pooled row pr = max of conv rows 2 pr, 2 pr + 1, 2 pr + 2, kept as running maxima in registers.  Positions
+    // outside the conv output are -inf (MaxPool2d's padding).
     const int r16 = lane & 15, kc = lane >> 4;
     const int boff = 16 * (r16 + kc);
     const float ls = NPL == 2 ? 1.0f / STM_F16_LOW_SCALE : 0.0f;
+    const float NEG = -__builtin_inff();
+    bool colok[ST_CT];
+#pragma unroll
+    for (int ct = 0; ct < ST_CT; ++ct) colok[ct] = (unsigned)(cx0 + 16 * ct + r16) < (unsigned)a.Wc;
+    float b4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b4[r] = a.bias ? a.bias[16 * wave + 4 * kc + r] : 0.0f;
+    const size_t n_out = (size_t)a.B * a.Hp * a.Wp;
+    const int ch0 = 16 * wave + 4 * kc;
+    f32x4 top[ST_CT];                     // horizontally pooled values of conv row 2 pr (carried from the previous pooled row's last row)
+    f32x4 run[ST_CT];                     // running maximum of the current pooled row
+#pragma unroll
+    for (int ct = 0; ct < ST_CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { top[ct][r] = NEG; run[ct][r] = NEG; }
     for (int cr = 0; cr < ST_CR; ++cr) {
         f32x4 acc[ST_CT], accl[ST_CT];
 #pragma unroll
@@ -126,58 +146,67 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const StemArgs a)
                 }
             }
         }
-        // lane holds channels 16 wave + 4 kc .. + 3 of conv position (cr, 16 ct + r16)
+        const bool rowok = (unsigned)(cy0 + cr) < (unsigned)a.Hc;       // wave-uniform
+        f32x4 v[ST_CT], hp[ST_CT];
 #pragma unroll
-        for (int ct = 0; ct < ST_CT; ++ct) {
-            f32x4 v;
+        for (int ct = 0; ct < ST_CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (NPL == 2 ? acc[ct][r] + accl[ct][r] * ls : acc[ct][r]) * a.out_scale;
-            *reinterpret_cast<f32x4*>(park + ((size_t)cr * ST_CC + 16 * ct + r16) * ST_OLD + 16 * wave + 4 * kc) = v;
-        }
-    }
-    __syncthreads();
-
-    // ---- 3. max-pool + bias + ReLU + plane split; item = (pooled pixel, 8 channels)
-    for (int it = tid; it < ST_PH * ST_PW * 8; it += 256) {
-        const int g = it & 7, pp = it >> 3;
-        const int pr = pp / ST_PW, pc = pp - pr * ST_PW;
-        const int py = py0 + pr, px = px0 + pc;
-        if (py >= a.Hp || px >= a.Wp) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = -__builtin_inff();
-#pragma unroll
-        for (int dr = 0; dr < 3; ++dr) {
-            const int cy = cy0 + 2 * pr + dr;
-            if ((unsigned)cy >= (unsigned)a.Hc) continue;
-#pragma unroll
-            for (int dc = 0; dc < 3; ++dc) {
-                const int cx = cx0 + 2 * pc + dc;
-                if ((unsigned)cx >= (unsigned)a.Wc) continue;
-                const float* p = park + ((size_t)(2 * pr + dr) * ST_CC + 2 * pc + dc) * ST_OLD + 8 * g;
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(p), q1 = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = fmaxf(v[e], q0[e]); v[4 + e] = fmaxf(v[4 + e], q1[e]); }
+            for (int r = 0; r < 4; ++r) {
+                const float c = (NPL == 2 ? acc[ct][r] + accl[ct][r] * ls : acc[ct][r]) * a.out_scale;
+                v[ct][r] = (rowok && colok[ct]) ? c : NEG;
             }
+        // horizontal 3-max at even positions: neighbours r16 + 1, r16 + 2 (the next tile's positions 0, 1 beyond position 15)
+#pragma unroll
+        for (int ct = 0; ct < ST_CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float nx = ct + 1 < ST_CT ? v[ct + 1 < ST_CT ? ct + 1 : ct][r] : NEG;
+                float n1 = __shfl(v[ct][r], (r16 + 1) & 15, 16), n2 = __shfl(v[ct][r], (r16 + 2) & 15, 16);
+                const float w1 = __shfl(nx, (r16 + 1) & 15, 16), w2 = __shfl(nx, (r16 + 2) & 15, 16);
+                if (r16 + 1 > 15) n1 = w1;
+                if (r16 + 2 > 15) n2 = w2;
+                hp[ct][r] = fmaxf(fmaxf(v[ct][r], n1), n2);
+            }
+        // vertical: conv row cr is row (cr - 2 pr) of pooled row pr = cr / 2 (rows 0, 1) and row 2 of pooled row pr - 1
+        const bool even = (cr & 1) == 0;
+#pragma unroll
+        for (int ct = 0; ct < ST_CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) run[ct][r] = fmaxf(run[ct][r], hp[ct][r]);
+        if (even && cr > 0) {
+            // pooled row pr = cr / 2 - 1 is complete: bias + ReLU + split + store (8 bytes per lane and plane: 4 channels of one pixel)
+            const int pr = cr / 2 - 1, py = py0 + pr;
+#pragma unroll
+            for (int ct = 0; ct < ST_CT; ++ct) {
+                const int pc = 8 * ct + (r16 >> 1), px = px0 + pc;
+                if ((r16 & 1) == 0 && pc < ST_PW && py < a.Hp && px < a.Wp) {
+                    float o[4];
+                    unsigned m4 = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = run[ct][r] + b4[r];
+                        o[r] = t > 0.0f ? t : 0.0f;
+                        m4 = max(m4, __builtin_bit_cast(unsigned, o[r]) & 0x7fffffffu);
+                    }
+                    if (m4 > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
+                    unsigned h0, h1, l0, l1;
+                    split2_f16(f32x2{o[0], o[1]}, h0, l0);
+                    split2_f16(f32x2{o[2], o[3]}, h1, l1);
+                    const size_t pix = ((size_t)b * a.Hp + py) * a.Wp + px;
+                    uint8_t* dst = a.out + (((size_t)(ch0 >> 5) * n_out + pix) * 32 + (ch0 & 31)) * 2;
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+                    if (a.out_fmt == 1) *reinterpret_cast<u32x2*>(dst + a.out_pstride) = u32x2{l0, l1};
+                }
+            }
+            // the row just finished is also the first row of the next pooled row
+#pragma unroll
+            for (int ct = 0; ct < ST_CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) run[ct][r] = hp[ct][r];
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float t = v[e] + (a.bias ? a.bias[8 * g + e] : 0.0f);
-            v[e] = t > 0.0f ? t : 0.0f;
-        }
-        unsigned q0[4], q1[4];
-        unsigned m8 = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) m8 = max(m8, __builtin_bit_cast(unsigned, v[e]) & 0x7fffffffu);
-        if (m8 > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
-        const size_t n_out = (size_t)a.B * a.Hp * a.Wp;
-        const size_t pix = ((size_t)b * a.Hp + py) * a.Wp + px;
-        uint8_t* dst = a.out + (((size_t)(g >> 2) * n_out + pix) * 32 + (g & 3) * 8) * 2;
-        __builtin_nontemporal_store(u32x4{q0[0], q0[1], q0[2], q0[3]}, reinterpret_cast<u32x4*>(dst));
-        if (a.out_fmt == 1) __builtin_nontemporal_store(u32x4{q1[0], q1[1], q1[2], q1[3]}, reinterpret_cast<u32x4*>(dst + a.out_pstride));
     }
+    (void)top;
 #endif
 }
 
@@ -246,7 +275,7 @@ extern "C" int stm_stem_fused_f32(const float* x, const void* packed_weight, con
     a.out_fmt = out_fmt;
     a.range_flag = stm_internal_range_flag();
     const int npl = fmt == 1 ? 2 : 1;
-    const size_t lds = (size_t)npl * ST_XPL + (size_t)ST_CR * ST_CC * ST_OLD * sizeof(float);
+    const size_t lds = (size_t)npl * ST_XPL;
     static std::atomic<bool> reserved[2][ST_MAX_DEVICES];
     int dev = 0;
     const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < ST_MAX_DEVICES;

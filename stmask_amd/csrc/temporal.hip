@@ -86,11 +86,8 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
     const int f1_xq = IN_NHWC ? tid / CQ : tid - f1_c * Wq;          // its x (channels-last) / x quad
     for (int idx = tid; idx < CORR_CCK * P * LW2; idx += 256) f2s[idx] = 0.0f;
 
-    // Two register sets: the loads of chunk k + 2 are issued while chunk k is multiplied, so a chunk's global round trip (1-2 us
-    // when every CU streams: longer than the ~350 FMAs of one chunk) has two chunks of arithmetic to hide behind.  (With one set
-    // the kernel ran at the latency of 16 dependent round trips per workgroup: 79 us for 78 MB at batch 32.)
-    float4 pfa[MAXU], pfb[MAXU], pf1a, pf1b;
-    auto prefetch = [&](int c0, float4 (&pf)[MAXU], float4& pf1) {           // channels beyond C read as zero
+    float4 pf[MAXU], pf1;
+    auto prefetch = [&](int c0) {           // channels beyond C read as zero
 #pragma unroll
         for (int u = 0; u < MAXU; ++u) {
             pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -110,7 +107,7 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
             else pf1 = *reinterpret_cast<const float4*>(f1b + (int64_t)(c0 + f1_c) * HW + (int64_t)y * W + f1_xq * 4);
         }
     };
-    auto commit = [&](const float4 (&pf)[MAXU], const float4& pf1) {
+    auto commit = [&]() {
 #pragma unroll
         for (int u = 0; u < MAXU; ++u)
             if (g_off[u] >= 0) {
@@ -141,7 +138,12 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < P; ++j) acc[p][j] = 0.0f;
 
-        auto multiply = [&]() {
+        prefetch(0);
+        for (int c0 = 0; c0 < C; c0 += CORR_CCK) {
+            __syncthreads();                 // previous chunk fully consumed (and the zero fill done)
+            commit();
+            __syncthreads();
+            if (c0 + CORR_CCK < C) prefetch(c0 + CORR_CCK);   // next chunk's loads fly behind the FMAs below
             if (active) {
 #pragma unroll 2
                 for (int cc = 0; cc < CORR_CCK / 2; ++cc) {
@@ -162,22 +164,6 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
 #pragma unroll
                         for (int j = 0; j < P; ++j) acc[p][j] = fmaf(av[p], win[p + j], acc[p][j]);
                 }
-            }
-        };
-        prefetch(0, pfa, pf1a);
-        prefetch(CORR_CCK, pfb, pf1b);               // (past C: zeros, no loads)
-        for (int c0 = 0; c0 < C; c0 += 2 * CORR_CCK) {
-            __syncthreads();                 // previous chunk fully consumed (and the zero fill done)
-            commit(pfa, pf1a);
-            __syncthreads();
-            prefetch(c0 + 2 * CORR_CCK, pfa, pf1a);  // the chunk after next: its loads fly behind two chunks of FMAs
-            multiply();
-            if (c0 + CORR_CCK < C) {
-                __syncthreads();
-                commit(pfb, pf1b);
-                __syncthreads();
-                prefetch(c0 + 3 * CORR_CCK, pfb, pf1b);
-                multiply();
             }
         }
         // sum the two channel halves held by lanes l and l + 32 (wavefront shuffle), activate, store
