@@ -17,6 +17,8 @@
 //                 so the result is exact for ANY offset.
 #include "stm_common.h"
 
+#include <atomic>
+
 namespace {
 
 struct ImcolArgs {
@@ -833,6 +835,177 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
     asm volatile("" ::"v"(pf));      // the touch above stays in the program
 }
 
+
+// ---- LDS-staged form of the planar sampler (the form BASELINE.json's north star names: "deformable im2col with LDS-staged input
+// tiles and coalesced HBM offset reads").  The register-gather kernel above fetches every bilinear corner through the vector-memory
+// path: 4 corners x 9 taps x C x 4 B = 18 KB per output pixel at C = 128 for 4.6 KB of columns, at the 64 B/clk a CU's L1 moves --
+// 460 cycles per pixel measured, 3.9 TB/s algorithmic.  Here a workgroup owns a tile of TH x TW output pixels and walks the channels
+// in chunks of CCH:
+//   A. once: the coefficients of its (pixel, tap) pairs -- corner weights with the mask folded in, the four clamped corner coordinates
+//      -- computed exactly as above and kept in LDS (24 B per pair); offsets / mask logits are read once, pixel-major rows;
+//   B. per chunk: the input rectangle the tile can reach with offsets up to HALO pixels is staged once, coalesced (64-byte runs per
+//      pixel, consecutive pixels consecutive), and the corners are gathered from LDS (256 B/clk); the columns leave as 16-byte
+//      nontemporal stores, 16 consecutive pixels of one (tap, channel slab) = 512 B or 1 KB contiguous per plane.
+// A pair with a contributing corner outside the staged rectangle (an offset beyond HALO) gathers that tap from global memory
+// instead: same values, any offset.  The blend is the same bilerp() on the same operands: columns bit-identical to the kernel above.
+constexpr int SL_TW = 16, SL_HALO = 3, SL_CCH = 16;
+struct SampleLdsArgs {
+    SampleArgs s;
+    int th, rh, rw, tiles_y, tiles_x, kh;
+};
+
+struct SlCoef { float w[4]; short y0, x0, y1, x1; unsigned flags; };   // flags bit 0: gather this pair from global memory
+
+template <bool MASK, int TH>
+__global__ __launch_bounds__(256) void dcn_sample_planar_lds_kernel(const SampleLdsArgs aa)
+{
+    const SampleArgs& a = aa.s;
+    extern __shared__ __align__(16) uint8_t sl_smem[];
+    const int K = aa.kh * a.kw;
+    constexpr int TP = TH * SL_TW;                                   // pixels of the tile (a power of two: item indices split with shifts)
+    constexpr int SL_MAXQ = 12;                                      // staged float4 per thread and chunk (rectangles of up to 768 pixels)
+    SlCoef* coef = reinterpret_cast<SlCoef*>(sl_smem);               // [TP][K]
+    float* reg = reinterpret_cast<float*>(sl_smem + (((size_t)TP * K * sizeof(SlCoef) + 15) & ~(size_t)15));   // [rh][rw][CCH]
+    const int64_t nblk = (int64_t)a.B * aa.tiles_y * aa.tiles_x;
+    const int64_t blk = a.xcd ? stm_xcd_block(nblk) : (int64_t)blockIdx.x;
+    if (blk < 0 || blk >= nblk) return;
+    const int tx = (int)(blk % aa.tiles_x), ty = (int)((blk / aa.tiles_x) % aa.tiles_y), b = (int)(blk / ((int64_t)aa.tiles_x * aa.tiles_y));
+    const int oy0 = ty * TH, ox0 = tx * SL_TW;
+    const int in_y0 = oy0 * a.sh - a.ph - SL_HALO, in_x0 = ox0 * a.sw - a.pw - SL_HALO;
+    const int tid = threadIdx.x;
+    const float* xb = a.x + (size_t)b * a.H * a.W * a.x_ld;
+
+    // ---- A. coefficients
+    for (int it = tid; it < TP * K; it += 256) {
+        const int p = it / K, k = it - p * K;
+        const int ho = oy0 + p / SL_TW, wo = ox0 + (p % SL_TW);
+        SlCoef c;
+        c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0.f;
+        c.y0 = c.x0 = c.y1 = c.x1 = 0;
+        c.flags = 0;
+        if (ho < a.Ho && wo < a.Wo) {
+            const int i = k / a.kw, j = k - a.kw * i;
+            const float* omp = a.om + ((size_t)(b * a.Ho + ho) * a.Wo + wo) * a.om_ld;
+            const float dy = omp[2 * k], dx = omp[2 * k + 1];
+            const float mk = MASK ? sigmoidf_dev(omp[2 * K + k]) : 1.0f;
+            const float fy = (float)(ho * a.sh - a.ph + i * a.dh) + dy;
+            const float fx = (float)(wo * a.sw - a.pw + j * a.dw) + dx;
+            if (fy > -1.0f && fx > -1.0f && fy < (float)a.H && fx < (float)a.W) {
+                const float fl_y = floorf(fy), fl_x = floorf(fx);
+                const int h_low = (int)fl_y, w_low = (int)fl_x, h_high = h_low + 1, w_high = w_low + 1;
+                const float lh = fy - fl_y, lw = fx - fl_x, hh = 1.0f - lh, hw = 1.0f - lw;
+                const bool t = h_low >= 0, l = w_low >= 0, bt = h_high <= a.H - 1, r = w_high <= a.W - 1;
+                const int hl = max(h_low, 0), wl = max(w_low, 0), hh_i = min(h_high, a.H - 1), wh_i = min(w_high, a.W - 1);
+                c.w[0] = (t && l) ? hh * hw * mk : 0.f;
+                c.w[1] = (t && r) ? hh * lw * mk : 0.f;
+                c.w[2] = (bt && l) ? lh * hw * mk : 0.f;
+                c.w[3] = (bt && r) ? lh * lw * mk : 0.f;
+                c.y0 = (short)hl; c.x0 = (short)wl; c.y1 = (short)hh_i; c.x1 = (short)wh_i;
+                // all four (clamped) corners inside the staged rectangle?  (clamped corners carry weight 0 but are still read)
+                const bool in = hl >= in_y0 && hh_i < in_y0 + aa.rh && wl >= in_x0 && wh_i < in_x0 + aa.rw;
+                c.flags = in ? 0u : 1u;
+            }
+        }
+        coef[it] = c;
+    }
+
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    constexpr int QPP = SL_CCH / 4;                                   // float4 per staged pixel
+    constexpr int GPP = SL_CCH / 8;                                   // 8-channel groups per pixel and chunk
+    const int nreg = aa.rh * aa.rw;
+    // staging plan, once: float4 number tid + 256 u of the rectangle -> element offset in the image (-1: outside, stays zero)
+    int g_off[SL_MAXQ];
+#pragma unroll
+    for (int u = 0; u < SL_MAXQ; ++u) {
+        const int it = tid + 256 * u;
+        g_off[u] = -1;
+        if (it < nreg * QPP) {
+            const int rp = it / QPP, q = it - rp * QPP;
+            const int ry = rp / aa.rw;
+            const int y = in_y0 + ry, x = in_x0 + (rp - ry * aa.rw);
+            if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) g_off[u] = (y * a.W + x) * a.x_ld + 4 * q;
+        }
+    }
+    // ---- B1. the rectangle of a chunk travels global -> registers -> LDS; the loads of chunk c + 1 are in flight while chunk c is
+    // blended.  Outside the image: zeros (never blended with a non-zero weight)
+    f32x4v st[SL_MAXQ];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < SL_MAXQ; ++u) {
+            st[u] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (g_off[u] >= 0) st[u] = *reinterpret_cast<const f32x4v*>(xb + g_off[u] + c0);
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < a.C; c0 += SL_CCH) {
+        __syncthreads();                                              // previous chunk consumed (first pass: coefficients written)
+#pragma unroll
+        for (int u = 0; u < SL_MAXQ; ++u)
+            if (tid + 256 * u < nreg * QPP) *reinterpret_cast<f32x4v*>(reg + (size_t)(tid + 256 * u) * 4) = st[u];
+        __syncthreads();
+        if (c0 + SL_CCH < a.C) fetch(c0 + SL_CCH);
+        // ---- B2. blend: item = (tap, pixel, 8-channel group); a wave's 64 items = 32 pixels x 2 groups of one tap
+        for (int it = tid; it < K * TP * GPP; it += 256) {
+            const int g8 = it % GPP, p = (it / GPP) % TP, k = it / (GPP * TP);     // (all powers of two)
+            const int ho = oy0 + p / SL_TW, wo = ox0 + (p % SL_TW);
+            if (ho >= a.Ho || wo >= a.Wo) continue;
+            const SlCoef c = coef[p * K + k];
+            float x1[8], x2[8], x3[8], x4[8], v[8];
+            if (c.flags & 1u) {
+                const float* gx = xb + c0 + 8 * g8;
+                const size_t a1 = ((size_t)c.y0 * a.W + c.x0) * a.x_ld, a2 = ((size_t)c.y0 * a.W + c.x1) * a.x_ld;
+                const size_t a3 = ((size_t)c.y1 * a.W + c.x0) * a.x_ld, a4 = ((size_t)c.y1 * a.W + c.x1) * a.x_ld;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4v q1 = *reinterpret_cast<const f32x4v*>(gx + a1 + 4 * h), q2 = *reinterpret_cast<const f32x4v*>(gx + a2 + 4 * h);
+                    const f32x4v q3 = *reinterpret_cast<const f32x4v*>(gx + a3 + 4 * h), q4 = *reinterpret_cast<const f32x4v*>(gx + a4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x1[4 * h + e] = q1[e]; x2[4 * h + e] = q2[e]; x3[4 * h + e] = q3[e]; x4[4 * h + e] = q4[e]; }
+                }
+            } else {
+                const float* lx = reg + 8 * g8;
+                const int r0 = (c.y0 - in_y0) * aa.rw - in_x0, r1 = (c.y1 - in_y0) * aa.rw - in_x0;
+                const int a1 = (r0 + c.x0) * SL_CCH, a2 = (r0 + c.x1) * SL_CCH, a3 = (r1 + c.x0) * SL_CCH, a4 = (r1 + c.x1) * SL_CCH;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4v q1 = *reinterpret_cast<const f32x4v*>(lx + a1 + 4 * h), q2 = *reinterpret_cast<const f32x4v*>(lx + a2 + 4 * h);
+                    const f32x4v q3 = *reinterpret_cast<const f32x4v*>(lx + a3 + 4 * h), q4 = *reinterpret_cast<const f32x4v*>(lx + a4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x1[4 * h + e] = q1[e]; x2[4 * h + e] = q2[e]; x3[4 * h + e] = q3[e]; x4[4 * h + e] = q4[e]; }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bilerp(c.w[0], c.w[1], c.w[2], c.w[3], x1[e], x2[e], x3[e], x4[e]);
+            unsigned q0[4], q1[4], q2[4] = {0, 0, 0, 0};
+            if (a.fmt >= 1) {
+                unsigned mag = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mag = max(mag, __builtin_bit_cast(unsigned, v[e]) & 0x7fffffffu);
+                if (mag > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2_planes_f16(v[2 * e], v[2 * e + 1], q0[e], q1[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2_planes(v[2 * e], v[2 * e + 1], q0[e], q1[e], q2[e]);
+            }
+            const u32x4v p0 = {q0[0], q0[1], q0[2], q0[3]}, p1 = {q1[0], q1[1], q1[2], q1[3]}, p2 = {q2[0], q2[1], q2[2], q2[3]};
+            const int kcol = k * a.C + c0 + 8 * g8;                  // K index of the item's first channel
+            const size_t mm = ((size_t)b * a.Ho + ho) * a.Wo + wo;
+            uint8_t* o = a.out + (((size_t)(kcol >> 5) * a.out_np + a.out_pix0 + mm) * 32 + (kcol & 31)) * 2;
+            if (a.nt) {
+                __builtin_nontemporal_store(p0, reinterpret_cast<u32x4v*>(o));
+                if (a.fmt != 2) __builtin_nontemporal_store(p1, reinterpret_cast<u32x4v*>(o + a.out_pstride));
+                if (a.fmt == 0) __builtin_nontemporal_store(p2, reinterpret_cast<u32x4v*>(o + 2 * a.out_pstride));
+            } else {
+                *reinterpret_cast<u32x4v*>(o) = p0;
+                if (a.fmt != 2) *reinterpret_cast<u32x4v*>(o + a.out_pstride) = p1;
+                if (a.fmt == 0) *reinterpret_cast<u32x4v*>(o + 2 * a.out_pstride) = p2;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int stm_dcn_sample_planar_fmt_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
@@ -890,6 +1063,43 @@ extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const floa
     a.nt = env_nt >= 0 ? env_nt : (g->C <= 256 ? 1 : 0);
     a.per_xcd = stm_cdiv(nblk, 8);
     a.prefetch = env_prefetch;
+    // LDS-staged form (STM_DCN_LDS, default on): tiles of 8 x 16 (stride 1) or 4 x 16 (stride 2) output pixels, 16-channel chunks
+    const int env_lds = STM_ENV_INT("STM_DCN_LDS", 1);
+    if (env_lds && g->dh == 1 && g->dw == 1 && g->sh == g->sw && (g->sh == 1 || g->sh == 2) && g->C % SL_CCH == 0 && g->H < 32768 && g->W < 32768) {
+        SampleLdsArgs aa;
+        aa.s = a;
+        aa.kh = g->kh;
+        aa.th = g->sh == 1 ? 8 : 4;
+        aa.rh = (aa.th - 1) * g->sh + (g->kh - 1) + 2 + 2 * SL_HALO;
+        aa.rw = (SL_TW - 1) * g->sw + (g->kw - 1) + 2 + 2 * SL_HALO;
+        aa.tiles_y = stm_cdiv(g->Ho, aa.th);
+        aa.tiles_x = stm_cdiv(g->Wo, SL_TW);
+        const size_t coef_b = ((size_t)aa.th * SL_TW * K * sizeof(SlCoef) + 15) & ~(size_t)15;
+        const size_t lds = coef_b + (size_t)aa.rh * aa.rw * SL_CCH * sizeof(float);
+        if (lds <= 80 * 1024 && aa.rh * aa.rw * (SL_CCH / 4) <= 12 * 256) {
+            const int64_t nb = (int64_t)g->B * aa.tiles_y * aa.tiles_x;
+            const dim3 grid_l(a.xcd ? stm_xcd_grid(nb) : (unsigned)nb);
+            static std::atomic<int> reserved[4][32];
+            int dev = 0;
+            const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32;
+            const int which = (has_mask ? 2 : 0) + (aa.th == 8 ? 1 : 0);
+            if (!have_dev || reserved[which][dev].load(std::memory_order_relaxed) < (int)lds) {
+                const void* fn = has_mask ? (aa.th == 8 ? reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<true, 8>)
+                                                        : reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<true, 4>))
+                                          : (aa.th == 8 ? reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<false, 8>)
+                                                        : reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<false, 4>));
+                STM_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, STM_ELAUNCH,
+                            "%s: cannot reserve %zu bytes of LDS", who, lds);
+                if (have_dev) reserved[which][dev].store((int)lds, std::memory_order_relaxed);
+            }
+            if (has_mask && aa.th == 8) hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<true, 8>), grid_l, dim3(256), lds, stm_hs(stream), aa);
+            else if (has_mask) hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<true, 4>), grid_l, dim3(256), lds, stm_hs(stream), aa);
+            else if (aa.th == 8) hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<false, 8>), grid_l, dim3(256), lds, stm_hs(stream), aa);
+            else hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<false, 4>), grid_l, dim3(256), lds, stm_hs(stream), aa);
+            STM_CHECK_LAUNCH("dcn_sample_planar_lds_kernel");
+            return STM_OK;
+        }
+    }
     const dim3 grid(a.xcd ? 8 * a.per_xcd : nblk);
     if (!has_mask && K == 15) hipLaunchKernelGGL((dcn_sample_planar_kernel<32, 15, false>), grid, dim3(256), 0, stm_hs(stream), a);
     else if (!has_mask) hipLaunchKernelGGL((dcn_sample_planar_kernel<32, 9, false>), grid, dim3(256), 0, stm_hs(stream), a);

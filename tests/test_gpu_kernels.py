@@ -658,3 +658,22 @@ def test_mask_iou_grouped_equals_full_masked_by_group():
     perm = torch.randperm(n2, generator=g)
     got_p = ops.mask_iou(m1.to(DEV), m2[perm].to(DEV), group1=g1.to(DEV), group2=g2[perm].to(DEV)).cpu()
     assert torch.equal(got_p, got[:, perm])
+
+
+@pytest.mark.parametrize("scale", [0.5, 6.0])
+@pytest.mark.parametrize("B,C,H,W,stride", [(2, 128, 21, 37, 1), (2, 128, 30, 45, 2), (1, 256, 17, 16, 1)])
+def test_dcn_sample_planar_lds_form_equals_register_gather(B, C, H, W, stride, scale, tunables):
+    """The LDS-staged sampler (tiles of 8 x 16 / 4 x 16 output pixels, 16-channel chunks, corners gathered from LDS; pairs whose
+    corners leave the staged rectangle gathered from global memory) against the register-gather kernel: the same planes bit for bit,
+    with offsets inside the halo (scale 0.5) and far outside it (scale 6: most pairs take the global path), partial tiles on both
+    axes, both strides."""
+    x = rnd(B, H, W, C, seed=C + H)
+    Ho, Wo = ops.conv_out_hw(H, W, 3, 3, stride, stride, 1, 1, 1, 1)
+    om = rnd(B * Ho * Wo, 27, seed=W, scale=scale)
+    outs = {}
+    for lds in ("1", "0"):
+        tunables.set(STM_DCN_LDS=lds)
+        outs[lds] = ops.dcn_sample_planar(x.to(DEV), om.to(DEV), stride, 1, 1, fmt=1).cpu()
+    tunables.clear("STM_DCN_LDS")
+    assert torch.equal(outs["1"], outs["0"])
+    assert outs["1"].abs().sum().item() > 0
