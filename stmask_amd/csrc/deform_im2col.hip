@@ -848,7 +848,10 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
 //      nontemporal stores, 16 consecutive pixels of one (tap, channel slab) = 512 B or 1 KB contiguous per plane.
 // A pair with a contributing corner outside the staged rectangle (an offset beyond HALO) gathers that tap from global memory
 // instead: same values, any offset.  The blend is the same bilerp() on the same operands: columns bit-identical to the kernel above.
-constexpr int SL_TW = 16, SL_HALO = 3, SL_CCH = 16;
+constexpr int SL_TW = 16, SL_HALO = 3, SL_CCH = 32;
+#ifndef SL_ABL
+#define SL_ABL 0     // diagnostic builds (make EXTRA=-DSL_ABL=n, RESULTS ARE WRONG): 1 no column stores, 2 no corner gathers, 4 no staging
+#endif
 struct SampleLdsArgs {
     SampleArgs s;
     int th, rh, rw, tiles_y, tiles_x, kh;
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_lds_kernel(const Sample
     extern __shared__ __align__(16) uint8_t sl_smem[];
     const int K = aa.kh * a.kw;
     constexpr int TP = TH * SL_TW;                                   // pixels of the tile (a power of two: item indices split with shifts)
-    constexpr int SL_MAXQ = 12;                                      // staged float4 per thread and chunk (rectangles of up to 768 pixels)
+    constexpr int SL_MAXQ = 16;                                      // staged float4 per thread and chunk (rectangles of up to 512 pixels)
     SlCoef* coef = reinterpret_cast<SlCoef*>(sl_smem);               // [TP][K]
     float* reg = reinterpret_cast<float*>(sl_smem + (((size_t)TP * K * sizeof(SlCoef) + 15) & ~(size_t)15));   // [rh][rw][CCH]
     const int64_t nblk = (int64_t)a.B * aa.tiles_y * aa.tiles_x;
@@ -934,7 +937,7 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_lds_kernel(const Sample
 #pragma unroll
         for (int u = 0; u < SL_MAXQ; ++u) {
             st[u] = f32x4v{0.f, 0.f, 0.f, 0.f};
-            if (g_off[u] >= 0) st[u] = *reinterpret_cast<const f32x4v*>(xb + g_off[u] + c0);
+            if (!(SL_ABL & 4) && g_off[u] >= 0) st[u] = *reinterpret_cast<const f32x4v*>(xb + g_off[u] + c0);
         }
     };
     fetch(0);
@@ -963,6 +966,9 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_lds_kernel(const Sample
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { x1[4 * h + e] = q1[e]; x2[4 * h + e] = q2[e]; x3[4 * h + e] = q3[e]; x4[4 * h + e] = q4[e]; }
                 }
+            } else if (SL_ABL & 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { x1[e] = 1.f; x2[e] = 2.f; x3[e] = 3.f; x4[e] = (float)e; }
             } else {
                 const float* lx = reg + 8 * g8;
                 const int r0 = (c.y0 - in_y0) * aa.rw - in_x0, r1 = (c.y1 - in_y0) * aa.rw - in_x0;
@@ -993,6 +999,7 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_lds_kernel(const Sample
             const int kcol = k * a.C + c0 + 8 * g8;                  // K index of the item's first channel
             const size_t mm = ((size_t)b * a.Ho + ho) * a.Wo + wo;
             uint8_t* o = a.out + (((size_t)(kcol >> 5) * a.out_np + a.out_pix0 + mm) * 32 + (kcol & 31)) * 2;
+            if ((SL_ABL & 1) && q0[0] != 0x12345678u) continue;
             if (a.nt) {
                 __builtin_nontemporal_store(p0, reinterpret_cast<u32x4v*>(o));
                 if (a.fmt != 2) __builtin_nontemporal_store(p1, reinterpret_cast<u32x4v*>(o + a.out_pstride));
@@ -1063,39 +1070,44 @@ extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const floa
     a.nt = env_nt >= 0 ? env_nt : (g->C <= 256 ? 1 : 0);
     a.per_xcd = stm_cdiv(nblk, 8);
     a.prefetch = env_prefetch;
-    // LDS-staged form (STM_DCN_LDS, default on): tiles of 8 x 16 (stride 1) or 4 x 16 (stride 2) output pixels, 16-channel chunks
-    const int env_lds = STM_ENV_INT("STM_DCN_LDS", 1);
+    // LDS-staged form (STM_DCN_LDS=1; default off): tiles of 4 x 16 (stride 1) or 2 x 16 (stride 2) output pixels, 32-channel chunks.
+    // Measured at batch 32 on cold inputs (scripts/ab_dcn_lds.py, profiles/r03_dcn_sampler_ab.txt): 241 vs 253 us and 183 vs 177 us on
+    // the two layer2 shapes, 1.1-2.7x SLOWER on the smaller layers (few tiles, two waves per SIMD).  Its ablations say why the staging
+    // does not pay: without the column stores 107 us, without the LDS gathers the same, with neither stores, gathers nor staging 83 us --
+    // the per-value arithmetic (blend, plane split, range check: ~10 VALU per value, 1152 values per pixel) and the loop around it are
+    // the floor of either form, and the register-gather kernel hides its gathers behind that arithmetic with 8 waves per SIMD.
+    const int env_lds = STM_ENV_INT("STM_DCN_LDS", 0);
     if (env_lds && g->dh == 1 && g->dw == 1 && g->sh == g->sw && (g->sh == 1 || g->sh == 2) && g->C % SL_CCH == 0 && g->H < 32768 && g->W < 32768) {
         SampleLdsArgs aa;
         aa.s = a;
         aa.kh = g->kh;
-        aa.th = g->sh == 1 ? 8 : 4;
+        aa.th = g->sh == 1 ? 4 : 2;
         aa.rh = (aa.th - 1) * g->sh + (g->kh - 1) + 2 + 2 * SL_HALO;
         aa.rw = (SL_TW - 1) * g->sw + (g->kw - 1) + 2 + 2 * SL_HALO;
         aa.tiles_y = stm_cdiv(g->Ho, aa.th);
         aa.tiles_x = stm_cdiv(g->Wo, SL_TW);
         const size_t coef_b = ((size_t)aa.th * SL_TW * K * sizeof(SlCoef) + 15) & ~(size_t)15;
         const size_t lds = coef_b + (size_t)aa.rh * aa.rw * SL_CCH * sizeof(float);
-        if (lds <= 80 * 1024 && aa.rh * aa.rw * (SL_CCH / 4) <= 12 * 256) {
+        if (lds <= 80 * 1024 && aa.rh * aa.rw * (SL_CCH / 4) <= 16 * 256) {
             const int64_t nb = (int64_t)g->B * aa.tiles_y * aa.tiles_x;
             const dim3 grid_l(a.xcd ? stm_xcd_grid(nb) : (unsigned)nb);
             static std::atomic<int> reserved[4][32];
             int dev = 0;
             const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32;
-            const int which = (has_mask ? 2 : 0) + (aa.th == 8 ? 1 : 0);
+            const int which = (has_mask ? 2 : 0) + (aa.th == 4 ? 1 : 0);   // (tile height 4: stride 1, 2: stride 2)
             if (!have_dev || reserved[which][dev].load(std::memory_order_relaxed) < (int)lds) {
-                const void* fn = has_mask ? (aa.th == 8 ? reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<true, 8>)
-                                                        : reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<true, 4>))
-                                          : (aa.th == 8 ? reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<false, 8>)
-                                                        : reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<false, 4>));
+                const void* fn = has_mask ? (aa.th == 4 ? reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<true, 4>)
+                                                        : reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<true, 2>))
+                                          : (aa.th == 4 ? reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<false, 4>)
+                                                        : reinterpret_cast<const void*>(dcn_sample_planar_lds_kernel<false, 2>));
                 STM_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, STM_ELAUNCH,
                             "%s: cannot reserve %zu bytes of LDS", who, lds);
                 if (have_dev) reserved[which][dev].store((int)lds, std::memory_order_relaxed);
             }
-            if (has_mask && aa.th == 8) hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<true, 8>), grid_l, dim3(256), lds, stm_hs(stream), aa);
-            else if (has_mask) hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<true, 4>), grid_l, dim3(256), lds, stm_hs(stream), aa);
-            else if (aa.th == 8) hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<false, 8>), grid_l, dim3(256), lds, stm_hs(stream), aa);
-            else hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<false, 4>), grid_l, dim3(256), lds, stm_hs(stream), aa);
+            if (has_mask && aa.th == 4) hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<true, 4>), grid_l, dim3(256), lds, stm_hs(stream), aa);
+            else if (has_mask) hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<true, 2>), grid_l, dim3(256), lds, stm_hs(stream), aa);
+            else if (aa.th == 4) hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<false, 4>), grid_l, dim3(256), lds, stm_hs(stream), aa);
+            else hipLaunchKernelGGL((dcn_sample_planar_lds_kernel<false, 2>), grid_l, dim3(256), lds, stm_hs(stream), aa);
             STM_CHECK_LAUNCH("dcn_sample_planar_lds_kernel");
             return STM_OK;
         }

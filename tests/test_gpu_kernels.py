@@ -663,7 +663,7 @@ def test_mask_iou_grouped_equals_full_masked_by_group():
 @pytest.mark.parametrize("scale", [0.5, 6.0])
 @pytest.mark.parametrize("B,C,H,W,stride", [(2, 128, 21, 37, 1), (2, 128, 30, 45, 2), (1, 256, 17, 16, 1)])
 def test_dcn_sample_planar_lds_form_equals_register_gather(B, C, H, W, stride, scale, tunables):
-    """The LDS-staged sampler (tiles of 8 x 16 / 4 x 16 output pixels, 16-channel chunks, corners gathered from LDS; pairs whose
+    """The LDS-staged sampler (STM_DCN_LDS=1: tiles of 4 x 16 / 2 x 16 output pixels, 32-channel chunks, corners gathered from LDS; pairs whose
     corners leave the staged rectangle gathered from global memory) against the register-gather kernel: the same planes bit for bit,
     with offsets inside the halo (scale 0.5) and far outside it (scale 6: most pairs take the global path), partial tiles on both
     axes, both strides."""
