@@ -306,6 +306,18 @@ typedef struct stm_conv_geom {
                              supported (the last fp16 layer of a ResNet stage hands both planes to the fp32-equivalent FPN) */
 } stm_conv_geom;
 
+/* Two-source 1x1 convolution on the planar kernel: y = W [x1 ; x2 (stride s2)] + bias (+ residual) (+ ReLU) -- the last 1x1 convolution of
+ * a ResNet stage's first bottleneck and its projection shortcut (backbone.py:38-58: out = bn3(conv3(out)); out += downsample(x); relu)
+ * as ONE product over the concatenated input channels, W = [W3 | Wds] (packed with stm_conv_pack_weights_fmt_f32 as a [Cout, C1 + C2, 1, 1]
+ * tensor), bias = b3 + bds.  g: B, H = Ho, W = Wo of the output, kh = kw = 1, stride 1, no padding, C = C1 + C2, fmt 1 or 2, x_np /
+ * x_plane_stride for x_planes (which holds the C1 = C - C2 channels, one pixel per output pixel).  x2_planes: C2 channels of B images of
+ * H2 x W2 (x2_np pixels per slab, 0 = B * H2 * W2; x2_plane_stride elements between planes, 0 = dense), read at stride s2:
+ * Ho = (H2 - 1) / s2 + 1.  The projection's output tensor (written once and read back as the residual) never exists. */
+int stm_conv2d_planar_dual_f32(const void* x_planes, const void* x2_planes, int C2, int H2, int W2, int s2, long long x2_np,
+                               long long x2_plane_stride, const void* packed_weight, const float* bias, const float* residual_f32,
+                               const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu,
+                               void* workspace, size_t workspace_bytes, stm_stream_t stream);
+
 /* ---- narrow-output stride-1 convolution with kx-reuse (csrc/conv_kxr.hip) ------------------------------------------------------
  * The same convolution for the layers with FEW output channels per group (<= 64 real ones, <= 4 groups), stride 1, "same" padding,
  * kw = 3 or 5, plane formats 1 / 2: the shared head's output layers (prediction_head_FC.py:146-195: conf / centerness + bbox / mask

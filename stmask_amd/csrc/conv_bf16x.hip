@@ -99,6 +99,13 @@ struct PlanarArgs {
     int splitk, kslabs, ldp;  // split-K: K-slabs per split, fp32 partial sums [splitk][M][ldp] in `partial`
     float* partial;
     int vec_epilogue;       // Cout, out_ld, res_ld multiples of 8 and 16-byte aligned pointers: vector epilogue
+    // two-source 1x1 convolution (DUAL instantiations): K-slabs [0, c1_slabs) come from xp (one pixel per output pixel), the others from
+    // xp2, a second planar tensor of B images of H2 x W2 read at stride s2 -- conv3 of a ResNet stage's first bottleneck and its
+    // projection shortcut as ONE product over the concatenated channels, W = [W3 | Wds]
+    const uint8_t* xp2;
+    long long x2_pstride;
+    unsigned plane2_bytes;
+    int c1_slabs, x2_np, H2, W2, s2;
 };
 
 // Epilogue shared by the planar kernels: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes.
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256) void planar_splitk_finish_kernel(const PlanarA
 // expanding 1x1 convolutions, 337 vs 345 us, for 32 more live registers and one wave per SIMD less; and resident workgroups
 // walking the tiles instead of one workgroup per tile -- 404 -> 451 us.  Neither the epilogue's second memory round trip nor
 // workgroup launch overhead is what holds these layers at 3.3 TB/s.)
-template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0>
+template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0, bool DUAL = false>
 __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
@@ -368,6 +375,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     // slab instead of the coordinate arithmetic (this loop is instruction-bound on the 64-channel tiles and on short K).
     int base[2], wl64[2];
     unsigned vmask[2];
+    int base2[2] = {0, 0};                               // DUAL: byte offset of the row's source pixel in the second tensor
     const int slot = lane & 3;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -376,6 +384,18 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
         const int swz16 = (slot ^ swz(r)) << 4;
+        if constexpr (DUAL) {
+            // output pixel (b, oy, ox) of B x Ho x Wo reads pixel (b, oy * s2, ox * s2) of the second tensor
+            const int hw = a.Ho * a.Wo;
+            int b = (int)((float)mm * a.inv_hw);
+            int rem = mm - b * hw;
+            if (rem < 0) { --b; rem += hw; } else if (rem >= hw) { ++b; rem -= hw; }
+            int oy = (int)((float)rem * a.inv_w);
+            const int t = rem - oy * a.Wo;
+            if (t < 0) --oy; else if (t >= a.Wo) ++oy;
+            const int ox = rem - oy * a.Wo;
+            base2[i] = ((b * a.H2 + oy * a.s2) * a.W2 + ox * a.s2) * 64 + swz16;
+        }
         if (a.pointwise) {
             // 1x1 convolution without stride or padding: input pixel == output pixel, one tap, always inside
             base[i] = mm * 64 + swz16;
@@ -438,6 +458,26 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     int s_t = s_ky * a.kw + s_kx;                                      // tap index of the next slab to stage
     auto dma_x = [&](int buf, bool issue = true) {
         uint8_t* xb = smem + buf * BUF;
+        if constexpr (DUAL) {
+            // (uniform selects, no branch: the slab's source tensor, its buffer descriptor and the row offsets within it)
+            const bool seg2 = s_c >= a.c1_slabs;
+            const uint8_t* pb = seg2 ? a.xp2 : a.xp;
+            const long long pstr = seg2 ? a.x2_pstride : a.x_pstride;
+            const int nrec = (int)(seg2 ? a.plane2_bytes : a.plane_bytes);
+            const int uni2 = seg2 ? (s_c - a.c1_slabs) * (a.x2_np * 64) : s_c * (a.x_np * 64);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned oob = (vmask[i] & 1u) ^ 1u;
+                const unsigned off = (unsigned)((seg2 ? base2[i] : base[i]) + uni2) | (oob << 31);
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+                    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(pb) + (size_t)p * pstr, 0, nrec, 0x00020000);
+                    if (issue) __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lds_ptr)(xb + p * (BM * 64) + (2 * wave + i) * 1024), 16, off, 0, 0, 0);
+                }
+            }
+            ++s_c;
+            return;
+        }
         const int uni = (grp * cslabs + s_c) * (a.x_np * 64) + s_kx * 64;  // uniform: this K-slab's channel slab + the tap's column
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1069,7 +1109,7 @@ const ConvTunables& tunables()
     return t;
 }
 
-template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0>
+template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0, bool DUAL = false>
 int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
 {
     size_t lds = (size_t)ST * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
@@ -1081,11 +1121,11 @@ int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
     int dev = 0;
     const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STM_MAX_DEVICES;
     if (!have_dev || !lds_reserved[dev].load(std::memory_order_relaxed)) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
         if (have_dev) lds_reserved[dev].store(true, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
+    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL, DUAL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kernel");
     return STM_OK;
 }
@@ -1274,11 +1314,44 @@ extern "C" int stm_stem_rows_planes_f32(const float* x, void* planes, int B, int
     return STM_OK;
 }
 
+namespace {
+struct DualSrc { const void* x2; int C2, H2, W2, s2; long long x2_np, x2_plane_stride; };
+int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
+                       const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
+                       int relu, void* workspace, size_t workspace_bytes, stm_stream_t stream, const DualSrc* dual);
+}  // namespace
+
 extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
                                         const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
                                         int relu, void* workspace, size_t workspace_bytes, stm_stream_t stream)
 {
-    const char* who = "stm_conv2d_planar_f32";
+    return conv2d_planar_impl(x_planes, packed_weight, bias, residual_f32, residual_planes, out_f32, out_planes, g, relu, workspace,
+                              workspace_bytes, stream, nullptr);
+}
+
+// Two-source 1x1 convolution: y = W [x1 ; x2(stride s2)] + bias (+ residual) -- the last 1x1 convolution of a ResNet stage's first
+// bottleneck and its projection shortcut (backbone.py:38-58: out = conv3(...); out += downsample(x); relu) as ONE product over the
+// concatenated channels.  g describes the output (B, Ho, Wo = H, W of the first source; kh = kw = 1, stride 1, no padding; C = C1 + C2
+// = the weight's input channels); x_planes holds the first C1 = g->C - C2 channels at one pixel per output pixel (x_np / x_plane_stride
+// of g), x2_planes the other C2 channels as B images of H2 x W2 read at stride s2 (Ho = (H2 - 1) / s2 + 1).  The projection's output
+// tensor -- 4 * planes channels written, then read back as conv3's residual: 1 GB per launch pair in layer1 at batch 32 -- never exists.
+extern "C" int stm_conv2d_planar_dual_f32(const void* x_planes, const void* x2_planes, int C2, int H2, int W2, int s2, long long x2_np,
+                                          long long x2_plane_stride, const void* packed_weight, const float* bias, const float* residual_f32,
+                                          const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu,
+                                          void* workspace, size_t workspace_bytes, stm_stream_t stream)
+{
+    STM_REQUIRE(x2_planes && g, STM_ENULL, "stm_conv2d_planar_dual_f32: x2_planes / geometry must be non-NULL");
+    DualSrc d{x2_planes, C2, H2, W2, s2, x2_np, x2_plane_stride};
+    return conv2d_planar_impl(x_planes, packed_weight, bias, residual_f32, residual_planes, out_f32, out_planes, g, relu, workspace,
+                              workspace_bytes, stream, &d);
+}
+
+namespace {
+int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
+                       const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
+                       int relu, void* workspace, size_t workspace_bytes, stm_stream_t stream, const DualSrc* dual)
+{
+    const char* who = dual ? "stm_conv2d_planar_dual_f32" : "stm_conv2d_planar_f32";
     STM_REQUIRE(x_planes && packed_weight && (out_f32 || out_planes), STM_ENULL,
                 "%s: x_planes/packed_weight and at least one output must be non-NULL", who);
     STM_REQUIRE(g, STM_ENULL, "%s: geometry is NULL", who);
@@ -1312,7 +1385,16 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     STM_REQUIRE(x_np >= in_pixels && out_np >= M && res_np >= M, STM_EINVAL, "%s: x_np / out_np / res_np smaller than the pixel count", who);
     STM_REQUIRE((uintptr_t)x_planes % 16 == 0 && (uintptr_t)packed_weight % 16 == 0, STM_EINVAL,
                 "%s: x_planes and packed_weight must be 16-byte aligned", who);
-    const int64_t x_slabs = (int64_t)groups * (g->C / CV_BK);
+    if (dual) {
+        STM_REQUIRE(groups == 1 && g->n_levels <= 0 && g->kh == 1 && g->kw == 1 && g->sh == 1 && g->sw == 1 && g->ph == 0 && g->pw == 0 &&
+                    g->H == g->Ho && g->W == g->Wo && (g->fmt == 1 || g->fmt == 2), STM_EUNSUPPORTED,
+                    "%s: 1x1 / stride 1 / one group / fp16 plane formats only", who);
+        STM_REQUIRE(dual->C2 > 0 && dual->C2 % CV_BK == 0 && dual->C2 < g->C && dual->s2 >= 1 && dual->H2 > 0 && dual->W2 > 0 &&
+                    (dual->H2 - 1) / dual->s2 + 1 == g->Ho && (dual->W2 - 1) / dual->s2 + 1 == g->Wo, STM_EINVAL,
+                    "%s: second source %d channels of %dx%d at stride %d does not match the %dx%d output", who, dual->C2, dual->H2, dual->W2, dual->s2,
+                    g->Ho, g->Wo);
+    }
+    const int64_t x_slabs = dual ? (int64_t)(g->C - dual->C2) / CV_BK : (int64_t)groups * (g->C / CV_BK);
     const int64_t plane_bytes = x_slabs * x_np * 64;          // the channel slabs this launch may address, from x_planes
     STM_REQUIRE(plane_bytes < ((int64_t)1 << 31), STM_EUNSUPPORTED, "%s: plane larger than 2 GiB", who);
     STM_REQUIRE(M < ((int64_t)1 << 30), STM_EUNSUPPORTED, "%s: too many output pixels", who);
@@ -1358,6 +1440,17 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     STM_REQUIRE(g->planes == want_planes || (a.fmt == 0 && g->planes == 2), STM_EINVAL, "%s: format %d has %d planes (planes = %d)", who, a.fmt,
                 want_planes, g->planes);
     a.splitk = 1; a.kslabs = a.slabs; a.partial = nullptr; a.ldp = a.n_tiles * bn;
+    a.xp2 = nullptr; a.x2_pstride = 0; a.plane2_bytes = 0; a.c1_slabs = a.slabs; a.x2_np = 0; a.H2 = a.W2 = 0; a.s2 = 1;
+    if (dual) {
+        const int64_t in2 = (int64_t)g->B * dual->H2 * dual->W2;
+        const int64_t np2 = dual->x2_np ? dual->x2_np : in2;
+        const int64_t slabs2 = dual->C2 / CV_BK;
+        const int64_t ps2 = dual->x2_plane_stride ? dual->x2_plane_stride : slabs2 * np2 * 32;
+        STM_REQUIRE(np2 >= in2 && slabs2 * np2 * 64 < ((int64_t)1 << 31) && ps2 % 8 == 0 && (uintptr_t)dual->x2 % 16 == 0, STM_EINVAL,
+                    "%s: bad second-source plane geometry", who);
+        a.xp2 = static_cast<const uint8_t*>(dual->x2); a.x2_pstride = ps2 * 2; a.plane2_bytes = (unsigned)(slabs2 * np2 * 64);
+        a.c1_slabs = (int)x_slabs; a.x2_np = (int)np2; a.H2 = dual->H2; a.W2 = dual->W2; a.s2 = dual->s2;
+    }
     // split-K for grids that would leave most CUs idle over a long K (small feature maps: ResNet stages 3/4, P5-P7):
     // parts write fp32 partial sums into the caller's workspace, planar_splitk_finish_kernel adds them and runs the epilogue.
     // (A fused reduction -- the part drawing a tile's last ticket adds the parts -- was built and measured twice.  Round 1 with
@@ -1419,7 +1512,10 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         // 880, 8 clips flat (1053), 32 clips 1219 .. 1226.
         const bool small_grid = tiles <= tn.ring64_small;
         const bool ring = full && (tn.ring64 == 3 ? (small_grid || (a.splitk == 1 && a.slabs >= 12 && a.slabs <= 40)) : tn.ring64 == 4);
-        if (a.fmt == 2) rc = ring ? launch_planar<1, 1, 1, 1, 3>(a, tiles, stream) : launch_planar<1, 1, 1, 1>(a, tiles, stream);
+        if (dual) {
+            if (a.fmt == 2) rc = ring ? launch_planar<1, 1, 1, 1, 3, 0, true>(a, tiles, stream) : launch_planar<1, 1, 1, 1, 2, 0, true>(a, tiles, stream);
+            else rc = ring ? launch_planar<2, 1, 1, 1, 3, 0, true>(a, tiles, stream) : launch_planar<2, 1, 1, 1, 2, 0, true>(a, tiles, stream);
+        } else if (a.fmt == 2) rc = ring ? launch_planar<1, 1, 1, 1, 3>(a, tiles, stream) : launch_planar<1, 1, 1, 1>(a, tiles, stream);
         else if (a.fmt == 1) rc = ring ? launch_planar<2, 1, 1, 1, 3>(a, tiles, stream) : launch_planar<2, 1, 1, 1>(a, tiles, stream);
         else rc = g->planes == 3 ? launch_planar<3, 1, 1>(a, tiles, stream) : launch_planar<2, 1, 1>(a, tiles, stream);
         return rc != STM_OK ? rc : finish_splitk();
@@ -1453,7 +1549,10 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
         return rc != STM_OK ? rc : finish_splitk();
     }
 #endif
-    if (a.fmt == 2) {
+    if (dual) {      // (the 128-wide tiles of the fp16 formats always take the ring loop here)
+        if (a.fmt == 2) rc = mg == 2 ? launch_planar<1, 2, 2, 1, 3, 0, true>(a, tiles, stream) : launch_planar<1, 1, 2, 1, 3, 0, true>(a, tiles, stream);
+        else rc = mg == 2 ? launch_planar<2, 2, 2, 1, 3, 0, true>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 3, 0, true>(a, tiles, stream);
+    } else if (a.fmt == 2) {
         if (ring) rc = mg == 2 ? launch_planar<1, 2, 2, 1, 3>(a, tiles, stream) : launch_planar<1, 1, 2, 1, 3>(a, tiles, stream);
         else rc = mg == 2 ? launch_planar<1, 2, 2, 1>(a, tiles, stream) : launch_planar<1, 1, 2, 1>(a, tiles, stream);
     } else if (a.fmt == 1) {
@@ -1463,6 +1562,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
     else rc = mg == 2 ? launch_planar<2, 2, 2>(a, tiles, stream) : launch_planar<2, 1, 2>(a, tiles, stream);
     return rc != STM_OK ? rc : finish_splitk();
 }
+}  // namespace
 
 extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
                                      const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,

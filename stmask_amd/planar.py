@@ -40,6 +40,7 @@ BACKBONE_FMT = None
 TILE64_MAX_SLABS = int(os.environ.get("STM_TILE64_MAX_SLABS", "8"))
 FCB_PLANAR = os.environ.get("STM_FCB_PLANAR", "1") != "0"
 STEM_PLANAR = os.environ.get("STM_STEM_PLANAR", "1") != "0"
+C3DS_FUSED = os.environ.get("STM_C3DS_FUSED", "1") != "0"    # conv3 + projection shortcut of a stage's first block as one two-source product
 STEM_FUSED = os.environ.get("STM_STEM_FUSED", "1") != "0"    # conv1 + ReLU + max-pool as one kernel (csrc/stem_fused.hip)
 CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 layers on the kx-reuse kernel (csrc/conv_kxr.hip)
 
@@ -120,7 +121,7 @@ class PlanarConv:
         return 128
 
     def __call__(self, xp, shape, out="planes", x_off=0, out_planes=None, out_f32=None, out_off=0, residual=None, x_ch_off=0,
-                 out_ch_off=0):
+                 out_ch_off=0, x2=None):
         """xp: [P, S, N, 32] planes in this layer's format (channel-slab major; 2 x fp16 or 3 x bf16).  shape: ("img", B, H, W) -> pixels [x_off, x_off + B*H*W)
         of xp are one image batch; ("levels", B, [(H, W), ...]) -> all of xp, concatenated levels.  The layer reads
         groups*C channels starting at channel x_ch_off.  out: "planes" | "f32" | "both" allocates dense outputs
@@ -136,8 +137,11 @@ class PlanarConv:
         if self.group_cout:
             for i, c in enumerate(self.group_cout):
                 g.group_cout[i] = c
-        if S * 32 < x_ch_off + self.groups * self.C or x_ch_off % 32:
-            raise StmError(f"PlanarConv: input has {S * 32} channels, layer reads {self.groups} x {self.C} from channel {x_ch_off}")
+        # x2 = (planes2, H2, W2, stride): a two-source 1x1 layer (stm_conv2d_planar_dual_f32) -- xp holds the first C - C2 input channels at
+        # the output's resolution, planes2 the other C2 channels as B images of H2 x W2 read at `stride`
+        c_first = self.C - (x2[0].shape[1] * 32 if x2 is not None else 0)
+        if S * 32 < x_ch_off + self.groups * c_first or x_ch_off % 32:
+            raise StmError(f"PlanarConv: input has {S * 32} channels, layer reads {self.groups} x {c_first} from channel {x_ch_off}")
         if shape[0] == "levels":
             _, B, sizes = shape
             g.n_levels = len(sizes)
@@ -213,6 +217,17 @@ class PlanarConv:
         g.fmt, g.out_scale = self.fmt, self.out_scale
         g.out_fmt_plus1 = 0 if self.out_fmt == self.fmt else self.out_fmt + 1
         ws = ops._workspace(self.SPLITK_WS_BYTES, dev, "conv_splitk")     # grow-only, shared: split-K partial sums
+        if x2 is not None:
+            p2, H2, W2, s2 = x2
+            if p2.dtype != dt or p2.dim() != 4 or p2.shape[0] < NP or p2.shape[3] != 32 or not p2.is_contiguous() or shape[0] != "img":
+                raise StmError("PlanarConv: the second source must be contiguous planes of this layer's format over one image size")
+            rc = _lib.lib().stm_conv2d_planar_dual_f32(ctypes.c_void_p(x_ptr), ops._p(p2), c_i(p2.shape[1] * 32), c_i(H2), c_i(W2), c_i(s2),
+                                                       ctypes.c_longlong(p2.shape[2]), ctypes.c_longlong(p2.shape[1] * p2.shape[2] * 32),
+                                                       ops._p(packed), ops._p(self.bias), ctypes.c_void_p(r32), ctypes.c_void_p(rpl),
+                                                       ctypes.c_void_p(p_f32), ctypes.c_void_p(p_pl), ctypes.byref(g), c_i(1 if self.relu else 0),
+                                                       ops._p(ws), ctypes.c_size_t(ws.numel()), ops._stream())
+            check(rc, "stm_conv2d_planar_dual_f32")
+            return self._finish(timing, e0 if timing is not None else None, M, shape, g, NP, NPo, dt, out, out_f32, out_planes, residual)
         rc = _lib.lib().stm_conv2d_planar_ws_f32(ctypes.c_void_p(x_ptr), ops._p(packed),
                                                  ops._p(self.bias), ctypes.c_void_p(r32), ctypes.c_void_p(rpl),
                                                  ctypes.c_void_p(p_f32), ctypes.c_void_p(p_pl), ctypes.byref(g),
@@ -677,6 +692,14 @@ class PlanarBackbone:
                 if blk.downsample is not None:
                     d = blk.downsample[0]
                     e["ds"] = PlanarConv(d.weight, d.bias, d.stride, 0, relu=False, fmt=fmt)
+                    if (C3DS_FUSED and fmt in (1, 2) and tuple(d.kernel_size) == (1, 1) and d.stride[0] == d.stride[1] and tuple(d.padding) == (0, 0)
+                            and d.bias is not None and c3.bias is not None and d.weight.shape[1] % 32 == 0):
+                        # conv3 and the projection shortcut as ONE two-source product (stm_conv2d_planar_dual_f32): W = [W3 | Wds],
+                        # bias = b3 + bds; the projection's output tensor is never written
+                        wcat = torch.cat([c3.weight.detach(), d.weight.detach()], 1)
+                        e["c3ds"] = PlanarConv(wcat, c3.bias.detach() + d.bias.detach(), 1, 0, relu=True, fmt=fmt,
+                                               out_fmt=self.graph_fmt if to_graph else fmt)
+                        e["ds_stride"] = d.stride[0]
                 e["stride"] = _pair(c2.stride)
                 blks.append(e)
             self.blocks.append(blks)
@@ -749,6 +772,14 @@ class PlanarBackbone:
                         mid = _split(_nhwc(t), self.fmt)
                 else:
                     mid = e["c2"](e["c1"](xp, shape), shape)
+                if "c3ds" in e:
+                    x2 = (xp, H, W, e["ds_stride"])
+                    H, W = Ho, Wo
+                    if last and not self.planes_only:
+                        y32, xp = e["c3ds"](mid, ("img", B, H, W), out="both", x2=x2)
+                    else:
+                        xp = e["c3ds"](mid, ("img", B, H, W), x2=x2)
+                    continue
                 res = e["ds"](xp, shape) if "ds" in e else xp
                 H, W = Ho, Wo
                 if last and not self.planes_only:

@@ -680,3 +680,34 @@ def test_stem_fused_equals_three_kernel_stem():
     old, _ = ops.bias_relu_maxpool_planes(y, b, 1)
     a, c = planes_to_f32(fused.cpu()), planes_to_f32(old.cpu())
     assert a.shape == c.shape and (a - c).abs().max().item() < 2e-6 * max(1.0, c.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------- conv3 + projection shortcut as one product
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("case", [(2, 24, 40, 64, 64, 256, 1, 64), (2, 25, 39, 128, 256, 512, 2, 64), (1, 12, 20, 256, 512, 1024, 2, 128),
+                                  (3, 6, 10, 512, 1024, 2048, 2, 128)])
+def test_conv_dual_source_vs_oracle(case, fmt):
+    """stm_conv2d_planar_dual_f32: relu(W3 mid + b3 + Wds x[::s, ::s] + bds) as one two-source 1x1 product (the first bottleneck of a ResNet
+    stage, backbone.py:38-58) against the fp64 oracle of the two convolutions -- the stated bound of the planar kernel, 2e-6 of sum |x w|
+    (1e-3 with one fp16 plane) -- on both tile widths, odd sizes, split-K grids, and against the two-launch form it replaces."""
+    from stmask_amd.planar import PlanarConv
+    B, H2, W2, P, Cin, O, s, tile_n = case
+    Ho, Wo = (H2 - 1) // s + 1, (W2 - 1) // s + 1
+    mid, x = rnd(B, Ho, Wo, P, seed=90), rnd(B, H2, W2, Cin, seed=91)
+    w3, wd = rnd(O, P, 1, 1, seed=92, scale=P ** -0.5), rnd(O, Cin, 1, 1, seed=93, scale=Cin ** -0.5)
+    b3, bd = rnd(O, seed=94), rnd(O, seed=95)
+    xs = x[:, ::s, ::s].contiguous()
+    ref = torch.relu(oracle.conv2d_nhwc(mid, w3, b3, None) + oracle.conv2d_nhwc(xs, wd, bd, None))
+    mag = oracle.conv2d_nhwc(mid.abs(), w3.abs(), b3.abs(), None) + oracle.conv2d_nhwc(xs.abs(), wd.abs(), bd.abs(), None)
+    conv = PlanarConv(torch.cat([w3, wd], 1).to(DEV), (b3 + bd).to(DEV), 1, 0, relu=True, fmt=fmt, tile_n=tile_n)
+    midp, xp = ops.split_planes(mid.to(DEV), fmt), ops.split_planes(x.to(DEV), fmt)
+    y32, ypl = conv(midp, ("img", B, Ho, Wo), out="both", x2=(xp, H2, W2, s))
+    y32 = y32.cpu().view(ref.shape)
+    tol = 2e-6 if fmt == 1 else 1e-3
+    assert ((y32 - ref).abs() / mag.clamp_min(1e-6)).max().item() < tol
+    assert (planes_to_f32(ypl.cpu()) - y32.view(-1, O)).abs().max().item() <= 2.0 ** (-21 if fmt == 1 else -10) * max(1.0, y32.abs().max().item())
+    # the two-launch form: projection -> planes, then conv3 with that residual (one more rounding of the projection to the plane format)
+    ds = PlanarConv(wd.to(DEV), bd.to(DEV), s, 0, relu=False, fmt=fmt, tile_n=tile_n)
+    c3 = PlanarConv(w3.to(DEV), b3.to(DEV), 1, 0, relu=True, fmt=fmt, tile_n=tile_n)
+    y2 = c3(midp, ("img", B, Ho, Wo), out="f32", residual=ds(xp, ("img", B, H2, W2))).cpu().view(ref.shape)
+    assert (y2 - y32).abs().max().item() < (1e-5 if fmt == 1 else 2e-2) * max(1.0, ref.abs().max().item())
