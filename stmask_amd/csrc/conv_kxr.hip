@@ -94,7 +94,7 @@ typedef const __attribute__((address_space(1))) void* glb_ptr;
 // DMA(s) goes into the buffer of stage s - D, which every consumer left before it reached barrier s - D + 1 -- the last barrier the
 // producers passed before issuing it.
 template <int KW, int NPL, int NC>
-__device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int tile, uint8_t* smem)
+__device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int tile_first, int n_seq, int tile_step, uint8_t* smem)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PT = kx_pt(KW, NPL, NC), D = kx_depth(KW, NPL, NC);
@@ -114,14 +114,21 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int lvl = 0;
-#pragma unroll
-    for (int l = 1; l < 8; ++l)
-        if (l < a.n_lvl && tile >= jb.lvl_tile0[l]) lvl = l;
-    const int H = a.lvl_h[lvl], W = a.lvl_w[lvl], lstart = a.lvl_start[lvl], lend = a.lvl_start[lvl + 1];
-    const int m0 = lstart + (tile - jb.lvl_tile0[lvl]) * BM;
-    const int HW = H * W;
     const int S = a.cslabs * a.kh;
+    // The workgroup is persistent over a sequence of this job's tiles (tile_first, tile_first + tile_step, ...: n_seq of them): the ring
+    // of stages runs straight through the tile boundaries, so the producers are already fetching the next tile while the consumers
+    // store the previous one -- per tile only the setup of the new pixel run remains of the workgroup's start-up cost.
+    struct TileGeo { int H, W, lstart, lend, m0; };
+    auto tile_geo = [&](int tile) {
+        int lvl = 0;
+#pragma unroll
+        for (int l = 1; l < 8; ++l)
+            if (l < a.n_lvl && tile >= jb.lvl_tile0[l]) lvl = l;
+        TileGeo g;
+        g.H = a.lvl_h[lvl]; g.W = a.lvl_w[lvl]; g.lstart = a.lvl_start[lvl]; g.lend = a.lvl_start[lvl + 1];
+        g.m0 = g.lstart + (tile - jb.lvl_tile0[lvl]) * BM;
+        return g;
+    };
 
     if (wave >= KX_CONSUMERS) {
         // ---------------------------------------------------------------------------------------------------------- producer
@@ -129,29 +136,36 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
         // j = input pixel m0 - pw + j of the ky-shifted run; per row: byte offset of ky = 0 within a channel slab, one validity bit per
         // ky (the shifted pixel lies in the same image; everything else, and rows >= BM + kw - 1, is zero-filled by the range check)
         const int pw_ = wave - KX_CONSUMERS;
-        int dbase[XDW];
-        unsigned dmask[XDW];
-#pragma unroll
-        for (int i = 0; i < XDW; ++i) {
-            const int piece = min(pw_ + KX_PRODUCERS * i, NXD - 1);
-            const int rg = piece % NRG;
-            const int j = rg * 16 + (lane >> 2);
-            const int q = m0 - a.pw + j;
-            const bool okq = j < BM + HALO && q >= lstart && q < lend;
-            const int local = okq ? q - lstart : 0;
-            const int y = (local % HW) / W;
-            unsigned vm = 0;
-            for (int ky = 0; ky < a.kh; ++ky)
-                if ((unsigned)(y + ky - a.ph) < (unsigned)H) vm |= 1u << ky;
-            dmask[i] = okq ? vm : 0u;
-            dbase[i] = (q - a.ph * W) * 64 + (((lane & 3) ^ swz(j)) << 4);
-        }
         __amdgpu_buffer_rsrc_t xr[NPL];
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
             xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
-        int cs = 0, ky = 0, buf = 0;
-        auto issue = [&](int s) {
+        int dbase[XDW];
+        unsigned dmask[XDW];
+        int W = 1;
+        auto setup = [&](int tile) {
+            const TileGeo tg = tile_geo(tile);
+            W = tg.W;
+            const int HW = tg.H * tg.W;
+#pragma unroll
+            for (int i = 0; i < XDW; ++i) {
+                const int piece = min(pw_ + KX_PRODUCERS * i, NXD - 1);
+                const int rg = piece % NRG;
+                const int j = rg * 16 + (lane >> 2);
+                const int q = tg.m0 - a.pw + j;
+                const bool okq = j < BM + HALO && q >= tg.lstart && q < tg.lend;
+                const int local = okq ? q - tg.lstart : 0;
+                const int y = (local % HW) / tg.W;
+                unsigned vm = 0;
+                for (int ky = 0; ky < a.kh; ++ky)
+                    if ((unsigned)(y + ky - a.ph) < (unsigned)tg.H) vm |= 1u << ky;
+                dmask[i] = okq ? vm : 0u;
+                dbase[i] = (q - a.ph * tg.W) * 64 + (((lane & 3) ^ swz(j)) << 4);
+            }
+        };
+        int cs = 0, ky = 0, buf = 0, s_in = 0, t_in = 0;       // (channel slab, ky), ring slot, stage and tile of the next stage to issue
+        auto issue = [&]() {
+            if (s_in == 0) setup(tile_first + t_in * tile_step);
             uint8_t* xb = smem + buf * BUF;
             const int uni = (jb.x_slab0 + cs) * (a.x_np * 64) + ky * (W * 64);
 #pragma unroll
@@ -163,7 +177,7 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
                 if (!(KX_ABL & 5)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[NPL == 2 ? (p & 1) : 0], (lds_ptr)(xb + p * XPL + rg * 1024), 16, off, 0, 0, 0);
             }
             uint8_t* wb = xb + XBUF;
-            const uint8_t* wsrc = jb.wp + (size_t)s * WBUF;
+            const uint8_t* wsrc = jb.wp + (size_t)s_in * WBUF;
 #pragma unroll
             for (int k = 0; k < WDW; ++k) {
                 const int idx = min(pw_ + KX_PRODUCERS * k, NWD - 1);
@@ -171,19 +185,19 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
             }
             if (++ky == a.kh) { ky = 0; ++cs; }
             if (++buf == D) buf = 0;
+            if (++s_in == S) { s_in = 0; cs = 0; ky = 0; ++t_in; }
         };
+        const int G = S * n_seq;                             // stages of the whole sequence
         // head: D - 2 stages go out before the first wait
-#pragma unroll
-        for (int s = 0; s < D - 2; ++s)
-            if (s < S) issue(s);
-        for (int s = D - 2; s < S; ++s) {
-            issue(s);
-            // stage s - (D - 2) has landed; the D - 2 stages behind it stay in flight across the barrier
+        for (int g = 0; g < D - 2 && g < G; ++g) issue();
+        for (int g = D - 2; g < G; ++g) {
+            issue();
+            // stage g - (D - 2) has landed; the D - 2 stages behind it stay in flight across the barrier
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((D - 2) * NPD) : "memory");
         }
-        // tail: the last D - 2 stages (issued above, or all of them when S < D - 1)
+        // tail: the last D - 2 stages (issued above, or all of them when G < D - 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int k = max(S - (D - 2), 0); k < S; ++k) asm volatile("s_barrier" ::: "memory");
+        for (int k = max(G - (D - 2), 0); k < G; ++k) asm volatile("s_barrier" ::: "memory");
         return;
     }
 
@@ -191,28 +205,9 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
     // B operand (activations): lane (pixel r16 of pixel tile t, chunk kc), tap kx -> staged row + kx, or the always-zero row where the
     // tap leaves the image row.  A operand (weights): lane (channel r16 of tile c, chunk kc).
     const int r16 = lane & 15, kc = lane >> 4;
-    int boff[PT][KW];
-#pragma unroll
-    for (int t = 0; t < PT; ++t) {
-        const int row0 = 16 * PT * wave + 16 * t + r16;
-        const int m = m0 + row0;
-        const bool okm = m < lend;
-        const int x = okm ? (m - lstart) % W : 0;
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-            const bool v = okm && (unsigned)(x + kx - a.pw) < (unsigned)W;
-            boff[t][kx] = lds_off(v ? row0 + kx : BM + HALO, kc);
-        }
-    }
     const int aoff = XBUF + lds_off(r16, kc);
-
+    int boff[PT][KW];
     f32x4 acc[NC][PT], accl[NC][PT];
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int t = 0; t < PT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { acc[c][t][r] = 0.0f; accl[c][t][r] = 0.0f; }
 
     constexpr int NRD = (PT + NC) * NPL;        // fragment reads per tap
     constexpr int NM = PT * NC * (NPL == 2 ? 3 : 1);   // MFMAs per tap
@@ -253,6 +248,27 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
         }
     };
     int buf = 0;
+    for (int t_seq = 0; t_seq < n_seq; ++t_seq) {
+    const TileGeo tg = tile_geo(tile_first + t_seq * tile_step);
+    const int lstart = tg.lstart, lend = tg.lend, m0 = tg.m0, W = tg.W;
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int row0 = 16 * PT * wave + 16 * t + r16;
+        const int m = m0 + row0;
+        const bool okm = m < lend;
+        const int x = okm ? (m - lstart) % W : 0;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const bool v = okm && (unsigned)(x + kx - a.pw) < (unsigned)W;
+            boff[t][kx] = lds_off(v ? row0 + kx : BM + HALO, kc);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[c][t][r] = 0.0f; accl[c][t][r] = 0.0f; }
     for (int s = 0; s < S; ++s) {
         asm volatile("s_barrier" ::: "memory");             // barrier s: stage s is in LDS (and every consumer has left stage s - 1)
         const uint8_t* xs = smem + buf * BUF;
@@ -322,31 +338,39 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
             }
         }
     }
+    }   // tiles of the sequence
 #endif
 }
 
-// One launch covers every group (job) of a layer, whatever its channel-tile count: the jobs are dealt widest first (their tiles take
-// longest), the body is selected per workgroup.  (Register budget 256: six waves per workgroup put two on two of the SIMDs.  With 512
+// One launch covers every group (job) of a layer, whatever its channel-tile count: the jobs are numbered widest first (their tiles take
+// longest), the body is selected per run of tiles.  (Register budget 256: six waves per workgroup put two on two of the SIMDs.  With 512
 // the compiler splits the file into VGPRs and AGPRs and moves accumulators between them at every stage.)
 template <int KW, int NPL>
 __global__ __launch_bounds__(KX_THREADS) void conv_kxr_kernel(const KxrArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __align__(16) uint8_t smem[];
-    const int per_xcd = (a.total + 7) >> 3;
-    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (logical >= a.total) return;
-    int j = 0;
+    // persistent workgroups: workgroup w takes the global tiles w, w + grid, w + 2 grid, ...; the tiles are numbered job by job (widest
+    // job first), so its list is a few runs of tiles of one job each -- one call of that job's body per run
+    const int grid = gridDim.x;
+    int g = blockIdx.x;
+    while (g < a.total) {
+        int j = 0;
 #pragma unroll
-    for (int i = 1; i < KX_MAX_JOBS; ++i)
-        if (i < a.n_jobs && logical >= a.job[i].tile0) j = i;
-    const KxrJob& jb = a.job[j];
-    const int tile = logical - jb.tile0;
-    switch (jb.nc) {
-        case 1: kxr_body<KW, NPL, 1>(a, jb, tile, smem); break;
-        case 2: kxr_body<KW, NPL, 2>(a, jb, tile, smem); break;
-        case 3: kxr_body<KW, NPL, 3>(a, jb, tile, smem); break;
-        default: kxr_body<KW, NPL, 4>(a, jb, tile, smem); break;
+        for (int i = 1; i < KX_MAX_JOBS; ++i)
+            if (i < a.n_jobs && g >= a.job[i].tile0) j = i;
+        const KxrJob& jb = a.job[j];
+        const int jend = j + 1 < a.n_jobs ? a.job[j + 1].tile0 : a.total;     // first global tile behind this job
+        const int n_seq = (jend - g + grid - 1) / grid;
+        const int tile = g - jb.tile0;
+        switch (jb.nc) {
+            case 1: kxr_body<KW, NPL, 1>(a, jb, tile, n_seq, grid, smem); break;
+            case 2: kxr_body<KW, NPL, 2>(a, jb, tile, n_seq, grid, smem); break;
+            case 3: kxr_body<KW, NPL, 3>(a, jb, tile, n_seq, grid, smem); break;
+            default: kxr_body<KW, NPL, 4>(a, jb, tile, n_seq, grid, smem); break;
+        }
+        g += n_seq * grid;
+        __syncthreads();        // the next job's ring starts on LDS this one has left
     }
 #endif
 }
@@ -447,7 +471,15 @@ int kxr_launch(KxrArgs a, stm_stream_t stream)
                                         (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_kxr_f32: cannot reserve %zu bytes of LDS", lds);
         if (have_dev) reserved[dev].store((int)lds, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((conv_kxr_kernel<KW, NPL>), dim3(8 * stm_cdiv(a.total, 8)), dim3(KX_THREADS), lds, stm_hs(stream), a);
+    // one persistent workgroup per CU (the ring takes most of a CU's LDS)
+    static std::atomic<int> n_cus[KX_MAX_DEVICES];
+    int cus = have_dev ? n_cus[dev].load(std::memory_order_relaxed) : 0;
+    if (cus <= 0) {
+        hipDeviceProp_t prop;
+        cus = (have_dev && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        if (have_dev) n_cus[dev].store(cus, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL((conv_kxr_kernel<KW, NPL>), dim3(std::min(a.total, cus)), dim3(KX_THREADS), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_kxr_kernel");
     return STM_OK;
 }
