@@ -33,4 +33,4 @@ while time.time() - t0 < 6.0:
 t.join()
 us = (time.time() - t0) / n * 1e6
 gf = 2.0 * B * 96 * 160 * 256 * 256 * 9 / 1e9
-print(mode, "launches", n, "avg us %.1f" % us, ("= %.1f TFLOP/s fp32-equivalent, %.0f TFLOP/s of issued fp16 MFMA" % (gf / us * 1e-3, 3 * gf / us * 1e-3)) if mode == "conv16" else "")
+print(mode, "launches", n, "avg us %.1f" % us, ("= %.1f TFLOP/s fp32-equivalent, %.0f TFLOP/s of issued fp16 MFMA (%.3f of 2500)" % (gf / us * 1e3, 3 * gf / us * 1e3, 3 * gf / us * 1e3 / 2500)) if mode == "conv16" else "")
