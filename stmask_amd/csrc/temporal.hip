@@ -16,11 +16,12 @@
 
 namespace {
 
-constexpr int CORR_CCK = 16;  // channels staged per chunk (8 per half-wave)
 
 // IN_NHWC: f1 / f2 are channels-last [B][H][W][C] (C % 4 == 0) -- the layout the trunk's fp32 outputs have; a staging unit is then
 // (f2 row, x, 4 channels) instead of (channel, f2 row, 4 x): same LDS image, same arithmetic, no NCHW copy of the feature maps.
-template <int P, bool IN_NHWC>
+// CCK: channels staged per chunk -- 16 for rows of up to 44 pixels, 8 for rows of up to 88 (the 46x80 P4 level of 736x1280 frames, BASELINE
+// config 5, which fell to the generic kernel before: 3.5 ms per step at 4 clips).
+template <int P, bool IN_NHWC, int CCK = 16>
 __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict__ f1, const float* __restrict__ f2,
                                                         float* __restrict__ out, int C, int H, int W, float scale,
                                                         float slope, int B, int out_ld)
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
     const int Wq = W / 4;                   // x quads (W % 4 == 0 on this path)
     const int LW2 = ((W + 2 * R + 3) / 4) * 4;   // padded f2 row length (multiple of 4)
     float* f1s = smem;                      // [CCK][W]
-    float* f2s = smem + CORR_CCK * W;       // [CCK][P][LW2], index x + R
+    float* f2s = smem + CCK * W;       // [CCK][P][LW2], index x + R
 
     // One workgroup per output row; the 11 workgroups whose windows share an f2 row must meet in ONE L2: workgroup ids are
     // dealt round-robin to the 8 XCDs, so the (image, row) list is cut into 8 contiguous runs, one per XCD (stm_xcd_block).
@@ -48,11 +49,11 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
     const int64_t HW = (int64_t)H * W;
     const float* f1b = f1 + (int64_t)b * C * HW;
     const float* f2b = f2 + (int64_t)b * C * HW;
-    constexpr int CQ = CORR_CCK / 4;        // channel quads per chunk (channels-last staging)
+    constexpr int CQ = CCK / 4;        // channel quads per chunk (channels-last staging)
 
     // ---- staging plan, computed ONCE: unit u = (channel c, f2 row rr, x quad) -> one float4 global load + 4 LDS words.
     //      Only in-image rows are ever loaded; halo columns and out-of-image rows are zeroed once and never touched again.
-    const int units = CORR_CCK * P * Wq;
+    const int units = CCK * P * Wq;
     int g_off[MAXU], l_off[MAXU];           // global offset (floats, relative to channel chunk), LDS word offset
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
@@ -81,10 +82,10 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
             }
         }
     }
-    const bool f1_unit = IN_NHWC ? tid < CQ * W : tid < CORR_CCK * Wq;
+    const bool f1_unit = IN_NHWC ? tid < CQ * W : tid < CCK * Wq;
     const int f1_c = IN_NHWC ? (tid % CQ) * 4 : tid / Wq;            // first channel of the unit
     const int f1_xq = IN_NHWC ? tid / CQ : tid - f1_c * Wq;          // its x (channels-last) / x quad
-    for (int idx = tid; idx < CORR_CCK * P * LW2; idx += 256) f2s[idx] = 0.0f;
+    for (int idx = tid; idx < CCK * P * LW2; idx += 256) f2s[idx] = 0.0f;
 
     float4 pf[MAXU], pf1;
     auto prefetch = [&](int c0) {           // channels beyond C read as zero
@@ -139,15 +140,15 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
             for (int j = 0; j < P; ++j) acc[p][j] = 0.0f;
 
         prefetch(0);
-        for (int c0 = 0; c0 < C; c0 += CORR_CCK) {
+        for (int c0 = 0; c0 < C; c0 += CCK) {
             __syncthreads();                 // previous chunk fully consumed (and the zero fill done)
             commit();
             __syncthreads();
-            if (c0 + CORR_CCK < C) prefetch(c0 + CORR_CCK);   // next chunk's loads fly behind the FMAs below
+            if (c0 + CCK < C) prefetch(c0 + CCK);   // next chunk's loads fly behind the FMAs below
             if (active) {
 #pragma unroll 2
-                for (int cc = 0; cc < CORR_CCK / 2; ++cc) {
-                    const int c = half * (CORR_CCK / 2) + cc;
+                for (int cc = 0; cc < CCK / 2; ++cc) {
+                    const int c = half * (CCK / 2) + cc;
                     const float4 a = *reinterpret_cast<const float4*>(&f1s[c * W + x0]);
                     const float* wrow = &f2s[(c * P + i) * LW2 + x0];  // window starts at x0 - R  (index x0)
                     float win[WIN];
@@ -292,19 +293,24 @@ int corr_patch_launch(const float* f1, const float* f2, float* out, int B, int C
     STM_REQUIRE(P > 0 && (P & 1) && dil > 0, STM_EINVAL, "stm_corr_patch_f32: patch_size must be odd, dilation > 0");
     const int force = STM_ENV_INT("STM_CORR_VARIANT", 0);        // 1: the generic kernel (tests)
     // tiled kernel: P = 11, rows of whole float4 quads, staging plan of <= 8 units per thread (W <= 44)
-    bool tiled = (P == 11 && dil == 1 && H <= 65535 && B <= 65535 && W % 4 == 0 && CORR_CCK * 11 * (W / 4) <= 8 * 256 &&
+    // tiled kernel: P = 11, rows of whole float4 quads, staging plan of <= 8 units per thread: 16-channel chunks up to W = 44, 8-channel up to 88
+    const int cck = 16 * 11 * (W / 4) <= 8 * 256 ? 16 : 8;
+    bool tiled = (P == 11 && dil == 1 && H <= 65535 && B <= 65535 && W % 4 == 0 && cck * 11 * (W / 4) <= 8 * 256 &&
                   ((uintptr_t)out % 16 == 0) && ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f2 % 16 == 0));
     if (force == 1 || (in_nhwc && C % 4 != 0)) tiled = false;
     if (tiled) {
         int LW2 = ((W + 10 + 3) / 4) * 4;
-        size_t lds = (size_t)(CORR_CCK * W + CORR_CCK * 11 * LW2) * sizeof(float);
+        size_t lds = (size_t)(cck * W + cck * 11 * LW2) * sizeof(float);
         if (lds <= 64 * 1024) {
-            if (in_nhwc)
-                hipLaunchKernelGGL((corr_patch_tiled<11, true>), dim3(stm_xcd_grid((int64_t)H * B)), dim3(256), lds, stm_hs(stream), f1, f2, out, C,
-                                   H, W, scale, leaky_slope, B, out_ld);
+            const dim3 grid(stm_xcd_grid((int64_t)H * B));
+            if (in_nhwc && cck == 16)
+                hipLaunchKernelGGL((corr_patch_tiled<11, true, 16>), grid, dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W, scale, leaky_slope, B, out_ld);
+            else if (in_nhwc)
+                hipLaunchKernelGGL((corr_patch_tiled<11, true, 8>), grid, dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W, scale, leaky_slope, B, out_ld);
+            else if (cck == 16)
+                hipLaunchKernelGGL((corr_patch_tiled<11, false, 16>), grid, dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W, scale, leaky_slope, B, out_ld);
             else
-                hipLaunchKernelGGL((corr_patch_tiled<11, false>), dim3(stm_xcd_grid((int64_t)H * B)), dim3(256), lds, stm_hs(stream), f1, f2, out, C,
-                                   H, W, scale, leaky_slope, B, out_ld);
+                hipLaunchKernelGGL((corr_patch_tiled<11, false, 8>), grid, dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W, scale, leaky_slope, B, out_ld);
             STM_CHECK_LAUNCH("corr_patch_tiled");
             return STM_OK;
         }

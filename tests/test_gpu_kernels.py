@@ -192,7 +192,10 @@ def test_correlation_vs_oracle(B, C, H, W):
     cl1, cl2 = (t.to(DEV).contiguous(memory_format=torch.channels_last) for t in (f1, f2))
     assert not cl1.is_contiguous() or C == 1
     nhwc_cl = ops.corr_patch_nhwc(cl1, cl2, 11, scale=1.0 / C, leaky_slope=0.1).cpu()
-    assert torch.equal(nhwc_cl[..., :121], nhwc[..., :121])
+    if C % 4 == 0 or W % 4 != 0:
+        assert torch.equal(nhwc_cl[..., :121], nhwc[..., :121])
+    else:       # NCHW inputs on the tiled kernel, channels-last ones on the generic kernel: another summation order
+        assert (nhwc_cl[..., :121] - nhwc[..., :121]).abs().max() < 2e-6
 
 
 def test_correlation_known_answers_and_generic_path(tunables):
