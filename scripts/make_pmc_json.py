@@ -35,14 +35,26 @@ def main():
     g = group("corr_patch_tiled")
     if g:
         doc["corr_patch"] = {"kernel": "corr_patch_tiled<11> (P4 24x40, 256 channels, batch 32: inputs 62.9 MB, output 14.9 MB)", **g}
-    g = group("conv_planar_kernel")
+    def group_any(prefixes):
+        fb = sum(v[0] for k, v in fetch.items() if any(p in k for p in prefixes)) * 1024 * 2
+        nf = sum(v[1] for k, v in fetch.items() if any(p in k for p in prefixes))
+        wb = sum(v[0] for k, v in write.items() if any(p in k for p in prefixes)) * 1024
+        nw = sum(v[1] for k, v in write.items() if any(p in k for p in prefixes))
+        if not nf or not nw:
+            return None
+        return {"launches": nf, "fetch_bytes_per_launch": fb / nf, "write_bytes_per_launch": wb / nw, "traffic_bytes_per_launch": fb / nf + wb / nw}
+
+    g = group_any(("conv_planar_kernel", "conv_kxr_kernel"))
     if g:
-        doc["conv_planar"] = {"kernel": "conv_planar_kernel<*> (all launches of bench.py at batch 32, fp16x2 plane format)", **g}
+        doc["conv_planar"] = {"kernel": "conv_planar_kernel<*> + conv_kxr_kernel<*> (all launches of bench.py at batch 32, fp16x2 plane format)", **g}
+    g = group("stem_fused_kernel")
+    if g:
+        doc["stem_fused"] = {"kernel": "stem_fused_kernel (32 frames 384x640: 94 MB in, 126 MB of planes out)", **g}
     doc["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 4 --warmup 2` (scripts/gpu_round.sh pmc); "
                      "counters are KiB; FETCH_SIZE doubled per the gfx950 correction (MI355X guide, HBM section); WRITE_SIZE exact for 16-byte streaming stores")
     per = {}
     for k in sorted(set(fetch) | set(write)):
-        if not any(t in k for t in ("anonymous namespace", "stm_", "conv_planar", "dcn_", "corr_", "lincomb", "nms", "head_assemble", "roi_align", "mask_", "gather_", "match_", "pack_", "keep_", "shift_")):
+        if not any(t in k for t in ("anonymous namespace", "stm_", "conv_planar", "conv_kxr", "stem_fused", "dcn_", "corr_", "lincomb", "nms", "head_assemble", "roi_align", "mask_", "gather_", "match_", "pack_", "keep_", "shift_")):
             continue
         nf, nw = max(fetch[k][1], 1), max(write[k][1], 1)
         name = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")

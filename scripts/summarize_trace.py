@@ -20,7 +20,8 @@ sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
 
 def cat(name):
     n = name
-    if "conv_planar_kernel" in n: return "ours: conv_planar_kernel (bf16-split dense conv)"
+    if "conv_planar_kernel" in n: return "ours: conv_planar_kernel (plane-split dense conv)"
+    if "conv_kxr_kernel" in n: return "ours: conv_kxr_kernel (narrow layers, kx-reuse)"
     if "conv_bf16x" in n: return "ours: conv_bf16x (register-staged variant)"
     if "split_planes" in n: return "ours: split_planes_kernel"
     if "gemm128" in n or "gemm_bias_f32" in n or "splitk_reduce" in n: return "ours: fp32 MFMA GEMM (DCN)"
