@@ -39,6 +39,7 @@ constexpr int KX_LDS_MAX = 160 * 1024;
 constexpr int kx_stage_bytes(int kw, int npl, int nc, int pt) { return npl * (64 * pt + 16) * 64 + kw * npl * nc * 1024; }
 constexpr int kx_pt(int kw, int npl, int nc)
 {
+    if (nc >= 4 && npl == 2) return 2;     // four channel tiles: 64 accumulator registers per wave leave room for the second fragment set
     for (int pt = 4; pt > 2; --pt)
         if (3 * kx_stage_bytes(kw, npl, nc, pt) <= KX_LDS_MAX) return pt;
     return 2;
@@ -211,7 +212,7 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
 
     constexpr int NRD = (PT + NC) * NPL;        // fragment reads per tap
     constexpr int NM = PT * NC * (NPL == 2 ? 3 : 1);   // MFMAs per tap
-    constexpr bool PF = NC <= 3;                // four channel tiles: the second fragment set does not fit beside the accumulators
+    constexpr bool PF = NC * PT <= 12 && !(NC == 4 && PT == 3);     // the second fragment set must fit beside the accumulators
     constexpr int NS = PF ? 2 : 1;
     f16x8 bh[NS][PT], bl[NS][PT], ah[NS][NC], al[NS][NC];
     auto read_frags = [&](const uint8_t* xs, int kx, int set) {
