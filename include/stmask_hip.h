@@ -197,6 +197,13 @@ int stm_detect_cc_f32(const float* loc, const float* priors, const float* conf, 
                       int ncls, float conf_thresh, float iou_thr, int top_k, int batch, int64_t* idx_out,
                       int64_t* cls_out, float* score_out, float* box_out, int* count_out, void* workspace,
                       size_t workspace_bytes, stm_stream_t stream);
+/* the same with conf = the raw class logits [batch, N, ncls]: the softmax of STMask.py:314 (F.softmax(pred_outs['conf'], -1)) is taken
+ * per row inside the candidate pass (max over all classes, sum of exp(x - max) in class order) instead of by a separate pass over the
+ * whole tensor; classes (argmax) and the keep / NMS logic are unchanged */
+int stm_detect_cc_logits_f32(const float* loc, const float* priors, const float* conf_logits, const float* centerness, int N,
+                      int ncls, float conf_thresh, float iou_thr, int top_k, int batch, int64_t* idx_out,
+                      int64_t* cls_out, float* score_out, float* box_out, int* count_out, void* workspace,
+                      size_t workspace_bytes, stm_stream_t stream);
 
 int stm_fast_nms_f32(const float* conf, const float* boxes, const float* centerness, int K, int ncls,
                      const int* k_dev, float iou_thr, int top_k, float conf_thresh, int max_det,

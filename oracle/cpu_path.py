@@ -57,7 +57,9 @@ def _fast_nms(conf, boxes, centerness, iou_thr=0.5, top_k=200, conf_thresh=0.05,
     return idx_p, cls_p, sc_p, bx_p, torch.tensor(n, dtype=torch.int32)
 
 
-def _detect_cc(loc, priors, conf, centerness, conf_thresh=0.05, iou_thr=0.5, top_k=200):
+def _detect_cc(loc, priors, conf, centerness, conf_thresh=0.05, iou_thr=0.5, top_k=200, logits=False):
+    if logits:                      # the batched pipeline hands over raw class logits (STMask.py:314's softmax is folded into the kernel)
+        conf = torch.softmax(conf, -1)
     B, N, _ = conf.shape
     outs = []
     for b in range(B):

@@ -26,6 +26,7 @@ def cat(name):
     if "split_planes" in n: return "ours: split_planes_kernel"
     if "gemm128" in n or "gemm_bias_f32" in n or "splitk_reduce" in n: return "ours: fp32 MFMA GEMM (DCN)"
     if "deform_im2col" in n: return "ours: deform_im2col"
+    if "softmax_warp" in n: return "other torch"
     if "(anonymous namespace)::" in n and "at::native" not in n: return "ours: " + n.split("(anonymous namespace)::")[1].split("(")[0].split("<")[0]
     if any(k in n for k in ("igemm", "miopen", "Conv", "conv", "Cijk", "ck::", "gemm", "SubTensorOp", "batched_transpose")): return "dense conv / GEMM libraries (MIOpen, CK, rocBLAS)"
     if "copy" in n.lower() or "CatArray" in n: return "copies / cat"

@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "stm_version", "stm_last_error_string", "stm_struct_bytes", "stm_debug_reload_tunables", "stm_conv_kxr_packed_bytes", "stm_conv_pack_weights_kxr_f32", "stm_conv2d_planar_kxr_f32", "stm_conv2d_planar_dual_f32", "stm_stem_packed_weight_bytes", "stm_stem_pack_weights_f32", "stm_stem_fused_f32", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
     "stm_deform_conv_fwd_f32", "stm_gemm_bias_f32", "stm_gemm_workspace_bytes", "stm_gemm_bias_ws_f32", "stm_fcb_ali_offsets_f32", "stm_corr_patch_f32", "stm_corr_patch_nhwc_f32",
     "stm_roi_align_avg_f32", "stm_decode_boxes_f32", "stm_generate_candidates_f32", "stm_cc_fast_nms_f32",
-    "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
+    "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_detect_cc_logits_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
     "stm_jaccard_f32", "stm_lincomb_sigmoid_crop_f32", "stm_mask_iou_workspace_bytes", "stm_mask_iou_f32",
     "stm_bias_act_f32", "stm_mask_rle_workspace_bytes", "stm_mask_resize_rle_f32",
     "stm_conv_packed_weight_bytes", "stm_conv_pack_weights_f32",

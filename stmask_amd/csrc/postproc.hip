@@ -68,6 +68,10 @@ __global__ void fcb_ali_kernel(const float* __restrict__ loc, float* __restrict_
 // 256 rows per workgroup; the [256][ncls] slab of conf is contiguous in memory, so it is copied coalesced into
 // LDS and each thread then scans its own row (row stride ncls words: conflict-free for odd ncls such as 41).
 // Writes, per row: decoded box (optional), flag = max_{c>=1} conf > thresh, score = maxconf * centerness.
+// LOGITS: `conf` holds the raw class logits and the row's softmax (STMask.py:314: F.softmax(pred_outs['conf'], -1)) is taken here --
+// max over all classes, sum of exp(x - max) in class order, p = exp(x_fg - max) / sum -- instead of by a separate pass that reads and
+// writes the whole [B, N, ncls] tensor (0.13 ms per step at batch 32).  Only the best foreground probability is needed downstream.
+template <bool LOGITS>
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ loc, const float* __restrict__ priors,
                                                         const float* __restrict__ conf,
                                                         const float* __restrict__ centerness, int N, int ncls,
@@ -86,6 +90,12 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
     const float* row = slab + r * ncls;
     float m = row[1];
     for (int c = 2; c < ncls; ++c) m = row[c] > m ? row[c] : m;
+    if constexpr (LOGITS) {
+        const float mx = row[0] > m ? row[0] : m;
+        float sum = 0.0f;
+        for (int c = 0; c < ncls; ++c) sum += expf(row[c] - mx);
+        m = expf(m - mx) / sum;
+    }
     const int64_t gi = (int64_t)b * N + r0 + r;
     if (box_out) {
         const float4 l = reinterpret_cast<const float4*>(loc)[gi];
@@ -589,8 +599,8 @@ extern "C" int stm_generate_candidates_f32(const float* loc, const float* priors
     STM_REQUIRE(((uintptr_t)loc % 16 == 0) && ((uintptr_t)priors % 16 == 0) && ((uintptr_t)cand_box % 16 == 0), STM_EINVAL,
                 "stm_generate_candidates_f32: loc/priors/cand_box must be 16-byte aligned");
     size_t lds = (size_t)256 * ncls * sizeof(float);
-    allow_big_lds(row_stats_kernel, lds);
-    hipLaunchKernelGGL(row_stats_kernel, dim3(stm_cdiv(N, 256), batch), dim3(256), lds, stm_hs(stream), loc, priors, conf,
+    allow_big_lds(row_stats_kernel<false>, lds);
+    hipLaunchKernelGGL(row_stats_kernel<false>, dim3(stm_cdiv(N, 256), batch), dim3(256), lds, stm_hs(stream), loc, priors, conf,
                        (const float*)nullptr, N, ncls, thresh, reinterpret_cast<float4*>(cand_box), keep_idx,
                        (float*)nullptr);
     STM_CHECK_LAUNCH("row_stats_kernel");
@@ -648,9 +658,9 @@ extern "C" int stm_cc_fast_nms_ws_f32(const float* conf, const float* boxes, con
                 "stm_cc_fast_nms_ws_f32: boxes / workspace / box_out must be 16-byte aligned");
     float* score_all = reinterpret_cast<float*>(workspace);
     const size_t lds1 = (size_t)256 * ncls * sizeof(float);
-    allow_big_lds(row_stats_kernel, lds1);
+    allow_big_lds(row_stats_kernel<false>, lds1);
     // every row is a candidate here (the caller filtered already): threshold -inf
-    hipLaunchKernelGGL(row_stats_kernel, dim3(stm_cdiv(K, 256), batch), dim3(256), lds1, stm_hs(stream), (const float*)nullptr,
+    hipLaunchKernelGGL(row_stats_kernel<false>, dim3(stm_cdiv(K, 256), batch), dim3(256), lds1, stm_hs(stream), (const float*)nullptr,
                        (const float*)nullptr, conf, centerness, K, ncls, -INFINITY, (float4*)nullptr, (int64_t*)nullptr, score_all);
     STM_CHECK_LAUNCH("row_stats_kernel");
     const int Kp = next_pow2(min(K, NMS_MAX_KEYS));
@@ -668,10 +678,34 @@ extern "C" int stm_cc_fast_nms_ws_f32(const float* conf, const float* boxes, con
 //   workspace: stm_detect_cc_workspace_bytes(N, batch) (decoded boxes + per-row scores).
 extern "C" size_t stm_detect_cc_workspace_bytes(int N, int batch) { return (size_t)batch * N * (16 + 4) + 256; }
 
+static int detect_cc_impl(const float* loc, const float* priors, const float* conf, const float* centerness, int N,
+                          int ncls, float conf_thresh, float iou_thr, int top_k, int batch, int64_t* idx_out,
+                          int64_t* cls_out, float* score_out, float* box_out, int* count_out, void* workspace,
+                          size_t workspace_bytes, stm_stream_t stream, bool logits);
+
 extern "C" int stm_detect_cc_f32(const float* loc, const float* priors, const float* conf, const float* centerness, int N,
                                  int ncls, float conf_thresh, float iou_thr, int top_k, int batch, int64_t* idx_out,
                                  int64_t* cls_out, float* score_out, float* box_out, int* count_out, void* workspace,
                                  size_t workspace_bytes, stm_stream_t stream)
+{
+    return detect_cc_impl(loc, priors, conf, centerness, N, ncls, conf_thresh, iou_thr, top_k, batch, idx_out, cls_out, score_out, box_out,
+                          count_out, workspace, workspace_bytes, stream, false);
+}
+
+// the same with `conf` = raw class logits [batch, N, ncls]: the softmax of STMask.py:314 is folded into the per-row pass
+extern "C" int stm_detect_cc_logits_f32(const float* loc, const float* priors, const float* conf_logits, const float* centerness, int N,
+                                        int ncls, float conf_thresh, float iou_thr, int top_k, int batch, int64_t* idx_out,
+                                        int64_t* cls_out, float* score_out, float* box_out, int* count_out, void* workspace,
+                                        size_t workspace_bytes, stm_stream_t stream)
+{
+    return detect_cc_impl(loc, priors, conf_logits, centerness, N, ncls, conf_thresh, iou_thr, top_k, batch, idx_out, cls_out, score_out,
+                          box_out, count_out, workspace, workspace_bytes, stream, true);
+}
+
+static int detect_cc_impl(const float* loc, const float* priors, const float* conf, const float* centerness, int N,
+                          int ncls, float conf_thresh, float iou_thr, int top_k, int batch, int64_t* idx_out,
+                          int64_t* cls_out, float* score_out, float* box_out, int* count_out, void* workspace,
+                          size_t workspace_bytes, stm_stream_t stream, bool logits)
 {
     STM_REQUIRE(loc && priors && conf && idx_out && cls_out && score_out && count_out, STM_ENULL,
                 "stm_detect_cc_f32: required pointer is NULL");
@@ -687,9 +721,15 @@ extern "C" int stm_detect_cc_f32(const float* loc, const float* priors, const fl
     float4* box_all = reinterpret_cast<float4*>(workspace);
     float* score_all = reinterpret_cast<float*>(box_all + (size_t)batch * N);
     size_t lds1 = (size_t)256 * ncls * sizeof(float);
-    allow_big_lds(row_stats_kernel, lds1);
-    hipLaunchKernelGGL(row_stats_kernel, dim3(stm_cdiv(N, 256), batch), dim3(256), lds1, stm_hs(stream), loc, priors, conf,
-                       centerness, N, ncls, conf_thresh, box_all, (int64_t*)nullptr, score_all);
+    if (logits) {
+        allow_big_lds(row_stats_kernel<true>, lds1);
+        hipLaunchKernelGGL(row_stats_kernel<true>, dim3(stm_cdiv(N, 256), batch), dim3(256), lds1, stm_hs(stream), loc, priors, conf,
+                           centerness, N, ncls, conf_thresh, box_all, (int64_t*)nullptr, score_all);
+    } else {
+        allow_big_lds(row_stats_kernel<false>, lds1);
+        hipLaunchKernelGGL(row_stats_kernel<false>, dim3(stm_cdiv(N, 256), batch), dim3(256), lds1, stm_hs(stream), loc, priors, conf,
+                           centerness, N, ncls, conf_thresh, box_all, (int64_t*)nullptr, score_all);
+    }
     STM_CHECK_LAUNCH("row_stats_kernel");
     const int Kp = next_pow2(min(N, NMS_MAX_KEYS));
     const size_t lds = nms_lds_bytes(Kp, top_k);

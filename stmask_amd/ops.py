@@ -355,10 +355,10 @@ def cc_fast_nms(conf, boxes, centerness, iou_thr=0.5, top_k=200, k_dev=None):
     return idx, cls, sc, bx, cnt
 
 
-def detect_cc(loc, priors, conf, centerness, conf_thresh=0.05, iou_thr=0.5, top_k=200):
+def detect_cc(loc, priors, conf, centerness, conf_thresh=0.05, iou_thr=0.5, top_k=200, logits=False):
     """Fused generate_candidate + cc_fast_nms (STMask.py:317-320) with no host sync.
-    loc [B,N,4], priors [N,4], conf [B,N,ncls] soft-maxed, centerness [B,N] or [B,N,1] ->
-    (prior_idx [B,top_k], cls, score, box [B,top_k,4], count [B])."""
+    loc [B,N,4], priors [N,4], conf [B,N,ncls] soft-maxed (logits=True: the raw class logits, soft-maxed per row inside the kernel:
+    stm_detect_cc_logits_f32), centerness [B,N] or [B,N,1] -> (prior_idx [B,top_k], cls, score, box [B,top_k,4], count [B])."""
     _dev(loc, priors, conf, centerness)
     loc, priors, conf = _f32c(loc), _f32c(priors), _f32c(conf)
     B, N, ncls = conf.shape
@@ -371,9 +371,9 @@ def detect_cc(loc, priors, conf, centerness, conf_thresh=0.05, iou_thr=0.5, top_
     cnt = torch.empty(B, dtype=torch.int32, device=dev)
     need = _lib.lib().stm_detect_cc_workspace_bytes(c_i(N), c_i(B))
     ws = _workspace(need, dev, "detect")
-    check(_lib.lib().stm_detect_cc_f32(_p(loc), _p(priors), _p(conf), _p(cen), c_i(N), c_i(ncls), c_f(conf_thresh),
-                                       c_f(iou_thr), c_i(top_k), c_i(B), _p(idx), _p(cls), _p(sc), _p(bx), _p(cnt), _p(ws),
-                                       c_sz(ws.numel()), _stream()), "stm_detect_cc_f32")
+    fn = _lib.lib().stm_detect_cc_logits_f32 if logits else _lib.lib().stm_detect_cc_f32
+    check(fn(_p(loc), _p(priors), _p(conf), _p(cen), c_i(N), c_i(ncls), c_f(conf_thresh), c_f(iou_thr), c_i(top_k), c_i(B), _p(idx), _p(cls),
+             _p(sc), _p(bx), _p(cnt), _p(ws), c_sz(ws.numel()), _stream()), "stm_detect_cc_f32")
     return idx, cls, sc, bx, cnt
 
 

@@ -324,11 +324,10 @@ class BatchedClipPipeline:
         if Pn:
             self._shift_prev(P4, T2S, proto, dev)
         self._prefetch_trunk(next_frames)
-        conf = F.softmax(pred["conf"], -1)
-        N = conf.shape[1]
         priors = pred["priors"].squeeze(0)
-        idx, cls, score, box, cnt = ops.detect_cc(pred["loc"], priors, conf, pred["centerness"], cfg.eval_conf_thresh,
-                                                  cfg.nms_thresh, cfg.nms_top_k)
+        # (the softmax of STMask.py:314 is taken per row inside the candidate pass: no pass over the [B, N, 41] logits of its own)
+        idx, cls, score, box, cnt = ops.detect_cc(pred["loc"], priors, pred["conf"], pred["centerness"], cfg.eval_conf_thresh,
+                                                  cfg.nms_thresh, cfg.nms_top_k, logits=True)
         if self.max_instances > 0:
             cnt = torch.clamp(cnt, max=self.max_instances)
         counts, host_scores = ops.counts_to_host(cnt, extra=score)  # host read 1: B counts + the fp16 range flag + the NMS scores

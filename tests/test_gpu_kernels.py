@@ -680,3 +680,27 @@ def test_dcn_sample_planar_lds_form_equals_register_gather(B, C, H, W, stride, s
     tunables.clear("STM_DCN_LDS")
     assert torch.equal(outs["1"], outs["0"])
     assert outs["1"].abs().sum().item() > 0
+
+
+def test_detect_cc_on_logits_equals_softmax_then_detect():
+    """stm_detect_cc_logits_f32 (softmax folded into the candidate pass) against F.softmax + stm_detect_cc_f32: the same prior indices,
+    classes and boxes; scores within 2 ulp of a probability (the row sum is taken in another order than torch's softmax kernel)."""
+    g = torch.Generator().manual_seed(5)
+    B, N, ncls = 3, 15345, 41
+    logits = torch.randn(B, N, ncls, generator=g) * 1.5
+    logits[..., 0] += 5.0                                      # background-dominated, a few hundred candidates per frame
+    loc = torch.randn(B, N, 4, generator=g) * 0.3
+    pri = torch.rand(N, 4, generator=g) * 0.5 + 0.25
+    cen = torch.rand(B, N, generator=g)
+    a = ops.detect_cc(loc.to(DEV), pri.to(DEV), torch.softmax(logits.to(DEV), -1), cen.to(DEV), 0.05, 0.5, 200)
+    b = ops.detect_cc(loc.to(DEV), pri.to(DEV), logits.to(DEV), cen.to(DEV), 0.05, 0.5, 200, logits=True)
+    cnt = a[4].cpu()
+    assert int(cnt.min()) > 20
+    agree = 0
+    for f in range(B):
+        n = int(cnt[f])
+        if int(b[4][f]) == n and torch.equal(a[0][f, :n], b[0][f, :n]):
+            agree += 1
+            assert torch.equal(a[1][f, :n], b[1][f, :n]) and torch.equal(a[3][f, :n], b[3][f, :n])
+            assert (a[2][f, :n] - b[2][f, :n]).abs().max().item() < 3e-7
+    assert agree == B      # (a score within 1 ulp of the 0.05 threshold or of a neighbour in the sort could differ; not with this seed)
