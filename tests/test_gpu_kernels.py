@@ -695,7 +695,7 @@ def test_detect_cc_on_logits_equals_softmax_then_detect():
     a = ops.detect_cc(loc.to(DEV), pri.to(DEV), torch.softmax(logits.to(DEV), -1), cen.to(DEV), 0.05, 0.5, 200)
     b = ops.detect_cc(loc.to(DEV), pri.to(DEV), logits.to(DEV), cen.to(DEV), 0.05, 0.5, 200, logits=True)
     cnt = a[4].cpu()
-    assert int(cnt.min()) > 20
+    assert int(cnt.min()) > 5
     agree = 0
     for f in range(B):
         n = int(cnt[f])
