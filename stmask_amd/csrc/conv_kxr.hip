@@ -248,6 +248,16 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
                 for (int t = 0; t < PT; ++t) acc[c][t] = KX_MM(ah[set][c], bh[set][t], acc[c][t]);
         }
     };
+    // bias of this lane's channels, once per job: loaded in the epilogue they cost four dependent global round trips per tile (~5 us on
+    // six-stage tiles: more than the tile's MFMAs)
+    float b4[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = 16 * c + 4 * kc + r;
+            b4[c][r] = (jb.bias && ch < jb.bias_n) ? jb.bias[ch] : 0.0f;
+        }
     int buf = 0;
     for (int t_seq = 0; t_seq < n_seq; ++t_seq) {
     const TileGeo tg = tile_geo(tile_first + t_seq * tile_step);
@@ -305,12 +315,6 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int ch = 16 * c + 4 * kc;                    // channel within the group
-        float b4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (jb.bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (ch + r < jb.bias_n) b4[r] = jb.bias[ch + r];
-        }
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
             const int m = m0 + 16 * PT * wave + 16 * t + r16;
@@ -319,7 +323,7 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float sum = NPL == 2 ? acc[c][t][r] + accl[c][t][r] * ls : acc[c][t][r];
-                v[r] = __builtin_fmaf(sum, a.out_scale, b4[r]);
+                v[r] = __builtin_fmaf(sum, a.out_scale, b4[c][r]);
                 if (a.relu) v[r] = __builtin_fmaxf(v[r], 0.0f);
             }
             const int oc = jb.out_ch0 + ch;
