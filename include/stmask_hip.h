@@ -342,6 +342,20 @@ int stm_conv_pack_weights_kxr_f32(const float* weight, void* packed, const struc
 int stm_conv2d_planar_kxr_f32(const void* x_planes, const void* packed_weight, const float* bias, float* out_f32, void* out_planes,
                               const struct stm_conv_geom* g, int relu, stm_stream_t stream);
 
+/* ---- bottleneck chain for the 64-channel blocks of ResNet layer1 (csrc/conv_chain.hip; reference backbone.py:38-58) ---------------
+ *   mid2 = relu(conv2_3x3(mid1) + b2);  y = relu(conv3_1x1(mid2) + b3 + x);  z = relu(next_conv1_1x1(y) + b1_next)   (BatchNorm folded)
+ * as one launch in plane format 1 (fp16 x 2): mid2 and y feed the next product from the accumulators, the 3x3's input, the identity
+ * shortcut and the outputs cross HBM once.  mid1 / z: [B, H, W, 64] planes, x / y: [B, H, W, 256] planes, all dense
+ * ([2][C/32][B*H*W][32]).  w2_packed = stm_conv_pack_weights_kxr_f32 of conv2's [64, 64, 3, 3] (C = 64, Cout = 64, one group, fmt 1);
+ * tail_packed = stm_chain_pack_tail_f32 of conv3's [256, 64] and (or NULL) the next block's conv1 [64, 256], each times its power-of-two
+ * weight scale; out_scale* = 1 / that scale.  z_planes may be NULL (then b1_next and the conv1 half of the tail are unused).
+ * Arithmetic = the three stm_conv2d_planar_f32 calls it replaces up to the order of the fp32 sums inside one 32-channel K-slab. */
+size_t stm_chain_tail_weight_bytes(void);
+int stm_chain_pack_tail_f32(const float* w3, const float* w1_next, void* packed, float wscale3, float wscale1, stm_stream_t stream);
+int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_planes, void* y_planes, void* z_planes, const void* w2_packed,
+                             const void* tail_packed, const float* b2, const float* b3, const float* b1_next, float out_scale2,
+                             float out_scale3, float out_scale1, int B, int H, int W, stm_stream_t stream);
+
 /* bytes of the packed (pre-split, pre-tiled) weight image; 0 on bad arguments */
 size_t stm_conv_packed_weight_bytes(int Cout, int Cin, int kh, int kw, int planes);
 /* weight [Cout, Cin, kh, kw] fp32 (torch OIHW, contiguous) -> packed image; done once per layer */

@@ -1,0 +1,502 @@
+// conv_chain.hip -- the tail of one ResNet bottleneck and the head of the next as ONE kernel (reference backbone.py:38-58, Bottleneck.forward):
+//
+//     mid2 = relu(conv2(mid1) + b2)          3x3, P -> P, stride 1        (BatchNorm folded)
+//     y    = relu(conv3(mid2) + b3 + x)      1x1, P -> 4P, + identity shortcut
+//     z    = relu(conv1'(y) + b1')           1x1, 4P -> P, the NEXT block's first convolution (optional)
+//
+// for the 64-channel bottlenecks of layer1 (P = 64).  As three launches these layers move 1.9 GB per block at batch 32 (mid2 written and
+// read, y written, read by conv1' and read again as the next shortcut) and run at the HBM rate: 519 us.  Chained, the 3x3's input (126 MB),
+// the shortcut (503 MB) and the two outputs (503 + 126 MB) cross HBM once.  No halo is recomputed: the only tensor that crosses a kernel
+// boundary between two 3x3 convolutions is the 64-channel z.
+//
+// Built on conv_kxr.hip's machinery (flat 128-pixel tiles, kx-reuse staging of the 3x3's input rows, two producer waves issuing every
+// LDS-DMA, four consumer waves of 32 pixels, ring of three stage buffers, persistent workgroups) plus what the TRANSPOSED product buys:
+// a consumer wave owns its 32 pixels for all channels, and the accumulator layout of D[channel][pixel] = W X^T -- a lane holds 4
+// consecutive channels of one pixel -- is, after bias / ReLU / plane split, exactly a B-operand fragment of the next product if that
+// product's K order is permuted accordingly (slab k' = 8 kc + j  <->  channel 4 kc + j of the slab's first 16-channel tile for j < 4, of
+// its second tile for j >= 4).  The permutation is baked into the packed weights of conv3 and conv1', so mid2 and y feed the next
+// product straight from registers: no LDS round trip, no barrier.  conv3 runs in eight half-groups of 32 output channels -- one K-slab
+// of conv1' each -- whose weights (conv3's two tiles, conv1's slab) arrive through the same ring as eight more stages of 16 KB.
+//
+// Arithmetic = the three planar convolutions: per K-slab acc += w_h x_h, accl += w_h x_l then w_l x_h, fp32 accumulation,
+// (acc + accl / 2048) * out_scale + bias, residual added as h + l / 2048, ReLU, results split into fp16 planes exactly as the separate
+// kernels' epilogues do.  Only the order of the 32 products INSIDE an MFMA differs (the K permutation): fp32-rounding-level differences.
+#include "planar_common.h"
+
+#include <algorithm>
+#include <atomic>
+
+namespace {
+
+constexpr int CH_P = 64;                  // bottleneck width
+constexpr int CH_PT = 2;                  // pixel tiles of 16 per consumer wave
+constexpr int CH_BM = 64 * CH_PT;         // 128 flat pixels per workgroup tile
+constexpr int CH_XROWS = CH_BM + 16, CH_NRG = CH_XROWS / 16;
+constexpr int CH_XPL = CH_XROWS * 64, CH_XBUF = 2 * CH_XPL;                 // staged rows: two planes
+constexpr int CH_WT = 4 * 16 * 64, CH_WBUF = 3 * 2 * CH_WT;                 // conv2 weights of one (channel slab, ky): 3 taps x 2 planes x 64 rows
+constexpr int CH_BUF = CH_XBUF + CH_WBUF;                                   // 43 008 B per ring slot
+constexpr int CH_D = 3;                                                     // (the producers' wait is written for a ring of three)
+// tail stage j = 0 .. 8: [conv3 weights of half-group j: 8 KB | conv1' weights of K-slab j - 1: 8 KB | shortcut of half-group j: 2 planes x 8 KB]
+constexpr int CH_TAIL_STAGES = 9, CH_TW3 = 0, CH_TW1 = 8192, CH_TRES = 16384, CH_TW_BYTES = 16384;
+constexpr int CH_BIAS_OFF = CH_D * CH_BUF, CH_LDS = CH_BIAS_OFF + (64 + 256 + 64) * 4;
+constexpr int CH_CONSUMERS = 4, CH_PRODUCERS = 2, CH_THREADS = 64 * (CH_CONSUMERS + CH_PRODUCERS);
+constexpr int CH_MAX_DEVICES = 32;
+static_assert(CH_TRES + 2 * CH_BM * 64 <= CH_BUF, "a tail stage must fit a ring slot");
+
+struct ChainArgs {
+    const uint8_t* xin;      // mid1 planes [2][2][np_in][32]
+    const uint8_t* res;      // shortcut planes [2][8][np_res][32]
+    uint8_t* y;              // [2][8][np_y][32]
+    uint8_t* z;              // [2][2][np_z][32] or null (no chained conv1')
+    const uint8_t* w2;       // conv2, conv_kxr layout: [stage (slab, ky)][kx][plane][64 rows][64 B]
+    const uint8_t* wt;       // tail: [stage 9][conv3 of half-group j: tile 2, slab 2, plane 2 x 1 KB | conv1' of K-slab j - 1: tile 4, plane 2 x 1 KB]
+    const float *b2, *b3, *b1;
+    float scale2, scale3, scale1;
+    int B, H, W, M;
+    int np_in, np_res, np_y, np_z;
+    long long ps_in, ps_res, ps_y, ps_z;      // bytes between planes
+    unsigned plane_bytes_in, plane_bytes_res;
+    int tiles;
+    int* range_flag;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* glb_ptr;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#define CH_MM(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c_, 0, 0, 0)
+
+__device__ __forceinline__ f16x8 pack_frag(u32x2 lo, u32x2 hi)
+{
+    const u32x4 q = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(f16x8, q);
+}
+
+// four fp32 -> the two fp16 planes of four consecutive channels (8 bytes per plane)
+__device__ __forceinline__ void split4_f16(const float (&v)[4], u32x2& h, u32x2& l)
+{
+    unsigned h0, h1, l0, l1;
+    split2_f16(f32x2{v[0], v[1]}, h0, l0);
+    split2_f16(f32x2{v[2], v[3]}, h1, l1);
+    h = u32x2{h0, h1};
+    l = u32x2{l0, l1};
+}
+
+// Workgroup = 4 consumer waves (32 pixels each, every channel) + 2 producer waves issuing all LDS-DMA -- activations and weights of the
+// 3x3's six (channel slab, ky) stages, then per tile nine tail stages carrying conv3's and conv1's weights AND the shortcut tensor, so
+// that every HBM read of the kernel is an asynchronous copy running two stages ahead of its use.  Ring of three slots, one barrier per
+// stage (conv_kxr.hip).  The consumers' tail is software-pipelined by one stage: stage j issues conv3 of half-group j, then conv1' of
+// K-slab j - 1 (whose B fragments the previous stage's epilogue left in registers), then the epilogue of half-group j -- which runs on
+// the VALU while conv1's MFMAs drain.
+__global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grid = gridDim.x;
+    const int n_seq = (a.tiles - (int)blockIdx.x + grid - 1) / grid;          // tiles blockIdx.x, + grid, ...
+    if (n_seq <= 0) return;
+    constexpr int S = (CH_P / 32) * 3;                                        // main stages per tile: (channel slab, ky)
+    constexpr int SG = S + CH_TAIL_STAGES;                                    // stages per tile
+    const int HW = a.H * a.W;
+    float* bias_lds = reinterpret_cast<float*>(smem + CH_BIAS_OFF);           // b2 [64] | b3 [256] | b1' [64]
+    for (int i = tid; i < 384; i += CH_THREADS)
+        bias_lds[i] = i < 64 ? (a.b2 ? a.b2[i] : 0.0f) : i < 320 ? (a.b3 ? a.b3[i - 64] : 0.0f) : ((a.z && a.b1) ? a.b1[i - 320] : 0.0f);
+    __syncthreads();
+
+    if (wave >= CH_CONSUMERS) {
+        // ------------------------------------------------------------------------------------------------------------ producer
+        constexpr int NXD = CH_NRG * 2, XDW = (NXD + CH_PRODUCERS - 1) / CH_PRODUCERS;       // 18 activation pieces: 9 per producer
+        constexpr int NWD = 3 * 2 * 4, WDW = NWD / CH_PRODUCERS;                              // 24 weight pieces: 12 per producer
+        constexpr int TWD = CH_TW_BYTES / 1024 / CH_PRODUCERS;                                // 16 tail weight pieces: 8 per producer
+        constexpr int TRD = 2 * (CH_BM / 16) / CH_PRODUCERS;                                  // 16 shortcut pieces: 8 per producer
+        const int pw_ = wave - CH_CONSUMERS;
+        __amdgpu_buffer_rsrc_t xr[2], rr[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xin) + (size_t)p * a.ps_in, 0, (int)a.plane_bytes_in, 0x00020000);
+            rr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.res) + (size_t)p * a.ps_res, 0, (int)a.plane_bytes_res, 0x00020000);
+        }
+        int dbase[XDW];
+        unsigned dmask[XDW];
+        int m0 = 0;
+        auto setup = [&](int tile) {
+            m0 = tile * CH_BM;
+#pragma unroll
+            for (int i = 0; i < XDW; ++i) {
+                const int piece = min(pw_ + CH_PRODUCERS * i, NXD - 1);
+                const int rg = piece % CH_NRG;
+                const int j = rg * 16 + (lane >> 2);
+                const int q = m0 - 1 + j;
+                const bool okq = j < CH_BM + 2 && q >= 0 && q < a.M;
+                const int local = okq ? q : 0;
+                const int y = (local % HW) / a.W;
+                unsigned vm = 0;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+                    if ((unsigned)(y + ky - 1) < (unsigned)a.H) vm |= 1u << ky;
+                dmask[i] = okq ? vm : 0u;
+                dbase[i] = (q - a.W) * 64 + (((lane & 3) ^ swz(j)) << 4);
+            }
+        };
+        int buf = 0, s_in = 0, t_in = 0;
+        // issues the next stage; returns its kind: 0 main (21 DMAs per producer), 1 tail with shortcut (16), 2 last tail (4)
+        auto issue = [&]() -> int {
+            uint8_t* sb = smem + buf * CH_BUF;
+            int kind = 0;
+            if (s_in < S) {
+                if (s_in == 0) setup((int)blockIdx.x + t_in * grid);
+                const int cs = s_in / 3, ky = s_in - 3 * cs;
+                const int uni = cs * (a.np_in * 64) + ky * (a.W * 64);
+#pragma unroll
+                for (int i = 0; i < XDW; ++i) {
+                    const int piece = min(pw_ + CH_PRODUCERS * i, NXD - 1);
+                    const int p = piece / CH_NRG, rg = piece - p * CH_NRG;
+                    const unsigned oob = ((dmask[i] >> ky) & 1u) ^ 1u;
+                    const unsigned off = (unsigned)(dbase[i] + uni) | (oob << 31);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p & 1], (lds_ptr)(sb + p * CH_XPL + rg * 1024), 16, off, 0, 0, 0);
+                }
+                const uint8_t* wsrc = a.w2 + (size_t)s_in * CH_WBUF;
+#pragma unroll
+                for (int k = 0; k < WDW; ++k) {
+                    const int idx = pw_ + CH_PRODUCERS * k;
+                    __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + CH_XBUF + idx * 1024), 16, 0, 0);
+                }
+            } else {
+                const int j = s_in - S;
+                const uint8_t* wsrc = a.wt + (size_t)j * CH_TW_BYTES;
+                if (j < CH_TAIL_STAGES - 1) {
+                    kind = 1;
+#pragma unroll
+                    for (int k = 0; k < TWD; ++k) {
+                        const int idx = pw_ + CH_PRODUCERS * k;
+                        __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + idx * 1024), 16, 0, 0);
+                    }
+                    // shortcut of half-group j (channel slab j): piece = (plane, 16 pixels); lane -> (pixel, 16-byte chunk), chunk-swizzled like the 3x3's rows
+                    const int uni = j * (a.np_res * 64);
+#pragma unroll
+                    for (int k = 0; k < TRD; ++k) {
+                        const int piece = pw_ + CH_PRODUCERS * k;
+                        const int p = piece >> 3, rg = piece & 7;
+                        const int row = rg * 16 + (lane >> 2);
+                        const unsigned oob = m0 + row >= a.M ? 1u : 0u;
+                        const unsigned off = (unsigned)((m0 + row) * 64 + (((lane & 3) ^ swz(row)) << 4) + uni) | (oob << 31);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr[p & 1], (lds_ptr)(sb + CH_TRES + p * (CH_BM * 64) + rg * 1024), 16, off, 0, 0, 0);
+                    }
+                } else {
+                    kind = 2;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int idx = 8 + pw_ + CH_PRODUCERS * k;       // conv1' half only
+                        __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + idx * 1024), 16, 0, 0);
+                    }
+                }
+            }
+            if (++buf == CH_D) buf = 0;
+            if (++s_in == SG) { s_in = 0; ++t_in; }
+            return kind;
+        };
+        const int G = SG * n_seq;
+        issue();                                     // G >= 15
+        for (int g = 1; g < G; ++g) {
+            // the stage before the one just issued has landed when only this one's DMAs are still in flight
+            const int kind = issue();
+            if (kind == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(XDW + WDW) : "memory");
+            else if (kind == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TWD + TRD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------- consumer
+    const int r16 = lane & 15, kc = lane >> 4;
+    const int aoff0 = lds_off(r16, kc);                    // a weight fragment's offset inside its 1-KB tile
+    const float ls = 1.0f / STM_F16_LOW_SCALE;
+    int boff[CH_PT][3];
+    f32x4 acc[4][CH_PT], accl[4][CH_PT];
+    int buf = 0;
+    for (int t_seq = 0; t_seq < n_seq; ++t_seq) {
+        const int m0 = ((int)blockIdx.x + t_seq * grid) * CH_BM;
+        int mpx[CH_PT], roff[CH_PT];
+#pragma unroll
+        for (int t = 0; t < CH_PT; ++t) {
+            const int row0 = 16 * CH_PT * wave + 16 * t + r16;
+            const int m = m0 + row0;
+            mpx[t] = m;
+            roff[t] = row0 * 64 + (kc & 1) * 8;            // this lane's 8 bytes of a staged shortcut row: chunk 2 q + (kc >> 1), half kc & 1
+            const bool okm = m < a.M;
+            const int x = okm ? m % a.W : 0;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const bool v = okm && (unsigned)(x + kx - 1) < (unsigned)a.W;
+                boff[t][kx] = lds_off(v ? row0 + kx : CH_BM + 2, kc);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < CH_PT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[c][t][r] = 0.0f; accl[c][t][r] = 0.0f; }
+
+        // ---- conv2: six stages of three taps
+        for (int s = 0; s < S; ++s) {
+            asm volatile("s_barrier" ::: "memory");
+            const uint8_t* xs = smem + buf * CH_BUF;
+            if (++buf == CH_D) buf = 0;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                f16x8 bh[CH_PT], bl[CH_PT];
+#pragma unroll
+                for (int t = 0; t < CH_PT; ++t) {
+                    bh[t] = *reinterpret_cast<const f16x8*>(xs + boff[t][kx]);
+                    bl[t] = *reinterpret_cast<const f16x8*>(xs + CH_XPL + boff[t][kx]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(xs + CH_XBUF + ((kx * 2) * 4 + c) * 1024 + aoff0);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(xs + CH_XBUF + ((kx * 2 + 1) * 4 + c) * 1024 + aoff0);
+#pragma unroll
+                    for (int t = 0; t < CH_PT; ++t) {
+                        accl[c][t] = CH_MM(ah, bl[t], accl[c][t]);
+                        acc[c][t] = CH_MM(ah, bh[t], acc[c][t]);
+                        accl[c][t] = CH_MM(al, bh[t], accl[c][t]);
+                    }
+                }
+            }
+        }
+        // ---- mid2 = relu(conv2 + b2), split: B fragments of conv3's two K-slabs (slab s = channel tiles 2s, 2s + 1)
+        f16x8 m2h[2][CH_PT], m2l[2][CH_PT];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < CH_PT; ++t) {
+                u32x2 h[2], l[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int c = 2 * s + q;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + 16 * c + 4 * kc);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaxf(__builtin_fmaf(acc[c][t][r] + accl[c][t][r] * ls, a.scale2, bv[r]), 0.0f);
+                    split4_f16(v, h[q], l[q]);
+                }
+                m2h[s][t] = pack_frag(h[0], h[1]);
+                m2l[s][t] = pack_frag(l[0], l[1]);
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < CH_PT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[c][t][r] = 0.0f; accl[c][t][r] = 0.0f; }       // now conv1's accumulators
+        // ---- tail: conv3 in eight half-groups of 32 output channels (= one K-slab of conv1'), pipelined by one stage
+        f16x8 yh[CH_PT], yl[CH_PT];
+#pragma unroll
+        for (int t = 0; t < CH_PT; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { yh[t][e] = (_Float16)0.0f; yl[t][e] = (_Float16)0.0f; }
+        for (int j = 0; j < CH_TAIL_STAGES; ++j) {
+            asm volatile("s_barrier" ::: "memory");
+            const uint8_t* wb = smem + buf * CH_BUF;
+            if (++buf == CH_D) buf = 0;
+            f32x4 a3[2][CH_PT], a3l[2][CH_PT];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int t = 0; t < CH_PT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a3[q][t][r] = 0.0f; a3l[q][t][r] = 0.0f; }
+            if (j < CH_TAIL_STAGES - 1) {
+                // conv3, half-group j: output channel tiles q = 0, 1 over the two K-slabs
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + CH_TW3 + ((q * 2 + s) * 2) * 1024 + aoff0);
+                        const f16x8 al = *reinterpret_cast<const f16x8*>(wb + CH_TW3 + ((q * 2 + s) * 2 + 1) * 1024 + aoff0);
+#pragma unroll
+                        for (int t = 0; t < CH_PT; ++t) {
+                            a3l[q][t] = CH_MM(ah, m2l[s][t], a3l[q][t]);
+                            a3[q][t] = CH_MM(ah, m2h[s][t], a3[q][t]);
+                            a3l[q][t] = CH_MM(al, m2h[s][t], a3l[q][t]);
+                        }
+                    }
+            }
+            if (j > 0 && a.z) {
+                // conv1', K-slab j - 1: the y fragments of the previous stage
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + CH_TW1 + (c * 2) * 1024 + aoff0);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(wb + CH_TW1 + (c * 2 + 1) * 1024 + aoff0);
+#pragma unroll
+                    for (int t = 0; t < CH_PT; ++t) {
+                        accl[c][t] = CH_MM(ah, yl[t], accl[c][t]);
+                        acc[c][t] = CH_MM(ah, yh[t], acc[c][t]);
+                        accl[c][t] = CH_MM(al, yh[t], accl[c][t]);
+                    }
+                }
+            }
+            if (j < CH_TAIL_STAGES - 1) {
+                // y = relu(conv3 + b3 + shortcut): store its planes, keep them as the B fragment of conv1's K-slab j
+#pragma unroll
+                for (int t = 0; t < CH_PT; ++t) {
+                    u32x2 h[2], l[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int och = 32 * j + 16 * q + 4 * kc;
+                        const uint8_t* rp = wb + CH_TRES + roff[t] + (((2 * q + (kc >> 1)) ^ swz(16 * t + r16)) << 4);
+                        const f16x4 rh = *reinterpret_cast<const f16x4*>(rp);
+                        const f16x4 rl = *reinterpret_cast<const f16x4*>(rp + CH_BM * 64);
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + 64 + och);
+                        float resv[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) resv[r] = __builtin_fmaf((float)rl[r], ls, (float)rh[r]);
+                        float v[4];
+                        unsigned m4 = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = __builtin_fmaf(a3[q][t][r] + a3l[q][t][r] * ls, a.scale3, bv[r]);
+                            v[r] += resv[r];
+                            v[r] = __builtin_fmaxf(v[r], 0.0f);
+                            m4 = max(m4, __builtin_bit_cast(unsigned, v[r]) & 0x7fffffffu);
+                        }
+                        if (m4 > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
+                        split4_f16(v, h[q], l[q]);
+                        if (mpx[t] < a.M) {
+                            uint8_t* yp = a.y + (((size_t)(och >> 5) * a.np_y + mpx[t]) * 32 + (och & 31)) * 2;
+                            *reinterpret_cast<u32x2*>(yp) = h[q];
+                            *reinterpret_cast<u32x2*>(yp + a.ps_y) = l[q];
+                        }
+                    }
+                    yh[t] = pack_frag(h[0], h[1]);
+                    yl[t] = pack_frag(l[0], l[1]);
+                }
+            }
+        }
+        // ---- z = relu(conv1' + b1')
+        if (a.z) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + 320 + 16 * c + 4 * kc);
+#pragma unroll
+                for (int t = 0; t < CH_PT; ++t) {
+                    if (mpx[t] >= a.M) continue;
+                    float v[4];
+                    unsigned m4 = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = __builtin_fmaxf(__builtin_fmaf(acc[c][t][r] + accl[c][t][r] * ls, a.scale1, bv[r]), 0.0f);
+                        m4 = max(m4, __builtin_bit_cast(unsigned, v[r]) & 0x7fffffffu);
+                    }
+                    if (m4 > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
+                    u32x2 h, l;
+                    split4_f16(v, h, l);
+                    const int zc = 16 * c + 4 * kc;
+                    uint8_t* zp = a.z + (((size_t)(zc >> 5) * a.np_z + mpx[t]) * 32 + (zc & 31)) * 2;
+                    *reinterpret_cast<u32x2*>(zp) = h;
+                    *reinterpret_cast<u32x2*>(zp + a.ps_z) = l;
+                }
+            }
+        }
+    }
+#endif
+}
+
+// Tail weights, stage j = 0 .. 8 of 16 KB:
+//   conv3 tiles [q 2][s 2][plane 2] x 1 KB of half-group j (rows = output channels 32 j + 16 q + r16, K-slab s of the 64 inputs; zeros for j = 8),
+//   conv1' tiles [c 4][plane 2] x 1 KB of K-slab j - 1 (rows = output channels 16 c + r16, inputs 32 (j - 1) ..; zeros for j = 0),
+// each 1-KB tile in the fragment layout lds_off(row, chunk kc) with the chained K order: value e of chunk kc = input channel
+// 32 slab + (e < 4 ? 4 kc + e : 16 + 4 kc + e - 4).  One thread per (stage, tile, row, chunk).
+__global__ __launch_bounds__(256) void chain_pack_tail_kernel(const float* __restrict__ w3, const float* __restrict__ w1, uint8_t* __restrict__ wt,
+                                                              float ws3, float ws1)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;                // 9 stages x 8 tiles x 16 rows x 4 chunks
+    if (idx >= CH_TAIL_STAGES * 8 * 64) return;
+    const int kcq = idx & 3, row = (idx >> 2) & 15, tl = (idx >> 6) & 7, j = idx >> 9;
+    unsigned pl[2][4];
+    const bool is3 = tl < 4;                                       // tiles 0..3: conv3 (q, s); 4..7: conv1' (c)
+    const int q = tl >> 1, s = tl & 1, c = tl - 4;
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = 2 * e2 + h;
+            const int perm = e < 4 ? 4 * kcq + e : 16 + 4 * kcq + (e - 4);
+            if (is3) v[h] = j < 8 ? w3[(size_t)(32 * j + 16 * q + row) * CH_P + 32 * s + perm] * ws3 : 0.0f;
+            else v[h] = (w1 && j > 0) ? w1[(size_t)(16 * c + row) * (4 * CH_P) + 32 * (j - 1) + perm] * ws1 : 0.0f;
+        }
+        split2_f16(f32x2{v[0], v[1]}, pl[0][e2], pl[1][e2]);
+    }
+    uint8_t* base = wt + (size_t)j * CH_TW_BYTES;
+    uint8_t* tile = is3 ? base + CH_TW3 + ((q * 2 + s) * 2) * 1024 : base + CH_TW1 + (c * 2) * 1024;
+    *reinterpret_cast<u32x4*>(tile + lds_off(row, kcq)) = u32x4{pl[0][0], pl[0][1], pl[0][2], pl[0][3]};
+    *reinterpret_cast<u32x4*>(tile + 1024 + lds_off(row, kcq)) = u32x4{pl[1][0], pl[1][1], pl[1][2], pl[1][3]};
+}
+
+}  // namespace
+
+extern "C" size_t stm_chain_tail_weight_bytes(void) { return (size_t)CH_TAIL_STAGES * CH_TW_BYTES; }
+
+// conv3 weight [256][64] and (optional) the next conv1 weight [64][256], both 1x1 OIHW fp32, times their power-of-two scales
+extern "C" int stm_chain_pack_tail_f32(const float* w3, const float* w1_next, void* packed, float wscale3, float wscale1, stm_stream_t stream)
+{
+    STM_REQUIRE(w3 && packed, STM_ENULL, "stm_chain_pack_tail_f32: w3 / packed must be non-NULL");
+    STM_REQUIRE((uintptr_t)packed % 16 == 0 && wscale3 > 0.0f && (!w1_next || wscale1 > 0.0f), STM_EINVAL, "stm_chain_pack_tail_f32: alignment / scales");
+    hipLaunchKernelGGL(chain_pack_tail_kernel, dim3(stm_cdiv(CH_TAIL_STAGES * 8 * 64, 256)), dim3(256), 0, stm_hs(stream), w3, w1_next, static_cast<uint8_t*>(packed),
+                       wscale3, wscale1);
+    STM_CHECK_LAUNCH("chain_pack_tail_kernel");
+    return STM_OK;
+}
+
+// mid1 [B, H, W, 64] planes, shortcut x [B, H, W, 256] planes -> y [B, H, W, 256] planes (and z [B, H, W, 64] planes when z_planes and the
+// packed tail holds the next block's conv1).  w2_packed: stm_conv_pack_weights_kxr_f32 of the 3x3 weight [64, 64, 3, 3] (one group, 64
+// real channels, fmt 1); tail_packed: stm_chain_pack_tail_f32.  np_* = pixels per channel slab of each buffer (0 = B*H*W), plane strides dense.
+extern "C" int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_planes, void* y_planes, void* z_planes, const void* w2_packed,
+                                        const void* tail_packed, const float* b2, const float* b3, const float* b1_next, float out_scale2,
+                                        float out_scale3, float out_scale1, int B, int H, int W, stm_stream_t stream)
+{
+    const char* who = "stm_bottleneck_chain_f32";
+    STM_REQUIRE(mid1_planes && x_planes && y_planes && w2_packed && tail_packed, STM_ENULL, "%s: NULL argument", who);
+    STM_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)B * H * W < ((int64_t)1 << 24), STM_EINVAL, "%s: bad image batch", who);
+    const int64_t M = (int64_t)B * H * W;
+    STM_REQUIRE(8 * M * 64 < ((int64_t)1 << 31), STM_EUNSUPPORTED, "%s: plane larger than 2 GiB", who);
+    for (const void* p : {mid1_planes, x_planes, (const void*)y_planes, (const void*)z_planes, w2_packed, tail_packed})
+        STM_REQUIRE((uintptr_t)p % 16 == 0, STM_EINVAL, "%s: 16-byte alignment required", who);
+    ChainArgs a;
+    a.xin = static_cast<const uint8_t*>(mid1_planes); a.res = static_cast<const uint8_t*>(x_planes);
+    a.y = static_cast<uint8_t*>(y_planes); a.z = static_cast<uint8_t*>(z_planes);
+    a.w2 = static_cast<const uint8_t*>(w2_packed); a.wt = static_cast<const uint8_t*>(tail_packed);
+    a.b2 = b2; a.b3 = b3; a.b1 = b1_next;
+    a.scale2 = out_scale2 > 0.0f ? out_scale2 : 1.0f; a.scale3 = out_scale3 > 0.0f ? out_scale3 : 1.0f; a.scale1 = out_scale1 > 0.0f ? out_scale1 : 1.0f;
+    a.B = B; a.H = H; a.W = W; a.M = (int)M;
+    a.np_in = a.np_res = a.np_y = a.np_z = (int)M;
+    a.ps_in = 2 * M * 64; a.ps_res = 8 * M * 64; a.ps_y = 8 * M * 64; a.ps_z = 2 * M * 64;
+    a.plane_bytes_in = (unsigned)(2 * M * 64);
+    a.plane_bytes_res = (unsigned)(8 * M * 64);
+    a.tiles = stm_cdiv(M, CH_BM);
+    a.range_flag = stm_internal_range_flag();
+    const size_t lds = CH_LDS;
+    static std::atomic<bool> reserved[CH_MAX_DEVICES];
+    static std::atomic<int> n_cus[CH_MAX_DEVICES];
+    int dev = 0;
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CH_MAX_DEVICES;
+    if (!have_dev || !reserved[dev].load(std::memory_order_relaxed)) {
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                    STM_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
+        if (have_dev) reserved[dev].store(true, std::memory_order_relaxed);
+    }
+    int cus = have_dev ? n_cus[dev].load(std::memory_order_relaxed) : 0;
+    if (cus <= 0) {
+        hipDeviceProp_t prop;
+        cus = (have_dev && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        if (have_dev) n_cus[dev].store(cus, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(conv_chain_kernel, dim3(std::min(a.tiles, cus)), dim3(CH_THREADS), lds, stm_hs(stream), a);
+    STM_CHECK_LAUNCH("conv_chain_kernel");
+    return STM_OK;
+}

@@ -327,6 +327,7 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
                 if (a.relu) v[r] = __builtin_fmaxf(v[r], 0.0f);
             }
             const int oc = jb.out_ch0 + ch;
+            if ((KX_ABL & 16) && v[0] != 12345.678f) continue;      // ablation: no output stores
             if (a.out_f32) *reinterpret_cast<f32x4*>(a.out_f32 + (size_t)m * a.out_ld + oc) = f32x4{v[0], v[1], v[2], v[3]};
             if (a.out_pl) {
                 unsigned m4 = 0;

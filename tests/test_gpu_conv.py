@@ -711,3 +711,94 @@ def test_conv_dual_source_vs_oracle(case, fmt):
     c3 = PlanarConv(w3.to(DEV), b3.to(DEV), 1, 0, relu=True, fmt=fmt, tile_n=tile_n)
     y2 = c3(midp, ("img", B, Ho, Wo), out="f32", residual=ds(xp, ("img", B, H2, W2))).cpu().view(ref.shape)
     assert (y2 - y32).abs().max().item() < (1e-5 if fmt == 1 else 2e-2) * max(1.0, ref.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------- layer1's bottleneck chain as one kernel
+def _chain_layers(seed=0):
+    """conv2 3x3 64 -> 64, conv3 1x1 64 -> 256, next conv1 1x1 256 -> 64 with BatchNorm-folded-like biases."""
+    w2 = rnd(64, 64, 3, 3, seed=seed + 1, scale=(64 * 9) ** -0.5)
+    w3 = rnd(256, 64, 1, 1, seed=seed + 2, scale=64 ** -0.5)
+    w1 = rnd(64, 256, 1, 1, seed=seed + 3, scale=256 ** -0.5)
+    b2, b3, b1 = rnd(64, seed=seed + 4, scale=0.3), rnd(256, seed=seed + 5, scale=0.3), rnd(64, seed=seed + 6, scale=0.3)
+    return w2, w3, w1, b2, b3, b1
+
+
+def _chain_pack(w2, w3, w1):
+    from stmask_amd import _lib
+    g = _lib.ConvGeom()
+    g.C, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.groups, g.fmt = 64, 64, 3, 3, 1, 1, 1, 1, 1, 1
+    ops.planar_range_flag()
+    w2p, s2 = ops.conv_pack_weights_kxr(w2.to(DEV), g)
+    tail, s3, s1 = ops.chain_pack_tail(w3.to(DEV), w1.to(DEV) if w1 is not None else None)
+    return w2p, tail, (s2, s3, s1)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 40), (3, 13, 17), (1, 5, 7), (1, 96, 160)])
+@pytest.mark.parametrize("with_next", [True, False])
+def test_bottleneck_chain_vs_fp64_and_vs_three_launches(case, with_next):
+    """stm_bottleneck_chain_f32 (csrc/conv_chain.hip): relu(conv3(relu(conv2(mid1))) + x) and the next block's relu(conv1(.)) from one
+    launch against (a) the same three layers in fp64 -- bound 4e-6 of the magnitude sums, twice a single layer's (two chained products
+    of plane-split intermediates) -- and (b) the three stm_conv2d_planar_f32 launches it replaces: same products, intermediates split
+    into the same fp16 planes, only the order of the sums inside a K-slab differs.  Tiles straddle rows and images, the last is ragged."""
+    from stmask_amd.planar import PlanarConv
+    B, H, W = case
+    w2, w3, w1, b2, b3, b1 = _chain_layers()
+    mid1 = rnd(B, H, W, 64, seed=11).abs()                       # post-ReLU input, like the real one
+    x = rnd(B, H, W, 256, seed=12).abs()
+    w2p, tail, scales = _chain_pack(w2, w3, w1 if with_next else None)
+    m1p, xp = ops.split_planes(mid1.to(DEV), 1), ops.split_planes(x.to(DEV), 1)
+    y, z = ops.bottleneck_chain(m1p, xp, w2p, tail, b2.to(DEV), b3.to(DEV), b1.to(DEV) if with_next else None, scales, B, H, W, want_z=with_next)
+    assert (z is None) == (not with_next)
+    # (a) fp64 of the layers, with the magnitude sums as the scale of the bound
+    d = torch.float64
+    c2 = F.conv2d(mid1.permute(0, 3, 1, 2).to(d), w2.to(d), b2.to(d), padding=1).relu()
+    c3 = (F.conv2d(c2, w3.to(d), b3.to(d)) + x.permute(0, 3, 1, 2).to(d)).relu()
+    mag3 = F.conv2d(F.conv2d(mid1.permute(0, 3, 1, 2).to(d), w2.abs().to(d), b2.abs().to(d), padding=1), w3.abs().to(d), b3.abs().to(d)) + x.permute(0, 3, 1, 2).to(d)
+    got_y = planes_to_f32(y).cpu().view(B, H, W, 256).permute(0, 3, 1, 2).to(d)
+    assert ((got_y - c3).abs() / mag3.clamp_min(1e-6)).max().item() < 4e-6
+    if with_next:
+        c1 = F.conv2d(c3, w1.to(d), b1.to(d)).relu()
+        mag1 = F.conv2d(mag3, w1.abs().to(d), b1.abs().to(d))
+        got_z = planes_to_f32(z).cpu().view(B, H, W, 64).permute(0, 3, 1, 2).to(d)
+        assert ((got_z - c1).abs() / mag1.clamp_min(1e-6)).max().item() < 6e-6
+    # (b) the three launches
+    l2 = PlanarConv(w2.to(DEV), b2.to(DEV), 1, 1, relu=True, fmt=1)
+    l3 = PlanarConv(w3.to(DEV), b3.to(DEV), 1, 0, relu=True, fmt=1)
+    m2 = l2(m1p, ("img", B, H, W))
+    y3 = l3(m2, ("img", B, H, W), residual=xp)
+    ya, yb = planes_to_f32(y), planes_to_f32(y3)
+    assert (ya - yb).abs().max().item() < 2e-5 * max(1.0, yb.abs().max().item())
+    if with_next:
+        l1 = PlanarConv(w1.to(DEV), b1.to(DEV), 1, 0, relu=True, fmt=1)
+        za, zb = planes_to_f32(z), planes_to_f32(l1(y3, ("img", B, H, W)))
+        assert (za - zb).abs().max().item() < 2e-5 * max(1.0, zb.abs().max().item())
+
+
+def test_bottleneck_chain_known_answers_and_arguments():
+    """Identity weights: conv2 = centre tap identity, conv3 = 4 copies, conv1' = pick-one-copy -> y = relu(mid1 copies + x), z = a copy of
+    y's channels; exact to the 22 bits of the planes.  One-hot off-centre taps shift the image with zero padding across rows / images.
+    Bad shapes are refused."""
+    B, H, W = 2, 6, 9
+    mid1, x = rnd(B, H, W, 64, seed=3).abs(), rnd(B, H, W, 256, seed=4)
+    for (ky, kx) in [(1, 1), (0, 0), (2, 1), (1, 2)]:
+        w2 = torch.zeros(64, 64, 3, 3)
+        w2[:, :, ky, kx] = torch.eye(64)
+        w3 = torch.zeros(256, 64)
+        for k in range(4):
+            w3[64 * k:64 * (k + 1)] = torch.eye(64) * (k + 1)
+        w1 = torch.zeros(64, 256)
+        w1[:, 64:128] = torch.eye(64)                         # z = y[:, 64:128]
+        w2p, tail, scales = _chain_pack(w2, w3.view(256, 64, 1, 1), w1.view(64, 256, 1, 1))
+        y, z = ops.bottleneck_chain(ops.split_planes(mid1.to(DEV), 1), ops.split_planes(x.to(DEV), 1), w2p, tail, None, None, None, scales, B, H, W)
+        sh = torch.zeros(B, H, W, 64)
+        dy, dx = ky - 1, kx - 1
+        ys, xs_ = slice(max(0, -dy), min(H, H - dy)), slice(max(0, -dx), min(W, W - dx))
+        yd, xd = slice(max(0, dy), min(H, H + dy)), slice(max(0, dx), min(W, W + dx))
+        sh[:, ys, xs_] = mid1[:, yd, xd]
+        exp = (torch.cat([sh * (k + 1) for k in range(4)], -1) + x).relu()
+        got = planes_to_f32(y).cpu().view(B, H, W, 256)
+        assert (got - exp).abs().max().item() <= 2.0 ** -20 * exp.abs().max().item(), (ky, kx)
+        gz = planes_to_f32(z).cpu().view(B, H, W, 64)
+        assert (gz - got[..., 64:128]).abs().max().item() <= 2.0 ** -20 * exp.abs().max().item(), (ky, kx)
+    with pytest.raises(StmError):
+        ops.bottleneck_chain(ops.split_planes(mid1.to(DEV), 1), ops.split_planes(x.to(DEV), 1)[:, :4].contiguous(), w2p, tail, None, None, None, scales, B, H, W)
