@@ -1,7 +1,8 @@
 """conv_chain.hip against the three planar launches it replaces, at layer1's shape (96 x 160, 64 / 256 channels)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stmask_amd import ops, _lib
 from stmask_amd.planar import PlanarConv
 

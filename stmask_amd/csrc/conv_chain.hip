@@ -35,13 +35,15 @@ constexpr int CH_XROWS = CH_BM + 16, CH_NRG = CH_XROWS / 16;
 constexpr int CH_XPL = CH_XROWS * 64, CH_XBUF = 2 * CH_XPL;                 // staged rows: two planes
 constexpr int CH_WT = 4 * 16 * 64, CH_WBUF = 3 * 2 * CH_WT;                 // conv2 weights of one (channel slab, ky): 3 taps x 2 planes x 64 rows
 constexpr int CH_BUF = CH_XBUF + CH_WBUF;                                   // 43 008 B per ring slot
-constexpr int CH_D = 3;                                                     // (the producers' wait is written for a ring of three)
-// tail stage j = 0 .. 8: [conv3 weights of half-group j: 8 KB | conv1' weights of K-slab j - 1: 8 KB | shortcut of half-group j: 2 planes x 8 KB]
-constexpr int CH_TAIL_STAGES = 9, CH_TW3 = 0, CH_TW1 = 8192, CH_TRES = 16384, CH_TW_BYTES = 16384;
-constexpr int CH_BIAS_OFF = CH_D * CH_BUF, CH_LDS = CH_BIAS_OFF + (64 + 256 + 64) * 4;
+constexpr int CH_D = 3;                                                     // ring slots (the producers' wait is written for three)
+// tail stage j = 0 .. 8: [conv3 weights of half-group j: 8 KB | conv1' weights of K-slab j - 1: 8 KB]
+constexpr int CH_TAIL_STAGES = 9, CH_TW3 = 0, CH_TW1 = 8192, CH_TW_BYTES = 16384;
+constexpr int CH_RSLOTS = 2;              // half-groups of the shortcut tensor in flight per consumer wave (registers)
+// behind the ring: the consumers' mid2 fragments (8 KB per wave: 32 registers the tail cannot spare) and the three bias vectors
+constexpr int CH_PARK_OFF = CH_D * CH_BUF, CH_BIAS_OFF = CH_PARK_OFF + 4 * 8192, CH_LDS = CH_BIAS_OFF + (64 + 256 + 64) * 4;
+static_assert(CH_LDS <= 160 * 1024, "LDS");
 constexpr int CH_CONSUMERS = 4, CH_PRODUCERS = 2, CH_THREADS = 64 * (CH_CONSUMERS + CH_PRODUCERS);
 constexpr int CH_MAX_DEVICES = 32;
-static_assert(CH_TRES + 2 * CH_BM * 64 <= CH_BUF, "a tail stage must fit a ring slot");
 
 struct ChainArgs {
     const uint8_t* xin;      // mid1 planes [2][2][np_in][32]
@@ -55,9 +57,10 @@ struct ChainArgs {
     int B, H, W, M;
     int np_in, np_res, np_y, np_z;
     long long ps_in, ps_res, ps_y, ps_z;      // bytes between planes
-    unsigned plane_bytes_in, plane_bytes_res;
+    unsigned plane_bytes_in;
     int tiles;
     int* range_flag;
+    unsigned long long* dbg;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -65,12 +68,40 @@ typedef const __attribute__((address_space(1))) void* glb_ptr;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CH_NT
+#define CH_NT 0           // cache policy of the shortcut loads and the y / z stores: 2 = streaming (nt), 0 = default
+#endif
+#ifndef CH_TIMING
+#define CH_TIMING 0       // 1: consumer wave 0 of workgroup 0 records s_memtime around every barrier into the buffer given to stm_debug_chain_timing
+#endif
+#ifndef CH_ABL
+#define CH_ABL 0      // diagnostic builds (make EXTRA=-DCH_ABL=n, RESULTS ARE WRONG): 1 no stores, 2 no shortcut loads, 4 no tail MFMAs, 8 no tail epilogue, 16 no 3x3 MFMAs, 32 no DMA
+#endif
 #define CH_MM(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c_, 0, 0, 0)
 
 __device__ __forceinline__ f16x8 pack_frag(u32x2 lo, u32x2 hi)
 {
     const u32x4 q = {lo.x, lo.y, hi.x, hi.y};
     return __builtin_bit_cast(f16x8, q);
+}
+
+// The accumulator layout gives lane (pixel r16, row kc) channels 4 kc .. 4 kc + 3 of each 16-channel tile: 8 bytes, and a store
+// instruction writes 32-byte pieces of sixteen 64-byte slab rows.  Two gfx950 row swaps turn the lane's values of the two tiles of a
+// 32-channel slab (x0: tile 0, x1: tile 1) into channels 8 kc .. 8 kc + 7 of the slab: 16 bytes per lane, one KB contiguous per
+// instruction -- a quarter of the L2 write requests.  v_permlane32_swap exchanges rows 2, 3 of its first operand with rows 0, 1 of
+// the second, v_permlane16_swap rows 1, 3 of the first with rows 0, 2 of the second; both are their own inverse.
+__device__ __forceinline__ u32x4 slab_gather(u32x2 x0, u32x2 x1)
+{
+    const u32x2 a = __builtin_amdgcn_permlane32_swap(x0.x, x1.x, false, false), b = __builtin_amdgcn_permlane32_swap(x0.y, x1.y, false, false);
+    const u32x2 a2 = __builtin_amdgcn_permlane16_swap(a.x, a.y, false, false), b2 = __builtin_amdgcn_permlane16_swap(b.x, b.y, false, false);
+    return u32x4{a2.x, b2.x, a2.y, b2.y};
+}
+__device__ __forceinline__ void slab_scatter(u32x4 v, u32x2& x0, u32x2& x1)
+{
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(v.x, v.z, false, false), b = __builtin_amdgcn_permlane16_swap(v.y, v.w, false, false);
+    const u32x2 a2 = __builtin_amdgcn_permlane32_swap(a.x, a.y, false, false), b2 = __builtin_amdgcn_permlane32_swap(b.x, b.y, false, false);
+    x0 = u32x2{a2.x, b2.x};
+    x1 = u32x2{a2.y, b2.y};
 }
 
 // four fp32 -> the two fp16 planes of four consecutive channels (8 bytes per plane)
@@ -83,12 +114,16 @@ __device__ __forceinline__ void split4_f16(const float (&v)[4], u32x2& h, u32x2&
     l = u32x2{l0, l1};
 }
 
-// Workgroup = 4 consumer waves (32 pixels each, every channel) + 2 producer waves issuing all LDS-DMA -- activations and weights of the
-// 3x3's six (channel slab, ky) stages, then per tile nine tail stages carrying conv3's and conv1's weights AND the shortcut tensor, so
-// that every HBM read of the kernel is an asynchronous copy running two stages ahead of its use.  Ring of three slots, one barrier per
-// stage (conv_kxr.hip).  The consumers' tail is software-pipelined by one stage: stage j issues conv3 of half-group j, then conv1' of
-// K-slab j - 1 (whose B fragments the previous stage's epilogue left in registers), then the epilogue of half-group j -- which runs on
-// the VALU while conv1's MFMAs drain.
+// Workgroup = 4 consumer waves (32 pixels each, every channel) + 2 producer waves issuing all LDS-DMA: activations and weights of the
+// 3x3's six (channel slab, ky) stages, then per tile nine tail stages with conv3's and conv1's weights.  Ring of three slots, one
+// barrier per stage (conv_kxr.hip).  The SHORTCUT tensor -- 80 % of the bytes read -- does not go through the ring: two stages of
+// look-ahead are ~1.5 us, less than a loaded HBM round trip, and a ring stalled on it ran the kernel at 2.5 TB/s.  Each consumer lane
+// loads the shortcut values of its own accumulator elements (8 bytes per plane, tile and pixel) straight into registers, four
+// half-groups (64 registers) ahead of their use: the slot a stage's epilogue frees is refilled at once with the half-group four stages
+// on, across tile boundaries -- the next tile's first four half-groups arrive under this tile's last stages and the next 3x3.
+// The consumers' tail is software-pipelined by one stage: stage j issues conv3 of half-group j, then conv1' of K-slab j - 1 (whose B
+// fragments the previous stage's epilogue left in registers), then the epilogue of half-group j -- on the VALU while conv1's MFMAs drain.
+template <bool HAS_Z>
 __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -96,14 +131,20 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grid = gridDim.x;
-    const int n_seq = (a.tiles - (int)blockIdx.x + grid - 1) / grid;          // tiles blockIdx.x, + grid, ...
+    // Persistent workgroups over the tile ids blockIdx.x, + grid, ...; ids are dealt round-robin to the 8 XCDs, so id -> tile
+    // (id & 7) * per_xcd + (id >> 3) gives each XCD (= each L2) a contiguous run of pixels: the rows a tile's three ky stages read are the
+    // rows of its neighbours, one L2 fill instead of three (measured: 943 MB fetched for 629 MB of input before).  Ids past the padded
+    // count map to tiles behind M: every access of such a tile is out of range.
+    const int per_xcd = (a.tiles + 7) >> 3;
+    const int n_seq = (8 * per_xcd - (int)blockIdx.x + grid - 1) / grid;
     if (n_seq <= 0) return;
+    auto tile_of = [&](int id) { return (id & 7) * per_xcd + (id >> 3); };
     constexpr int S = (CH_P / 32) * 3;                                        // main stages per tile: (channel slab, ky)
     constexpr int SG = S + CH_TAIL_STAGES;                                    // stages per tile
     const int HW = a.H * a.W;
     float* bias_lds = reinterpret_cast<float*>(smem + CH_BIAS_OFF);           // b2 [64] | b3 [256] | b1' [64]
     for (int i = tid; i < 384; i += CH_THREADS)
-        bias_lds[i] = i < 64 ? (a.b2 ? a.b2[i] : 0.0f) : i < 320 ? (a.b3 ? a.b3[i - 64] : 0.0f) : ((a.z && a.b1) ? a.b1[i - 320] : 0.0f);
+        bias_lds[i] = i < 64 ? (a.b2 ? a.b2[i] : 0.0f) : i < 320 ? (a.b3 ? a.b3[i - 64] : 0.0f) : ((HAS_Z && a.b1) ? a.b1[i - 320] : 0.0f);
     __syncthreads();
 
     if (wave >= CH_CONSUMERS) {
@@ -111,23 +152,17 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
         constexpr int NXD = CH_NRG * 2, XDW = (NXD + CH_PRODUCERS - 1) / CH_PRODUCERS;       // 18 activation pieces: 9 per producer
         constexpr int NWD = 3 * 2 * 4, WDW = NWD / CH_PRODUCERS;                              // 24 weight pieces: 12 per producer
         constexpr int TWD = CH_TW_BYTES / 1024 / CH_PRODUCERS;                                // 16 tail weight pieces: 8 per producer
-        constexpr int TRD = 2 * (CH_BM / 16) / CH_PRODUCERS;                                  // 16 shortcut pieces: 8 per producer
         const int pw_ = wave - CH_CONSUMERS;
-        __amdgpu_buffer_rsrc_t xr[2], rr[2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xin) + (size_t)p * a.ps_in, 0, (int)a.plane_bytes_in, 0x00020000);
-            rr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.res) + (size_t)p * a.ps_res, 0, (int)a.plane_bytes_res, 0x00020000);
-        }
+        // activations: producer p stages plane p (nine row groups of 16 staged rows); the weight pieces are dealt round-robin
+        static_assert(CH_PRODUCERS == 2 && XDW == CH_NRG, "one activation plane per producer");
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xin) + (size_t)pw_ * a.ps_in, 0, (int)a.plane_bytes_in, 0x00020000);
         int dbase[XDW];
         unsigned dmask[XDW];
-        int m0 = 0;
         auto setup = [&](int tile) {
-            m0 = tile * CH_BM;
+            const int m0 = tile * CH_BM;
 #pragma unroll
             for (int i = 0; i < XDW; ++i) {
-                const int piece = min(pw_ + CH_PRODUCERS * i, NXD - 1);
-                const int rg = piece % CH_NRG;
+                const int rg = i;
                 const int j = rg * 16 + (lane >> 2);
                 const int q = m0 - 1 + j;
                 const bool okq = j < CH_BM + 2 && q >= 0 && q < a.M;
@@ -142,27 +177,26 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
             }
         };
         int buf = 0, s_in = 0, t_in = 0;
-        // issues the next stage; returns its kind: 0 main (21 DMAs per producer), 1 tail with shortcut (16), 2 last tail (4)
+        // issues the next stage; returns its kind: 0 main (21 DMAs per producer), 1 tail (8), 2 last tail (4)
         auto issue = [&]() -> int {
             uint8_t* sb = smem + buf * CH_BUF;
+            if (++buf == CH_D) buf = 0;
             int kind = 0;
             if (s_in < S) {
-                if (s_in == 0) setup((int)blockIdx.x + t_in * grid);
+                if (s_in == 0) setup(tile_of((int)blockIdx.x + t_in * grid));
                 const int cs = s_in / 3, ky = s_in - 3 * cs;
                 const int uni = cs * (a.np_in * 64) + ky * (a.W * 64);
 #pragma unroll
                 for (int i = 0; i < XDW; ++i) {
-                    const int piece = min(pw_ + CH_PRODUCERS * i, NXD - 1);
-                    const int p = piece / CH_NRG, rg = piece - p * CH_NRG;
                     const unsigned oob = ((dmask[i] >> ky) & 1u) ^ 1u;
                     const unsigned off = (unsigned)(dbase[i] + uni) | (oob << 31);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p & 1], (lds_ptr)(sb + p * CH_XPL + rg * 1024), 16, off, 0, 0, 0);
+                    if (!(CH_ABL & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + pw_ * CH_XPL + i * 1024), 16, off, 0, 0, 0);
                 }
                 const uint8_t* wsrc = a.w2 + (size_t)s_in * CH_WBUF;
 #pragma unroll
                 for (int k = 0; k < WDW; ++k) {
                     const int idx = pw_ + CH_PRODUCERS * k;
-                    __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + CH_XBUF + idx * 1024), 16, 0, 0);
+                    if (!(CH_ABL & 32)) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + CH_XBUF + idx * 1024), 16, 0, 0);
                 }
             } else {
                 const int j = s_in - S;
@@ -172,39 +206,28 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
 #pragma unroll
                     for (int k = 0; k < TWD; ++k) {
                         const int idx = pw_ + CH_PRODUCERS * k;
-                        __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + idx * 1024), 16, 0, 0);
-                    }
-                    // shortcut of half-group j (channel slab j): piece = (plane, 16 pixels); lane -> (pixel, 16-byte chunk), chunk-swizzled like the 3x3's rows
-                    const int uni = j * (a.np_res * 64);
-#pragma unroll
-                    for (int k = 0; k < TRD; ++k) {
-                        const int piece = pw_ + CH_PRODUCERS * k;
-                        const int p = piece >> 3, rg = piece & 7;
-                        const int row = rg * 16 + (lane >> 2);
-                        const unsigned oob = m0 + row >= a.M ? 1u : 0u;
-                        const unsigned off = (unsigned)((m0 + row) * 64 + (((lane & 3) ^ swz(row)) << 4) + uni) | (oob << 31);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr[p & 1], (lds_ptr)(sb + CH_TRES + p * (CH_BM * 64) + rg * 1024), 16, off, 0, 0, 0);
+                        if (!(CH_ABL & 32)) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + idx * 1024), 16, 0, 0);
                     }
                 } else {
                     kind = 2;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int idx = 8 + pw_ + CH_PRODUCERS * k;       // conv1' half only
-                        __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + idx * 1024), 16, 0, 0);
+                        if (!(CH_ABL & 32)) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + idx * 1024), 16, 0, 0);
                     }
                 }
             }
-            if (++buf == CH_D) buf = 0;
             if (++s_in == SG) { s_in = 0; ++t_in; }
             return kind;
         };
         const int G = SG * n_seq;
         issue();                                     // G >= 15
         for (int g = 1; g < G; ++g) {
-            // the stage before the one just issued has landed when only this one's DMAs are still in flight
+            // the stage before the one just issued has landed when only this one's DMAs are still in flight.  (A deeper look-ahead -- a
+            // ring of nine 16-KB sub-slots, up to eight tail stages ahead -- was measured: no change; the kernel is not waiting for LDS-DMA.)
             const int kind = issue();
             if (kind == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(XDW + WDW) : "memory");
-            else if (kind == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TWD + TRD) : "memory");
+            else if (kind == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TWD) : "memory");
             else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -217,16 +240,48 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
     const float ls = 1.0f / STM_F16_LOW_SCALE;
     int boff[CH_PT][3];
     f32x4 acc[4][CH_PT], accl[4][CH_PT];
+    // shortcut values of this lane's accumulator elements: slot = half-group mod 4, [channel tile q][pixel tile t], high / low plane
+    u32x4 rsh[CH_RSLOTS][CH_PT], rsl[CH_RSLOTS][CH_PT];     // as loaded: channels 8 kc .. 8 kc + 7 of the slab (slab_scatter at use)
+    // shortcut / y / z through buffer descriptors covering both planes: a pixel behind M gets bit 31 in its offset -- loads return 0, stores
+    // are dropped, and the epilogues stay free of branches (one basic block per stage: the scheduler can put the VALU work under the MFMAs)
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.res), 0, (int)(a.ps_res + (long long)a.np_res * 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(a.ps_y + (long long)a.np_y * 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(HAS_Z ? a.z : a.y, 0, HAS_Z ? (int)(a.ps_z + (long long)a.np_z * 128) : 0, 0x00020000);
+    auto px_off = [&](int m) { return (unsigned)(m * 64 + 16 * kc) | (m >= a.M ? 0x80000000u : 0u); };     // byte offset of (pixel m, channel 8 kc) in a slab
+    auto load_res = [&](int slot, int hg, const unsigned (&po)[CH_PT]) {
+#pragma unroll
+        for (int t = 0; t < CH_PT; ++t) {
+            if (CH_ABL & 2) { rsh[slot][t] = u32x4{0u, 0u, 0u, 0u}; rsl[slot][t] = u32x4{0u, 0u, 0u, 0u}; continue; }
+            rsh[slot][t] = __builtin_amdgcn_raw_buffer_load_b128(rr, po[t], hg * a.np_res * 64, CH_NT);
+            rsl[slot][t] = __builtin_amdgcn_raw_buffer_load_b128(rr, po[t], hg * a.np_res * 64 + (int)a.ps_res, CH_NT);
+        }
+    };
+    {
+        unsigned po[CH_PT];
+#pragma unroll
+        for (int t = 0; t < CH_PT; ++t) po[t] = px_off(tile_of((int)blockIdx.x) * CH_BM + 16 * CH_PT * wave + 16 * t + r16);
+#pragma unroll
+        for (int k = 0; k < CH_RSLOTS; ++k) load_res(k, k, po);
+    }
+    unsigned rng = 0;          // largest magnitude bits this lane produced (all values are post-ReLU: non-negative)
     int buf = 0;
+    int dbg_i = 0;
+    auto tick = [&]() {
+        if (CH_TIMING && a.dbg && blockIdx.x == 0 && wave == 0) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) a.dbg[dbg_i] = t; ++dbg_i; }
+    };
     for (int t_seq = 0; t_seq < n_seq; ++t_seq) {
-        const int m0 = ((int)blockIdx.x + t_seq * grid) * CH_BM;
-        int mpx[CH_PT], roff[CH_PT];
+        const int m0 = tile_of((int)blockIdx.x + t_seq * grid) * CH_BM;
+        const int m0_next = tile_of((int)blockIdx.x + (t_seq + 1) * grid) * CH_BM;
+        tick();
+        int mpx[CH_PT];
+        unsigned po[CH_PT], po_next[CH_PT];
 #pragma unroll
         for (int t = 0; t < CH_PT; ++t) {
             const int row0 = 16 * CH_PT * wave + 16 * t + r16;
             const int m = m0 + row0;
             mpx[t] = m;
-            roff[t] = row0 * 64 + (kc & 1) * 8;            // this lane's 8 bytes of a staged shortcut row: chunk 2 q + (kc >> 1), half kc & 1
+            po[t] = px_off(m);
+            po_next[t] = px_off(m0_next + row0);            // (behind the last tile: out of range, nothing is fetched)
             const bool okm = m < a.M;
             const int x = okm ? m % a.W : 0;
 #pragma unroll
@@ -244,9 +299,12 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
 
         // ---- conv2: six stages of three taps
         for (int s = 0; s < S; ++s) {
+            tick();
             asm volatile("s_barrier" ::: "memory");
+            tick();
             const uint8_t* xs = smem + buf * CH_BUF;
             if (++buf == CH_D) buf = 0;
+            if constexpr ((CH_ABL & 16) != 0) continue;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 f16x8 bh[CH_PT], bl[CH_PT];
@@ -268,8 +326,9 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                 }
             }
         }
-        // ---- mid2 = relu(conv2 + b2), split: B fragments of conv3's two K-slabs (slab s = channel tiles 2s, 2s + 1)
-        f16x8 m2h[2][CH_PT], m2l[2][CH_PT];
+        // ---- mid2 = relu(conv2 + b2), split: B fragments of conv3's two K-slabs (slab s = channel tiles 2s, 2s + 1), parked in this
+        // wave's own 8 KB of LDS (fragment (s, t, plane) at 1 KB each, lane-contiguous): every tail stage reads them back
+        uint8_t* park = smem + CH_PARK_OFF + wave * 8192 + lane * 16;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -284,8 +343,8 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                     for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaxf(__builtin_fmaf(acc[c][t][r] + accl[c][t][r] * ls, a.scale2, bv[r]), 0.0f);
                     split4_f16(v, h[q], l[q]);
                 }
-                m2h[s][t] = pack_frag(h[0], h[1]);
-                m2l[s][t] = pack_frag(l[0], l[1]);
+                *reinterpret_cast<f16x8*>(park + ((s * 2 + t) * 2) * 1024) = pack_frag(h[0], h[1]);
+                *reinterpret_cast<f16x8*>(park + ((s * 2 + t) * 2 + 1) * 1024) = pack_frag(l[0], l[1]);
             }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -299,34 +358,79 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
         for (int t = 0; t < CH_PT; ++t)
 #pragma unroll
             for (int e = 0; e < 8; ++e) { yh[t][e] = (_Float16)0.0f; yl[t][e] = (_Float16)0.0f; }
-        for (int j = 0; j < CH_TAIL_STAGES; ++j) {
+#pragma unroll
+        for (int j = 0; j < CH_TAIL_STAGES; ++j) {       // (unrolled: the shortcut slots are registers)
+            tick();
             asm volatile("s_barrier" ::: "memory");
+            tick();
             const uint8_t* wb = smem + buf * CH_BUF;
             if (++buf == CH_D) buf = 0;
+            // Order of a stage: conv3 tile q = 0 | conv3 tile q = 1 with the epilogue of q = 0 | conv1' of K-slab j - 1 with the epilogue of
+            // q = 1.  Each epilogue is ~90 VALU instructions behind 12 / 24 independent MFMAs.
             f32x4 a3[2][CH_PT], a3l[2][CH_PT];
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
+            u32x2 h[2][CH_PT], l[2][CH_PT];
+            auto conv3_tile = [&](int q) {
 #pragma unroll
                 for (int t = 0; t < CH_PT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { a3[q][t][r] = 0.0f; a3l[q][t][r] = 0.0f; }
-            if (j < CH_TAIL_STAGES - 1) {
-                // conv3, half-group j: output channel tiles q = 0, 1 over the two K-slabs
+                if (CH_ABL & 4) return;
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < 2; ++s) {
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + CH_TW3 + ((q * 2 + s) * 2) * 1024 + aoff0);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(wb + CH_TW3 + ((q * 2 + s) * 2 + 1) * 1024 + aoff0);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + CH_TW3 + ((q * 2 + s) * 2) * 1024 + aoff0);
-                        const f16x8 al = *reinterpret_cast<const f16x8*>(wb + CH_TW3 + ((q * 2 + s) * 2 + 1) * 1024 + aoff0);
-#pragma unroll
-                        for (int t = 0; t < CH_PT; ++t) {
-                            a3l[q][t] = CH_MM(ah, m2l[s][t], a3l[q][t]);
-                            a3[q][t] = CH_MM(ah, m2h[s][t], a3[q][t]);
-                            a3l[q][t] = CH_MM(al, m2h[s][t], a3l[q][t]);
-                        }
+                    for (int t = 0; t < CH_PT; ++t) {
+                        const f16x8 mh = *reinterpret_cast<const f16x8*>(park + ((s * 2 + t) * 2) * 1024);
+                        const f16x8 ml = *reinterpret_cast<const f16x8*>(park + ((s * 2 + t) * 2 + 1) * 1024);
+                        a3l[q][t] = CH_MM(ah, ml, a3l[q][t]);
+                        a3[q][t] = CH_MM(ah, mh, a3[q][t]);
+                        a3l[q][t] = CH_MM(al, mh, a3l[q][t]);
                     }
+                }
+            };
+            // y = relu(conv3 + b3 + shortcut) of channel tile q: its planes for the store and for the B fragment of conv1's K-slab j
+            u32x2 rq_h[2][CH_PT], rq_l[2][CH_PT];
+            auto epilogue = [&](int q) {
+                if (CH_ABL & 8) {
+#pragma unroll
+                    for (int t = 0; t < CH_PT; ++t) { h[q][t] = u32x2{0u, 0u}; l[q][t] = u32x2{0u, 0u}; }
+                    return;
+                }
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + 64 + 32 * j + 16 * q + 4 * kc);
+#pragma unroll
+                for (int t = 0; t < CH_PT; ++t) {
+                    const f16x4 rh = __builtin_bit_cast(f16x4, rq_h[q][t]);
+                    const f16x4 rl = __builtin_bit_cast(f16x4, rq_l[q][t]);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = __builtin_fmaf(a3[q][t][r] + a3l[q][t][r] * ls, a.scale3, bv[r]);
+                        v[r] += __builtin_fmaf((float)rl[r], ls, (float)rh[r]);
+                        v[r] = __builtin_fmaxf(v[r], 0.0f);
+                        rng = max(rng, __builtin_bit_cast(unsigned, v[r]));
+                    }
+                    split4_f16(v, h[q][t], l[q][t]);
+                }
+            };
+            if (j < CH_TAIL_STAGES - 1) {
+#pragma unroll
+                for (int t = 0; t < CH_PT; ++t) {
+                    slab_scatter(rsh[j % CH_RSLOTS][t], rq_h[0][t], rq_h[1][t]);
+                    slab_scatter(rsl[j % CH_RSLOTS][t], rq_l[0][t], rq_l[1][t]);
+                }
+                conv3_tile(0);
+                __builtin_amdgcn_sched_barrier(0);
+                conv3_tile(1);
+                epilogue(0);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {               // one MFMA of tile 1, then a share of tile 0's epilogue
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (j > 0 && a.z) {
+            if (j > 0 && HAS_Z && !(CH_ABL & 4)) {
                 // conv1', K-slab j - 1: the y fragments of the previous stage
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -341,68 +445,55 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                 }
             }
             if (j < CH_TAIL_STAGES - 1) {
-                // y = relu(conv3 + b3 + shortcut): store its planes, keep them as the B fragment of conv1's K-slab j
+                epilogue(1);
+#pragma unroll
+                for (int k = 0; k < 24; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < CH_PT; ++t) {
-                    u32x2 h[2], l[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int och = 32 * j + 16 * q + 4 * kc;
-                        const uint8_t* rp = wb + CH_TRES + roff[t] + (((2 * q + (kc >> 1)) ^ swz(16 * t + r16)) << 4);
-                        const f16x4 rh = *reinterpret_cast<const f16x4*>(rp);
-                        const f16x4 rl = *reinterpret_cast<const f16x4*>(rp + CH_BM * 64);
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + 64 + och);
-                        float resv[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) resv[r] = __builtin_fmaf((float)rl[r], ls, (float)rh[r]);
-                        float v[4];
-                        unsigned m4 = 0;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            v[r] = __builtin_fmaf(a3[q][t][r] + a3l[q][t][r] * ls, a.scale3, bv[r]);
-                            v[r] += resv[r];
-                            v[r] = __builtin_fmaxf(v[r], 0.0f);
-                            m4 = max(m4, __builtin_bit_cast(unsigned, v[r]) & 0x7fffffffu);
-                        }
-                        if (m4 > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
-                        split4_f16(v, h[q], l[q]);
-                        if (mpx[t] < a.M) {
-                            uint8_t* yp = a.y + (((size_t)(och >> 5) * a.np_y + mpx[t]) * 32 + (och & 31)) * 2;
-                            *reinterpret_cast<u32x2*>(yp) = h[q];
-                            *reinterpret_cast<u32x2*>(yp + a.ps_y) = l[q];
-                        }
+                    yh[t] = pack_frag(h[0][t], h[1][t]);
+                    yl[t] = pack_frag(l[0][t], l[1][t]);
+                    if (!(CH_ABL & 1)) {
+                        __builtin_amdgcn_raw_buffer_store_b128(slab_gather(h[0][t], h[1][t]), yr, po[t], j * a.np_y * 64, CH_NT);
+                        __builtin_amdgcn_raw_buffer_store_b128(slab_gather(l[0][t], l[1][t]), yr, po[t], j * a.np_y * 64 + (int)a.ps_y, CH_NT);
                     }
-                    yh[t] = pack_frag(h[0], h[1]);
-                    yl[t] = pack_frag(l[0], l[1]);
                 }
+                // the slot is free: refill it with the half-group four stages on (this tile's, or the next tile's first four)
+                if (j < 8 - CH_RSLOTS) load_res(j % CH_RSLOTS, j + CH_RSLOTS, po);
+                else load_res(j % CH_RSLOTS, j + CH_RSLOTS - 8, po_next);
             }
         }
         // ---- z = relu(conv1' + b1')
-        if (a.z) {
+        if constexpr (HAS_Z) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + 320 + 16 * c + 4 * kc);
+            for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
                 for (int t = 0; t < CH_PT; ++t) {
-                    if (mpx[t] >= a.M) continue;
-                    float v[4];
-                    unsigned m4 = 0;
+                    u32x2 zh[2], zl[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = __builtin_fmaxf(__builtin_fmaf(acc[c][t][r] + accl[c][t][r] * ls, a.scale1, bv[r]), 0.0f);
-                        m4 = max(m4, __builtin_bit_cast(unsigned, v[r]) & 0x7fffffffu);
+                    for (int q = 0; q < 2; ++q) {
+                        const int c = 2 * sl + q;
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + 320 + 16 * c + 4 * kc);
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = __builtin_fmaxf(__builtin_fmaf(acc[c][t][r] + accl[c][t][r] * ls, a.scale1, bv[r]), 0.0f);
+                            rng = max(rng, __builtin_bit_cast(unsigned, v[r]));
+                        }
+                        split4_f16(v, zh[q], zl[q]);
                     }
-                    if (m4 > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
-                    u32x2 h, l;
-                    split4_f16(v, h, l);
-                    const int zc = 16 * c + 4 * kc;
-                    uint8_t* zp = a.z + (((size_t)(zc >> 5) * a.np_z + mpx[t]) * 32 + (zc & 31)) * 2;
-                    *reinterpret_cast<u32x2*>(zp) = h;
-                    *reinterpret_cast<u32x2*>(zp + a.ps_z) = l;
+                    if (!(CH_ABL & 1)) {
+                        __builtin_amdgcn_raw_buffer_store_b128(slab_gather(zh[0], zh[1]), zr, po[t], sl * a.np_z * 64, CH_NT);
+                        __builtin_amdgcn_raw_buffer_store_b128(slab_gather(zl[0], zl[1]), zr, po[t], sl * a.np_z * 64 + (int)a.ps_z, CH_NT);
+                    }
                 }
-            }
         }
     }
+    tick();
+    if (rng > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
 #endif
 }
 
@@ -440,6 +531,11 @@ __global__ __launch_bounds__(256) void chain_pack_tail_kernel(const float* __res
 
 }  // namespace
 
+#if CH_TIMING
+static unsigned long long* g_chain_dbg = nullptr;
+extern "C" void stm_debug_chain_timing(void* p) { g_chain_dbg = static_cast<unsigned long long*>(p); }
+#endif
+
 extern "C" size_t stm_chain_tail_weight_bytes(void) { return (size_t)CH_TAIL_STAGES * CH_TW_BYTES; }
 
 // conv3 weight [256][64] and (optional) the next conv1 weight [64][256], both 1x1 OIHW fp32, times their power-of-two scales
@@ -464,7 +560,7 @@ extern "C" int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_p
     STM_REQUIRE(mid1_planes && x_planes && y_planes && w2_packed && tail_packed, STM_ENULL, "%s: NULL argument", who);
     STM_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)B * H * W < ((int64_t)1 << 24), STM_EINVAL, "%s: bad image batch", who);
     const int64_t M = (int64_t)B * H * W;
-    STM_REQUIRE(8 * M * 64 < ((int64_t)1 << 31), STM_EUNSUPPORTED, "%s: plane larger than 2 GiB", who);
+    STM_REQUIRE(2 * 8 * M * 64 < ((int64_t)1 << 31), STM_EUNSUPPORTED, "%s: more than 2 GiB per tensor", who);
     for (const void* p : {mid1_planes, x_planes, (const void*)y_planes, (const void*)z_planes, w2_packed, tail_packed})
         STM_REQUIRE((uintptr_t)p % 16 == 0, STM_EINVAL, "%s: 16-byte alignment required", who);
     ChainArgs a;
@@ -477,16 +573,21 @@ extern "C" int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_p
     a.np_in = a.np_res = a.np_y = a.np_z = (int)M;
     a.ps_in = 2 * M * 64; a.ps_res = 8 * M * 64; a.ps_y = 8 * M * 64; a.ps_z = 2 * M * 64;
     a.plane_bytes_in = (unsigned)(2 * M * 64);
-    a.plane_bytes_res = (unsigned)(8 * M * 64);
     a.tiles = stm_cdiv(M, CH_BM);
     a.range_flag = stm_internal_range_flag();
+#if CH_TIMING
+    a.dbg = g_chain_dbg;
+#else
+    a.dbg = nullptr;
+#endif
     const size_t lds = CH_LDS;
     static std::atomic<bool> reserved[CH_MAX_DEVICES];
     static std::atomic<int> n_cus[CH_MAX_DEVICES];
     int dev = 0;
     const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CH_MAX_DEVICES;
     if (!have_dev || !reserved[dev].load(std::memory_order_relaxed)) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
                     STM_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
         if (have_dev) reserved[dev].store(true, std::memory_order_relaxed);
     }
@@ -496,7 +597,9 @@ extern "C" int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_p
         cus = (have_dev && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         if (have_dev) n_cus[dev].store(cus, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(conv_chain_kernel, dim3(std::min(a.tiles, cus)), dim3(CH_THREADS), lds, stm_hs(stream), a);
+    const int grid = std::min((a.tiles + 7) / 8 * 8, cus / 8 * 8 > 0 ? cus / 8 * 8 : 8);       // a multiple of 8: the id -> tile map needs id & 7 = XCD
+    if (a.z) hipLaunchKernelGGL(conv_chain_kernel<true>, dim3(grid), dim3(CH_THREADS), lds, stm_hs(stream), a);
+    else hipLaunchKernelGGL(conv_chain_kernel<false>, dim3(grid), dim3(CH_THREADS), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_chain_kernel");
     return STM_OK;
 }
