@@ -616,6 +616,7 @@ def main():
                 for t in conv_t:
                     a = agg.setdefault(t[3], [0, 0.0, 0.0])
                     a[0] += 1; a[1] += t[0].elapsed_time(t[1]); a[2] += t[2]
+                # (tile 0 = conv_kxr_kernel, -1 = conv_chain_kernel: conv2 3x3 + conv3 + shortcut + the next conv1 of a 64-channel bottleneck)
                 print("%9s %5s %5s %2s %2s %2s %4s %6s %9s %8s %7s" % ("M", "C", "O", "k", "s", "g", "tile", "calls", "us/call", "TF", "ms/step"), file=sys.stderr)
                 for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     print("%9d %5d %5d %2d %2d %2d %4d %6d %9.1f %8.1f %7.3f" % (*key, n, ms * 1e3 / n, fl / (ms * 1e-3) / 1e12, ms / args.steps),

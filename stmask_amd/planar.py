@@ -43,6 +43,7 @@ STEM_PLANAR = os.environ.get("STM_STEM_PLANAR", "1") != "0"
 C3DS_FUSED = os.environ.get("STM_C3DS_FUSED", "1") != "0"    # conv3 + projection shortcut of a stage's first block as one two-source product
 STEM_FUSED = os.environ.get("STM_STEM_FUSED", "1") != "0"    # conv1 + ReLU + max-pool as one kernel (csrc/stem_fused.hip)
 CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 layers on the kx-reuse kernel (csrc/conv_kxr.hip)
+CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"  # layer1's identity-shortcut blocks: conv2 -> conv3 + shortcut -> next conv1 as one kernel (csrc/conv_chain.hip)
 
 
 def set_format(fmt, backbone_fmt=None):
@@ -631,6 +632,51 @@ class PlanarTemporalNet:
         return self.fc(pooled), self.fc_coeff(pooled)
 
 
+class PlanarChain:
+    """The tail of one 64-channel bottleneck and the head of the next as one launch (stm_bottleneck_chain_f32, csrc/conv_chain.hip;
+    reference backbone.py:38-58): relu(conv3(relu(conv2(mid1))) + x) and, when the next block's conv1 is given, relu(conv1(.))."""
+
+    def __init__(self, c2, c3, c1_next=None):
+        self.w2, self.b2 = c2.weight.detach().float().contiguous(), (c2.bias.detach().float().contiguous() if c2.bias is not None else None)
+        self.w3, self.b3 = c3.weight.detach().float().contiguous(), (c3.bias.detach().float().contiguous() if c3.bias is not None else None)
+        self.w1 = c1_next.weight.detach().float().contiguous() if c1_next is not None else None
+        self.b1 = c1_next.bias.detach().float().contiguous() if (c1_next is not None and c1_next.bias is not None) else None
+        self._packed = None
+        self.role = "trunk"
+
+    @staticmethod
+    def eligible(c2, c3, blk, fmt, out_fmt):
+        return (CONV_CHAIN and fmt == 1 and out_fmt == 1 and blk.downsample is None and isinstance(c2, torch.nn.Conv2d)
+                and tuple(c2.weight.shape) == (64, 64, 3, 3) and tuple(c2.stride) == (1, 1) and tuple(c2.padding) == (1, 1)
+                and tuple(c2.dilation) == (1, 1) and c2.groups == 1 and tuple(c3.weight.shape) == (256, 64, 1, 1) and tuple(c3.stride) == (1, 1))
+
+    @staticmethod
+    def takes_z(c1):
+        return isinstance(c1, torch.nn.Conv2d) and tuple(c1.weight.shape) == (64, 256, 1, 1) and tuple(c1.stride) == (1, 1) and c1.groups == 1
+
+    def __call__(self, mid1, x, B, H, W):
+        if self._packed is None:
+            g = _lib.ConvGeom()
+            g.C, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.groups, g.fmt = 64, 64, 3, 3, 1, 1, 1, 1, 1, 1
+            ops.planar_range_flag()
+            w2p, s2 = ops.conv_pack_weights_kxr(self.w2, g)
+            tail, s3, s1 = ops.chain_pack_tail(self.w3, self.w1)
+            self._packed = (w2p, tail, (s2, s3, s1))
+        w2p, tail, scales = self._packed
+        timing = ops._conv_timing
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        y, z = ops.bottleneck_chain(mid1, x, w2p, tail, self.b2, self.b3, self.b1, scales, B, H, W, want_z=self.w1 is not None)
+        if timing is not None:
+            e1.record()
+            M = B * H * W
+            macs = 64 * 64 * 9 + 256 * 64 + (256 * 64 if self.w1 is not None else 0)
+            nbytes = M * 4 * (64 + 256 + 256 + (64 if self.w1 is not None else 0)) + 4 * macs
+            timing.append((e0, e1, 2.0 * M * macs, (M, 64, 256, 3, 1, 1, -1), 3, self.role, float(nbytes)))
+        return y, z
+
+
 class PlanarBackbone:
     """ResNet bottlenecks (backbone.py:38-58 of the reference, eval BatchNorm folded) with every 1x1 convolution, the
     plain 3x3 convolutions and the stride-s downsample projections on the planar convolution; residual add + ReLU in
@@ -701,6 +747,10 @@ class PlanarBackbone:
                                                out_fmt=self.graph_fmt if to_graph else fmt)
                         e["ds_stride"] = d.stride[0]
                 e["stride"] = _pair(c2.stride)
+                if PlanarChain.eligible(c2, c3, blk, fmt, e["c3"].out_fmt):
+                    nxt = layer[bi + 1] if bi + 1 < len(layer) else None
+                    give_z = nxt is not None and not isinstance(nxt.conv2, DCN) and PlanarChain.takes_z(nxt.conv1)
+                    e["chain"] = PlanarChain(c2, c3, nxt.conv1 if give_z else None)
                 blks.append(e)
             self.blocks.append(blks)
 
@@ -742,11 +792,16 @@ class PlanarBackbone:
         outs, self.out_planes = [], []
         for blks in self.blocks:
             y32 = None
+            z_next = None         # the next block's conv1 output, when the previous block's chain kernel already produced it
             for bi, e in enumerate(blks):
                 last = bi == len(blks) - 1
                 shape = ("img", B, H, W)
                 sh, sw = e["stride"]
                 Ho, Wo = (H - 1) // sh + 1, (W - 1) // sw + 1
+                if "chain" in e and not (last and not self.planes_only):
+                    mid1 = z_next if z_next is not None else e["c1"](xp, shape)
+                    xp, z_next = e["chain"](mid1, xp, B, H, W)
+                    continue
                 if "dcn" in e:
                     # conv1 -> fp32 (NCHW copy for the deformable sampler) and planes (offset / mask convolution);
                     # the sampler reads the raw conv_offset_mask output (sigmoid folded in), GEMM adds bias + ReLU
@@ -771,7 +826,8 @@ class PlanarBackbone:
                                             d.deformable_groups, relu=True, fused_om=om)
                         mid = _split(_nhwc(t), self.fmt)
                 else:
-                    mid = e["c2"](e["c1"](xp, shape), shape)
+                    mid = e["c2"](z_next if z_next is not None else e["c1"](xp, shape), shape)
+                    z_next = None
                 if "c3ds" in e:
                     x2 = (xp, H, W, e["ds_stride"])
                     H, W = Ho, Wo
