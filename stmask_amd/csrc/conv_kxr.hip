@@ -57,7 +57,8 @@ struct KxrJob {
     int x_slab0;           // first input channel slab of the group
     int out_ch0;           // first output channel of the group in the output tensors
     int nc;                // 16-channel tiles
-    int tile0;             // first workgroup of this job
+    int tile0;             // first tile id of this job (ids are padded to a multiple of 8 per job)
+    int per_xcd;           // tile ids of this job per XCD: id -> tile (id & 7) * per_xcd + (id >> 3)
     int lvl_tile0[9];      // first tile of each level, in this job's tile size
 };
 
@@ -120,7 +121,11 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
     // of stages runs straight through the tile boundaries, so the producers are already fetching the next tile while the consumers
     // store the previous one -- per tile only the setup of the new pixel run remains of the workgroup's start-up cost.
     struct TileGeo { int H, W, lstart, lend, m0; };
-    auto tile_geo = [&](int tile) {
+    // Tile ids are dealt round-robin to the 8 XCDs (id & 7 = blockIdx.x & 7: the grid and every job's first id are multiples of 8); the
+    // map gives each XCD -- each L2 -- a contiguous run of the job's tiles, so the rows a tile's ky stages share with its neighbours are
+    // filled into one L2 once.  Ids of the padding map to tiles behind the last level: every access of such a tile is out of range.
+    auto tile_geo = [&](int id) {
+        const int tile = (id & 7) * jb.per_xcd + (id >> 3);
         int lvl = 0;
 #pragma unroll
         for (int l = 1; l < 8; ++l)
@@ -467,7 +472,8 @@ int kxr_launch(KxrArgs a, stm_stream_t stream)
         int t0 = 0;
         for (int l = 0; l < a.n_lvl; ++l) { j.lvl_tile0[l] = t0; t0 += stm_cdiv(a.lvl_start[l + 1] - a.lvl_start[l], 64 * pt); }
         j.lvl_tile0[a.n_lvl] = t0;
-        a.total += t0;
+        j.per_xcd = (t0 + 7) / 8;
+        a.total += 8 * j.per_xcd;
     }
     static std::atomic<int> reserved[KX_MAX_DEVICES];      // bytes reserved so far, per instantiation and device
     int dev = 0;
@@ -485,7 +491,7 @@ int kxr_launch(KxrArgs a, stm_stream_t stream)
         cus = (have_dev && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         if (have_dev) n_cus[dev].store(cus, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((conv_kxr_kernel<KW, NPL>), dim3(std::min(a.total, cus)), dim3(KX_THREADS), lds, stm_hs(stream), a);
+    hipLaunchKernelGGL((conv_kxr_kernel<KW, NPL>), dim3(std::min(a.total, std::max(cus / 8 * 8, 8))), dim3(KX_THREADS), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_kxr_kernel");
     return STM_OK;
 }
