@@ -349,12 +349,21 @@ int stm_conv2d_planar_kxr_f32(const void* x_planes, const void* packed_weight, c
  * ([2][C/32][B*H*W][32]).  w2_packed = stm_conv_pack_weights_kxr_f32 of conv2's [64, 64, 3, 3] (C = 64, Cout = 64, one group, fmt 1);
  * tail_packed = stm_chain_pack_tail_f32 of conv3's [256, 64] and (or NULL) the next block's conv1 [64, 256], each times its power-of-two
  * weight scale; out_scale* = 1 / that scale.  z_planes may be NULL (then b1_next and the conv1 half of the tail are unused).
- * Arithmetic = the three stm_conv2d_planar_f32 calls it replaces up to the order of the fp32 sums inside one 32-channel K-slab. */
+ * Arithmetic = the three stm_conv2d_planar_f32 calls it replaces up to the order of the fp32 sums inside one 32-channel K-slab.
+ * The _proj forms are a stage's FIRST block at stride 1 (projection shortcut, backbone.py:52-53): x0 = the block's 64-channel input
+ * [B, H, W, 64] planes, y = relu(conv3(mid2) + proj(x0) + b3) with b3 = conv3's bias + the projection's and both weight matrices
+ * ([256, 64] each) under ONE scale wscale3 -- the product stm_conv2d_planar_dual_f32 computes, chained the same way. */
 size_t stm_chain_tail_weight_bytes(void);
+size_t stm_chain_tail_weight_bytes_proj(void);
 int stm_chain_pack_tail_f32(const float* w3, const float* w1_next, void* packed, float wscale3, float wscale1, stm_stream_t stream);
+int stm_chain_pack_tail_proj_f32(const float* w3, const float* wds, const float* w1_next, void* packed, float wscale3, float wscale1,
+                                 stm_stream_t stream);
 int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_planes, void* y_planes, void* z_planes, const void* w2_packed,
                              const void* tail_packed, const float* b2, const float* b3, const float* b1_next, float out_scale2,
                              float out_scale3, float out_scale1, int B, int H, int W, stm_stream_t stream);
+int stm_bottleneck_chain_proj_f32(const void* mid1_planes, const void* x0_planes, void* y_planes, void* z_planes, const void* w2_packed,
+                                  const void* tail_packed, const float* b2, const float* b3, const float* b1_next, float out_scale2,
+                                  float out_scale3, float out_scale1, int B, int H, int W, stm_stream_t stream);
 
 /* bytes of the packed (pre-split, pre-tiled) weight image; 0 on bad arguments */
 size_t stm_conv_packed_weight_bytes(int Cout, int Cin, int kh, int kw, int planes);

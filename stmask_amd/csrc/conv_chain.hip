@@ -38,6 +38,9 @@ constexpr int CH_BUF = CH_XBUF + CH_WBUF;                                   // 4
 constexpr int CH_D = 3;                                                     // ring slots (the producers' wait is written for three)
 // tail stage j = 0 .. 8: [conv3 weights of half-group j: 8 KB | conv1' weights of K-slab j - 1: 8 KB]
 constexpr int CH_TAIL_STAGES = 9, CH_TW3 = 0, CH_TW1 = 8192, CH_TW_BYTES = 16384;
+// projection-shortcut form (a stage's first block: y = relu(conv3(mid2) + proj(x0) + b)): conv3 runs over four K-slabs -- mid2's two and the two of
+// the 64-channel block input x0 -- so a tail stage carries 16 KB of conv3 tiles [q 2][s 4][plane 2] and conv1's 8 KB behind them
+constexpr int CH_TW1_P = 16384, CH_TWP_BYTES = 24576;
 constexpr int CH_RSLOTS = 2;              // half-groups of the shortcut tensor in flight per consumer wave (registers)
 // behind the ring: the consumers' mid2 fragments (8 KB per wave: 32 registers the tail cannot spare) and the three bias vectors
 constexpr int CH_PARK_OFF = CH_D * CH_BUF, CH_BIAS_OFF = CH_PARK_OFF + 4 * 8192, CH_LDS = CH_BIAS_OFF + (64 + 256 + 64) * 4;
@@ -123,7 +126,7 @@ __device__ __forceinline__ void split4_f16(const float (&v)[4], u32x2& h, u32x2&
 // on, across tile boundaries -- the next tile's first four half-groups arrive under this tile's last stages and the next 3x3.
 // The consumers' tail is software-pipelined by one stage: stage j issues conv3 of half-group j, then conv1' of K-slab j - 1 (whose B
 // fragments the previous stage's epilogue left in registers), then the epilogue of half-group j -- on the VALU while conv1's MFMAs drain.
-template <bool HAS_Z>
+template <bool HAS_Z, bool PROJ>
 __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -151,7 +154,8 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
         // ------------------------------------------------------------------------------------------------------------ producer
         constexpr int NXD = CH_NRG * 2, XDW = (NXD + CH_PRODUCERS - 1) / CH_PRODUCERS;       // 18 activation pieces: 9 per producer
         constexpr int NWD = 3 * 2 * 4, WDW = NWD / CH_PRODUCERS;                              // 24 weight pieces: 12 per producer
-        constexpr int TWD = CH_TW_BYTES / 1024 / CH_PRODUCERS;                                // 16 tail weight pieces: 8 per producer
+        constexpr int TWB = PROJ ? CH_TWP_BYTES : CH_TW_BYTES, TW1 = PROJ ? CH_TW1_P : CH_TW1;
+        constexpr int TWD = TWB / 1024 / CH_PRODUCERS;                                        // 16 (24) tail weight pieces: 8 (12) per producer
         const int pw_ = wave - CH_CONSUMERS;
         // activations: producer p stages plane p (nine row groups of 16 staged rows); the weight pieces are dealt round-robin
         static_assert(CH_PRODUCERS == 2 && XDW == CH_NRG, "one activation plane per producer");
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                 }
             } else {
                 const int j = s_in - S;
-                const uint8_t* wsrc = a.wt + (size_t)j * CH_TW_BYTES;
+                const uint8_t* wsrc = a.wt + (size_t)j * TWB;
                 if (j < CH_TAIL_STAGES - 1) {
                     kind = 1;
 #pragma unroll
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                     kind = 2;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int idx = 8 + pw_ + CH_PRODUCERS * k;       // conv1' half only
+                        const int idx = TW1 / 1024 + pw_ + CH_PRODUCERS * k;       // conv1' part only
                         if (!(CH_ABL & 32)) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + idx * 1024), 16, 0, 0);
                     }
                 }
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
     u32x4 rsh[CH_RSLOTS][CH_PT], rsl[CH_RSLOTS][CH_PT];     // as loaded: channels 8 kc .. 8 kc + 7 of the slab (slab_scatter at use)
     // shortcut / y / z through buffer descriptors covering both planes: a pixel behind M gets bit 31 in its offset -- loads return 0, stores
     // are dropped, and the epilogues stay free of branches (one basic block per stage: the scheduler can put the VALU work under the MFMAs)
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.res), 0, (int)(a.ps_res + (long long)a.np_res * 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.res), 0, (int)(a.ps_res + (long long)a.np_res * (PROJ ? 128 : 512)), 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(a.ps_y + (long long)a.np_y * 512), 0x00020000);
     const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(HAS_Z ? a.z : a.y, 0, HAS_Z ? (int)(a.ps_z + (long long)a.np_z * 128) : 0, 0x00020000);
     auto px_off = [&](int m) { return (unsigned)(m * 64 + 16 * kc) | (m >= a.M ? 0x80000000u : 0u); };     // byte offset of (pixel m, channel 8 kc) in a slab
@@ -256,13 +260,16 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
             rsl[slot][t] = __builtin_amdgcn_raw_buffer_load_b128(rr, po[t], hg * a.np_res * 64 + (int)a.ps_res, CH_NT);
         }
     };
-    {
+    if constexpr (!PROJ) {
         unsigned po[CH_PT];
 #pragma unroll
         for (int t = 0; t < CH_PT; ++t) po[t] = px_off(tile_of((int)blockIdx.x) * CH_BM + 16 * CH_PT * wave + 16 * t + r16);
 #pragma unroll
         for (int k = 0; k < CH_RSLOTS; ++k) load_res(k, k, po);
     }
+    // projection form: the block input x0 of this lane's pixels, B fragments of conv3's K-slabs 2 and 3 in their natural order (chunk kc
+    // = channels 8 kc ..: exactly the 16 bytes a lane loads); they take the registers of the shortcut slots, fetched at the tile's start
+    u32x4 (&xfh)[CH_RSLOTS][CH_PT] = rsh, (&xfl)[CH_RSLOTS][CH_PT] = rsl;
     unsigned rng = 0;          // largest magnitude bits this lane produced (all values are post-ReLU: non-negative)
     int buf = 0;
     int dbg_i = 0;
@@ -282,6 +289,13 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
             mpx[t] = m;
             po[t] = px_off(m);
             po_next[t] = px_off(m0_next + row0);            // (behind the last tile: out of range, nothing is fetched)
+            if constexpr (PROJ) {
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    xfh[sl][t] = __builtin_amdgcn_raw_buffer_load_b128(rr, po[t], sl * a.np_res * 64, 0);
+                    xfl[sl][t] = __builtin_amdgcn_raw_buffer_load_b128(rr, po[t], sl * a.np_res * 64 + (int)a.ps_res, 0);
+                }
+            }
             const bool okm = m < a.M;
             const int x = okm ? m % a.W : 0;
 #pragma unroll
@@ -375,14 +389,15 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { a3[q][t][r] = 0.0f; a3l[q][t][r] = 0.0f; }
                 if (CH_ABL & 4) return;
+                constexpr int NS = PROJ ? 4 : 2;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + CH_TW3 + ((q * 2 + s) * 2) * 1024 + aoff0);
-                    const f16x8 al = *reinterpret_cast<const f16x8*>(wb + CH_TW3 + ((q * 2 + s) * 2 + 1) * 1024 + aoff0);
+                for (int s = 0; s < NS; ++s) {
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + CH_TW3 + ((q * NS + s) * 2) * 1024 + aoff0);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(wb + CH_TW3 + ((q * NS + s) * 2 + 1) * 1024 + aoff0);
 #pragma unroll
                     for (int t = 0; t < CH_PT; ++t) {
-                        const f16x8 mh = *reinterpret_cast<const f16x8*>(park + ((s * 2 + t) * 2) * 1024);
-                        const f16x8 ml = *reinterpret_cast<const f16x8*>(park + ((s * 2 + t) * 2 + 1) * 1024);
+                        const f16x8 mh = s < 2 ? *reinterpret_cast<const f16x8*>(park + (((s & 1) * 2 + t) * 2) * 1024) : __builtin_bit_cast(f16x8, xfh[s & 1][t]);
+                        const f16x8 ml = s < 2 ? *reinterpret_cast<const f16x8*>(park + (((s & 1) * 2 + t) * 2 + 1) * 1024) : __builtin_bit_cast(f16x8, xfl[s & 1][t]);
                         a3l[q][t] = CH_MM(ah, ml, a3l[q][t]);
                         a3[q][t] = CH_MM(ah, mh, a3[q][t]);
                         a3l[q][t] = CH_MM(al, mh, a3l[q][t]);
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v[r] = __builtin_fmaf(a3[q][t][r] + a3l[q][t][r] * ls, a.scale3, bv[r]);
-                        v[r] += __builtin_fmaf((float)rl[r], ls, (float)rh[r]);
+                        if constexpr (!PROJ) v[r] += __builtin_fmaf((float)rl[r], ls, (float)rh[r]);
                         v[r] = __builtin_fmaxf(v[r], 0.0f);
                         rng = max(rng, __builtin_bit_cast(unsigned, v[r]));
                     }
@@ -416,6 +431,7 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
             if (j < CH_TAIL_STAGES - 1) {
 #pragma unroll
                 for (int t = 0; t < CH_PT; ++t) {
+                    if constexpr (PROJ) { rq_h[0][t] = rq_h[1][t] = rq_l[0][t] = rq_l[1][t] = u32x2{0u, 0u}; continue; }
                     slab_scatter(rsh[j % CH_RSLOTS][t], rq_h[0][t], rq_h[1][t]);
                     slab_scatter(rsl[j % CH_RSLOTS][t], rq_l[0][t], rq_l[1][t]);
                 }
@@ -424,9 +440,9 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                 conv3_tile(1);
                 epilogue(0);
 #pragma unroll
-                for (int k = 0; k < 12; ++k) {               // one MFMA of tile 1, then a share of tile 0's epilogue
+                for (int k = 0; k < (PROJ ? 24 : 12); ++k) {               // one MFMA of tile 1, then a share of tile 0's epilogue
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, PROJ ? 4 : 8, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -434,8 +450,8 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                 // conv1', K-slab j - 1: the y fragments of the previous stage
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + CH_TW1 + (c * 2) * 1024 + aoff0);
-                    const f16x8 al = *reinterpret_cast<const f16x8*>(wb + CH_TW1 + (c * 2 + 1) * 1024 + aoff0);
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(wb + (PROJ ? CH_TW1_P : CH_TW1) + (c * 2) * 1024 + aoff0);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(wb + (PROJ ? CH_TW1_P : CH_TW1) + (c * 2 + 1) * 1024 + aoff0);
 #pragma unroll
                     for (int t = 0; t < CH_PT; ++t) {
                         accl[c][t] = CH_MM(ah, yl[t], accl[c][t]);
@@ -462,8 +478,10 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                     }
                 }
                 // the slot is free: refill it with the half-group four stages on (this tile's, or the next tile's first four)
-                if (j < 8 - CH_RSLOTS) load_res(j % CH_RSLOTS, j + CH_RSLOTS, po);
-                else load_res(j % CH_RSLOTS, j + CH_RSLOTS - 8, po_next);
+                if constexpr (!PROJ) {
+                    if (j < 8 - CH_RSLOTS) load_res(j % CH_RSLOTS, j + CH_RSLOTS, po);
+                    else load_res(j % CH_RSLOTS, j + CH_RSLOTS - 8, po_next);
+                }
             }
         }
         // ---- z = relu(conv1' + b1')
@@ -497,20 +515,22 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
 #endif
 }
 
-// Tail weights, stage j = 0 .. 8 of 16 KB:
-//   conv3 tiles [q 2][s 2][plane 2] x 1 KB of half-group j (rows = output channels 32 j + 16 q + r16, K-slab s of the 64 inputs; zeros for j = 8),
-//   conv1' tiles [c 4][plane 2] x 1 KB of K-slab j - 1 (rows = output channels 16 c + r16, inputs 32 (j - 1) ..; zeros for j = 0),
-// each 1-KB tile in the fragment layout lds_off(row, chunk kc) with the chained K order: value e of chunk kc = input channel
-// 32 slab + (e < 4 ? 4 kc + e : 16 + 4 kc + e - 4).  One thread per (stage, tile, row, chunk).
-__global__ __launch_bounds__(256) void chain_pack_tail_kernel(const float* __restrict__ w3, const float* __restrict__ w1, uint8_t* __restrict__ wt,
-                                                              float ws3, float ws1)
+// Tail weights, stage j = 0 .. 8 of 16 KB (24 KB in the projection form):
+//   conv3 tiles [q 2][s NS][plane 2] x 1 KB of half-group j (rows = output channels 32 j + 16 q + r16; zeros for j = 8): K-slabs s = 0, 1 are
+//   the 64 channels of mid2 in the CHAINED order -- value e of chunk kc = channel 32 s + (e < 4 ? 4 kc + e : 16 + 4 kc + e - 4) -- and, in the
+//   projection form (NS = 4), s = 2, 3 the 64 channels of the block input in their natural order (8 kc + e) from the projection weight wds,
+//   conv1' tiles [c 4][plane 2] x 1 KB of K-slab j - 1 (rows = output channels 16 c + r16, inputs 32 (j - 1) .. in the chained order; zeros for j = 0),
+// each 1-KB tile in the fragment layout lds_off(row, chunk kc).  One thread per (stage, tile, row, chunk).
+__global__ __launch_bounds__(256) void chain_pack_tail_kernel(const float* __restrict__ w3, const float* __restrict__ wds, const float* __restrict__ w1,
+                                                              uint8_t* __restrict__ wt, float ws3, float ws1)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;                // 9 stages x 8 tiles x 16 rows x 4 chunks
-    if (idx >= CH_TAIL_STAGES * 8 * 64) return;
-    const int kcq = idx & 3, row = (idx >> 2) & 15, tl = (idx >> 6) & 7, j = idx >> 9;
+    const int ns = wds ? 4 : 2, n3 = 2 * ns, ntl = n3 + 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;                // 9 stages x (8 | 12) tiles x 16 rows x 4 chunks
+    if (idx >= CH_TAIL_STAGES * ntl * 64) return;
+    const int kcq = idx & 3, row = (idx >> 2) & 15, tl = (idx >> 6) % ntl, j = (idx >> 6) / ntl;
     unsigned pl[2][4];
-    const bool is3 = tl < 4;                                       // tiles 0..3: conv3 (q, s); 4..7: conv1' (c)
-    const int q = tl >> 1, s = tl & 1, c = tl - 4;
+    const bool is3 = tl < n3;                                      // conv3 tiles (q, s) first, then conv1' tiles c
+    const int q = tl / ns, s = tl - q * ns, c = tl - n3;
 #pragma unroll
     for (int e2 = 0; e2 < 4; ++e2) {
         float v[2];
@@ -518,13 +538,15 @@ __global__ __launch_bounds__(256) void chain_pack_tail_kernel(const float* __res
         for (int h = 0; h < 2; ++h) {
             const int e = 2 * e2 + h;
             const int perm = e < 4 ? 4 * kcq + e : 16 + 4 * kcq + (e - 4);
-            if (is3) v[h] = j < 8 ? w3[(size_t)(32 * j + 16 * q + row) * CH_P + 32 * s + perm] * ws3 : 0.0f;
+            const int orow = 32 * j + 16 * q + row;
+            if (is3 && s < 2) v[h] = j < 8 ? w3[(size_t)orow * CH_P + 32 * s + perm] * ws3 : 0.0f;
+            else if (is3) v[h] = j < 8 ? wds[(size_t)orow * CH_P + 32 * (s - 2) + 8 * kcq + e] * ws3 : 0.0f;
             else v[h] = (w1 && j > 0) ? w1[(size_t)(16 * c + row) * (4 * CH_P) + 32 * (j - 1) + perm] * ws1 : 0.0f;
         }
         split2_f16(f32x2{v[0], v[1]}, pl[0][e2], pl[1][e2]);
     }
-    uint8_t* base = wt + (size_t)j * CH_TW_BYTES;
-    uint8_t* tile = is3 ? base + CH_TW3 + ((q * 2 + s) * 2) * 1024 : base + CH_TW1 + (c * 2) * 1024;
+    uint8_t* base = wt + (size_t)j * (wds ? CH_TWP_BYTES : CH_TW_BYTES);
+    uint8_t* tile = is3 ? base + CH_TW3 + ((q * ns + s) * 2) * 1024 : base + (wds ? CH_TW1_P : CH_TW1) + (c * 2) * 1024;
     *reinterpret_cast<u32x4*>(tile + lds_off(row, kcq)) = u32x4{pl[0][0], pl[0][1], pl[0][2], pl[0][3]};
     *reinterpret_cast<u32x4*>(tile + 1024 + lds_off(row, kcq)) = u32x4{pl[1][0], pl[1][1], pl[1][2], pl[1][3]};
 }
@@ -537,26 +559,37 @@ extern "C" void stm_debug_chain_timing(void* p) { g_chain_dbg = static_cast<unsi
 #endif
 
 extern "C" size_t stm_chain_tail_weight_bytes(void) { return (size_t)CH_TAIL_STAGES * CH_TW_BYTES; }
+extern "C" size_t stm_chain_tail_weight_bytes_proj(void) { return (size_t)CH_TAIL_STAGES * CH_TWP_BYTES; }
 
-// conv3 weight [256][64] and (optional) the next conv1 weight [64][256], both 1x1 OIHW fp32, times their power-of-two scales
-extern "C" int stm_chain_pack_tail_f32(const float* w3, const float* w1_next, void* packed, float wscale3, float wscale1, stm_stream_t stream)
+static int chain_pack_tail(const char* who, const float* w3, const float* wds, const float* w1_next, void* packed, float wscale3, float wscale1,
+                           stm_stream_t stream)
 {
-    STM_REQUIRE(w3 && packed, STM_ENULL, "stm_chain_pack_tail_f32: w3 / packed must be non-NULL");
-    STM_REQUIRE((uintptr_t)packed % 16 == 0 && wscale3 > 0.0f && (!w1_next || wscale1 > 0.0f), STM_EINVAL, "stm_chain_pack_tail_f32: alignment / scales");
-    hipLaunchKernelGGL(chain_pack_tail_kernel, dim3(stm_cdiv(CH_TAIL_STAGES * 8 * 64, 256)), dim3(256), 0, stm_hs(stream), w3, w1_next, static_cast<uint8_t*>(packed),
-                       wscale3, wscale1);
+    STM_REQUIRE(w3 && packed, STM_ENULL, "%s: w3 / packed must be non-NULL", who);
+    STM_REQUIRE((uintptr_t)packed % 16 == 0 && wscale3 > 0.0f && (!w1_next || wscale1 > 0.0f), STM_EINVAL, "%s: alignment / scales", who);
+    hipLaunchKernelGGL(chain_pack_tail_kernel, dim3(stm_cdiv(CH_TAIL_STAGES * (wds ? 12 : 8) * 64, 256)), dim3(256), 0, stm_hs(stream), w3, wds, w1_next,
+                       static_cast<uint8_t*>(packed), wscale3, wscale1);
     STM_CHECK_LAUNCH("chain_pack_tail_kernel");
     return STM_OK;
 }
 
-// mid1 [B, H, W, 64] planes, shortcut x [B, H, W, 256] planes -> y [B, H, W, 256] planes (and z [B, H, W, 64] planes when z_planes and the
-// packed tail holds the next block's conv1).  w2_packed: stm_conv_pack_weights_kxr_f32 of the 3x3 weight [64, 64, 3, 3] (one group, 64
-// real channels, fmt 1); tail_packed: stm_chain_pack_tail_f32.  np_* = pixels per channel slab of each buffer (0 = B*H*W), plane strides dense.
-extern "C" int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_planes, void* y_planes, void* z_planes, const void* w2_packed,
-                                        const void* tail_packed, const float* b2, const float* b3, const float* b1_next, float out_scale2,
-                                        float out_scale3, float out_scale1, int B, int H, int W, stm_stream_t stream)
+// conv3 weight [256][64] and (optional) the next conv1 weight [64][256], both 1x1 OIHW fp32, times their power-of-two scales
+extern "C" int stm_chain_pack_tail_f32(const float* w3, const float* w1_next, void* packed, float wscale3, float wscale1, stm_stream_t stream)
 {
-    const char* who = "stm_bottleneck_chain_f32";
+    return chain_pack_tail("stm_chain_pack_tail_f32", w3, nullptr, w1_next, packed, wscale3, wscale1, stream);
+}
+
+// projection form: conv3 [256][64] and the shortcut's 1x1 projection [256][64] share wscale3 (they are one product over [mid2 ; x0])
+extern "C" int stm_chain_pack_tail_proj_f32(const float* w3, const float* wds, const float* w1_next, void* packed, float wscale3, float wscale1,
+                                            stm_stream_t stream)
+{
+    STM_REQUIRE(wds, STM_ENULL, "stm_chain_pack_tail_proj_f32: wds must be non-NULL");
+    return chain_pack_tail("stm_chain_pack_tail_proj_f32", w3, wds, w1_next, packed, wscale3, wscale1, stream);
+}
+
+static int chain_launch(const char* who, bool proj, const void* mid1_planes, const void* x_planes, void* y_planes, void* z_planes, const void* w2_packed,
+                        const void* tail_packed, const float* b2, const float* b3, const float* b1_next, float out_scale2, float out_scale3,
+                        float out_scale1, int B, int H, int W, stm_stream_t stream)
+{
     STM_REQUIRE(mid1_planes && x_planes && y_planes && w2_packed && tail_packed, STM_ENULL, "%s: NULL argument", who);
     STM_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)B * H * W < ((int64_t)1 << 24), STM_EINVAL, "%s: bad image batch", who);
     const int64_t M = (int64_t)B * H * W;
@@ -571,7 +604,7 @@ extern "C" int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_p
     a.scale2 = out_scale2 > 0.0f ? out_scale2 : 1.0f; a.scale3 = out_scale3 > 0.0f ? out_scale3 : 1.0f; a.scale1 = out_scale1 > 0.0f ? out_scale1 : 1.0f;
     a.B = B; a.H = H; a.W = W; a.M = (int)M;
     a.np_in = a.np_res = a.np_y = a.np_z = (int)M;
-    a.ps_in = 2 * M * 64; a.ps_res = 8 * M * 64; a.ps_y = 8 * M * 64; a.ps_z = 2 * M * 64;
+    a.ps_in = 2 * M * 64; a.ps_res = (proj ? 2 : 8) * M * 64; a.ps_y = 8 * M * 64; a.ps_z = 2 * M * 64;
     a.plane_bytes_in = (unsigned)(2 * M * 64);
     a.tiles = stm_cdiv(M, CH_BM);
     a.range_flag = stm_internal_range_flag();
@@ -586,9 +619,11 @@ extern "C" int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_p
     int dev = 0;
     const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CH_MAX_DEVICES;
     if (!have_dev || !reserved[dev].load(std::memory_order_relaxed)) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
-                    STM_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
+        const void* fns[4] = {reinterpret_cast<const void*>(conv_chain_kernel<true, false>), reinterpret_cast<const void*>(conv_chain_kernel<false, false>),
+                              reinterpret_cast<const void*>(conv_chain_kernel<true, true>), reinterpret_cast<const void*>(conv_chain_kernel<false, true>)};
+        for (const void* fn : fns)
+            STM_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, STM_ELAUNCH,
+                        "%s: cannot reserve %zu bytes of LDS", who, lds);
         if (have_dev) reserved[dev].store(true, std::memory_order_relaxed);
     }
     int cus = have_dev ? n_cus[dev].load(std::memory_order_relaxed) : 0;
@@ -598,8 +633,35 @@ extern "C" int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_p
         if (have_dev) n_cus[dev].store(cus, std::memory_order_relaxed);
     }
     const int grid = std::min((a.tiles + 7) / 8 * 8, cus / 8 * 8 > 0 ? cus / 8 * 8 : 8);       // a multiple of 8: the id -> tile map needs id & 7 = XCD
-    if (a.z) hipLaunchKernelGGL(conv_chain_kernel<true>, dim3(grid), dim3(CH_THREADS), lds, stm_hs(stream), a);
-    else hipLaunchKernelGGL(conv_chain_kernel<false>, dim3(grid), dim3(CH_THREADS), lds, stm_hs(stream), a);
+    const dim3 g(grid), b(CH_THREADS);
+    if (proj) {
+        if (a.z) hipLaunchKernelGGL((conv_chain_kernel<true, true>), g, b, lds, stm_hs(stream), a);
+        else hipLaunchKernelGGL((conv_chain_kernel<false, true>), g, b, lds, stm_hs(stream), a);
+    } else {
+        if (a.z) hipLaunchKernelGGL((conv_chain_kernel<true, false>), g, b, lds, stm_hs(stream), a);
+        else hipLaunchKernelGGL((conv_chain_kernel<false, false>), g, b, lds, stm_hs(stream), a);
+    }
     STM_CHECK_LAUNCH("conv_chain_kernel");
     return STM_OK;
+}
+
+// mid1 [B, H, W, 64] planes, shortcut x [B, H, W, 256] planes -> y [B, H, W, 256] planes (and z [B, H, W, 64] planes when z_planes and the
+// packed tail holds the next block's conv1).  w2_packed: stm_conv_pack_weights_kxr_f32 of the 3x3 weight [64, 64, 3, 3] (one group, 64
+// real channels, fmt 1); tail_packed: stm_chain_pack_tail_f32.  All tensors dense.
+extern "C" int stm_bottleneck_chain_f32(const void* mid1_planes, const void* x_planes, void* y_planes, void* z_planes, const void* w2_packed,
+                                        const void* tail_packed, const float* b2, const float* b3, const float* b1_next, float out_scale2,
+                                        float out_scale3, float out_scale1, int B, int H, int W, stm_stream_t stream)
+{
+    return chain_launch("stm_bottleneck_chain_f32", false, mid1_planes, x_planes, y_planes, z_planes, w2_packed, tail_packed, b2, b3, b1_next, out_scale2,
+                        out_scale3, out_scale1, B, H, W, stream);
+}
+
+// the same for a stage's FIRST block at stride 1: x0 [B, H, W, 64] planes is the block's input, the shortcut its 1x1 projection, folded into
+// conv3's product (tail_packed: stm_chain_pack_tail_proj_f32; b3 = conv3's bias + the projection's)
+extern "C" int stm_bottleneck_chain_proj_f32(const void* mid1_planes, const void* x0_planes, void* y_planes, void* z_planes, const void* w2_packed,
+                                             const void* tail_packed, const float* b2, const float* b3, const float* b1_next, float out_scale2,
+                                             float out_scale3, float out_scale1, int B, int H, int W, stm_stream_t stream)
+{
+    return chain_launch("stm_bottleneck_chain_proj_f32", true, mid1_planes, x0_planes, y_planes, z_planes, w2_packed, tail_packed, b2, b3, b1_next,
+                        out_scale2, out_scale3, out_scale1, B, H, W, stream);
 }

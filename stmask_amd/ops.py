@@ -589,29 +589,38 @@ def _pow2_wscale(weight):
     return 2.0 ** (10 - math.floor(math.log2(wmax))) if wmax > 0 else 1.0
 
 
-def chain_pack_tail(w3, w1_next=None):
-    """conv3 [256, 64(,1,1)] and (optionally) the next block's conv1 [64, 256(,1,1)] -> the tail image of stm_bottleneck_chain_f32.
+def chain_pack_tail(w3, w1_next=None, wds=None):
+    """conv3 [256, 64(,1,1)] and (optionally) the next block's conv1 [64, 256(,1,1)] -> the tail image of stm_bottleneck_chain_f32; with
+    wds [256, 64(,1,1)] (the projection shortcut of a stage's first block) the image of stm_bottleneck_chain_proj_f32.
     Returns (packed, out_scale3, out_scale1)."""
     _dev(w3)
     w3 = _f32c(w3.reshape(256, 64))
-    ws3 = _pow2_wscale(w3)
+    if wds is not None:
+        wds = _f32c(wds.reshape(256, 64))
+    ws3 = _pow2_wscale(torch.cat([w3, wds], 1) if wds is not None else w3)
     ws1 = 1.0
     if w1_next is not None:
         w1_next = _f32c(w1_next.reshape(64, 256))
         ws1 = _pow2_wscale(w1_next)
-    packed = torch.zeros(_lib.lib().stm_chain_tail_weight_bytes(), device=w3.device, dtype=torch.uint8)
-    check(_lib.lib().stm_chain_pack_tail_f32(_p(w3), _p(w1_next) if w1_next is not None else None, _p(packed), c_f(ws3), c_f(ws1), _stream()),
-          "stm_chain_pack_tail_f32")
+    L = _lib.lib()
+    packed = torch.zeros(L.stm_chain_tail_weight_bytes_proj() if wds is not None else L.stm_chain_tail_weight_bytes(), device=w3.device, dtype=torch.uint8)
+    pw1 = _p(w1_next) if w1_next is not None else None
+    if wds is not None:
+        check(L.stm_chain_pack_tail_proj_f32(_p(w3), _p(wds), pw1, _p(packed), c_f(ws3), c_f(ws1), _stream()), "stm_chain_pack_tail_proj_f32")
+    else:
+        check(L.stm_chain_pack_tail_f32(_p(w3), pw1, _p(packed), c_f(ws3), c_f(ws1), _stream()), "stm_chain_pack_tail_f32")
     return packed, 1.0 / ws3, 1.0 / ws1
 
 
-def bottleneck_chain(mid1, x, w2_packed, tail_packed, b2, b3, b1_next, scales, B, H, W, y=None, z=None, want_z=True):
+def bottleneck_chain(mid1, x, w2_packed, tail_packed, b2, b3, b1_next, scales, B, H, W, y=None, z=None, want_z=True, proj=False):
     """csrc/conv_chain.hip: mid1 [2, 2, BHW, 32] and x [2, 8, BHW, 32] fp16 planes -> (y [2, 8, BHW, 32], z [2, 2, BHW, 32] or None):
-    relu(conv3(relu(conv2(mid1))) + x) and the next block's relu(conv1(y)) in one launch (reference backbone.py:38-58)."""
+    relu(conv3(relu(conv2(mid1))) + x) and the next block's relu(conv1(y)) in one launch (reference backbone.py:38-58).  proj=True: x is
+    the 64-channel input [2, 2, BHW, 32] of a stage's first block and the shortcut its projection (tail from chain_pack_tail(..., wds=))."""
     _dev(mid1)
     n = B * H * W
-    if tuple(mid1.shape) != (2, 2, n, 32) or tuple(x.shape) != (2, 8, n, 32) or mid1.dtype != torch.float16 or x.dtype != torch.float16:
-        raise StmError(f"bottleneck_chain: planes {tuple(mid1.shape)} / {tuple(x.shape)} do not match [2, 2|8, {n}, 32] fp16")
+    xs = 2 if proj else 8
+    if tuple(mid1.shape) != (2, 2, n, 32) or tuple(x.shape) != (2, xs, n, 32) or mid1.dtype != torch.float16 or x.dtype != torch.float16:
+        raise StmError(f"bottleneck_chain: planes {tuple(mid1.shape)} / {tuple(x.shape)} do not match [2, 2, {n}, 32] / [2, {xs}, {n}, 32] fp16")
     if not (mid1.is_contiguous() and x.is_contiguous()):
         raise StmError("bottleneck_chain: planes must be dense")
     if y is None:
@@ -619,10 +628,11 @@ def bottleneck_chain(mid1, x, w2_packed, tail_packed, b2, b3, b1_next, scales, B
     if want_z and z is None:
         z = torch.empty(2, 2, n, 32, device=mid1.device, dtype=torch.float16)
     s2, s3, s1 = scales
-    check(_lib.lib().stm_bottleneck_chain_f32(_p(mid1), _p(x), _p(y), _p(z) if want_z else None, _p(w2_packed), _p(tail_packed),
-                                              _p(b2) if b2 is not None else None, _p(b3) if b3 is not None else None,
-                                              _p(b1_next) if (want_z and b1_next is not None) else None, c_f(s2), c_f(s3), c_f(s1),
-                                              c_i(B), c_i(H), c_i(W), _stream()), "stm_bottleneck_chain_f32")
+    fn = _lib.lib().stm_bottleneck_chain_proj_f32 if proj else _lib.lib().stm_bottleneck_chain_f32
+    check(fn(_p(mid1), _p(x), _p(y), _p(z) if want_z else None, _p(w2_packed), _p(tail_packed),
+             _p(b2) if b2 is not None else None, _p(b3) if b3 is not None else None,
+             _p(b1_next) if (want_z and b1_next is not None) else None, c_f(s2), c_f(s3), c_f(s1),
+             c_i(B), c_i(H), c_i(W), _stream()), "stm_bottleneck_chain_proj_f32" if proj else "stm_bottleneck_chain_f32")
     return y, (z if want_z else None)
 
 

@@ -636,17 +636,24 @@ class PlanarChain:
     """The tail of one 64-channel bottleneck and the head of the next as one launch (stm_bottleneck_chain_f32, csrc/conv_chain.hip;
     reference backbone.py:38-58): relu(conv3(relu(conv2(mid1))) + x) and, when the next block's conv1 is given, relu(conv1(.))."""
 
-    def __init__(self, c2, c3, c1_next=None):
+    def __init__(self, c2, c3, c1_next=None, proj=None):
+        """proj: the 1x1 / stride-1 projection of a stage's first block (its shortcut), None = identity shortcut."""
+        self.wds = proj.weight.detach().float().contiguous() if proj is not None else None
         self.w2, self.b2 = c2.weight.detach().float().contiguous(), (c2.bias.detach().float().contiguous() if c2.bias is not None else None)
         self.w3, self.b3 = c3.weight.detach().float().contiguous(), (c3.bias.detach().float().contiguous() if c3.bias is not None else None)
         self.w1 = c1_next.weight.detach().float().contiguous() if c1_next is not None else None
         self.b1 = c1_next.bias.detach().float().contiguous() if (c1_next is not None and c1_next.bias is not None) else None
+        if proj is not None and proj.bias is not None:
+            self.b3 = proj.bias.detach().float() + (self.b3 if self.b3 is not None else 0.0)
         self._packed = None
         self.role = "trunk"
 
     @staticmethod
     def eligible(c2, c3, blk, fmt, out_fmt):
-        return (CONV_CHAIN and fmt == 1 and out_fmt == 1 and blk.downsample is None and isinstance(c2, torch.nn.Conv2d)
+        d = blk.downsample[0] if blk.downsample is not None else None
+        proj_ok = d is None or (isinstance(d, torch.nn.Conv2d) and tuple(d.weight.shape) == (256, 64, 1, 1) and tuple(d.stride) == (1, 1)
+                                and tuple(d.padding) == (0, 0) and d.groups == 1)
+        return (CONV_CHAIN and fmt == 1 and out_fmt == 1 and proj_ok and isinstance(c2, torch.nn.Conv2d)
                 and tuple(c2.weight.shape) == (64, 64, 3, 3) and tuple(c2.stride) == (1, 1) and tuple(c2.padding) == (1, 1)
                 and tuple(c2.dilation) == (1, 1) and c2.groups == 1 and tuple(c3.weight.shape) == (256, 64, 1, 1) and tuple(c3.stride) == (1, 1))
 
@@ -660,19 +667,19 @@ class PlanarChain:
             g.C, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.groups, g.fmt = 64, 64, 3, 3, 1, 1, 1, 1, 1, 1
             ops.planar_range_flag()
             w2p, s2 = ops.conv_pack_weights_kxr(self.w2, g)
-            tail, s3, s1 = ops.chain_pack_tail(self.w3, self.w1)
+            tail, s3, s1 = ops.chain_pack_tail(self.w3, self.w1, self.wds)
             self._packed = (w2p, tail, (s2, s3, s1))
         w2p, tail, scales = self._packed
         timing = ops._conv_timing
         if timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        y, z = ops.bottleneck_chain(mid1, x, w2p, tail, self.b2, self.b3, self.b1, scales, B, H, W, want_z=self.w1 is not None)
+        y, z = ops.bottleneck_chain(mid1, x, w2p, tail, self.b2, self.b3, self.b1, scales, B, H, W, want_z=self.w1 is not None, proj=self.wds is not None)
         if timing is not None:
             e1.record()
             M = B * H * W
-            macs = 64 * 64 * 9 + 256 * 64 + (256 * 64 if self.w1 is not None else 0)
-            nbytes = M * 4 * (64 + 256 + 256 + (64 if self.w1 is not None else 0)) + 4 * macs
+            macs = 64 * 64 * 9 + 256 * 64 * (2 if self.wds is not None else 1) + (256 * 64 if self.w1 is not None else 0)
+            nbytes = M * 4 * (64 + (64 if self.wds is not None else 256) + 256 + (64 if self.w1 is not None else 0)) + 4 * macs
             timing.append((e0, e1, 2.0 * M * macs, (M, 64, 256, 3, 1, 1, -1), 3, self.role, float(nbytes)))
         return y, z
 
@@ -750,7 +757,7 @@ class PlanarBackbone:
                 if PlanarChain.eligible(c2, c3, blk, fmt, e["c3"].out_fmt):
                     nxt = layer[bi + 1] if bi + 1 < len(layer) else None
                     give_z = nxt is not None and not isinstance(nxt.conv2, DCN) and PlanarChain.takes_z(nxt.conv1)
-                    e["chain"] = PlanarChain(c2, c3, nxt.conv1 if give_z else None)
+                    e["chain"] = PlanarChain(c2, c3, nxt.conv1 if give_z else None, blk.downsample[0] if blk.downsample is not None else None)
                 blks.append(e)
             self.blocks.append(blks)
 

@@ -802,3 +802,42 @@ def test_bottleneck_chain_known_answers_and_arguments():
         assert (gz - got[..., 64:128]).abs().max().item() <= 2.0 ** -20 * exp.abs().max().item(), (ky, kx)
     with pytest.raises(StmError):
         ops.bottleneck_chain(ops.split_planes(mid1.to(DEV), 1), ops.split_planes(x.to(DEV), 1)[:, :4].contiguous(), w2p, tail, None, None, None, scales, B, H, W)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 40), (3, 13, 17), (1, 96, 160)])
+def test_bottleneck_chain_projection_form(case):
+    """stm_bottleneck_chain_proj_f32: a stage's first block -- y = relu(conv3(relu(conv2(mid1))) + proj(x0) + b3 + bds), z = relu(conv1'(y))
+    -- against fp64 and against the launches it replaces (3x3, then the two-source product stm_conv2d_planar_dual_f32, then the 1x1)."""
+    from stmask_amd.planar import PlanarConv
+    B, H, W = case
+    w2, w3, w1, b2, b3, b1 = _chain_layers(seed=20)
+    wds, bds = rnd(256, 64, 1, 1, seed=31, scale=64 ** -0.5), rnd(256, seed=32, scale=0.3)
+    mid1, x0 = rnd(B, H, W, 64, seed=13).abs(), rnd(B, H, W, 64, seed=14).abs()
+    from stmask_amd import _lib
+    g = _lib.ConvGeom()
+    g.C, g.Cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.groups, g.fmt = 64, 64, 3, 3, 1, 1, 1, 1, 1, 1
+    ops.planar_range_flag()
+    w2p, s2 = ops.conv_pack_weights_kxr(w2.to(DEV), g)
+    tail, s3, s1 = ops.chain_pack_tail(w3.to(DEV), w1.to(DEV), wds.to(DEV))
+    m1p, x0p = ops.split_planes(mid1.to(DEV), 1), ops.split_planes(x0.to(DEV), 1)
+    y, z = ops.bottleneck_chain(m1p, x0p, w2p, tail, b2.to(DEV), (b3 + bds).to(DEV), b1.to(DEV), (s2, s3, s1), B, H, W, proj=True)
+    d = torch.float64
+    n = lambda t: t.permute(0, 3, 1, 2).to(d)
+    c2 = F.conv2d(n(mid1), w2.to(d), b2.to(d), padding=1).relu()
+    c3 = (F.conv2d(c2, w3.to(d), b3.to(d)) + F.conv2d(n(x0), wds.to(d), bds.to(d))).relu()
+    c1 = F.conv2d(c3, w1.to(d), b1.to(d)).relu()
+    mag3 = (F.conv2d(F.conv2d(n(mid1), w2.abs().to(d), b2.abs().to(d), padding=1), w3.abs().to(d), b3.abs().to(d))
+            + F.conv2d(n(x0), wds.abs().to(d), bds.abs().to(d)))
+    mag1 = F.conv2d(mag3, w1.abs().to(d), b1.abs().to(d))
+    got_y = planes_to_f32(y).cpu().view(B, H, W, 256).permute(0, 3, 1, 2).to(d)
+    got_z = planes_to_f32(z).cpu().view(B, H, W, 64).permute(0, 3, 1, 2).to(d)
+    assert ((got_y - c3).abs() / mag3.clamp_min(1e-6)).max().item() < 4e-6
+    assert ((got_z - c1).abs() / mag1.clamp_min(1e-6)).max().item() < 6e-6
+    l2 = PlanarConv(w2.to(DEV), b2.to(DEV), 1, 1, relu=True, fmt=1)
+    l3 = PlanarConv(torch.cat([w3, wds], 1).to(DEV), (b3 + bds).to(DEV), 1, 0, relu=True, fmt=1)
+    l1 = PlanarConv(w1.to(DEV), b1.to(DEV), 1, 0, relu=True, fmt=1)
+    y3 = l3(l2(m1p, ("img", B, H, W)), ("img", B, H, W), x2=(x0p, H, W, 1))
+    ya, yb = planes_to_f32(y), planes_to_f32(y3)
+    assert (ya - yb).abs().max().item() < 2e-5 * max(1.0, yb.abs().max().item())
+    za, zb = planes_to_f32(z), planes_to_f32(l1(y3, ("img", B, H, W)))
+    assert (za - zb).abs().max().item() < 2e-5 * max(1.0, zb.abs().max().item())
