@@ -40,7 +40,10 @@ constexpr int kx_stage_bytes(int kw, int npl, int nc, int pt) { return npl * (64
 constexpr int kx_pt(int kw, int npl, int nc)
 {
     if (nc >= 4 && npl == 2) return 2;     // four channel tiles: 64 accumulator registers per wave leave room for the second fragment set
-    for (int pt = 4; pt > 2; --pt)
+#ifndef KX_PT_MAX
+#define KX_PT_MAX 4      // (experiments: narrower tiles leave room for a deeper ring)
+#endif
+    for (int pt = KX_PT_MAX; pt > 2; --pt)
         if (3 * kx_stage_bytes(kw, npl, nc, pt) <= KX_LDS_MAX) return pt;
     return 2;
 }
