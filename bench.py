@@ -235,7 +235,8 @@ def conv_roofline(conv_t, steps, planes, traffic=None, traffic_src=None, timed_i
                 "traffic_source": (f"profiles/{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
                                    "correction); average over all launches") if traffic_src else None,
                 "peak_note": "algorithmic (reference) flops against 2500 TFLOP/s dense 16-bit MFMA divided by the MFMA products issued per "
-                             "reference product (3 for fp16x2 layers, 6 for bf16x3, 1 for fp16x1 layers; flop-weighted over the launches) "
+                             "reference product (3 for fp16x2 layers, 6 for bf16x3, 1 for fp16x1 layers, 3 x 361 / 441 for TemporalNet's 3x3 layers, whose border-class "
+                             "windows skip the taps that lie in the zero padding of the 7x7 RoI maps; flop-weighted over the launches) "
                              "-- i.e. frac = issued MFMA flops / time / 2500 (fp32 MFMA peak is 157)",
                 "avg_launch_us": round(allo["ms_per_step"] * steps * 1e3 / len(conv_t), 2),
                 "algorithmic_gflop_per_launch": round(allo["tflop_per_step"] * steps * 1e3 / len(conv_t), 2),
@@ -616,7 +617,8 @@ def main():
                 for t in conv_t:
                     a = agg.setdefault(t[3], [0, 0.0, 0.0])
                     a[0] += 1; a[1] += t[0].elapsed_time(t[1]); a[2] += t[2]
-                # (tile 0 = conv_kxr_kernel, -1 = conv_chain_kernel: conv2 3x3 + conv3 + shortcut + the next conv1 of a 64-channel bottleneck)
+                # (tile 0 = conv_kxr_kernel, -1 = conv_chain_kernel: conv2 3x3 + conv3 + shortcut + the next conv1 of a 64-channel bottleneck,
+                # -2 = the nine border-class windows of a TemporalNet layer in one conv_planar_kernel grid; TF = reference flops / time)
                 print("%9s %5s %5s %2s %2s %2s %4s %6s %9s %8s %7s" % ("M", "C", "O", "k", "s", "g", "tile", "calls", "us/call", "TF", "ms/step"), file=sys.stderr)
                 for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     print("%9d %5d %5d %2d %2d %2d %4d %6d %9.1f %8.1f %7.3f" % (*key, n, ms * 1e3 / n, fl / (ms * 1e-3) / 1e12, ms / args.steps),

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define STM_ABI_VERSION 2
+#define STM_ABI_VERSION 3
 
 enum stm_status {
     STM_OK = 0,
@@ -311,7 +311,26 @@ typedef struct stm_conv_geom {
                              (few output channels) and layers with few pixel tiles */
     int out_fmt_plus1;    /* 0: out_planes in `fmt`; k + 1: out_planes in format k.  Only fmt 2 -> out format 1 is
                              supported (the last fp16 layer of a ResNet stage hands both planes to the fp32-equivalent FPN) */
+    int win_h, win_w, win_y0, win_x0; /* (ABI 3) win_w > 0: WINDOW launch of stm_conv2d_planar_f32 -- the launch computes only the
+                             Ho x Wo outputs starting at (win_y0, win_x0) of every win_h x win_w output image and writes them to rows
+                             b * win_h * win_w + (win_y0 + oy) * win_w + win_x0 + ox of the output tensors (out_np / the fp32 matrix
+                             cover B * win_h * win_w rows).  Ho / Wo are free and ph / pw may be negative: output (oy, ox) reads input
+                             (oy * sh - ph + ky, ox * sw - pw + kx).  With the kernel cut to the taps that can be inside the image this
+                             runs the border classes of a "same" convolution without their zero taps (TemporalNet's 3x3 layers on 7x7
+                             RoI maps: 361 of 441 tap-pixels are real).  No residual, no levels, no second source. */
 } stm_conv_geom;
+
+/* One layer as several window launches in ONE grid (csrc/conv_bf16x.hip, CLS instantiation): window i = the Ho x Wo outputs at (y0, x0) of every
+ * g->win_h x g->win_w output image, computed with its own kh x kw sub-kernel (packed_weights[i], packed with stm_conv_pack_weights_fmt_f32 at
+ * tile_n 128 and ONE common wscale, g->out_scale = 1 / wscale) and padding ph / pw (may be negative: output (oy, ox) of the window reads input
+ * (oy - ph + ky, ox - pw + kx)).  g: B, H, W, C, Cout, sh = sw = 1, fmt 1, planes 2, win_h / win_w, x_np / out_np / strides as usual (the
+ * outputs have B * win_h * win_w rows); its kh / kw / ph / pw / Ho / Wo / win_y0 / win_x0 are ignored.  At most 9 windows.
+ * Use: the border classes of a "same" 3x3 convolution on small maps (TemporalNet, track_to_segment_head.py:10-37: three 3x3 / pad-1 layers on
+ * 7x7 RoI maps) -- rows {0}, {1..H-2}, {H-1} x columns likewise, each with the taps that can be inside the map: 361 of 441 tap-pixels are
+ * multiplied instead of 441, and the results are the same sums (bit-equal to the padded launch). */
+typedef struct stm_conv_window { int kh, kw, ph, pw, Ho, Wo, y0, x0; } stm_conv_window;
+int stm_conv2d_planar_windows_f32(const void* x_planes, const void* const* packed_weights, const stm_conv_window* windows, int n_windows,
+                                  const float* bias, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu, stm_stream_t stream);
 
 /* Two-source 1x1 convolution on the planar kernel: y = W [x1 ; x2 (stride s2)] + bias (+ residual) (+ ReLU) -- the last 1x1 convolution of
  * a ResNet stage's first bottleneck and its projection shortcut (backbone.py:38-58: out = bn3(conv3(out)); out += downsample(x); relu)

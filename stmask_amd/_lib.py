@@ -13,9 +13,9 @@ _lib = None
 c_i, c_l, c_f, c_p, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
 # every symbol include/stmask_hip.h declares (tests/test_abi.py checks the library exports all of them)
-ABI_VERSION = 2   # include/stmask_hip.h STM_ABI_VERSION
+ABI_VERSION = 3   # include/stmask_hip.h STM_ABI_VERSION
 ABI_SYMBOLS = [
-    "stm_version", "stm_last_error_string", "stm_struct_bytes", "stm_debug_reload_tunables", "stm_conv_kxr_packed_bytes", "stm_conv_pack_weights_kxr_f32", "stm_conv2d_planar_kxr_f32", "stm_conv2d_planar_dual_f32", "stm_stem_packed_weight_bytes", "stm_stem_pack_weights_f32", "stm_stem_fused_f32", "stm_chain_tail_weight_bytes", "stm_chain_tail_weight_bytes_proj", "stm_chain_pack_tail_f32", "stm_chain_pack_tail_proj_f32", "stm_bottleneck_chain_f32", "stm_bottleneck_chain_proj_f32", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
+    "stm_version", "stm_last_error_string", "stm_struct_bytes", "stm_debug_reload_tunables", "stm_conv_kxr_packed_bytes", "stm_conv_pack_weights_kxr_f32", "stm_conv2d_planar_kxr_f32", "stm_conv2d_planar_dual_f32", "stm_conv2d_planar_windows_f32", "stm_stem_packed_weight_bytes", "stm_stem_pack_weights_f32", "stm_stem_fused_f32", "stm_chain_tail_weight_bytes", "stm_chain_tail_weight_bytes_proj", "stm_chain_pack_tail_f32", "stm_chain_pack_tail_proj_f32", "stm_bottleneck_chain_f32", "stm_bottleneck_chain_proj_f32", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
     "stm_deform_conv_fwd_f32", "stm_gemm_bias_f32", "stm_gemm_workspace_bytes", "stm_gemm_bias_ws_f32", "stm_fcb_ali_offsets_f32", "stm_corr_patch_f32", "stm_corr_patch_nhwc_f32",
     "stm_roi_align_avg_f32", "stm_decode_boxes_f32", "stm_generate_candidates_f32", "stm_cc_fast_nms_f32",
     "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_detect_cc_logits_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
@@ -41,7 +41,12 @@ class ConvGeom(ctypes.Structure):
     _fields_ = ([(n, c_i) for n in ("B", "H", "W", "C", "Ho", "Wo", "Cout", "kh", "kw", "sh", "sw", "ph", "pw", "x_ld",
                                     "out_ld", "res_ld", "planes", "groups", "n_levels")] +
                 [("lvl_start", c_i * 9), ("lvl_h", c_i * 8), ("lvl_w", c_i * 8),
-                 ("x_plane_stride", c_l), ("out_plane_stride", c_l), ("res_plane_stride", c_l), ("x_np", c_i), ("out_np", c_i), ("res_np", c_i), ("group_cout", c_i * 8), ("fmt", c_i), ("out_scale", c_f), ("tile_n", c_i), ("out_fmt_plus1", c_i)])
+                 ("x_plane_stride", c_l), ("out_plane_stride", c_l), ("res_plane_stride", c_l), ("x_np", c_i), ("out_np", c_i), ("res_np", c_i), ("group_cout", c_i * 8), ("fmt", c_i), ("out_scale", c_f), ("tile_n", c_i), ("out_fmt_plus1", c_i),
+                 ("win_h", c_i), ("win_w", c_i), ("win_y0", c_i), ("win_x0", c_i)])
+
+
+class ConvWindow(ctypes.Structure):
+    _fields_ = [(n, c_i) for n in ("kh", "kw", "ph", "pw", "Ho", "Wo", "y0", "x0")]
 
 
 class HeadLayout(ctypes.Structure):

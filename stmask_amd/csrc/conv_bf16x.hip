@@ -106,6 +106,13 @@ struct PlanarArgs {
     long long x2_pstride;
     unsigned plane2_bytes;
     int c1_slabs, x2_np, H2, W2, s2;
+    // window launches (stm_conv_geom.win_w > 0): the launch computes a Ho x Wo window of every output image; output pixel (b, oy, ox) is row
+    // b * win_hw + oy * win_w + ox + win_off of the output tensors
+    int win_w, win_hw, win_off;
+    // several window launches in ONE grid (CLS instantiation; stm_conv2d_planar_windows_f32): class c = tiles [tile0, next tile0) with its own
+    // weights, sub-kernel, window and pixel count -- the fields below replace wp / kh / kw / ph / pw / Ho / Wo / M / slabs / win_off per tile
+    int n_cls, cls_tiles;
+    struct Cls { const uint8_t* wp; int kh, kw, ph, pw, Ho, Wo, M, slabs, win_off, tile0; float inv_hw, inv_w; } cls[9];
 };
 
 // Epilogue shared by the planar kernels: bias + residual (+ReLU) in fp32, then fp32 NHWC and/or the three bf16 planes.
@@ -142,6 +149,17 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
     const size_t opl = (size_t)(a.out_pstride >> 1), rpl = (size_t)(a.res_pstride >> 1);   // plane strides in elements
     // element index of (pixel m, channel co) in a slab-major planar buffer with np pixels per slab
     auto pidx = [](int m_, int co_, int np) { return ((size_t)(co_ >> 5) * np + m_) * 32 + (co_ & 31); };
+    int mo = m;                                          // output row (differs from the pixel index of the launch in window launches)
+    if (a.win_w) {
+        const int hw = a.Ho * a.Wo;
+        int b = (int)((float)m * a.inv_hw);
+        int rem = m - b * hw;
+        if (rem < 0) { --b; rem += hw; } else if (rem >= hw) { ++b; rem -= hw; }
+        int oy = (int)((float)rem * a.inv_w);
+        const int t = rem - oy * a.Wo;
+        if (t < 0) --oy; else if (t >= a.Wo) ++oy;
+        mo = b * a.win_hw + oy * a.win_w + (rem - oy * a.Wo) + a.win_off;
+    }
     if constexpr (SCALE_BIAS) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], a.out_scale, (a.bias && e < nvalid) ? a.bias[co + e] : 0.0f);
@@ -177,12 +195,12 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
             for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaxf(v[e], 0.0f);   // (nan -> 0 and -0 -> +0, as `v > 0 ? v : 0` gives)
         }
         if (a.out_f32) {
-            float* o = a.out_f32 + (size_t)m * a.out_ld + co;
+            float* o = a.out_f32 + (size_t)mo * a.out_ld + co;
             *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
         }
         if (a.out_pl) {
-            uint8_t* o = a.out_pl + pidx(m, co, a.out_np) * 2;
+            uint8_t* o = a.out_pl + pidx(mo, co, a.out_np) * 2;
             store_planes8(o, opl * 2, v, ofmt, a.range_flag, a.nt_out != 0);
         }
         return;
@@ -205,9 +223,9 @@ __device__ __forceinline__ void epilogue_store8(const PlanarArgs& a, int m, int 
             }
         }
         if (a.relu) x = x > 0.0f ? x : 0.0f;
-        if (a.out_f32) a.out_f32[(size_t)m * a.out_ld + co + e] = x;
+        if (a.out_f32) a.out_f32[(size_t)mo * a.out_ld + co + e] = x;
         if (outp) {
-            const size_t oi = pidx(m, co + e, a.out_np);
+            const size_t oi = pidx(mo, co + e, a.out_np);
             if (ofmt >= 1) {
                 _Float16* oh = reinterpret_cast<_Float16*>(a.out_pl);
                 const _Float16 h = (_Float16)x;
@@ -333,8 +351,8 @@ __global__ __launch_bounds__(256) void planar_splitk_finish_kernel(const PlanarA
 // expanding 1x1 convolutions, 337 vs 345 us, for 32 more live registers and one wave per SIMD less; and resident workgroups
 // walking the tiles instead of one workgroup per tile -- 404 -> 451 us.  Neither the epilogue's second memory round trip nor
 // workgroup launch overhead is what holds these layers at 3.3 TB/s.)
-template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0, bool DUAL = false>
-__global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
+template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0, bool DUAL = false, bool CLS = false>
+__global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a_in)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
     extern __shared__ __align__(16) uint8_t smem[];
@@ -347,10 +365,34 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a)
     static_assert((BN / 16) * NPL % NWAVES == 0, "weight tile must split evenly over the waves");
     static_assert(ST == 2 || (ST == 3 && DT == 1 && NPL <= 2), "the three-buffer ring is built for the fp16 formats");
 
-    const int tiles = a.m_tiles * a.n_tiles * a.splitk;
+    const int tiles = CLS ? a_in.cls_tiles : a_in.m_tiles * a_in.n_tiles * a_in.splitk;
     const int per_xcd = (tiles + 7) >> 3;
-    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if constexpr (CLS) {
+        // the classes' tiles differ in length (4, 6 or 9 taps): a contiguous run of tile ids per XCD would give one XCD the short classes and
+        // another the long one.  Pixel tiles are dealt round-robin to the XCDs instead, each with all its channel tiles (they share its rows).
+        const int j = blockIdx.x >> 3, jm = j / a_in.n_tiles;
+        logical = (jm * 8 + (int)(blockIdx.x & 7)) * a_in.n_tiles + (j - jm * a_in.n_tiles);
+    }
     if (logical >= tiles) return;
+    // CLS: the grid is the concatenation of several window launches (classes); this tile's class supplies the fields that differ
+    PlanarArgs a_cls;
+    const PlanarArgs* ap = &a_in;
+    if constexpr (CLS) {
+        int c = 0;
+#pragma unroll
+        for (int i = 1; i < 9; ++i)
+            if (i < a_in.n_cls && logical >= a_in.cls[i].tile0) c = i;
+        a_cls = a_in;
+        a_cls.wp = a_in.cls[c].wp;
+        a_cls.kh = a_in.cls[c].kh; a_cls.kw = a_in.cls[c].kw; a_cls.ph = a_in.cls[c].ph; a_cls.pw = a_in.cls[c].pw;
+        a_cls.Ho = a_in.cls[c].Ho; a_cls.Wo = a_in.cls[c].Wo; a_cls.M = a_in.cls[c].M;
+        a_cls.slabs = a_in.cls[c].slabs; a_cls.kslabs = a_in.cls[c].slabs; a_cls.win_off = a_in.cls[c].win_off;
+        a_cls.inv_hw = a_in.cls[c].inv_hw; a_cls.inv_w = a_in.cls[c].inv_w;
+        logical -= a_in.cls[c].tile0;
+        ap = &a_cls;
+    }
+    const PlanarArgs& a = *ap;
     // (integer divisions cost ~40 instructions each on this ISA and a short-K tile is only a few hundred MFMA cycles long: the
     // common cases -- no split-K, one n-tile, one group -- take none)
     const int ksp = a.splitk == 1 ? 0 : logical % a.splitk;      // split-K part (the parts of one tile sit on one XCD)
@@ -1109,7 +1151,7 @@ const ConvTunables& tunables()
     return t;
 }
 
-template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0, bool DUAL = false>
+template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0, bool DUAL = false, bool CLS = false>
 int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
 {
     size_t lds = (size_t)ST * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
@@ -1121,11 +1163,11 @@ int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
     int dev = 0;
     const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STM_MAX_DEVICES;
     if (!have_dev || !lds_reserved[dev].load(std::memory_order_relaxed)) {
-        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL, DUAL, CLS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) == hipSuccess, STM_ELAUNCH, "stm_conv2d_planar_f32: cannot reserve %zu bytes of LDS", lds);
         if (have_dev) lds_reserved[dev].store(true, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL, DUAL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
+    hipLaunchKernelGGL((conv_planar_kernel<NPL, MG, NJ, DT, ST, ABL, DUAL, CLS>), dim3(8 * stm_cdiv(tiles, 8)), dim3(256 * MG), lds, stm_hs(stream), a);
     STM_CHECK_LAUNCH("conv_planar_kernel");
     return STM_OK;
 }
@@ -1134,12 +1176,18 @@ bool geom_ok(const stm_conv_geom* g, const char* who)
 {
     if (!g) { stm_set_error("%s: geometry is NULL", who); return false; }
     if (g->B <= 0 || g->H <= 0 || g->W <= 0 || g->C <= 0 || g->Cout <= 0 || g->kh <= 0 || g->kw <= 0 || g->sh <= 0 ||
-        g->sw <= 0 || g->ph < 0 || g->pw < 0 || g->Ho <= 0 || g->Wo <= 0) {
+        g->sw <= 0 || g->Ho <= 0 || g->Wo <= 0 || (g->win_w <= 0 && (g->ph < 0 || g->pw < 0))) {
         stm_set_error("%s: bad geometry", who);
         return false;
     }
     if (g->C % CV_BK != 0) { stm_set_error("%s: input channels (%d) must be a multiple of 32", who, g->C); return false; }
-    if (g->Ho != (g->H + 2 * g->ph - g->kh) / g->sh + 1 || g->Wo != (g->W + 2 * g->pw - g->kw) / g->sw + 1) {
+    if (g->win_w > 0) {
+        // window launch: Ho x Wo outputs per image starting at (win_y0, win_x0) of the win_h x win_w output image; ph / pw may be negative
+        if (g->win_h <= 0 || g->win_y0 < 0 || g->win_x0 < 0 || g->win_y0 + g->Ho > g->win_h || g->win_x0 + g->Wo > g->win_w || g->n_levels > 0) {
+            stm_set_error("%s: the %dx%d window at (%d, %d) leaves the %dx%d output image", who, g->Ho, g->Wo, g->win_y0, g->win_x0, g->win_h, g->win_w);
+            return false;
+        }
+    } else if (g->Ho != (g->H + 2 * g->ph - g->kh) / g->sh + 1 || g->Wo != (g->W + 2 * g->pw - g->kw) / g->sw + 1) {
         stm_set_error("%s: Ho/Wo do not match the convolution arithmetic", who);
         return false;
     }
@@ -1315,10 +1363,11 @@ extern "C" int stm_stem_rows_planes_f32(const float* x, void* planes, int B, int
 }
 
 namespace {
+struct WinSet { const void* const* packed; const stm_conv_window* win; int n; };
 struct DualSrc { const void* x2; int C2, H2, W2, s2; long long x2_np, x2_plane_stride; };
 int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
                        const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
-                       int relu, void* workspace, size_t workspace_bytes, stm_stream_t stream, const DualSrc* dual);
+                       int relu, void* workspace, size_t workspace_bytes, stm_stream_t stream, const DualSrc* dual, const WinSet* wset);
 }  // namespace
 
 extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
@@ -1326,7 +1375,7 @@ extern "C" int stm_conv2d_planar_ws_f32(const void* x_planes, const void* packed
                                         int relu, void* workspace, size_t workspace_bytes, stm_stream_t stream)
 {
     return conv2d_planar_impl(x_planes, packed_weight, bias, residual_f32, residual_planes, out_f32, out_planes, g, relu, workspace,
-                              workspace_bytes, stream, nullptr);
+                              workspace_bytes, stream, nullptr, nullptr);
 }
 
 // Two-source 1x1 convolution: y = W [x1 ; x2(stride s2)] + bias (+ residual) -- the last 1x1 convolution of a ResNet stage's first
@@ -1343,13 +1392,35 @@ extern "C" int stm_conv2d_planar_dual_f32(const void* x_planes, const void* x2_p
     STM_REQUIRE(x2_planes && g, STM_ENULL, "stm_conv2d_planar_dual_f32: x2_planes / geometry must be non-NULL");
     DualSrc d{x2_planes, C2, H2, W2, s2, x2_np, x2_plane_stride};
     return conv2d_planar_impl(x_planes, packed_weight, bias, residual_f32, residual_planes, out_f32, out_planes, g, relu, workspace,
-                              workspace_bytes, stream, &d);
+                              workspace_bytes, stream, &d, nullptr);
+}
+
+// Several window launches (stm_conv_geom.win_*) of ONE layer as one grid: window i has its own sub-kernel (kh x kw taps, packed weights
+// packed[i], all under the same weight scale) and its own Ho x Wo rectangle at (y0, x0) of every win_h x win_w output image.  g gives what
+// the windows share: B, H, W, C, Cout, sh = sw = 1, fmt 1, planes, tile_n 128, out_scale, win_h / win_w, the buffer geometry.  The tiles of
+// all windows form one grid, so the small windows (a row or a corner of a 7x7 RoI map) do not pay a launch and a partial last round each:
+// TemporalNet's 3x3 layers run their nine border classes -- the taps that can be inside the map, 361 of 441 tap-pixels -- at the
+// efficiency of the single padded launch.  Same sums as that launch (a skipped tap added exact zeros): bit-equal.
+extern "C" int stm_conv2d_planar_windows_f32(const void* x_planes, const void* const* packed_weights, const stm_conv_window* windows, int n_windows,
+                                             const float* bias, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu, stm_stream_t stream)
+{
+    const char* who = "stm_conv2d_planar_windows_f32";
+    STM_REQUIRE(packed_weights && windows && g, STM_ENULL, "%s: NULL argument", who);
+    STM_REQUIRE(n_windows >= 1 && n_windows <= 9, STM_EINVAL, "%s: 1 .. 9 windows", who);
+    STM_REQUIRE(g->win_w > 0 && g->win_h > 0 && g->fmt == 1 && g->sh == 1 && g->sw == 1 && (g->groups <= 1) && g->n_levels <= 0 &&
+                (g->tile_n == 0 || g->tile_n == 128), STM_EUNSUPPORTED, "%s: fp16x2 planes, stride 1, one group, 128-channel tiles, win_h / win_w set", who);
+    for (int i = 0; i < n_windows; ++i) STM_REQUIRE(packed_weights[i], STM_ENULL, "%s: packed weight %d is NULL", who, i);
+    stm_conv_geom g0 = *g;                       // window 0 stands in for the common checks and fields
+    g0.kh = windows[0].kh; g0.kw = windows[0].kw; g0.ph = windows[0].ph; g0.pw = windows[0].pw;
+    g0.Ho = windows[0].Ho; g0.Wo = windows[0].Wo; g0.win_y0 = windows[0].y0; g0.win_x0 = windows[0].x0;
+    WinSet ws{packed_weights, windows, n_windows};
+    return conv2d_planar_impl(x_planes, packed_weights[0], bias, nullptr, nullptr, out_f32, out_planes, &g0, relu, nullptr, 0, stream, nullptr, &ws);
 }
 
 namespace {
 int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
                        const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
-                       int relu, void* workspace, size_t workspace_bytes, stm_stream_t stream, const DualSrc* dual)
+                       int relu, void* workspace, size_t workspace_bytes, stm_stream_t stream, const DualSrc* dual, const WinSet* wset)
 {
     const char* who = dual ? "stm_conv2d_planar_dual_f32" : "stm_conv2d_planar_f32";
     STM_REQUIRE(x_planes && packed_weight && (out_f32 || out_planes), STM_ENULL,
@@ -1381,8 +1452,11 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
     // fp32 tensors: [pixels][ld]; planar buffers: [plane][channel slab][np pixels][32]
     const int out_ld = g->out_ld ? g->out_ld : g->Cout, res_ld = g->res_ld ? g->res_ld : g->Cout;
     STM_REQUIRE(out_ld >= g->Cout && res_ld >= g->Cout, STM_EINVAL, "%s: bad leading dimensions out_ld=%d res_ld=%d", who, out_ld, res_ld);
-    const int64_t x_np = g->x_np ? g->x_np : in_pixels, out_np = g->out_np ? g->out_np : M, res_np = g->res_np ? g->res_np : M;
-    STM_REQUIRE(x_np >= in_pixels && out_np >= M && res_np >= M, STM_EINVAL, "%s: x_np / out_np / res_np smaller than the pixel count", who);
+    const bool win = g->n_levels <= 0 && g->win_w > 0;
+    const int64_t out_rows = win ? (int64_t)g->B * g->win_h * g->win_w : M;       // rows of the output tensors
+    const int64_t x_np = g->x_np ? g->x_np : in_pixels, out_np = g->out_np ? g->out_np : out_rows, res_np = g->res_np ? g->res_np : M;
+    STM_REQUIRE(!win || (!residual_f32 && !residual_planes && !dual), STM_EUNSUPPORTED, "%s: window launches take no residual / second source", who);
+    STM_REQUIRE(x_np >= in_pixels && out_np >= out_rows && res_np >= M, STM_EINVAL, "%s: x_np / out_np / res_np smaller than the pixel count", who);
     STM_REQUIRE((uintptr_t)x_planes % 16 == 0 && (uintptr_t)packed_weight % 16 == 0, STM_EINVAL,
                 "%s: x_planes and packed_weight must be 16-byte aligned", who);
     if (dual) {
@@ -1425,7 +1499,8 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
                      ((uintptr_t)out_planes % 16 == 0) && ((uintptr_t)residual_f32 % 16 == 0) && ((uintptr_t)residual_planes % 16 == 0) &&
                      (ops % 8 == 0) && (rps % 8 == 0) && !tn.scalar_epilogue;
     STM_REQUIRE(g->kh * g->kw <= 32, STM_EUNSUPPORTED, "%s: more than 32 taps", who);
-    a.pointwise = (g->n_levels <= 0 && g->kh == 1 && g->kw == 1 && g->sh == 1 && g->sw == 1 && g->ph == 0 && g->pw == 0) ? 1 : 0;
+    a.pointwise = (g->n_levels <= 0 && !win && g->kh == 1 && g->kw == 1 && g->sh == 1 && g->sw == 1 && g->ph == 0 && g->pw == 0) ? 1 : 0;
+    a.win_w = win ? g->win_w : 0; a.win_hw = win ? g->win_h * g->win_w : 0; a.win_off = win ? g->win_y0 * g->win_w + g->win_x0 : 0;
     a.inv_hw = g->n_levels > 0 ? 0.0f : 1.0f / (float)((int64_t)g->Ho * g->Wo);
     a.inv_w = g->n_levels > 0 ? 0.0f : 1.0f / (float)g->Wo;
     STM_REQUIRE(g->n_levels > 0 || M < ((int64_t)1 << 24), STM_EUNSUPPORTED, "%s: more than 2^24 output pixels in one launch", who);
@@ -1494,6 +1569,32 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
         STM_CHECK_LAUNCH("planar_splitk_finish_kernel");
         return STM_OK;
     };
+    if (wset) {
+        STM_REQUIRE(bn == 128 && a.fmt == 1 && !dual && win, STM_EUNSUPPORTED, "%s: window sets run on the 256 x 128 ring tiles of the fp16x2 format", who);
+        a.n_cls = wset->n;
+        int t0 = 0;
+        for (int i = 0; i < wset->n; ++i) {
+            const stm_conv_window& w = wset->win[i];
+            STM_REQUIRE(w.kh > 0 && w.kw > 0 && w.kh * w.kw <= 32 && w.Ho > 0 && w.Wo > 0 && w.y0 >= 0 && w.x0 >= 0 && w.y0 + w.Ho <= g->win_h &&
+                            w.x0 + w.Wo <= g->win_w, STM_EINVAL, "%s: window %d (%dx%d at %d, %d, kernel %dx%d) is not inside the %dx%d output", who, i, w.Ho,
+                        w.Wo, w.y0, w.x0, w.kh, w.kw, g->win_h, g->win_w);
+            STM_REQUIRE((uintptr_t)wset->packed[i] % 16 == 0, STM_EINVAL, "%s: packed weight %d is not 16-byte aligned", who, i);
+            const int64_t Mc = (int64_t)g->B * w.Ho * w.Wo;
+            STM_REQUIRE(Mc < ((int64_t)1 << 24), STM_EUNSUPPORTED, "%s: more than 2^24 output pixels in one window", who);
+            PlanarArgs::Cls& c = a.cls[i];
+            c.wp = static_cast<const uint8_t*>(wset->packed[i]);
+            c.kh = w.kh; c.kw = w.kw; c.ph = w.ph; c.pw = w.pw; c.Ho = w.Ho; c.Wo = w.Wo; c.M = (int)Mc;
+            c.slabs = w.kh * w.kw * (g->C / CV_BK); c.win_off = w.y0 * g->win_w + w.x0; c.tile0 = t0;
+            c.inv_hw = 1.0f / (float)(w.Ho * w.Wo); c.inv_w = 1.0f / (float)w.Wo;
+            t0 += stm_cdiv(Mc, 2 * CV_BM) * a.n_tiles;
+        }
+        for (int i = wset->n; i < 9; ++i) a.cls[i] = a.cls[0];
+        a.cls_tiles = t0;
+        a.m_tiles = 0;
+        // (grid: every XCD gets the same number of pixel tiles x all channel tiles; ids past the last tile leave at once)
+        return launch_planar<2, 2, 2, 1, 3, 0, false, true>(a, stm_cdiv(t0 / a.n_tiles, 8) * 8 * a.n_tiles, stream);
+    }
+    a.n_cls = 0; a.cls_tiles = 0;
     int rc;
     if (bn == 64) {
         // 128 x 64 tiles, 72 KB of LDS: two independent workgroups per CU, each one's barrier / staging gaps filled by

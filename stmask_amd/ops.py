@@ -518,7 +518,7 @@ def mask_resize_rle(masks, crop_h, crop_w, out_h, out_w, thr=0.5, max_runs=4096)
     return counts, n_runs
 
 
-def conv_pack_weights(weight, planes=3, tile_n=128, fmt=0):
+def conv_pack_weights(weight, planes=3, tile_n=128, fmt=0, wscale=None):
     """OIHW fp32 weights -> the pre-split, pre-tiled image the convolution kernels stream (done once per layer).
     tile_n = 64 packs for the 128 x 64-tile planar kernel (stm_conv_geom.tile_n must say so too).
     fmt = 1 / 2: two / one fp16 plane(s) of weight * wscale (power of two bringing max |w| to ~2^10) -> returns
@@ -534,14 +534,43 @@ def conv_pack_weights(weight, planes=3, tile_n=128, fmt=0):
     packed = torch.empty(nbytes, device=weight.device, dtype=torch.uint8)
     if fmt >= 1:
         import math
-        wmax = float(weight.abs().max())
-        wscale = 2.0 ** (10 - math.floor(math.log2(wmax))) if wmax > 0 else 1.0
+        if wscale is None:          # (given: several weight tensors packed under one scale, e.g. the sub-kernels of a window set)
+            wmax = float(weight.abs().max())
+            wscale = 2.0 ** (10 - math.floor(math.log2(wmax))) if wmax > 0 else 1.0
         check(_lib.lib().stm_conv_pack_weights_fmt_f32(_p(weight), _p(packed), c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(tile_n), c_i(fmt),
                                                        c_f(wscale), _stream()), "stm_conv_pack_weights_fmt_f32")
         return packed, 1.0 / wscale
     check(_lib.lib().stm_conv_pack_weights_tiled_f32(_p(weight), _p(packed), c_i(O), c_i(C), c_i(kh), c_i(kw), c_i(planes),
                                                      c_i(tile_n), _stream()), "stm_conv_pack_weights_tiled_f32")
     return packed
+
+
+def conv2d_planar_windows(xp, packed_list, windows, bias, B, H, W, C, O, out_h, out_w, out_scale, relu=True, out_f32=None, out_planes=None):
+    """stm_conv2d_planar_windows_f32: several window launches of one fp16x2 layer as one grid.  xp [2, C/32, >= B*H*W, 32]; packed_list[i] /
+    windows[i] = (kh, kw, ph, pw, Ho, Wo, y0, x0): sub-kernel weights (conv_pack_weights(..., tile_n=128, fmt=1, wscale=common)) and window of
+    the out_h x out_w output image; out_f32 [B*out_h*out_w, O] and / or out_planes [2, O/32, B*out_h*out_w, 32] are written in place."""
+    _dev(xp)
+    if out_f32 is None and out_planes is None:
+        raise StmError("conv2d_planar_windows: no output given")
+    n = len(windows)
+    g = _lib.ConvGeom()
+    g.B, g.H, g.W, g.C, g.Cout, g.sh, g.sw, g.planes, g.fmt, g.tile_n = B, H, W, C, O, 1, 1, 2, 1, 128
+    g.kh, g.kw, g.Ho, g.Wo = windows[0][0], windows[0][1], windows[0][4], windows[0][5]
+    g.win_h, g.win_w = out_h, out_w
+    g.out_scale = out_scale
+    g.x_np, g.x_plane_stride = xp.shape[2], xp.shape[1] * xp.shape[2] * 32
+    if out_planes is not None:
+        g.out_np, g.out_plane_stride = out_planes.shape[2], out_planes.shape[1] * out_planes.shape[2] * 32
+    if out_f32 is not None:
+        g.out_ld = out_f32.shape[-1]
+    wins = (_lib.ConvWindow * n)()
+    for i, wv in enumerate(windows):
+        wins[i].kh, wins[i].kw, wins[i].ph, wins[i].pw, wins[i].Ho, wins[i].Wo, wins[i].y0, wins[i].x0 = wv
+    ptrs = (ctypes.c_void_p * n)(*[p.data_ptr() for p in packed_list])
+    check(_lib.lib().stm_conv2d_planar_windows_f32(_p(xp), ptrs, wins, c_i(n), _p(bias) if bias is not None else None,
+                                                   _p(out_f32) if out_f32 is not None else None, _p(out_planes) if out_planes is not None else None,
+                                                   ctypes.byref(g), c_i(1 if relu else 0), _stream()), "stm_conv2d_planar_windows_f32")
+    return out_f32 if out_f32 is not None else out_planes
 
 
 def conv_kxr_supported(O, C, kh, kw, stride, padding, groups, group_cout, fmt, max_tiles=4):

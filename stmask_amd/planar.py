@@ -43,6 +43,7 @@ STEM_PLANAR = os.environ.get("STM_STEM_PLANAR", "1") != "0"
 C3DS_FUSED = os.environ.get("STM_C3DS_FUSED", "1") != "0"    # conv3 + projection shortcut of a stage's first block as one two-source product
 STEM_FUSED = os.environ.get("STM_STEM_FUSED", "1") != "0"    # conv1 + ReLU + max-pool as one kernel (csrc/stem_fused.hip)
 CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 layers on the kx-reuse kernel (csrc/conv_kxr.hip)
+TN_BORDER = os.environ.get("STM_TN_BORDER", "1") != "0"     # TemporalNet's 3x3 layers as nine window launches without the zero taps of the RoI borders
 CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"  # layer1's identity-shortcut blocks: conv2 -> conv3 + shortcut -> next conv1 as one kernel (csrc/conv_chain.hip)
 
 
@@ -122,7 +123,7 @@ class PlanarConv:
         return 128
 
     def __call__(self, xp, shape, out="planes", x_off=0, out_planes=None, out_f32=None, out_off=0, residual=None, x_ch_off=0,
-                 out_ch_off=0, x2=None):
+                 out_ch_off=0, x2=None, window=None):
         """xp: [P, S, N, 32] planes in this layer's format (channel-slab major; 2 x fp16 or 3 x bf16).  shape: ("img", B, H, W) -> pixels [x_off, x_off + B*H*W)
         of xp are one image batch; ("levels", B, [(H, W), ...]) -> all of xp, concatenated levels.  The layer reads
         groups*C channels starting at channel x_ch_off.  out: "planes" | "f32" | "both" allocates dense outputs
@@ -157,6 +158,15 @@ class PlanarConv:
         else:
             _, B, H, W = shape
             Ho, Wo = ops.conv_out_hw(H, W, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, 1, 1)
+            out_rows = None
+            if window is not None:
+                # window launch (stm_conv_geom.win_*): (y0, x0, ho, wo, ph, pw, full_h, full_w) -- only the ho x wo outputs from (y0, x0) of
+                # every full_h x full_w output image, written in place into the full output tensors; ph / pw may be negative
+                y0, x0, Ho, Wo, g.ph, g.pw, fh, fw = window
+                g.win_h, g.win_w, g.win_y0, g.win_x0 = fh, fw, y0, x0
+                out_rows = B * fh * fw
+                if residual is not None or x2 is not None:
+                    raise StmError("PlanarConv: window launches take no residual / second source")
             g.B, g.H, g.W, g.Ho, g.Wo = B, H, W, Ho, Wo
             M = B * Ho * Wo
             if x_off + B * H * W > N:
@@ -165,11 +175,13 @@ class PlanarConv:
         # measured against the 128 x 64 tiles (scripts/bench_kxr.py, 1 / 4 / 8 / 32 clips): the head's grouped output layers win from
         # ~20 000 pixels (x1.3-1.8), single-group layers of up to 48 channels from ~30 000 (x1.1-1.4); below that its 256-pixel tiles
         # leave CUs idle, and four channel tiles (layer1's 64 -> 64) stay on the general kernel (x0.65)
-        use_kxr = (self.kxr and residual is None and (shape[0] == "levels" or (Ho, Wo) == (H, W))
+        use_kxr = (self.kxr and residual is None and window is None and (shape[0] == "levels" or (Ho, Wo) == (H, W))
                    and M >= (self.kxr_min_pixels if self.kxr_min_pixels is not None else (20000 if self.groups > 1 else 30000)))
         g.tile_n = 0 if use_kxr else self.pick_tile(M)
         dev = xp.device
         NPo, dto = _planes_dtype(self.out_fmt)
+        if window is not None and ((out in ("planes", "both") and out_planes is None) or (out in ("f32", "both") and out_f32 is None)):
+            raise StmError("PlanarConv: a window launch writes into caller-provided full-size outputs")
         if out in ("planes", "both") and out_planes is None:
             out_planes, out_off_p = torch.empty(NPo, -(-self.O // 32), M, 32, device=dev, dtype=dto), 0
         else:
@@ -617,6 +629,18 @@ class PlanarTemporalNet:
         self.fmt = FMT
         for c in (self.c1, self.c2, self.c3):
             c.role = "temporal"
+        # Border classes.  A 3x3 / pad-1 convolution on 7x7 RoI maps multiplies zeros in 80 of its 441 tap-pixels: the top row has no
+        # ky = 0 tap, the left column no kx = 0 tap, ...  Output pixels of one (row class, column class) share their set of real taps --
+        # a contiguous sub-kernel -- and form a rectangle of every RoI map, so each class is a plain convolution with that sub-kernel on a
+        # window of the map, and the nine classes of a layer run as ONE grid (stm_conv2d_planar_windows_f32): 361 / 441 of the matrix work,
+        # the same sums (a skipped tap added exact zeros).  Classes: rows {0}, {1 .. H-2}, {H-1} x columns likewise.  (As nine separate
+        # launches the small classes -- 2 500 .. 20 000 pixels -- lost in partial last rounds what the skipped taps saved.)
+        self.border = None
+        ws = [(w1, tn.conv1.bias, self.cin / self.cpad), (tn.conv2.weight.detach(), tn.conv2.bias, 1.0), (tn.conv3.weight.detach(), tn.conv3.bias, 1.0)]
+        if (TN_BORDER and self.fmt == 1 and all(tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 128 == 0 for w, _, _ in ws)
+                and all(tuple(_pair(c.padding)) == (1, 1) and tuple(_pair(c.stride)) == (1, 1) for c in (tn.conv1, tn.conv2, tn.conv3))):
+            self.border = [{"w": w.float().contiguous(), "b": (b.detach().float().contiguous() if b is not None else None), "frac": frac, "packed": None}
+                           for w, b, frac in ws]
 
     def __call__(self, roi_feats):
         """roi_feats [n, 633, 7, 7] fp32 -> (loc shift [n, 4], coeff shift [n, 32])."""
@@ -624,10 +648,53 @@ class PlanarTemporalNet:
         x = F.pad(roi_feats.index_select(1, self.perm.to(roi_feats.device)).permute(0, 2, 3, 1), (0, self.cpad - c)).contiguous()   # NHWC, padded
         return self.forward_planes(ops.split_planes(x, self.fmt), n, h, w)
 
+    _CLASSES = [(ry, rx, k0y, k1y, k0x, k1x) for ry, (k0y, k1y) in enumerate(((1, 3), (0, 3), (0, 2)))
+                for rx, (k0x, k1x) in enumerate(((1, 3), (0, 3), (0, 2)))]
+
+    def _border_layer(self, li, xp, n, h, w, out):
+        """One 3x3 layer as its nine border-class windows in one launch; returns planes [2, O/32, n*h*w, 32] or the fp32 matrix [n*h*w, O]."""
+        L = self.border[li]
+        O, C = L["w"].shape[0], L["w"].shape[1]
+        if L["packed"] is None:
+            ops.planar_range_flag()
+            wscale = ops._pow2_wscale(L["w"])
+            L["packed"] = [ops.conv_pack_weights(L["w"][:, :, k0y:k1y, k0x:k1x].contiguous(), tile_n=128, fmt=1, wscale=wscale)[0]
+                           for _, _, k0y, k1y, k0x, k1x in self._CLASSES]
+            L["out_scale"] = 1.0 / wscale
+        dev = xp.device
+        out_planes = torch.empty(2, O // 32, n * h * w, 32, device=dev, dtype=torch.float16) if out == "planes" else None
+        out_f32 = torch.empty(n * h * w, O, device=dev, dtype=torch.float32) if out == "f32" else None
+        rows, cols = ((0, 1), (1, h - 1), (h - 1, h)), ((0, 1), (1, w - 1), (w - 1, w))
+        wins, packed, macs = [], [], 0
+        for (ry, rx, k0y, k1y, k0x, k1x), pk in zip(self._CLASSES, L["packed"]):
+            (y0, y1), (x0, x1) = rows[ry], cols[rx]
+            if y1 <= y0 or x1 <= x0:
+                continue
+            # output (y0 + oy, x0 + ox) reads input (y0 + oy + k0y - 1 + ky', x0 + ox + k0x - 1 + kx'): padding = 1 - y0 - k0y (<= 0)
+            wins.append((k1y - k0y, k1x - k0x, 1 - y0 - k0y, 1 - x0 - k0x, y1 - y0, x1 - x0, y0, x0))
+            packed.append(pk)
+            macs += (y1 - y0) * (x1 - x0) * (k1y - k0y) * (k1x - k0x)
+        timing = ops._conv_timing
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        ops.conv2d_planar_windows(xp, packed, wins, L["b"], n, h, w, C, O, h, w, L["out_scale"], relu=True, out_f32=out_f32, out_planes=out_planes)
+        if timing is not None:
+            e1.record()
+            M = n * h * w
+            nbytes = M * C * 4 + M * O * 4 + L["w"].numel() * 4
+            # algorithmic flops as for every other layer: the reference's 2 M Cout Cin kh kw (its padded taps included); the MFMA products
+            # issued per reference product are 3 x (real tap-pixels / all tap-pixels) = 3 x 361 / 441 on a 7x7 map
+            timing.append((e0, e1, 2.0 * M * 9 * O * C * L["frac"], (M, C, O, 3, 1, 1, -2), 3.0 * macs / (h * w * 9), "temporal", float(nbytes)))
+        return out_planes if out == "planes" else out_f32
+
     def forward_planes(self, xp, n, h=7, w=7):
         """xp: the RoI features as planes [P, cpad/32, n*h*w, 32] in this object's channel order (ops.roi_align_planes)."""
         shape = ("img", n, h, w)
-        y = self.c3(self.c2(self.c1(xp, shape), shape), shape, out="f32")                # [n*h*w, 1024]
+        if self.border is not None and h >= 3 and w >= 3 and n > 0:
+            y = self._border_layer(2, self._border_layer(1, self._border_layer(0, xp, n, h, w, "planes"), n, h, w, "planes"), n, h, w, "f32")
+        else:
+            y = self.c3(self.c2(self.c1(xp, shape), shape), shape, out="f32")                # [n*h*w, 1024]
         pooled = y.view(n, h * w, -1).mean(dim=1)                                        # AvgPool2d((7, 7)) on a 7x7 map
         return self.fc(pooled), self.fc_coeff(pooled)
 

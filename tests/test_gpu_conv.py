@@ -841,3 +841,80 @@ def test_bottleneck_chain_projection_form(case):
     assert (ya - yb).abs().max().item() < 2e-5 * max(1.0, yb.abs().max().item())
     za, zb = planes_to_f32(z), planes_to_f32(l1(y3, ("img", B, H, W)))
     assert (za - zb).abs().max().item() < 2e-5 * max(1.0, zb.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------- window launches (TemporalNet's border classes)
+@pytest.mark.parametrize("hw", [(7, 7), (5, 9), (3, 3)])
+def test_conv_window_launches_equal_the_padded_convolution(hw):
+    """stm_conv_geom.win_*: a 3x3 / pad-1 convolution computed as nine window launches -- row classes {0}, {1..H-2}, {H-1} x column
+    classes, each with the sub-kernel of its real taps and negative padding -- writes the same tensor as the single launch: the skipped
+    taps only ever added exact zeros, so the fp32 sums are the same sums (bit-equal where no launch is split along K; both against fp64)."""
+    from stmask_amd.planar import PlanarConv
+    H, W = hw
+    n, C, O = 37, 64, 128
+    x = rnd(n, H, W, C, seed=70)
+    w = rnd(O, C, 3, 3, seed=71, scale=(C * 9) ** -0.5)
+    b = rnd(O, seed=72)
+    xp = ops.split_planes(x.to(DEV), 1)
+    ref_conv = PlanarConv(w.to(DEV), b.to(DEV), 1, 1, relu=True, fmt=1, tile_n=64)
+    ref32, refpl = ref_conv(xp, ("img", n, H, W), out="both")
+    out32 = torch.full((n * H * W, O), float("nan"), device=DEV)
+    outpl = torch.zeros_like(refpl)
+    rows, cols = ((0, 1), (1, H - 1), (H - 1, H)), ((0, 1), (1, W - 1), (W - 1, W))
+    for ry, (ky0, ky1) in enumerate(((1, 3), (0, 3), (0, 2))):
+        for rx, (kx0, kx1) in enumerate(((1, 3), (0, 3), (0, 2))):
+            (y0, y1), (x0, x1) = rows[ry], cols[rx]
+            if y1 <= y0 or x1 <= x0:
+                continue
+            conv = PlanarConv(w[:, :, ky0:ky1, kx0:kx1].contiguous().to(DEV), b.to(DEV), 1, 0, relu=True, fmt=1, tile_n=64)
+            win = (y0, x0, y1 - y0, x1 - x0, 1 - y0 - ky0, 1 - x0 - kx0, H, W)
+            conv(xp, ("img", n, H, W), out="both", out_planes=outpl, out_f32=out32, window=win)
+    assert torch.isfinite(out32).all()                     # every output row was written by exactly the class that owns it
+    assert torch.equal(out32, ref32) and torch.equal(outpl, refpl)
+    exp = oracle.conv2d_nhwc(x, w, b, None, padding=1, relu=True)
+    mag = oracle.conv2d_nhwc(x.abs(), w.abs(), b.abs(), None, padding=1)
+    assert ((out32.cpu().view(n, H, W, O) - exp).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
+    with pytest.raises(StmError):                          # a window that leaves the image is refused
+        conv(xp, ("img", n, H, W), out="both", out_planes=outpl, out_f32=out32, window=(H - 1, 0, 2, 1, 0, 0, H, W))
+    # ... and all windows as ONE grid (stm_conv2d_planar_windows_f32, the form TemporalNet uses): 128-channel tiles, one weight scale
+    wsc = ops._pow2_wscale(w)
+    wins, packed = [], []
+    for ry, (ky0, ky1) in enumerate(((1, 3), (0, 3), (0, 2))):
+        for rx, (kx0, kx1) in enumerate(((1, 3), (0, 3), (0, 2))):
+            (y0, y1), (x0, x1) = rows[ry], cols[rx]
+            if y1 <= y0 or x1 <= x0:
+                continue
+            wins.append((ky1 - ky0, kx1 - kx0, 1 - y0 - ky0, 1 - x0 - kx0, y1 - y0, x1 - x0, y0, x0))
+            packed.append(ops.conv_pack_weights(w[:, :, ky0:ky1, kx0:kx1].contiguous().to(DEV), tile_n=128, fmt=1, wscale=wsc)[0])
+    o32 = torch.full((n * H * W, O), float("nan"), device=DEV)
+    opl = torch.zeros_like(refpl)
+    ops.conv2d_planar_windows(xp, packed, wins, b.to(DEV), n, H, W, C, O, H, W, 1.0 / wsc, relu=True, out_f32=o32, out_planes=opl)
+    assert torch.equal(o32, ref32) and torch.equal(opl, refpl)
+    with pytest.raises(StmError):
+        ops.conv2d_planar_windows(xp, packed, [(3, 3, 0, 0, H, W, 1, 0)] + wins[1:], b.to(DEV), n, H, W, C, O, H, W, 1.0 / wsc, out_f32=o32)
+
+
+def test_temporalnet_border_classes_equal_the_three_launches():
+    """PlanarTemporalNet with the border-class launches against the same object running its three padded convolutions (equal up to the
+    split of small launches along K, which changes the order of the fp32 sums)."""
+    from stmask_amd import planar
+    import types
+    tn = types.SimpleNamespace()
+    g = torch.Generator().manual_seed(5)
+    mk = lambda o, c: torch.nn.Conv2d(c, o, 3, padding=1)
+    tn.conv1, tn.conv2, tn.conv3 = mk(128, 96), mk(128, 128), mk(256, 128)
+    tn.fc, tn.fc_coeff = torch.nn.Linear(256, 4), torch.nn.Linear(256, 8)
+    for m in (tn.conv1, tn.conv2, tn.conv3, tn.fc, tn.fc_coeff):
+        m.to(DEV)
+    old_fmt = planar.FMT
+    planar.FMT = 1
+    try:
+        net = planar.PlanarTemporalNet(tn, corr_channels=32)
+        assert net.border is not None
+        feats = torch.randn(23, 96, 7, 7, generator=g).to(DEV)
+        a_loc, a_co = net(feats)
+        net.border = None
+        b_loc, b_co = net(feats)
+    finally:
+        planar.FMT = old_fmt
+    assert (a_loc - b_loc).abs().max().item() < 1e-6 and (a_co - b_co).abs().max().item() < 1e-6
