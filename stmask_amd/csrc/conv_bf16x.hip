@@ -19,6 +19,7 @@
 // DESIGN.md section 4 has the history of this kernel and what bounds it.
 #include "planar_common.h"
 #include <algorithm>
+#include <type_traits>
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
@@ -109,8 +110,11 @@ struct PlanarArgs {
     // window launches (stm_conv_geom.win_w > 0): the launch computes a Ho x Wo window of every output image; output pixel (b, oy, ox) is row
     // b * win_hw + oy * win_w + ox + win_off of the output tensors
     int win_w, win_hw, win_off;
-    // several window launches in ONE grid (CLS instantiation; stm_conv2d_planar_windows_f32): class c = tiles [tile0, next tile0) with its own
-    // weights, sub-kernel, window and pixel count -- the fields below replace wp / kh / kw / ph / pw / Ho / Wo / M / slabs / win_off per tile
+};
+// several window launches in ONE grid (CLS instantiation; stm_conv2d_planar_windows_f32): class c = tiles [tile0, next tile0) with its own
+// weights, sub-kernel, window and pixel count -- they replace wp / kh / kw / ph / pw / Ho / Wo / M / slabs / win_off per tile.  (A type of
+// its own: half a KB more of kernel arguments on EVERY convolution launch cost the single-stream step 0.1 ms.)
+struct PlanarArgsCls : PlanarArgs {
     int n_cls, cls_tiles;
     struct Cls { const uint8_t* wp; int kh, kw, ph, pw, Ho, Wo, M, slabs, win_off, tile0; float inv_hw, inv_w; } cls[9];
 };
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256) void planar_splitk_finish_kernel(const PlanarA
 // walking the tiles instead of one workgroup per tile -- 404 -> 451 us.  Neither the epilogue's second memory round trip nor
 // workgroup launch overhead is what holds these layers at 3.3 TB/s.)
 template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0, bool DUAL = false, bool CLS = false>
-__global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a_in)
+__global__ __launch_bounds__(512, 1) void conv_planar_kernel(const typename std::conditional<CLS, PlanarArgsCls, PlanarArgs>::type a_in)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the LDS-DMA builtins exist only in the device pass; the host pass needs just the launch stub
     extern __shared__ __align__(16) uint8_t smem[];
@@ -365,7 +369,9 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a_
     static_assert((BN / 16) * NPL % NWAVES == 0, "weight tile must split evenly over the waves");
     static_assert(ST == 2 || (ST == 3 && DT == 1 && NPL <= 2), "the three-buffer ring is built for the fp16 formats");
 
-    const int tiles = CLS ? a_in.cls_tiles : a_in.m_tiles * a_in.n_tiles * a_in.splitk;
+    int tiles_ = a_in.m_tiles * a_in.n_tiles * a_in.splitk;
+    if constexpr (CLS) tiles_ = a_in.cls_tiles;
+    const int tiles = tiles_;
     const int per_xcd = (tiles + 7) >> 3;
     int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if constexpr (CLS) {
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const PlanarArgs a_
 #pragma unroll
         for (int i = 1; i < 9; ++i)
             if (i < a_in.n_cls && logical >= a_in.cls[i].tile0) c = i;
-        a_cls = a_in;
+        a_cls = static_cast<const PlanarArgs&>(a_in);
         a_cls.wp = a_in.cls[c].wp;
         a_cls.kh = a_in.cls[c].kh; a_cls.kw = a_in.cls[c].kw; a_cls.ph = a_in.cls[c].ph; a_cls.pw = a_in.cls[c].pw;
         a_cls.Ho = a_in.cls[c].Ho; a_cls.Wo = a_in.cls[c].Wo; a_cls.M = a_in.cls[c].M;
@@ -1152,7 +1158,7 @@ const ConvTunables& tunables()
 }
 
 template <int NPL, int MG, int NJ, int DT = 0, int ST = 2, int ABL = 0, bool DUAL = false, bool CLS = false>
-int launch_planar(const PlanarArgs& a, int tiles, stm_stream_t stream)
+int launch_planar(const typename std::conditional<CLS, PlanarArgsCls, PlanarArgs>::type& a, int tiles, stm_stream_t stream)
 {
     size_t lds = (size_t)ST * (NPL * CV_BM * MG * 64 + NPL * (64 * NJ) * 64);
     const size_t park = (size_t)4 * MG * 64 * (32 * NJ + 4) * sizeof(float);   // the epilogue parks one 64 x 32NJ tile per wave
@@ -1571,7 +1577,9 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
     };
     if (wset) {
         STM_REQUIRE(bn == 128 && a.fmt == 1 && !dual && win, STM_EUNSUPPORTED, "%s: window sets run on the 256 x 128 ring tiles of the fp16x2 format", who);
-        a.n_cls = wset->n;
+        PlanarArgsCls ac;
+        static_cast<PlanarArgs&>(ac) = a;
+        ac.n_cls = wset->n;
         int t0 = 0;
         for (int i = 0; i < wset->n; ++i) {
             const stm_conv_window& w = wset->win[i];
@@ -1581,20 +1589,19 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
             STM_REQUIRE((uintptr_t)wset->packed[i] % 16 == 0, STM_EINVAL, "%s: packed weight %d is not 16-byte aligned", who, i);
             const int64_t Mc = (int64_t)g->B * w.Ho * w.Wo;
             STM_REQUIRE(Mc < ((int64_t)1 << 24), STM_EUNSUPPORTED, "%s: more than 2^24 output pixels in one window", who);
-            PlanarArgs::Cls& c = a.cls[i];
+            PlanarArgsCls::Cls& c = ac.cls[i];
             c.wp = static_cast<const uint8_t*>(wset->packed[i]);
             c.kh = w.kh; c.kw = w.kw; c.ph = w.ph; c.pw = w.pw; c.Ho = w.Ho; c.Wo = w.Wo; c.M = (int)Mc;
             c.slabs = w.kh * w.kw * (g->C / CV_BK); c.win_off = w.y0 * g->win_w + w.x0; c.tile0 = t0;
             c.inv_hw = 1.0f / (float)(w.Ho * w.Wo); c.inv_w = 1.0f / (float)w.Wo;
             t0 += stm_cdiv(Mc, 2 * CV_BM) * a.n_tiles;
         }
-        for (int i = wset->n; i < 9; ++i) a.cls[i] = a.cls[0];
-        a.cls_tiles = t0;
-        a.m_tiles = 0;
+        for (int i = wset->n; i < 9; ++i) ac.cls[i] = ac.cls[0];
+        ac.cls_tiles = t0;
+        ac.m_tiles = 0;
         // (grid: every XCD gets the same number of pixel tiles x all channel tiles; ids past the last tile leave at once)
-        return launch_planar<2, 2, 2, 1, 3, 0, false, true>(a, stm_cdiv(t0 / a.n_tiles, 8) * 8 * a.n_tiles, stream);
+        return launch_planar<2, 2, 2, 1, 3, 0, false, true>(ac, stm_cdiv(t0 / a.n_tiles, 8) * 8 * a.n_tiles, stream);
     }
-    a.n_cls = 0; a.cls_tiles = 0;
     int rc;
     if (bn == 64) {
         // 128 x 64 tiles, 72 KB of LDS: two independent workgroups per CU, each one's barrier / staging gaps filled by

@@ -911,7 +911,7 @@ def test_temporalnet_border_classes_equal_the_three_launches():
     try:
         net = planar.PlanarTemporalNet(tn, corr_channels=32)
         assert net.border is not None
-        feats = torch.randn(23, 96, 7, 7, generator=g).to(DEV)
+        feats = torch.randn(340, 96, 7, 7, generator=g).to(DEV)
         a_loc, a_co = net(feats)
         net.border = None
         b_loc, b_co = net(feats)
