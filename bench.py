@@ -195,7 +195,8 @@ def conv_roofline(conv_t, steps, planes, traffic=None, traffic_src=None, timed_i
 
     achieved = fp32-equivalent algorithmic flops (2*M*Cout*Cin*kh*kw of the reference layers, zero-padded channels excluded) /
     launch time; peak = dense 16-bit MFMA peak / n_prod, because each product of the reference is carried by n_prod MFMA products
-    (3 fp16x2, 6 bf16x3, 1 fp16x1) -- i.e. frac = issued MFMA flops / time / 2500.
+    (3 fp16x2, 6 bf16x3, 1 fp16x1) -- i.e. frac = the format's MFMA products for the reference's flops / time / 2500 (equal to the issued
+    MFMA rate except for TemporalNet's window sets, which skip the products of the padded taps: `mfma_tflops_issued` reports those).
     Beside the overall figure: `frac_trunk_only` (TemporalNet's launches excluded: with the synthetic weights the tracker keeps
     ~114 instances per clip, whose 0.98 GF each are the most efficient launches of the step), and the launches split by what bounds
     each one algorithmically -- a launch whose algorithmic bytes / 8 TB/s exceed its issued flops / 2500 TF is HBM-bound (the
@@ -207,12 +208,13 @@ def conv_roofline(conv_t, steps, planes, traffic=None, traffic_src=None, timed_i
         c_ms = sum(ms(t) for t in sel)
         c_fl = sum(t[2] for t in sel)
         c_mfma = sum(t[2] * t[4] for t in sel)
+        c_issued = sum(t[2] * t[4] * (t[7] if len(t) > 7 else 1.0) for t in sel)      # (window sets skip the taps that lie in the zero padding)
         if not sel or c_ms <= 0 or c_mfma <= 0:
             return None
         tf = c_fl / (c_ms * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TF * c_fl / c_mfma
         return {"achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                "mfma_tflops_issued": round(c_mfma / (c_ms * 1e-3) / 1e12, 1), "launches": len(sel),
+                "mfma_tflops_issued": round(c_issued / (c_ms * 1e-3) / 1e12, 1), "launches": len(sel),
                 "ms_per_step": round(c_ms / steps, 3), "tflop_per_step": round(c_fl / steps / 1e12, 3)}
 
     hbm_sel = [t for t in conv_t if t[6] / (HBM_PEAK_GBS * 1e9) > t[2] * t[4] / (BF16_MFMA_PEAK_TF * 1e12)]
@@ -235,9 +237,10 @@ def conv_roofline(conv_t, steps, planes, traffic=None, traffic_src=None, timed_i
                 "traffic_source": (f"profiles/{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
                                    "correction); average over all launches") if traffic_src else None,
                 "peak_note": "algorithmic (reference) flops against 2500 TFLOP/s dense 16-bit MFMA divided by the MFMA products issued per "
-                             "reference product (3 for fp16x2 layers, 6 for bf16x3, 1 for fp16x1 layers, 3 x 361 / 441 for TemporalNet's 3x3 layers, whose border-class "
-                             "windows skip the taps that lie in the zero padding of the 7x7 RoI maps; flop-weighted over the launches) "
-                             "-- i.e. frac = issued MFMA flops / time / 2500 (fp32 MFMA peak is 157)",
+                             "reference product (3 for fp16x2 layers, 6 for bf16x3, 1 for fp16x1 layers; flop-weighted over the launches).  TemporalNet's 3x3 layers keep the "
+                             "reference's flop count (2 M Cout Cin 9, padded taps included like every layer's) while their border-class windows ISSUE 361 / 441 of "
+                             "the products: `mfma_tflops_issued` counts what is issued, `achieved` what the reference computes "
+                             "-- frac = MFMA products the format needs for the reference's flops / time / 2500 (fp32 MFMA peak is 157)",
                 "avg_launch_us": round(allo["ms_per_step"] * steps * 1e3 / len(conv_t), 2),
                 "algorithmic_gflop_per_launch": round(allo["tflop_per_step"] * steps * 1e3 / len(conv_t), 2),
                 "timed_in": timed_in,

@@ -683,9 +683,9 @@ class PlanarTemporalNet:
             e1.record()
             M = n * h * w
             nbytes = M * C * 4 + M * O * 4 + L["w"].numel() * 4
-            # algorithmic flops as for every other layer: the reference's 2 M Cout Cin kh kw (its padded taps included); the MFMA products
-            # issued per reference product are 3 x (real tap-pixels / all tap-pixels) = 3 x 361 / 441 on a 7x7 map
-            timing.append((e0, e1, 2.0 * M * 9 * O * C * L["frac"], (M, C, O, 3, 1, 1, -2), 3.0 * macs / (h * w * 9), "temporal", float(nbytes)))
+            # algorithmic flops as for every other layer: the reference's 2 M Cout Cin kh kw (its padded taps included), priced against the
+            # format's peak (3 MFMA products per fp32 product); 8th field: share of those products that is actually issued (361 / 441 on 7x7)
+            timing.append((e0, e1, 2.0 * M * 9 * O * C * L["frac"], (M, C, O, 3, 1, 1, -2), 3, "temporal", float(nbytes), macs / (h * w * 9.0)))
         return out_planes if out == "planes" else out_f32
 
     def forward_planes(self, xp, n, h=7, w=7):
