@@ -160,6 +160,9 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
         // activations: producer p stages plane p (nine row groups of 16 staged rows); the weight pieces are dealt round-robin
         static_assert(CH_PRODUCERS == 2 && XDW == CH_NRG, "one activation plane per producer");
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xin) + (size_t)pw_ * a.ps_in, 0, (int)a.plane_bytes_in, 0x00020000);
+        // (the weights go through buffer descriptors too: one kind of instruction for every LDS-DMA of a wave)
+        const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.w2), 0, S * CH_WBUF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wtr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.wt), 0, CH_TAIL_STAGES * TWB, 0x00020000);
         int dbase[XDW];
         unsigned dmask[XDW];
         auto setup = [&](int tile) {
@@ -196,28 +199,28 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                     const unsigned off = (unsigned)(dbase[i] + uni) | (oob << 31);
                     if (!(CH_ABL & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + pw_ * CH_XPL + i * 1024), 16, off, 0, 0, 0);
                 }
-                const uint8_t* wsrc = a.w2 + (size_t)s_in * CH_WBUF;
+                const int wsrc = s_in * CH_WBUF;        // byte offset in the packed conv2 weights
 #pragma unroll
                 for (int k = 0; k < WDW; ++k) {
                     const int idx = pw_ + CH_PRODUCERS * k;
-                    if (!(CH_ABL & 32)) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + CH_XBUF + idx * 1024), 16, 0, 0);
+                    if (!(CH_ABL & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(w2r, (lds_ptr)(sb + CH_XBUF + idx * 1024), 16, lane * 16, wsrc + idx * 1024, 0, 0);
                 }
             } else {
                 const int j = s_in - S;
-                const uint8_t* wsrc = a.wt + (size_t)j * TWB;
+                const int wsrc = j * TWB;               // byte offset in the packed tail weights
                 if (j < CH_TAIL_STAGES - 1) {
                     kind = 1;
 #pragma unroll
                     for (int k = 0; k < TWD; ++k) {
                         const int idx = pw_ + CH_PRODUCERS * k;
-                        if (!(CH_ABL & 32)) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + idx * 1024), 16, 0, 0);
+                        if (!(CH_ABL & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(wtr, (lds_ptr)(sb + idx * 1024), 16, lane * 16, wsrc + idx * 1024, 0, 0);
                     }
                 } else {
                     kind = 2;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int idx = TW1 / 1024 + pw_ + CH_PRODUCERS * k;       // conv1' part only
-                        if (!(CH_ABL & 32)) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + idx * 1024 + lane * 16), (lds_ptr)(sb + idx * 1024), 16, 0, 0);
+                        if (!(CH_ABL & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(wtr, (lds_ptr)(sb + idx * 1024), 16, lane * 16, wsrc + idx * 1024, 0, 0);
                     }
                 }
             }
@@ -225,14 +228,18 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
             return kind;
         };
         const int G = SG * n_seq;
+        // Stage g goes out after barrier g - 2 (its slot held stage g - 3, which every consumer has left) and must have landed at barrier g.
+        // The landing wait is s_waitcnt vmcnt(0) BEFORE the next stage is issued -- never a counted wait with younger DMAs in flight:
+        // LDS-DMA completions of one wave are not ordered among themselves (a stage of L2-resident weight pieces overtakes the HBM rows of the
+        // stage before it), so "at most N outstanding" does not say WHICH N.  With the counted form (issue g + 1, wait until only its DMAs are
+        // out, barrier g) one pipeline run in ten differed in a tile's worth of pixels: stale low-plane pieces in the last bits, stale
+        // high-plane pieces as whole values (scripts/chain_pipeline_probe2.py; the isolated kernel never showed it).  One stage stays in
+        // flight across every barrier as before; a deeper look-ahead was measured to change nothing.
         issue();                                     // G >= 15
         for (int g = 1; g < G; ++g) {
-            // the stage before the one just issued has landed when only this one's DMAs are still in flight.  (A deeper look-ahead -- a
-            // ring of nine 16-KB sub-slots, up to eight tail stages ahead -- was measured: no change; the kernel is not waiting for LDS-DMA.)
-            const int kind = issue();
-            if (kind == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(XDW + WDW) : "memory");
-            else if (kind == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TWD) : "memory");
-            else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage g - 1 has landed
+            issue();                                              // stage g flies across the barrier
+            asm volatile("s_barrier" ::: "memory");               // barrier g - 1
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         return;

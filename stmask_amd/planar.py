@@ -44,7 +44,8 @@ C3DS_FUSED = os.environ.get("STM_C3DS_FUSED", "1") != "0"    # conv3 + projectio
 STEM_FUSED = os.environ.get("STM_STEM_FUSED", "1") != "0"    # conv1 + ReLU + max-pool as one kernel (csrc/stem_fused.hip)
 CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 layers on the kx-reuse kernel (csrc/conv_kxr.hip)
 TN_BORDER = os.environ.get("STM_TN_BORDER", "1") != "0"     # TemporalNet's 3x3 layers as nine window launches without the zero taps of the RoI borders
-CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"  # layer1's identity-shortcut blocks: conv2 -> conv3 + shortcut -> next conv1 as one kernel (csrc/conv_chain.hip)
+CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"
+CHAIN_MODE = int(os.environ.get("STM_CHAIN_MODE", "3"))      # diagnostics: bit 0 = the projection form (a stage's first block), bit 1 = hand z to the next block  # layer1's identity-shortcut blocks: conv2 -> conv3 + shortcut -> next conv1 as one kernel (csrc/conv_chain.hip)
 
 
 def set_format(fmt, backbone_fmt=None):
@@ -721,6 +722,8 @@ class PlanarChain:
         d = blk.downsample[0] if blk.downsample is not None else None
         proj_ok = d is None or (isinstance(d, torch.nn.Conv2d) and tuple(d.weight.shape) == (256, 64, 1, 1) and tuple(d.stride) == (1, 1)
                                 and tuple(d.padding) == (0, 0) and d.groups == 1)
+        if d is not None and not (CHAIN_MODE & 1):
+            return False
         return (CONV_CHAIN and fmt == 1 and out_fmt == 1 and proj_ok and isinstance(c2, torch.nn.Conv2d)
                 and tuple(c2.weight.shape) == (64, 64, 3, 3) and tuple(c2.stride) == (1, 1) and tuple(c2.padding) == (1, 1)
                 and tuple(c2.dilation) == (1, 1) and c2.groups == 1 and tuple(c3.weight.shape) == (256, 64, 1, 1) and tuple(c3.stride) == (1, 1))
@@ -824,7 +827,7 @@ class PlanarBackbone:
                 e["stride"] = _pair(c2.stride)
                 if PlanarChain.eligible(c2, c3, blk, fmt, e["c3"].out_fmt):
                     nxt = layer[bi + 1] if bi + 1 < len(layer) else None
-                    give_z = nxt is not None and not isinstance(nxt.conv2, DCN) and PlanarChain.takes_z(nxt.conv1)
+                    give_z = bool(CHAIN_MODE & 2) and nxt is not None and not isinstance(nxt.conv2, DCN) and PlanarChain.takes_z(nxt.conv1)
                     e["chain"] = PlanarChain(c2, c3, nxt.conv1 if give_z else None, blk.downsample[0] if blk.downsample is not None else None)
                 blks.append(e)
             self.blocks.append(blks)
