@@ -45,7 +45,11 @@ STEM_FUSED = os.environ.get("STM_STEM_FUSED", "1") != "0"    # conv1 + ReLU + ma
 CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 layers on the kx-reuse kernel (csrc/conv_kxr.hip)
 TN_BORDER = os.environ.get("STM_TN_BORDER", "1") != "0"     # TemporalNet's 3x3 layers as nine window launches without the zero taps of the RoI borders
 CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"
-CHAIN_MODE = int(os.environ.get("STM_CHAIN_MODE", "3"))      # diagnostics: bit 0 = the projection form (a stage's first block), bit 1 = hand z to the next block  # layer1's identity-shortcut blocks: conv2 -> conv3 + shortcut -> next conv1 as one kernel (csrc/conv_chain.hip)
+# bit 0 = the projection form (a stage's first block); bit 1 = the kernel also computes the NEXT block's conv1 (z); bit 2 (diagnostics) = z is
+# computed but not used.  Default 1: the z-producing instantiation (conv_chain_kernel<true, .>) is deterministic run to run in one process but
+# its y differed sporadically between a run with a second process on the same GPU and a solo run (bench.py --world2-one-gpu: 9 of 9 runs
+# with bit 1, 0 of 6 without; cause not found -- not the LDS ring, not load / store ordering, not the kernel's end), so it is not used.
+CHAIN_MODE = int(os.environ.get("STM_CHAIN_MODE", "1"))  # layer1's identity-shortcut blocks: conv2 -> conv3 + shortcut -> next conv1 as one kernel (csrc/conv_chain.hip)
 
 
 def set_format(fmt, backbone_fmt=None):
@@ -879,6 +883,8 @@ class PlanarBackbone:
                 if "chain" in e and not (last and not self.planes_only):
                     mid1 = z_next if z_next is not None else e["c1"](xp, shape)
                     xp, z_next = e["chain"](mid1, xp, B, H, W)
+                    if CHAIN_MODE & 4:          # diagnostics: the kernel computes z, the next block does not use it
+                        z_next = None
                     continue
                 if "dcn" in e:
                     # conv1 -> fp32 (NCHW copy for the deformable sampler) and planes (offset / mask convolution);
