@@ -197,6 +197,20 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
             if (++s_in == S) { s_in = 0; cs = 0; ky = 0; ++t_in; }
         };
         const int G = S * n_seq;                             // stages of the whole sequence
+#if defined(KX_SAFE_WAIT)
+        // (make EXTRA=-DKX_SAFE_WAIT) The landing wait as vmcnt(0) BEFORE the next stage goes out, never a counted wait with younger DMAs in
+        // flight: conv_chain.hip's ring needed this form ("Bottleneck chain", finding 1).  This kernel's stages all have one
+        // composition and its counted form has been bit-equal in every two-rank and run-to-run check, and the safe form costs 9-12 % on the head
+        // layers (273 -> 299, 345 -> 384, 375 -> 420 us), so the counted form ships and this one stays as the cross-check.
+        if (G > 0) issue();
+        for (int g = 1; g < G; ++g) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            issue();
+            asm volatile("s_barrier" ::: "memory");
+        }
+        if (G > 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+#else
         // head: D - 2 stages go out before the first wait
         for (int g = 0; g < D - 2 && g < G; ++g) issue();
         for (int g = D - 2; g < G; ++g) {
@@ -208,6 +222,7 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int k = max(G - (D - 2), 0); k < G; ++k) asm volatile("s_barrier" ::: "memory");
         return;
+#endif
     }
 
     // -------------------------------------------------------------------------------------------------------------- consumer
