@@ -77,6 +77,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #ifndef CH_TIMING
 #define CH_TIMING 0       // 1: consumer wave 0 of workgroup 0 records s_memtime around every barrier into the buffer given to stm_debug_chain_timing
 #endif
+#ifndef CH_ZX
+#define CH_ZX 0        // diagnosis of the z-producing instantiation: 1 no z stores, 2 no conv1' MFMAs, 4 no schedule hints in the tail
+#endif
 #ifndef CH_ABL
 #define CH_ABL 0      // diagnostic builds (make EXTRA=-DCH_ABL=n, RESULTS ARE WRONG): 1 no stores, 2 no shortcut loads, 4 no tail MFMAs, 8 no tail epilogue, 16 no 3x3 MFMAs, 32 no DMA
 #endif
@@ -447,13 +450,13 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                 conv3_tile(1);
                 epilogue(0);
 #pragma unroll
-                for (int k = 0; k < (PROJ ? 24 : 12); ++k) {               // one MFMA of tile 1, then a share of tile 0's epilogue
+                for (int k = 0; k < ((CH_ZX & 4) ? 0 : (PROJ ? 24 : 12)); ++k) {               // one MFMA of tile 1, then a share of tile 0's epilogue
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, PROJ ? 4 : 8, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (j > 0 && HAS_Z && !(CH_ABL & 4)) {
+            if (j > 0 && HAS_Z && !(CH_ABL & 4) && !(CH_ZX & 2)) {
                 // conv1', K-slab j - 1: the y fragments of the previous stage
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
             if (j < CH_TAIL_STAGES - 1) {
                 epilogue(1);
 #pragma unroll
-                for (int k = 0; k < 24; ++k) {
+                for (int k = 0; k < ((CH_ZX & 4) ? 0 : 24); ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 }
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                         }
                         split4_f16(v, zh[q], zl[q]);
                     }
-                    if (!(CH_ABL & 1)) {
+                    if (!(CH_ABL & 1) && !(CH_ZX & 1)) {
                         __builtin_amdgcn_raw_buffer_store_b128(slab_gather(zh[0], zh[1]), zr, po[t], sl * a.np_z * 64, CH_NT);
                         __builtin_amdgcn_raw_buffer_store_b128(slab_gather(zl[0], zl[1]), zr, po[t], sl * a.np_z * 64 + (int)a.ps_z, CH_NT);
                     }
