@@ -611,6 +611,26 @@ class PlanarGraph:
         return fpn_outs, pred
 
 
+# (row class, column class, first / end kernel row, first / end kernel column) of the nine border classes of a 3x3 / pad-1 convolution
+_BORDER_CLASSES = [(ry, rx, k0y, k1y, k0x, k1x) for ry, (k0y, k1y) in enumerate(((1, 3), (0, 3), (0, 2)))
+                   for rx, (k0x, k1x) in enumerate(((1, 3), (0, 3), (0, 2)))]
+
+
+def border_windows(h, w):
+    """The non-empty border classes of a 3x3 / pad-1 convolution on an h x w map as windows of stm_conv2d_planar_windows_f32:
+    [(class index into _BORDER_CLASSES, (kh, kw, ph, pw, Ho, Wo, y0, x0))].  Class (ry, rx) holds output rows {0} / {1..h-2} / {h-1} and
+    columns likewise; its sub-kernel is the taps that can be inside the map; output (y0 + oy, x0 + ox) reads input
+    (y0 + oy + k0y - 1 + ky', x0 + ox + k0x - 1 + kx'), i.e. padding 1 - y0 - k0y (<= 0)."""
+    rows, cols = ((0, 1), (1, h - 1), (h - 1, h)), ((0, 1), (1, w - 1), (w - 1, w))
+    out = []
+    for ci, (ry, rx, k0y, k1y, k0x, k1x) in enumerate(_BORDER_CLASSES):
+        (y0, y1), (x0, x1) = rows[ry], cols[rx]
+        if y1 <= y0 or x1 <= x0:
+            continue
+        out.append((ci, (k1y - k0y, k1x - k0x, 1 - y0 - k0y, 1 - x0 - k0x, y1 - y0, x1 - x0, y0, x0)))
+    return out
+
+
 class PlanarTemporalNet:
     """TemporalNet (track_to_segment_head.py:10-37: 3 x (3x3 conv + ReLU) on 7x7 RoI features, 7x7 average pool, two
     linear layers) on the planar convolution.  The 633 input channels (121 correlation + 2 x 256 features) are padded to
@@ -653,8 +673,7 @@ class PlanarTemporalNet:
         x = F.pad(roi_feats.index_select(1, self.perm.to(roi_feats.device)).permute(0, 2, 3, 1), (0, self.cpad - c)).contiguous()   # NHWC, padded
         return self.forward_planes(ops.split_planes(x, self.fmt), n, h, w)
 
-    _CLASSES = [(ry, rx, k0y, k1y, k0x, k1x) for ry, (k0y, k1y) in enumerate(((1, 3), (0, 3), (0, 2)))
-                for rx, (k0x, k1x) in enumerate(((1, 3), (0, 3), (0, 2)))]
+    _CLASSES = _BORDER_CLASSES
 
     def _border_layer(self, li, xp, n, h, w, out):
         """One 3x3 layer as its nine border-class windows in one launch; returns planes [2, O/32, n*h*w, 32] or the fp32 matrix [n*h*w, O]."""
@@ -669,16 +688,11 @@ class PlanarTemporalNet:
         dev = xp.device
         out_planes = torch.empty(2, O // 32, n * h * w, 32, device=dev, dtype=torch.float16) if out == "planes" else None
         out_f32 = torch.empty(n * h * w, O, device=dev, dtype=torch.float32) if out == "f32" else None
-        rows, cols = ((0, 1), (1, h - 1), (h - 1, h)), ((0, 1), (1, w - 1), (w - 1, w))
         wins, packed, macs = [], [], 0
-        for (ry, rx, k0y, k1y, k0x, k1x), pk in zip(self._CLASSES, L["packed"]):
-            (y0, y1), (x0, x1) = rows[ry], cols[rx]
-            if y1 <= y0 or x1 <= x0:
-                continue
-            # output (y0 + oy, x0 + ox) reads input (y0 + oy + k0y - 1 + ky', x0 + ox + k0x - 1 + kx'): padding = 1 - y0 - k0y (<= 0)
-            wins.append((k1y - k0y, k1x - k0x, 1 - y0 - k0y, 1 - x0 - k0x, y1 - y0, x1 - x0, y0, x0))
-            packed.append(pk)
-            macs += (y1 - y0) * (x1 - x0) * (k1y - k0y) * (k1x - k0x)
+        for ci, win in border_windows(h, w):
+            wins.append(win)
+            packed.append(L["packed"][ci])
+            macs += win[4] * win[5] * win[0] * win[1]
         timing = ops._conv_timing
         if timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
