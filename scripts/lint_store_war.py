@@ -1,0 +1,94 @@
+"""Static check of the compiled kernels for a VMEM-store write-after-read exposure.
+
+A `buffer_store_dwordx3/x4` (or global / flat / scratch store of more than 64 bits) reads its data VGPRs over several cycles AFTER it has issued.
+The ISA's rule -- and the compiler's hazard recogniser (llvm GCNHazardRecognizer::createsVALUHazard) -- asks for wait states before a VALU
+instruction overwrites those VGPRs, EXCEPT for MUBUF stores whose soffset operand is an SGPR.  Round 4 measured on MI355X that this exception
+does not hold (scripts/vmem_store_war_probe.hip, profiles/r04_store_war_probe.txt): the 16 lanes 12-15 / 28-31 / 44-47 / 60-63 of such a store can
+pick up the NEW register contents when the texture path is back-pressured.  This script lists every wide store whose data registers are
+written again within `--window` instructions, so that a kernel change that re-creates the exposure fails tests/test_isa_lint.py.
+
+usage: lint_store_war.py file.s [...] [--window N]      exit code 1 if an exposure is found
+"""
+import re
+import sys
+
+# buffer stores name their data first, global / flat / scratch stores their address first and the data second
+STORE = re.compile(r"^\s*(?:(buffer_store_dwordx[34]|buffer_store_format_xyzw?)\s+|(global_store_dwordx[34]|flat_store_dwordx[34]|scratch_store_dwordx[34])\s+(?:v\[\d+:\d+\]|v\d+|off)\s*,\s*)v\[(\d+):(\d+)\]")
+DEF = re.compile(r"^\s*(v_\S+|ds_read\S*|ds_bpermute\S*|buffer_load\S*|global_load\S*|flat_load\S*|scratch_load\S*)\s+(.*)$")
+VREG = re.compile(r"v(\d+)\b|v\[(\d+):(\d+)\]")
+TWO_DEST = ("v_permlane16_swap", "v_permlane32_swap", "v_swap")
+
+
+def dests(line):
+    """VGPRs an instruction writes (first operand; both operands for the swap instructions)."""
+    m = DEF.match(line)
+    if not m:
+        return set(), False
+    op, rest = m.group(1), m.group(2)
+    if op.startswith(("v_cmp", "v_cmpx")) and not op.startswith("v_cmpx") and "_e64" not in op:
+        return set(), True
+    ops = [o.strip() for o in rest.split(",")]
+    n = 2 if op.startswith(TWO_DEST) else 1
+    out = set()
+    for o in ops[:n]:
+        mm = VREG.match(o)
+        if mm:
+            if mm.group(1) is not None:
+                out.add(int(mm.group(1)))
+            else:
+                out.update(range(int(mm.group(2)), int(mm.group(3)) + 1))
+    if "lds" in ops[-1].split() and op.startswith(("buffer_load", "global_load")):
+        return set(), False            # LDS-DMA: writes no VGPR
+    return out, op.startswith("v_")
+
+
+def scan(path, window):
+    found = []
+    kernel = "?"
+    lines = open(path).read().splitlines()
+    code = []
+    for i, l in enumerate(lines):
+        s = l.split(";")[0].rstrip()
+        if re.match(r"^[A-Za-z_$.][\w$.]*:", s) and not s.startswith(".L"):
+            kernel = s[:-1]
+        if s.strip() and not s.strip().startswith((".", "#")) and not s.endswith(":"):
+            code.append((i + 1, s, kernel))
+    for k, (ln, s, kern) in enumerate(code):
+        m = STORE.match(s)
+        if not m:
+            continue
+        data = set(range(int(m.group(3)), int(m.group(4)) + 1))
+        sgpr_soffset = bool(re.search(r",\s*s\d+\s+(offen|idxen|offset)|,\s*s\d+\s*$", s)) and m.group(1) is not None
+        waited = 0
+        for (ln2, s2, kern2) in code[k + 1:k + 1 + window]:
+            if kern2 != kern or re.match(r"^\s*(s_cbranch|s_branch|s_endpgm|s_setpc)", s2):
+                break
+            mm = re.match(r"^\s*s_nop\s+(\d+)", s2)
+            if mm:
+                waited += int(mm.group(1)) + 1
+                continue
+            d, is_valu = dests(s2)
+            if is_valu and d & data:
+                found.append((path, kern, ln, s.strip(), ln2, s2.strip(), waited, sgpr_soffset))
+                break
+            waited += 1
+    return found
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    window = 3
+    if "--window" in sys.argv:
+        window = int(sys.argv[sys.argv.index("--window") + 1])
+        args = [a for a in args if a != str(window)]
+    bad = []
+    for p in args:
+        bad += scan(p, window)
+    for (path, kern, ln, s, ln2, s2, waited, sg) in bad:
+        print(f"{path}:{ln}: [{kern[:60]}] {s}\n    {ln2}: {s2}    <- overwrites the store's data after {waited} wait state(s){' (SGPR soffset: the compiler adds none)' if sg else ''}")
+    print(f"lint_store_war: {len(bad)} exposure(s) within {window} instruction(s) of a wide store in {len(args)} file(s)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

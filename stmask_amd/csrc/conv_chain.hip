@@ -77,6 +77,22 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #ifndef CH_TIMING
 #define CH_TIMING 0       // 1: consumer wave 0 of workgroup 0 records s_memtime around every barrier into the buffer given to stm_debug_chain_timing
 #endif
+#ifndef CH_PROBE
+#define CH_PROBE 0        // 1: every wave records {HW_ID | XCC_ID at start and end, largest s_memrealtime gap between two of its barriers, the stage of that gap}
+                          //    into the buffer given to stm_debug_chain_timing: [block][wave][4] u64 -- shows a wave that was context-switched (CWSR) mid-kernel
+#endif
+#ifndef CH_STORE_NOPS
+#define CH_STORE_NOPS 4   // wait states pinned behind every 16-byte y / z store (0: none = round 3's code; see store16 below)
+#endif
+#ifndef CH_STORE_VOFF
+#define CH_STORE_VOFF 0   // 1: the stores' slab offset is added to the VGPR offset and soffset is 0 -- the form llvm's hazard recogniser pads by itself
+#endif
+#ifndef CH_COUNTED
+#define CH_COUNTED 0      // 1: the producers' landing wait as a counted vmcnt with the next stage in flight (round 3's first form)
+#endif
+#ifndef CH_LGKM
+#define CH_LGKM 0         // 1: consumers drain their LDS reads (s_waitcnt lgkmcnt(0)) before every barrier (hypothesis test: a ring slot restaged under a pending ds_read)
+#endif
 #ifndef CH_ZX
 #define CH_ZX 0        // diagnosis of the z-producing instantiation: 1 no z stores, 2 no conv1' MFMAs, 4 no schedule hints in the tail
 #endif
@@ -120,6 +136,28 @@ __device__ __forceinline__ void split4_f16(const float (&v)[4], u32x2& h, u32x2&
     l = u32x2{l0, l1};
 }
 
+// A 16-byte buffer store reads its data registers over several cycles AFTER it has issued.  The ISA's wait-state table asks for wait states before
+// a VALU instruction overwrites them and exempts MUBUF stores with an SGPR soffset; llvm's hazard recogniser follows it (GCNHazardRecognizer::
+// createsVALUHazard), so `buffer_store_dwordx4 v[24:27], v160, s[48:51], s14 offen` / `v_mov_b32 v24, v16` came out back to back in the
+// z-producing instantiations, whose register pressure makes consecutive stores share their data registers.  On MI355X the exemption does not
+// hold when the texture path is back-pressured: lanes 12-15 / 28-31 / 44-47 / 60-63 of such a store -- the last 256 B of the wave's 1 KB --
+// pick up the NEW contents (scripts/vmem_store_war_probe.hip, profiles/r04_store_war_probe.txt; in the kernel: wrong y / z in exactly those
+// pixels, only beside a second process, only in the instantiations with the sequence: scripts/ring_stress.py, scripts/lint_store_war.py).
+// Every store therefore goes through store16: the wait states are pinned behind it (nothing crosses a sched_barrier).
+__device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+#if CH_STORE_VOFF
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + (unsigned)soff, 0, CH_NT);
+#else
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, CH_NT);
+#endif
+#if CH_STORE_NOPS > 0
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop %0" ::"n"(CH_STORE_NOPS - 1));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // Workgroup = 4 consumer waves (32 pixels each, every channel) + 2 producer waves issuing all LDS-DMA: activations and weights of the
 // 3x3's six (channel slab, ky) stages, then per tile nine tail stages with conv3's and conv1's weights.  Ring of three slots, one
 // barrier per stage (conv_kxr.hip).  The SHORTCUT tensor -- 80 % of the bytes read -- does not go through the ring: two stages of
@@ -148,6 +186,28 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
     constexpr int S = (CH_P / 32) * 3;                                        // main stages per tile: (channel slab, ky)
     constexpr int SG = S + CH_TAIL_STAGES;                                    // stages per tile
     const int HW = a.H * a.W;
+#if CH_PROBE
+    const unsigned pr_id0 = __builtin_amdgcn_s_getreg((31 << 11) | 4) ^ (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 28);     // HW_ID, XCC_ID
+    unsigned long long pr_prev = __builtin_amdgcn_s_memrealtime(), pr_max = 0;
+    int pr_stage = 0, pr_at = -1;
+    auto probe = [&]() {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (t - pr_prev > pr_max) { pr_max = t - pr_prev; pr_at = pr_stage; }
+        pr_prev = t;
+        ++pr_stage;
+    };
+    auto probe_end = [&]() {
+        const unsigned id1 = __builtin_amdgcn_s_getreg((31 << 11) | 4) ^ (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 28);
+        if (a.dbg && lane == 0) {
+            unsigned long long* d = a.dbg + ((size_t)blockIdx.x * (CH_CONSUMERS + CH_PRODUCERS) + wave) * 4;
+            d[0] = (unsigned long long)pr_id0 | ((unsigned long long)id1 << 32);
+            d[1] = pr_max; d[2] = (unsigned long long)(unsigned)pr_at; d[3] = (unsigned long long)pr_stage;
+        }
+    };
+#else
+    auto probe = [&]() {};
+    auto probe_end = [&]() {};
+#endif
     float* bias_lds = reinterpret_cast<float*>(smem + CH_BIAS_OFF);           // b2 [64] | b3 [256] | b1' [64]
     for (int i = tid; i < 384; i += CH_THREADS)
         bias_lds[i] = i < 64 ? (a.b2 ? a.b2[i] : 0.0f) : i < 320 ? (a.b3 ? a.b3[i - 64] : 0.0f) : ((HAS_Z && a.b1) ? a.b1[i - 320] : 0.0f);
@@ -238,13 +298,32 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
         // out, barrier g) one pipeline run in ten differed in a tile's worth of pixels: stale low-plane pieces in the last bits, stale
         // high-plane pieces as whole values (scripts/chain_pipeline_probe2.py; the isolated kernel never showed it).  One stage stays in
         // flight across every barrier as before; a deeper look-ahead was measured to change nothing.
+#if CH_COUNTED
+        // (diagnosis build, make EXTRA=-DCH_COUNTED=1) round 3's first producer loop: stage g + 1 goes out, then a COUNTED wait that leaves only
+        // its DMAs outstanding, then barrier g -- scripts/ring_stress.py runs it beside a second process to see whether this form ever hands
+        // over a stage that has not landed (scripts/ldsdma_order_probe.hip asks the same of the bare instructions)
+        issue();
+        for (int g = 1; g < G; ++g) {
+            const int kind = issue();
+            if (kind == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDW + WDW) : "memory");
+            else if (kind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TWD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            probe();
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        probe_end();
+        return;
+#endif
         issue();                                     // G >= 15
         for (int g = 1; g < G; ++g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage g - 1 has landed
             issue();                                              // stage g flies across the barrier
             asm volatile("s_barrier" ::: "memory");               // barrier g - 1
+            probe();
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        probe_end();
         return;
     }
 
@@ -324,7 +403,9 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
         // ---- conv2: six stages of three taps
         for (int s = 0; s < S; ++s) {
             tick();
+            if (CH_LGKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
+            probe();
             tick();
             const uint8_t* xs = smem + buf * CH_BUF;
             if (++buf == CH_D) buf = 0;
@@ -385,7 +466,9 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
 #pragma unroll
         for (int j = 0; j < CH_TAIL_STAGES; ++j) {       // (unrolled: the shortcut slots are registers)
             tick();
+            if (CH_LGKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
+            probe();
             tick();
             const uint8_t* wb = smem + buf * CH_BUF;
             if (++buf == CH_D) buf = 0;
@@ -483,8 +566,8 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                     yh[t] = pack_frag(h[0][t], h[1][t]);
                     yl[t] = pack_frag(l[0][t], l[1][t]);
                     if (!(CH_ABL & 1)) {
-                        __builtin_amdgcn_raw_buffer_store_b128(slab_gather(h[0][t], h[1][t]), yr, po[t], j * a.np_y * 64, CH_NT);
-                        __builtin_amdgcn_raw_buffer_store_b128(slab_gather(l[0][t], l[1][t]), yr, po[t], j * a.np_y * 64 + (int)a.ps_y, CH_NT);
+                        store16(slab_gather(h[0][t], h[1][t]), yr, po[t], j * a.np_y * 64);
+                        store16(slab_gather(l[0][t], l[1][t]), yr, po[t], j * a.np_y * 64 + (int)a.ps_y);
                     }
                 }
                 // the slot is free: refill it with the half-group four stages on (this tile's, or the next tile's first four)
@@ -514,13 +597,14 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                         split4_f16(v, zh[q], zl[q]);
                     }
                     if (!(CH_ABL & 1) && !(CH_ZX & 1)) {
-                        __builtin_amdgcn_raw_buffer_store_b128(slab_gather(zh[0], zh[1]), zr, po[t], sl * a.np_z * 64, CH_NT);
-                        __builtin_amdgcn_raw_buffer_store_b128(slab_gather(zl[0], zl[1]), zr, po[t], sl * a.np_z * 64 + (int)a.ps_z, CH_NT);
+                        store16(slab_gather(zh[0], zh[1]), zr, po[t], sl * a.np_z * 64);
+                        store16(slab_gather(zl[0], zl[1]), zr, po[t], sl * a.np_z * 64 + (int)a.ps_z);
                     }
                 }
         }
     }
     tick();
+    probe_end();
     if (rng > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
 #endif
 }
@@ -563,7 +647,7 @@ __global__ __launch_bounds__(256) void chain_pack_tail_kernel(const float* __res
 
 }  // namespace
 
-#if CH_TIMING
+#if CH_TIMING || CH_PROBE
 static unsigned long long* g_chain_dbg = nullptr;
 extern "C" void stm_debug_chain_timing(void* p) { g_chain_dbg = static_cast<unsigned long long*>(p); }
 #endif
@@ -618,7 +702,7 @@ static int chain_launch(const char* who, bool proj, const void* mid1_planes, con
     a.plane_bytes_in = (unsigned)(2 * M * 64);
     a.tiles = stm_cdiv(M, CH_BM);
     a.range_flag = stm_internal_range_flag();
-#if CH_TIMING
+#if CH_TIMING || CH_PROBE
     a.dbg = g_chain_dbg;
 #else
     a.dbg = nullptr;
