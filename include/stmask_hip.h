@@ -25,7 +25,13 @@
  *     the error string is per thread.
  *   - STM_ABI_VERSION changes whenever a struct of this header changes size or an entry point changes signature or disappears
  *     (2: stm_conv_geom gained out_fmt_plus1, stm_conv2d_nhwc_f32 was removed, stm_struct_bytes and
- *     stm_debug_reload_tunables are declared).  stm_struct_bytes(which) lets a client check its struct layout against the library.
+ *     stm_debug_reload_tunables are declared;
+ *      3: stm_conv_geom gained win_h / win_w / win_y0 / win_x0 and ph / pw may be negative (window launches), struct stm_conv_window and
+ *     stm_conv2d_planar_windows_f32; the kx-reuse narrow-layer entries stm_conv_kxr_packed_bytes / stm_conv_pack_weights_kxr_f32 /
+ *     stm_conv2d_planar_kxr_f32; stm_conv2d_planar_dual_f32; the fused stem stm_stem_packed_weight_bytes / stm_stem_pack_weights_f32 /
+ *     stm_stem_fused_f32; the bottleneck chain stm_chain_tail_weight_bytes(_proj) / stm_chain_pack_tail(_proj)_f32 /
+ *     stm_bottleneck_chain(_proj)_f32; stm_detect_cc_logits_f32; stm_corr_patch_nhwc_f32 / stm_roi_align_planes_nhwc_f32).
+ *     stm_struct_bytes(which) lets a client check its layout of EVERY struct of this header against the library.
  */
 #ifndef STMASK_HIP_H_
 #define STMASK_HIP_H_
@@ -52,7 +58,8 @@ typedef void* stm_stream_t; /* hipStream_t */
 
 int stm_version(void);
 const char* stm_last_error_string(void);
-/* sizeof of the library's own view of a header struct: which = 0 stm_deform_geom, 1 stm_conv_geom; 0 for anything else */
+/* sizeof of the library's own view of a header struct: which = 0 stm_deform_geom, 1 stm_conv_geom, 2 stm_conv_window (passed as an
+ * array: a wrong size is a wrong stride), 3 stm_head_layout; 0 for anything else */
 size_t stm_struct_bytes(int which);
 /* Diagnostics: the STM_* environment switches are read once per process; this makes the next call read them again (tests, A/B
  * scripts).  Not needed in production. */

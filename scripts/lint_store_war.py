@@ -7,7 +7,8 @@ does not hold (scripts/vmem_store_war_probe.hip, profiles/r04_store_war_probe.tx
 pick up the NEW register contents when the texture path is back-pressured.  This script lists every wide store whose data registers are
 written again within `--window` instructions, so that a kernel change that re-creates the exposure fails tests/test_isa_lint.py.
 
-usage: lint_store_war.py file.s [...] [--window N]      exit code 1 if an exposure is found
+usage: lint_store_war.py file.s [...] [--window N] [--min-wait W]      exit code 1 if a store's data is overwritten after fewer than W wait states
+(default W = 2: measured need 1 for the SGPR-soffset form, 2 for soffset 0 and what the compiler gives the global / flat forms)
 """
 import re
 import sys
@@ -77,16 +78,19 @@ def scan(path, window):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    window = 3
+    window, min_wait = 3, 2
     if "--window" in sys.argv:
         window = int(sys.argv[sys.argv.index("--window") + 1])
-        args = [a for a in args if a != str(window)]
+        args.remove(str(window))
+    if "--min-wait" in sys.argv:
+        min_wait = int(sys.argv[sys.argv.index("--min-wait") + 1])
+        args.remove(str(min_wait))
     bad = []
     for p in args:
-        bad += scan(p, window)
+        bad += [b for b in scan(p, window) if b[6] < min_wait]
     for (path, kern, ln, s, ln2, s2, waited, sg) in bad:
         print(f"{path}:{ln}: [{kern[:60]}] {s}\n    {ln2}: {s2}    <- overwrites the store's data after {waited} wait state(s){' (SGPR soffset: the compiler adds none)' if sg else ''}")
-    print(f"lint_store_war: {len(bad)} exposure(s) within {window} instruction(s) of a wide store in {len(args)} file(s)")
+    print(f"lint_store_war: {len(bad)} wide store(s) in {len(args)} file(s) whose data registers are overwritten after fewer than {min_wait} wait state(s)")
     return 1 if bad else 0
 
 

@@ -80,7 +80,8 @@ def lib():
         _lib.stm_debug_reload_tunables.restype = None
         # this binding and the library must describe the same structs (a stale .so would read garbage past a shorter struct)
         if _lib.stm_version() != ABI_VERSION or _lib.stm_struct_bytes(0) != ctypes.sizeof(DeformGeom) or \
-                _lib.stm_struct_bytes(1) != ctypes.sizeof(ConvGeom):
+                _lib.stm_struct_bytes(1) != ctypes.sizeof(ConvGeom) or _lib.stm_struct_bytes(2) != ctypes.sizeof(ConvWindow) or \
+                _lib.stm_struct_bytes(3) != ctypes.sizeof(HeadLayout):
             v = _lib.stm_version()
             _lib = None
             raise StmError(f"{LIB_PATH} has ABI version {v}, this binding was written for {ABI_VERSION} (or a struct size "

@@ -20,7 +20,13 @@ extern "C" int stm_version(void) { return STM_ABI_VERSION; }
 extern "C" const char* stm_last_error_string(void) { return g_err; }
 extern "C" size_t stm_struct_bytes(int which)
 {
-    return which == 0 ? sizeof(stm_deform_geom) : (which == 1 ? sizeof(stm_conv_geom) : 0);
+    switch (which) {
+        case 0: return sizeof(stm_deform_geom);
+        case 1: return sizeof(stm_conv_geom);
+        case 2: return sizeof(stm_conv_window);
+        case 3: return sizeof(stm_head_layout);
+        default: return 0;
+    }
 }
 
 static std::atomic<int> g_env_gen{0};

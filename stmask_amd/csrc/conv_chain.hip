@@ -88,10 +88,11 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define CH_STORE_VOFF 0   // 1: the stores' slab offset is added to the VGPR offset and soffset is 0 -- the form llvm's hazard recogniser pads by itself
 #endif
 #ifndef CH_COUNTED
-#define CH_COUNTED 0      // 1: the producers' landing wait as a counted vmcnt with the next stage in flight (round 3's first form)
+#define CH_COUNTED 1      // the producers' landing wait as a counted vmcnt with the next stage in flight; 0 = vmcnt(0) before the next stage goes out
 #endif
 #ifndef CH_LGKM
-#define CH_LGKM 0         // 1: consumers drain their LDS reads (s_waitcnt lgkmcnt(0)) before every barrier (hypothesis test: a ring slot restaged under a pending ds_read)
+#define CH_LGKM 1         // consumers drain their LDS reads (s_waitcnt lgkmcnt(0)) before every barrier; 0 = round 3's barrier (diagnosis: a ring slot is
+                          // then restaged under ds_reads that are still queued)
 #endif
 #ifndef CH_ZX
 #define CH_ZX 0        // diagnosis of the z-producing instantiation: 1 no z stores, 2 no conv1' MFMAs, 4 no schedule hints in the tail
@@ -291,17 +292,19 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
             return kind;
         };
         const int G = SG * n_seq;
-        // Stage g goes out after barrier g - 2 (its slot held stage g - 3, which every consumer has left) and must have landed at barrier g.
-        // The landing wait is s_waitcnt vmcnt(0) BEFORE the next stage is issued -- never a counted wait with younger DMAs in flight:
-        // LDS-DMA completions of one wave are not ordered among themselves (a stage of L2-resident weight pieces overtakes the HBM rows of the
-        // stage before it), so "at most N outstanding" does not say WHICH N.  With the counted form (issue g + 1, wait until only its DMAs are
-        // out, barrier g) one pipeline run in ten differed in a tile's worth of pixels: stale low-plane pieces in the last bits, stale
-        // high-plane pieces as whole values (scripts/chain_pipeline_probe2.py; the isolated kernel never showed it).  One stage stays in
-        // flight across every barrier as before; a deeper look-ahead was measured to change nothing.
+        // Stage g goes out after barrier g - 2 (its slot held stage g - 3, which every consumer has left: they drain lgkmcnt in front of their
+        // barriers) and must have landed at barrier g.  The landing wait is a COUNTED vmcnt that leaves only the stage just issued outstanding:
+        // a wave's loads, stores and LDS-DMAs complete in issue order (MI355X_MICROARCH.md; asked of the hardware by scripts/ldsdma_order_probe.hip:
+        // 0 stale words in 3.1e9 per variant, stages of HBM rows followed by L2-resident pieces, out-of-range pieces and mixed instruction kinds
+        // included -- profiles/r04_ldsdma_order_probe.txt).
+        // History: round 3 ran this loop with UNDRAINED consumer barriers, saw one pipeline pass in ten differ, blamed the counted wait and
+        // went to vmcnt(0)-before-issue (CH_COUNTED=0).  The wait was innocent: with the counted form the producers restage slot (g + 1) % 3
+        // the moment barrier g - 1 opens, while the consumers' last fragment reads of stage g - 2 -- issued before that barrier, their MFMAs
+        // sunk below it by the compiler -- can still be queued in the LDS pipe, and a weight piece from L2 lands within a few hundred cycles.
+        // vmcnt(0)-before-issue only delays the restaging by the landing time of the stage in flight.  Measured beside a second process
+        // (scripts/ring_stress.py, 1 200 launches per case): counted + undrained 34 wrong outputs in 19 200 launches (whole 16-pixel fragments,
+        // every instantiation), counted + drained 0, vmcnt(0)-before-issue + drained 0 (profiles/r04_ring_stress_chain_variants.txt).
 #if CH_COUNTED
-        // (diagnosis build, make EXTRA=-DCH_COUNTED=1) round 3's first producer loop: stage g + 1 goes out, then a COUNTED wait that leaves only
-        // its DMAs outstanding, then barrier g -- scripts/ring_stress.py runs it beside a second process to see whether this form ever hands
-        // over a stage that has not landed (scripts/ldsdma_order_probe.hip asks the same of the bare instructions)
         issue();
         for (int g = 1; g < G; ++g) {
             const int kind = issue();
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
         probe_end();
         return;
 #endif
+        // (CH_COUNTED=0, the cross-check form)
         issue();                                     // G >= 15
         for (int g = 1; g < G; ++g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage g - 1 has landed
@@ -445,7 +449,10 @@ __global__ __launch_bounds__(CH_THREADS) void conv_chain_kernel(const ChainArgs 
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + 16 * c + 4 * kc);
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaxf(__builtin_fmaf(acc[c][t][r] + accl[c][t][r] * ls, a.scale2, bv[r]), 0.0f);
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = __builtin_fmaxf(__builtin_fmaf(acc[c][t][r] + accl[c][t][r] * ls, a.scale2, bv[r]), 0.0f);
+                        rng = max(rng, __builtin_bit_cast(unsigned, v[r]));          // (mid2 never leaves the kernel, but an overflowed plane would zero y silently)
+                    }
                     split4_f16(v, h[q], l[q]);
                 }
                 *reinterpret_cast<f16x8*>(park + ((s * 2 + t) * 2) * 1024) = pack_frag(h[0], h[1]);

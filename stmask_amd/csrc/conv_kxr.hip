@@ -198,10 +198,10 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
         };
         const int G = S * n_seq;                             // stages of the whole sequence
 #if defined(KX_SAFE_WAIT)
-        // (make EXTRA=-DKX_SAFE_WAIT) The landing wait as vmcnt(0) BEFORE the next stage goes out, never a counted wait with younger DMAs in
-        // flight: conv_chain.hip's ring needed this form ("Bottleneck chain", finding 1).  This kernel's stages all have one
-        // composition and its counted form has been bit-equal in every two-rank and run-to-run check, and the safe form costs 9-12 % on the head
-        // layers (273 -> 299, 345 -> 384, 375 -> 420 us), so the counted form ships and this one stays as the cross-check.
+        // (make EXTRA=-DKX_SAFE_WAIT) cross-check build: vmcnt(0) for stage g - 1 BEFORE stage g goes out.  Round 3 believed the counted wait
+        // below could hand over a stage that had not landed; scripts/ldsdma_order_probe.hip shows it cannot (LDS-DMA completes in issue order,
+        // mixed buffer_load ... lds / global_load_lds included: 0 stale words in 3.1e9 per variant, profiles/r04_ldsdma_order_probe.txt).  What
+        // that form really did was delay the restaging of a slot the consumers were still reading -- see the consumers' barrier.
         if (G > 0) issue();
         for (int g = 1; g < G; ++g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -304,7 +304,12 @@ __device__ __forceinline__ void kxr_body(const KxrArgs& a, const KxrJob& jb, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc[c][t][r] = 0.0f; accl[c][t][r] = 0.0f; }
     for (int s = 0; s < S; ++s) {
-        asm volatile("s_barrier" ::: "memory");             // barrier s: stage s is in LDS (and every consumer has left stage s - 1)
+        // barrier s: stage s is in LDS, and every consumer has LEFT stage s - 1 -- which takes the lgkmcnt(0) in front of the barrier: the
+        // producers restage that slot as soon as the barrier opens, and a fragment read that is still queued in the LDS pipe then returns
+        // the NEW stage's bytes (measured on conv_chain.hip's copy of this ring: 34 wrong outputs in 19 200 launches beside a second
+        // process without the drain, 0 with it; profiles/r04_ring_stress_chain_variants.txt).  The compiler sinks the stage's last MFMAs
+        // below an undrained barrier together with the lgkmcnt wait of their fragments.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const uint8_t* xs = smem + buf * BUF;
         if (++buf == D) buf = 0;
         if constexpr ((KX_ABL & 2) != 0) continue;

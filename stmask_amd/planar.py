@@ -46,10 +46,12 @@ CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 laye
 TN_BORDER = os.environ.get("STM_TN_BORDER", "1") != "0"     # TemporalNet's 3x3 layers as nine window launches without the zero taps of the RoI borders
 CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"
 # bit 0 = the projection form (a stage's first block); bit 1 = the kernel also computes the NEXT block's conv1 (z); bit 2 (diagnostics) = z is
-# computed but not used.  Default 1: the z-producing instantiation (conv_chain_kernel<true, .>) is deterministic run to run in one process but
-# its y differed sporadically between a run with a second process on the same GPU and a solo run (bench.py --world2-one-gpu: 9 of 9 runs
-# with bit 1, 0 of 6 without; cause not found -- not the LDS ring, not load / store ordering, not the kernel's end), so it is not used.
-CHAIN_MODE = int(os.environ.get("STM_CHAIN_MODE", "1"))  # layer1's identity-shortcut blocks: conv2 -> conv3 + shortcut -> next conv1 as one kernel (csrc/conv_chain.hip)
+# computed but not used.  Round 3 shipped 1 because the z-producing instantiation (conv_chain_kernel<true, .>) gave wrong y / z beside a
+# second process on the GPU.  Round 4 found why (csrc/conv_chain.hip, store16: a 16-byte buffer store with an SGPR soffset reads its data
+# after the next VALU write; only those instantiations had the two back to back) and fixed it: 0 differing outputs in 38 400 launches
+# beside the second process where round 3's code gave 36 in 12 800 (profiles/r04_ring_stress_chain_variants.txt).
+CHAIN_MODE = int(os.environ.get("STM_CHAIN_MODE", "3"))  # layer1's identity-shortcut blocks: conv2 -> conv3 + shortcut -> next conv1 as one kernel (csrc/conv_chain.hip)
+CHAIN_MAX_PIXELS = (1 << 21) - 1     # stm_bottleneck_chain_f32 addresses a 256-channel plane pair with 31-bit byte offsets (2 * 8 * M * 64 < 2^31)
 
 
 def set_format(fmt, backbone_fmt=None):
@@ -894,7 +896,7 @@ class PlanarBackbone:
                 shape = ("img", B, H, W)
                 sh, sw = e["stride"]
                 Ho, Wo = (H - 1) // sh + 1, (W - 1) // sw + 1
-                if "chain" in e and not (last and not self.planes_only):
+                if "chain" in e and not (last and not self.planes_only) and B * H * W <= CHAIN_MAX_PIXELS:
                     mid1 = z_next if z_next is not None else e["c1"](xp, shape)
                     xp, z_next = e["chain"](mid1, xp, B, H, W)
                     if CHAIN_MODE & 4:          # diagnostics: the kernel computes z, the next block does not use it

@@ -40,6 +40,8 @@ def test_struct_layouts_of_binding_and_library_agree():
     lib.stm_struct_bytes.restype = ctypes.c_size_t
     assert lib.stm_struct_bytes(0) == ctypes.sizeof(_lib.DeformGeom)
     assert lib.stm_struct_bytes(1) == ctypes.sizeof(_lib.ConvGeom)
+    assert lib.stm_struct_bytes(2) == ctypes.sizeof(_lib.ConvWindow) == 32         # passed as an array: the size is the stride
+    assert lib.stm_struct_bytes(3) == ctypes.sizeof(_lib.HeadLayout)
     assert lib.stm_struct_bytes(7) == 0
 
 
