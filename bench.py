@@ -214,7 +214,9 @@ def conv_roofline(conv_t, steps, planes, traffic=None, traffic_src=None, timed_i
         tf = c_fl / (c_ms * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TF * c_fl / c_mfma
         return {"achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                "mfma_tflops_issued": round(c_issued / (c_ms * 1e-3) / 1e12, 1), "launches": len(sel),
+                "mfma_tflops_issued": round(c_issued / (c_ms * 1e-3) / 1e12, 1),
+                # MFMA products actually ISSUED / time / 2500: moves only when the hardware runs faster, never with an accounting change
+                "frac_issued": round(c_issued / (c_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4), "launches": len(sel),
                 "ms_per_step": round(c_ms / steps, 3), "tflop_per_step": round(c_fl / steps / 1e12, 3)}
 
     hbm_sel = [t for t in conv_t if t[6] / (HBM_PEAK_GBS * 1e9) > t[2] * t[4] / (BF16_MFMA_PEAK_TF * 1e12)]
@@ -297,7 +299,7 @@ def world2_report(args, run, dev, rank, world, elapsed, use_dist):
                "what": "Runner + BatchedClipPipeline + clip sharding (clip i -> rank i mod N) + one fixed-shape all-gather per step + "
                        "barrier / max-over-ranks timing executed with 2 processes; every step's gathered block of every rank compared "
                        "bit for bit with a single-process run of that rank's clips"}
-        print(json.dumps(res), flush=True)
+        emit(json.dumps(res))
         rc = 0 if ok else 4
     if use_dist:
         dist.barrier()
@@ -498,6 +500,18 @@ def parity_block(args, dev, net, ref_dets):
             "ref": "CPU oracle path (cpu_baseline leg), same clip / weights; arithmetic of the HIP side: " + args.planes}
 
 
+_RESULT_FD = None       # the real stdout of a rank under torch.distributed.run (see main)
+
+
+def emit(line):
+    """The result line, on the process's real stdout."""
+    if _RESULT_FD is None:
+        print(line, flush=True)
+    else:
+        sys.stdout.flush()
+        os.write(_RESULT_FD, (line + "\n").encode())
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -533,6 +547,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if use_dist:
+        # RCCL prints a version banner on STDOUT when its communicator comes up (at the first collective); the contract is ONE JSON line on
+        # rank 0's stdout.  File descriptor 1 is pointed at stderr for the run, the result line goes to the saved descriptor.
+        global _RESULT_FD
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev if args.backend == "nccl" else None)
 
     # MIOpen immediate mode (only --no-planar graphs reach the library at all)
@@ -595,6 +615,17 @@ def main():
                        "why_32_clips": "SURVEY §8(d) names 8 clips/GPU; throughput plateaus from 32 (extras.clips8 / extras.clips1 "
                                        "carry the 8-clip and single-stream lines)"},
         }
+        if use_dist:
+            # the data-path collective of SURVEY 8(e) as it ran: backend, how many all-gathers went out on the communication stream, and --
+            # at world size 1, where the gathered block must BE the local block -- whether the last one came back bit-equal
+            g = run.gatherer
+            run.gatherer.wait()
+            last_local = run.pipe._pack_outputs(dev) if run.batched else None
+            res["collective"] = {"backend": dist.get_backend(), "world_size": world, "all_gathers_on_comm_stream": g.n_collectives,
+                                 "comm_stream": (g._comm is not None and g._comm != torch.cuda.default_stream(dev)),
+                                 "gathered_shape": list(out.shape),
+                                 "last_gather_equals_local_block": (bool(torch.equal(out[rank * args.clips:(rank + 1) * args.clips], last_local))
+                                                                    if last_local is not None else None)}
         ker_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
         ker_bytes = sum(b for _, _, b in timing)
         n_launch = max(len(timing), 1)
@@ -686,7 +717,7 @@ def main():
                 res["mask_l2"], res["mask_max_abs"] = res["parity"]["mask_l2"], res["parity"]["mask_max_abs"]
             except Exception as e:
                 res["parity"] = {"error": repr(e)[:300]}
-        print(json.dumps(res), flush=True)
+        emit(json.dumps(res))
         par = res.get("parity")
         if par is not None:
             # the benchmark's own parity block is a gate, not a report: a fast run with wrong results exits non-zero

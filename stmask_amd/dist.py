@@ -70,6 +70,7 @@ class DetectionGatherer:
         self.device = device
         self._comm = None
         self._events = []
+        self.n_collectives = 0          # all-gathers enqueued on the communication stream (the RCCL branch)
 
     def gather(self, packed):
         if not (dist.is_available() and dist.is_initialized()):
@@ -86,6 +87,7 @@ class DetectionGatherer:
             ev = torch.cuda.Event()
             ev.record()
         self._events = [ev]
+        self.n_collectives += 1
         return out
 
     def wait(self):
