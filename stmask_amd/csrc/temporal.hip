@@ -21,14 +21,17 @@ namespace {
 // (f2 row, x, 4 channels) instead of (channel, f2 row, 4 x): same LDS image, same arithmetic, no NCHW copy of the feature maps.
 // CCK: channels staged per chunk -- 16 for rows of up to 44 pixels, 8 for rows of up to 88 (the 46x80 P4 level of 736x1280 frames, BASELINE
 // config 5, which fell to the generic kernel before: 3.5 ms per step at 4 clips).
-template <int P, bool IN_NHWC, int CCK = 16>
-__global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict__ f1, const float* __restrict__ f2,
+// MAXU: float4 staging units per thread and chunk (8 covers every row length the launcher sends here, 7 covers W <= 40 at CCK = 16 -- the 24x40 level
+// of 384x640 frames); WPS: waves per SIMD the register allocation must leave room for.  Round 4: the kernel sat at 188 VGPRs = 2 waves per SIMD, so
+// the 768 workgroups of a 32-clip step ran as 1.5 rounds over 512 slots; with the staging plan packed into one register per unit (global offset in
+// the low 20 bits, LDS word offset above), 7 units and a 168-register budget all 768 are resident at once.
+template <int P, bool IN_NHWC, int CCK = 16, int MAXU = 8, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void corr_patch_tiled(const float* __restrict__ f1, const float* __restrict__ f2,
                                                         float* __restrict__ out, int C, int H, int W, float scale,
                                                         float slope, int B, int out_ld)
 {
     constexpr int R = P / 2;
     constexpr int WIN = 4 + P - 1;          // f2 values per item per channel (14 for P = 11)
-    constexpr int MAXU = 8;                 // float4 staging units per thread and chunk (W <= 44 at P = 11)
     extern __shared__ float smem[];
     const int Wq = W / 4;                   // x quads (W % 4 == 0 on this path)
     const int LW2 = ((W + 2 * R + 3) / 4) * 4;   // padded f2 row length (multiple of 4)
@@ -54,12 +57,13 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
     // ---- staging plan, computed ONCE: unit u = (channel c, f2 row rr, x quad) -> one float4 global load + 4 LDS words.
     //      Only in-image rows are ever loaded; halo columns and out-of-image rows are zeroed once and never touched again.
     const int units = CCK * P * Wq;
-    int g_off[MAXU], l_off[MAXU];           // global offset (floats, relative to channel chunk), LDS word offset
+    // plan[u] = global offset in float4 units (low 18 bits; NHWC: (pixel * C + 4 cq) / 4, NCHW: (c * HW + pixel) / 4 -- both < 2^18 for the maps
+    // the launcher admits) | LDS word offset << 18; 0xffffffff = nothing to stage
+    unsigned plan[MAXU];
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
         int id = tid + u * 256;
-        g_off[u] = -1;
-        l_off[u] = 0;
+        int g_off_u = -1, l_off_u = 0;
         if (id < units) {
             if constexpr (IN_NHWC) {
                 // unit = (f2 row rr, x, channel quad): 16 bytes of 4 channels at one pixel; the quad is the fastest index, so the
@@ -68,19 +72,20 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
                 const int rr = rem / W, x = rem - rr * W;
                 const int yy = y + rr - R;
                 if (yy >= 0 && yy < H) {
-                    g_off[u] = (yy * W + x) * C + cq * 4;
-                    l_off[u] = (cq * 4 * P + rr) * LW2 + R + x;
+                    g_off_u = (yy * W + x) * C + cq * 4;
+                    l_off_u = (cq * 4 * P + rr) * LW2 + R + x;
                 }
             } else {
                 int c = id / (P * Wq), rem = id - c * (P * Wq);
                 int rr = rem / Wq, xq = rem - rr * Wq;
                 int yy = y + rr - R;
                 if (yy >= 0 && yy < H) {
-                    g_off[u] = c * (int)HW + yy * W + xq * 4;
-                    l_off[u] = (c * P + rr) * LW2 + R + xq * 4;
+                    g_off_u = c * (int)HW + yy * W + xq * 4;
+                    l_off_u = (c * P + rr) * LW2 + R + xq * 4;
                 }
             }
         }
+        plan[u] = g_off_u < 0 ? 0xffffffffu : ((unsigned)g_off_u >> 2) | ((unsigned)l_off_u << 18);
     }
     const bool f1_unit = IN_NHWC ? tid < CQ * W : tid < CCK * Wq;
     const int f1_c = IN_NHWC ? (tid % CQ) * 4 : tid / Wq;            // first channel of the unit
@@ -92,13 +97,14 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < MAXU; ++u) {
             pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g_off[u] >= 0) {
+            if (plan[u] != 0xffffffffu) {
+                const int g4 = (int)(plan[u] & 0x3ffffu) * 4;
                 if constexpr (IN_NHWC) {
                     const int c = ((tid + u * 256) % CQ) * 4;     // C % 4 == 0: a quad is inside or outside as a whole
-                    if (c0 + c < C) pf[u] = *reinterpret_cast<const float4*>(f2b + g_off[u] + c0);
+                    if (c0 + c < C) pf[u] = *reinterpret_cast<const float4*>(f2b + g4 + c0);
                 } else {
                     int c = (tid + u * 256) / (P * Wq);
-                    if (c0 + c < C) pf[u] = *reinterpret_cast<const float4*>(f2b + (int64_t)c0 * HW + g_off[u]);
+                    if (c0 + c < C) pf[u] = *reinterpret_cast<const float4*>(f2b + (int64_t)c0 * HW + g4);
                 }
             }
         }
@@ -111,8 +117,8 @@ __global__ __launch_bounds__(256) void corr_patch_tiled(const float* __restrict_
     auto commit = [&]() {
 #pragma unroll
         for (int u = 0; u < MAXU; ++u)
-            if (g_off[u] >= 0) {
-                float* d = f2s + l_off[u];
+            if (plan[u] != 0xffffffffu) {
+                float* d = f2s + (plan[u] >> 18);
                 constexpr int ST = IN_NHWC ? 0 : 1;              // word stride between the unit's 4 values: channels (P * LW2) or x (1)
                 const int st = ST ? 1 : P * LW2;
                 d[0] = pf[u].x; d[st] = pf[u].y; d[2 * st] = pf[u].z; d[3 * st] = pf[u].w;
@@ -291,19 +297,22 @@ int corr_patch_launch(const float* f1, const float* f2, float* out, int B, int C
     STM_REQUIRE(f1 && f2 && out, STM_ENULL, "stm_corr_patch_f32: f1/f2/out must be non-NULL");
     STM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, STM_EINVAL, "stm_corr_patch_f32: empty input");
     STM_REQUIRE(P > 0 && (P & 1) && dil > 0, STM_EINVAL, "stm_corr_patch_f32: patch_size must be odd, dilation > 0");
-    const int force = STM_ENV_INT("STM_CORR_VARIANT", 0);        // 1: the generic kernel (tests)
+    const int force = STM_ENV_INT("STM_CORR_VARIANT", 0);        // 1: the generic kernel (tests); 2: round 3's 2-waves-per-SIMD form of the tiled kernel (A/B)
     // tiled kernel: P = 11, rows of whole float4 quads, staging plan of <= 8 units per thread (W <= 44)
     // tiled kernel: P = 11, rows of whole float4 quads, staging plan of <= 8 units per thread: 16-channel chunks up to W = 44, 8-channel up to 88
     const int cck = 16 * 11 * (W / 4) <= 8 * 256 ? 16 : 8;
     bool tiled = (P == 11 && dil == 1 && H <= 65535 && B <= 65535 && W % 4 == 0 && cck * 11 * (W / 4) <= 8 * 256 &&
-                  ((uintptr_t)out % 16 == 0) && ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f2 % 16 == 0));
+                  ((uintptr_t)out % 16 == 0) && ((uintptr_t)f1 % 16 == 0) && ((uintptr_t)f2 % 16 == 0) &&
+                  (int64_t)C * H * W < ((int64_t)1 << 20));      // (the packed staging plan: float4 offsets of one image below 2^18)
     if (force == 1 || (in_nhwc && C % 4 != 0)) tiled = false;
     if (tiled) {
         int LW2 = ((W + 10 + 3) / 4) * 4;
         size_t lds = (size_t)(cck * W + cck * 11 * LW2) * sizeof(float);
         if (lds <= 64 * 1024) {
             const dim3 grid(stm_xcd_grid((int64_t)H * B));
-            if (in_nhwc && cck == 16)
+            if (in_nhwc && cck == 16 && force != 2 && 16 * 11 * (W / 4) <= 7 * 256)
+                hipLaunchKernelGGL((corr_patch_tiled<11, true, 16, 7, 3>), grid, dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W, scale, leaky_slope, B, out_ld);
+            else if (in_nhwc && cck == 16)
                 hipLaunchKernelGGL((corr_patch_tiled<11, true, 16>), grid, dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W, scale, leaky_slope, B, out_ld);
             else if (in_nhwc)
                 hipLaunchKernelGGL((corr_patch_tiled<11, true, 8>), grid, dim3(256), lds, stm_hs(stream), f1, f2, out, C, H, W, scale, leaky_slope, B, out_ld);
