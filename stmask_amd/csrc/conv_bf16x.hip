@@ -84,6 +84,7 @@ struct PlanarArgs {
     int x_np, out_np, res_np;                        // pixels per channel slab of the planar buffers
     int relu;
     int M, n_tiles, m_tiles, slabs;
+    int nsub;                // 0, or the channel tiles of one pixel tile that run TOGETHER on an XCD (STM_CONV_NSUB; see the tile map)
     unsigned plane_bytes;   // bytes of one input plane that may be addressed (buffer range)
     long long x_pstride, out_pstride, res_pstride;   // bytes between planes
     int groups, ntpg, cout_g;                        // grouped conv: n-tiles per group, output channels per group
@@ -374,11 +375,29 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const typename std:
     const int tiles = tiles_;
     const int per_xcd = (tiles + 7) >> 3;
     int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    // Which tiles share an XCD at one time decides what its 4-MB L2 must fetch: the 32 workgroups an XCD runs together are 32 / n_tiles pixel
+    // tiles x all n_tiles channel tiles in the plain order, i.e. every K-slab of EVERY channel tile's weights for only 4 pixel tiles at
+    // n_tiles = 8 (rocprofv3: 3.3 GB fetched per TemporalNet launch for 0.45 GB of input -- the 19-MB weight set streams from the Infinity Cache
+    // once per 4 pixel tiles).  With nsub (2 or 4) the order inside a group of (32 / nsub) pixel tiles is: nsub channel tiles of each pixel
+    // tile, then the next nsub, ... -- 32 / nsub pixel tiles x nsub channel tiles together.  Same tiles, same results.
+    auto regroup = [&](int j, int nt_all, int& mt_o, int& nt_o) {
+        const int pg = 32 / a_in.nsub, G = pg * nt_all;
+        const int gq = j / G, r = j - gq * G;
+        const int nh = r >> 5, rr = r & 31;
+        mt_o = gq * pg + rr / a_in.nsub;
+        nt_o = nh * a_in.nsub + rr % a_in.nsub;
+    };
     if constexpr (CLS) {
         // the classes' tiles differ in length (4, 6 or 9 taps): a contiguous run of tile ids per XCD would give one XCD the short classes and
         // another the long one.  Pixel tiles are dealt round-robin to the XCDs instead, each with all its channel tiles (they share its rows).
-        const int j = blockIdx.x >> 3, jm = j / a_in.n_tiles;
-        logical = (jm * 8 + (int)(blockIdx.x & 7)) * a_in.n_tiles + (j - jm * a_in.n_tiles);
+        const int j = blockIdx.x >> 3;
+        int jm = j / a_in.n_tiles, nt_ = j - jm * a_in.n_tiles;
+        if (a_in.nsub) regroup(j, a_in.n_tiles, jm, nt_);
+        logical = (jm * 8 + (int)(blockIdx.x & 7)) * a_in.n_tiles + nt_;
+    } else if (a_in.nsub) {
+        int mt_, nt_;
+        regroup(logical, a_in.n_tiles, mt_, nt_);
+        logical = mt_ * a_in.n_tiles + nt_;        // (a trailing partial group maps past `tiles` only where the plain order would too: see launch)
     }
     if (logical >= tiles) return;
     // CLS: the grid is the concatenation of several window launches (classes); this tile's class supplies the fields that differ
@@ -406,6 +425,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const typename std:
     const int mt = a.n_tiles == 1 ? tile : (a.n_tiles == 2 ? tile >> 1 : (a.n_tiles == 4 ? tile >> 2 : tile / a.n_tiles));
     const int nt = tile - mt * a.n_tiles;
     const int m0 = mt * BM;
+    if (m0 >= a.M) return;                           // (pixel tiles the regrouped tile map pads the grid with)
     const int s_begin = ksp * a.kslabs, s_end = min(a.slabs, s_begin + a.kslabs);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1131,6 +1151,7 @@ struct ConvTunables {
     long long nt_mb = 0;   // STM_CONV_NT: nontemporal plane stores for outputs of at least this many MB (0 = off; no gain measured)
     int scalar_epilogue = 0;   // STM_CONV_SCALAR_EPILOGUE: element-wise epilogue stores (tests)
     int abl = 0;           // STM_CONV_ABL (builds with -DSTM_ABLATE only)
+    int nsub = 0;          // STM_CONV_NSUB: 2 / 4 = channel tiles of a pixel tile that share an XCD's L2 at one time (tile map of conv_planar_kernel)
 };
 ConvTunables read_tunables()
 {
@@ -1146,6 +1167,7 @@ ConvTunables read_tunables()
     t.nt_mb = geti("STM_CONV_NT", 0);
     t.scalar_epilogue = (int)geti("STM_CONV_SCALAR_EPILOGUE", 0);
     t.abl = (int)geti("STM_CONV_ABL", 0);
+    t.nsub = (int)geti("STM_CONV_NSUB", 0);
     return t;
 }
 const ConvTunables& tunables()
@@ -1493,6 +1515,7 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
     a.x_ld = x_ld; a.out_ld = out_ld; a.res_ld = res_ld; a.relu = relu;
     a.x_np = (int)x_np; a.out_np = (int)out_np; a.res_np = (int)res_np;
     a.M = (int)M; a.n_tiles = stm_cdiv(g->Cout, bn); a.slabs = g->kh * g->kw * (g->C / CV_BK);
+    a.nsub = 0;
     a.plane_bytes = (unsigned)plane_bytes;
     a.x_pstride = xps * 2; a.out_pstride = ops * 2; a.res_pstride = rps * 2;
     a.groups = groups; a.cout_g = cout_g; a.ntpg = stm_cdiv(cout_g, bn);
@@ -1599,8 +1622,11 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
         for (int i = wset->n; i < 9; ++i) ac.cls[i] = ac.cls[0];
         ac.cls_tiles = t0;
         ac.m_tiles = 0;
-        // (grid: every XCD gets the same number of pixel tiles x all channel tiles; ids past the last tile leave at once)
-        return launch_planar<2, 2, 2, 1, 3, 0, false, true>(ac, stm_cdiv(t0 / a.n_tiles, 8) * 8 * a.n_tiles, stream);
+        ac.nsub = ((tn.nsub == 2 || tn.nsub == 4) && a.n_tiles > tn.nsub && a.n_tiles % tn.nsub == 0 && g->groups == 1) ? tn.nsub : 0;
+        // (grid: every XCD gets the same number of pixel tiles x all channel tiles -- a multiple of 32 / nsub of them under the regrouped tile
+        // map, so that its groups are whole; ids past the last tile leave at once)
+        const int pg = ac.nsub ? 32 / ac.nsub : 1;
+        return launch_planar<2, 2, 2, 1, 3, 0, false, true>(ac, stm_cdiv(stm_cdiv(t0 / a.n_tiles, 8), pg) * pg * 8 * a.n_tiles, stream);
     }
     int rc;
     if (bn == 64) {
@@ -1644,6 +1670,10 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
     const int mg = tn.mg ? tn.mg : (t2 >= 192 ? 2 : 1);
     a.m_tiles = stm_cdiv(M, CV_BM * mg);
     plan_splitk(a.m_tiles * a.n_tiles);
+    // regrouped tile map (STM_CONV_NSUB): whole groups of 32 / nsub pixel tiles -- the padding tiles leave at once
+    a.nsub = ((tn.nsub == 2 || tn.nsub == 4) && a.splitk == 1 && a.n_tiles > tn.nsub && a.n_tiles % tn.nsub == 0 && g->groups == 1 &&
+              a.m_tiles >= 4 * (32 / tn.nsub)) ? tn.nsub : 0;
+    if (a.nsub) a.m_tiles = stm_cdiv(a.m_tiles, 32 / a.nsub) * (32 / a.nsub);
     const int tiles = a.m_tiles * a.n_tiles * a.splitk;
     const bool ring = tn.ring == 3;
 #ifdef STM_ABLATE
