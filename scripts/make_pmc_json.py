@@ -47,6 +47,10 @@ def main():
     g = group_any(("conv_planar_kernel", "conv_kxr_kernel"))
     if g:
         doc["conv_planar"] = {"kernel": "conv_planar_kernel<*> + conv_kxr_kernel<*> (all launches of bench.py at batch 32, fp16x2 plane format)", **g}
+    g = group("conv_chain_kernel")
+    if g:
+        doc["conv_chain"] = {"kernel": "conv_chain_kernel<*> (layer1's three bottlenecks at batch 32: conv2 3x3 -> conv3 + shortcut -> the next block's conv1; "
+                                       "algorithmic bytes per launch 4 * M * (64 + 256 + 256 + 64) = 1258 MB, projection form 881 MB)", **g}
     g = group("stem_fused_kernel")
     if g:
         doc["stem_fused"] = {"kernel": "stem_fused_kernel (32 frames 384x640: 94 MB in, 126 MB of planes out)", **g}
@@ -54,7 +58,7 @@ def main():
                      "counters are KiB; FETCH_SIZE doubled per the gfx950 correction (MI355X guide, HBM section); WRITE_SIZE exact for 16-byte streaming stores")
     per = {}
     for k in sorted(set(fetch) | set(write)):
-        if not any(t in k for t in ("anonymous namespace", "stm_", "conv_planar", "conv_kxr", "stem_fused", "dcn_", "corr_", "lincomb", "nms", "head_assemble", "roi_align", "mask_", "gather_", "match_", "pack_", "keep_", "shift_")):
+        if not any(t in k for t in ("anonymous namespace", "stm_", "conv_planar", "conv_kxr", "conv_chain", "stem_fused", "dcn_", "corr_", "lincomb", "nms", "head_assemble", "roi_align", "mask_", "gather_", "match_", "pack_", "keep_", "shift_")):
             continue
         nf, nw = max(fetch[k][1], 1), max(write[k][1], 1)
         name = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round 4, final measurement session: store-WAR probe (all store forms), full GPU tests, smoke, bench (+ layer table), rocprofv3 kernel stats, PMC traffic
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r04; mkdir -p $OUT; cd $R
+export TMPDIR=/tmp
+echo "== 1. store WAR probe, every store form"; timeout 600 scripts/bin/vmem_store_war_probe 300 > $OUT/store_war_probe_forms.txt 2>&1; echo "exit $?"; cut -c1-250 $OUT/store_war_probe_forms.txt | head -45
+echo "== 2. pytest -m gpu"; timeout 2700 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu_final.log 2>&1; echo "pytest exit $?"; tail -4 $OUT/pytest_gpu_final.log
+echo "== 3. smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -2 $OUT/smoke.log
+echo "== 4. bench (driver command) + layer table"; timeout 1500 python bench.py --steps 20 --warmup 4 --layer-table > $OUT/bench_final.json 2> $OUT/bench_final_layers.txt; echo "bench exit $?"
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r04/bench_final.json'))
+r=d['roofline']
+print(d['value'], d['ms_per_step'], 'frac', r['frac'], 'issued', r.get('frac_issued'), 'trunk', r.get('frac_trunk_only'), 'conv ms', r.get('ms_per_step'))
+print('mfma', r['mfma_bound_launches']['frac'], r['mfma_bound_launches']['ms_per_step'], 'hbm', r['hbm_bound_launches']['frac'], r['hbm_bound_launches']['ms_per_step'])
+print('im2col', d['roofline_im2col']['frac'], d['roofline_im2col']['avg_launch_us'])
+for k,v in d['extras'].items(): print(k, v.get('value'), v.get('ms_per_step'), (v.get('roofline') or {}).get('frac'))
+print(d['parity']['matched_frac'], d['parity']['mask_l2'], d['cpu_baseline']['value'])
+PY
+echo "== 5. rocprofv3 kernel trace + stats"
+cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/prof.log 2>&1; echo "prof exit $?"; cd $R
+f=$(ls $OUT/prof/*/*kernel_stats.csv $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1); echo "stats: $f"; head -12 "$f" | cut -c1-200
+t=$(ls $OUT/prof/*/*kernel_trace.csv $OUT/prof/*kernel_trace.csv 2>/dev/null | head -1); python scripts/summarize_trace.py "$t" > $OUT/kernel_stats_final.md 2>&1; head -30 $OUT/kernel_stats_final.md | cut -c1-160
+cp "$f" $OUT/kernel_stats_final.csv; find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete
+echo "== 6. PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes)"
+rm -rf $OUT/pmc_fetch $OUT/pmc_write
+cd /tmp
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?"
+cd $R; python scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt | cut -c1-200 | head -30
+cp profiles/r03_pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null; python scripts/make_pmc_json.py $OUT $OUT/pmc_traffic.json | head -40
+find $OUT/pmc_fetch $OUT/pmc_write -name '*.csv' -size +8M -delete

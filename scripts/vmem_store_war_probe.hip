@@ -12,8 +12,9 @@
 //
 //   every wave writes pattern A to v[200:203], stores them (1 KB per wave and iteration, each to its own address), overwrites v[200:203] with
 //   pattern B after W wait states (W = 0, 1, 2, 3, 5, 9), and stores B elsewhere.  A checker then counts the words of the FIRST store's region that
-//   hold B: each one is a store that read its data after the overwrite.  Forms: soffset in an SGPR (no compiler protection) or folded into the
-//   VGPR offset with soffset = 0 (the form the compiler pads), 4 or 8 waves per CU streaming stores (texture-path back-pressure) or one.
+//   hold B: each one is a store that read its data after the overwrite.  Forms: buffer stores with the soffset in an SGPR (no compiler protection) or 0 (the
+//   form the compiler pads), global stores with a 64-bit VGPR address or an SGPR base, 16 / 12 / 8 bytes per lane; 8 waves per CU streaming stores
+//   (texture-path back-pressure) or one.
 //
 // build: hipcc -O2 --offload-arch=gfx950 scripts/vmem_store_war_probe.hip -o scripts/bin/vmem_store_war_probe      run: scripts/bin/vmem_store_war_probe [iterations]
 #include <hip/hip_runtime.h>
@@ -44,21 +45,44 @@ struct Result {
 #define NOPS_5 "s_nop 4\n\t"
 #define NOPS_9 "s_nop 8\n\t"
 
-#define STORE_SEQ(NOPS, SOFF)                                                                                                                      \
+// store forms: data always v[200:203] (the x2 / x3 forms store its first 2 / 3 registers, 16 bytes apart per lane all the same)
+enum Form { BUF4_SGPR = 0, BUF4_IMM = 1, GLB4_VADDR = 2, GLB4_SADDR = 3, BUF2_SGPR = 4, GLB2_SADDR = 5, BUF3_SGPR = 6, N_FORMS = 7 };
+__host__ __device__ constexpr int form_dwords(int f) { return (f == BUF2_SGPR || f == GLB2_SADDR) ? 2 : (f == BUF3_SGPR ? 3 : 4); }
+static const char* form_name(int f)
+{
+    switch (f) {
+        case BUF4_SGPR: return "buffer_store_dwordx4, soffset in an SGPR   ";
+        case BUF4_IMM: return "buffer_store_dwordx4, soffset 0            ";
+        case GLB4_VADDR: return "global_store_dwordx4 v[addr64], off        ";
+        case GLB4_SADDR: return "global_store_dwordx4 v_off, s[base]        ";
+        case BUF2_SGPR: return "buffer_store_dwordx2, soffset in an SGPR   ";
+        case GLB2_SADDR: return "global_store_dwordx2 v_off, s[base]        ";
+        default: return "buffer_store_dwordx3, soffset in an SGPR   ";
+    }
+}
+
+#define SEQ(ST1, NOPS, ST2)                                                                                                                          \
     asm volatile("v_mov_b32 v200, %[a0]\n\tv_mov_b32 v201, %[a1]\n\tv_mov_b32 v202, %[a2]\n\tv_mov_b32 v203, %[a3]\n\t"                            \
-                 "s_nop 7\n\t"                                                                                                                      \
-                 "buffer_store_dwordx4 v[200:203], %[vo], %[rs], " SOFF " offen\n\t" NOPS                                                           \
+                 "s_nop 7\n\t" ST1 "\n\t" NOPS                                                                                                      \
                  "v_mov_b32 v200, %[b0]\n\tv_mov_b32 v201, %[b1]\n\tv_mov_b32 v202, %[b2]\n\tv_mov_b32 v203, %[b3]\n\t"                            \
-                 "s_nop 7\n\t"                                                                                                                      \
-                 "buffer_store_dwordx4 v[200:203], %[vo2], %[rs], " SOFF " offen\n\t"                                                               \
+                 "s_nop 7\n\t" ST2 "\n\t"                                                                                                           \
                  "s_nop 7\n\t"                                                                                                                      \
                  :                                                                                                                                  \
                  : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [b0] "v"(a0 | 0x80000000u), [b1] "v"(a1 | 0x80000000u),                  \
-                   [b2] "v"(a2 | 0x80000000u), [b3] "v"(a3 | 0x80000000u), [vo] "v"(vo), [vo2] "v"(vo2), [rs] "s"(rs), [so] "s"(so)                 \
+                   [b2] "v"(a2 | 0x80000000u), [b3] "v"(a3 | 0x80000000u), [vo] "v"(vo), [vo2] "v"(vo2), [rs] "s"(rs), [so] "s"(so),                \
+                   [ga] "v"(ga), [ga2] "v"(ga2), [sb] "s"(ba)                                                                                       \
                  : "v200", "v201", "v202", "v203", "memory")
 
-// SG = 1: the slot's byte offset rides in an SGPR soffset (the exempted form); SG = 0: it is added to the VGPR offset, soffset = 0
-template <int W, int SG>
+#define SEQ_FORM(NOPS)                                                                                                                               \
+    if constexpr (FORM == BUF4_SGPR) SEQ("buffer_store_dwordx4 v[200:203], %[vo], %[rs], %[so] offen", NOPS, "buffer_store_dwordx4 v[200:203], %[vo2], %[rs], %[so] offen"); \
+    else if constexpr (FORM == BUF4_IMM) SEQ("buffer_store_dwordx4 v[200:203], %[vo], %[rs], 0 offen", NOPS, "buffer_store_dwordx4 v[200:203], %[vo2], %[rs], 0 offen"); \
+    else if constexpr (FORM == GLB4_VADDR) SEQ("global_store_dwordx4 %[ga], v[200:203], off", NOPS, "global_store_dwordx4 %[ga2], v[200:203], off"); \
+    else if constexpr (FORM == GLB4_SADDR) SEQ("global_store_dwordx4 %[vo], v[200:203], %[sb]", NOPS, "global_store_dwordx4 %[vo2], v[200:203], %[sb]"); \
+    else if constexpr (FORM == BUF2_SGPR) SEQ("buffer_store_dwordx2 v[200:201], %[vo], %[rs], %[so] offen", NOPS, "buffer_store_dwordx2 v[200:201], %[vo2], %[rs], %[so] offen"); \
+    else if constexpr (FORM == GLB2_SADDR) SEQ("global_store_dwordx2 %[vo], v[200:201], %[sb]", NOPS, "global_store_dwordx2 %[vo2], v[200:201], %[sb]"); \
+    else SEQ("buffer_store_dwordx3 v[200:202], %[vo], %[rs], %[so] offen", NOPS, "buffer_store_dwordx3 v[200:202], %[vo2], %[rs], %[so] offen")
+
+template <int W, int FORM>
 __global__ __launch_bounds__(256) void store_kernel(unsigned* buf, unsigned half_bytes, int iters, unsigned slots_per_iter)
 {
     const unsigned lane = threadIdx.x & 63;
@@ -67,25 +91,28 @@ __global__ __launch_bounds__(256) void store_kernel(unsigned* buf, unsigned half
     const unsigned long long ba = reinterpret_cast<unsigned long long>(buf);
     const u32x4 rs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ba), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((ba >> 32) & 0xffffu)), 0x7fffffffu,
                       0x00020000u};
+    constexpr bool SGOFF = FORM == BUF4_SGPR || FORM == BUF2_SGPR || FORM == BUF3_SGPR;     // the slot's byte offset rides in the SGPR soffset
     for (int it = 0; it < iters; ++it) {
         const unsigned slot = (unsigned)it * slots_per_iter + wave;
         const unsigned a0 = pat_a(slot, lane, 0), a1 = pat_a(slot, lane, 1), a2 = pat_a(slot, lane, 2), a3 = pat_a(slot, lane, 3);
-        const unsigned so = SG ? slot * 1024u : 0u;
-        const unsigned vo = lane * 16u + (SG ? 0u : slot * 1024u), vo2 = vo + half_bytes;
-        if (W == 0) { if (SG) STORE_SEQ(NOPS_0, "%[so]"); else STORE_SEQ(NOPS_0, "0"); }
-        if (W == 1) { if (SG) STORE_SEQ(NOPS_1, "%[so]"); else STORE_SEQ(NOPS_1, "0"); }
-        if (W == 2) { if (SG) STORE_SEQ(NOPS_2, "%[so]"); else STORE_SEQ(NOPS_2, "0"); }
-        if (W == 3) { if (SG) STORE_SEQ(NOPS_3, "%[so]"); else STORE_SEQ(NOPS_3, "0"); }
-        if (W == 5) { if (SG) STORE_SEQ(NOPS_5, "%[so]"); else STORE_SEQ(NOPS_5, "0"); }
-        if (W == 9) { if (SG) STORE_SEQ(NOPS_9, "%[so]"); else STORE_SEQ(NOPS_9, "0"); }
+        const unsigned so = SGOFF ? slot * 1024u : 0u;
+        const unsigned vo = lane * 16u + (SGOFF ? 0u : slot * 1024u), vo2 = vo + half_bytes;
+        const unsigned long long ga = ba + (unsigned long long)slot * 1024u + lane * 16u, ga2 = ga + half_bytes;
+        if constexpr (W == 0) { SEQ_FORM(NOPS_0); }
+        if constexpr (W == 1) { SEQ_FORM(NOPS_1); }
+        if constexpr (W == 2) { SEQ_FORM(NOPS_2); }
+        if constexpr (W == 3) { SEQ_FORM(NOPS_3); }
+        if constexpr (W == 5) { SEQ_FORM(NOPS_5); }
+        if constexpr (W == 9) { SEQ_FORM(NOPS_9); }
     }
 }
 
-__global__ void check_kernel(const unsigned* buf, size_t words, Result* res)
+__global__ void check_kernel(const unsigned* buf, size_t words, Result* res, int nd)
 {
     unsigned long long nb = 0, no = 0, nc = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
         const unsigned slot = (unsigned)(i >> 8), lane = (unsigned)(i >> 2) & 63u, d = (unsigned)i & 3u;
+        if ((int)d >= nd) continue;                 // (the x2 / x3 forms leave the rest of a lane's 16 bytes untouched)
         const unsigned a = pat_a(slot, lane, d), w = buf[i];
         ++nc;
         if (w == a) continue;
@@ -97,7 +124,7 @@ __global__ void check_kernel(const unsigned* buf, size_t words, Result* res)
     atomicAdd(&res->checked, nc);
 }
 
-template <int W, int SG>
+template <int W, int FORM>
 static void run(unsigned* buf, size_t half_bytes, Result* dres, int iters, int grid, int threads)
 {
     const unsigned slots_per_iter = (unsigned)grid * threads / 64;
@@ -108,18 +135,18 @@ static void run(unsigned* buf, size_t half_bytes, Result* dres, int iters, int g
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((store_kernel<W, SG>), dim3(grid), dim3(threads), 0, 0, buf, (unsigned)half_bytes, iters, slots_per_iter);
+    hipLaunchKernelGGL((store_kernel<W, FORM>), dim3(grid), dim3(threads), 0, 0, buf, (unsigned)half_bytes, iters, slots_per_iter);
     CK(hipGetLastError());
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    hipLaunchKernelGGL(check_kernel, dim3(2048), dim3(256), 0, 0, buf, used / 4, dres);
+    hipLaunchKernelGGL(check_kernel, dim3(2048), dim3(256), 0, 0, buf, used / 4, dres, form_dwords(FORM));
     CK(hipDeviceSynchronize());
     Result r;
     CK(hipMemcpy(&r, dres, sizeof(r), hipMemcpyDeviceToHost));
-    printf("soffset %-4s  %d wait state(s) before the overwrite  %4d x %3d threads: %12llu words stored, %10llu hold the NEW register contents, %llu other; %.2f TB/s of stores",
-           SG ? "SGPR" : "0", W, grid, threads, r.checked, r.b_words, r.other_words, 2.0 * used / (ms * 1e-3) / 1e12);
+    printf("%s %d wait state(s) before the overwrite  %4d x %3d threads: %12llu words stored, %10llu hold the NEW register contents, %llu other; %.2f TB/s",
+           form_name(FORM), W, grid, threads, r.checked, r.b_words, r.other_words, 2.0 * used * form_dwords(FORM) / 4 / (ms * 1e-3) / 1e12);
     if (r.b_words) {
         printf("; lanes:");
         for (int l = 0; l < 64; ++l)
@@ -144,23 +171,14 @@ int main(int argc, char** argv)
     for (int rep = 0; rep < 2; ++rep) {
         const int it8 = iters, it1 = iters * 4;
         // 8 waves per CU (two 256-thread blocks): the store path saturated
-        run<0, 1>(buf, half_bytes, dres, it8, cus * 2, 256);
-        run<1, 1>(buf, half_bytes, dres, it8, cus * 2, 256);
-        run<2, 1>(buf, half_bytes, dres, it8, cus * 2, 256);
-        run<3, 1>(buf, half_bytes, dres, it8, cus * 2, 256);
-        run<5, 1>(buf, half_bytes, dres, it8, cus * 2, 256);
-        run<9, 1>(buf, half_bytes, dres, it8, cus * 2, 256);
-        run<0, 0>(buf, half_bytes, dres, it8, cus * 2, 256);
-        run<1, 0>(buf, half_bytes, dres, it8, cus * 2, 256);
-        run<2, 0>(buf, half_bytes, dres, it8, cus * 2, 256);
-        run<3, 0>(buf, half_bytes, dres, it8, cus * 2, 256);
+#define ROW(F) run<0, F>(buf, half_bytes, dres, it8, cus * 2, 256); run<1, F>(buf, half_bytes, dres, it8, cus * 2, 256); \
+               run<2, F>(buf, half_bytes, dres, it8, cus * 2, 256); run<3, F>(buf, half_bytes, dres, it8, cus * 2, 256);
+        ROW(BUF4_SGPR) run<5, BUF4_SGPR>(buf, half_bytes, dres, it8, cus * 2, 256); run<9, BUF4_SGPR>(buf, half_bytes, dres, it8, cus * 2, 256);
+        ROW(BUF4_IMM) ROW(GLB4_VADDR) ROW(GLB4_SADDR) ROW(BUF3_SGPR) ROW(BUF2_SGPR) ROW(GLB2_SADDR)
         // one wave per CU: an idle store path
-        run<0, 1>(buf, half_bytes, dres, it1, cus, 64);
-        run<0, 0>(buf, half_bytes, dres, it1, cus, 64);
-        // 16 waves per CU
-        run<0, 1>(buf, half_bytes, dres, it8 / 2, cus * 4, 256);
-        run<1, 1>(buf, half_bytes, dres, it8 / 2, cus * 4, 256);
-        run<2, 1>(buf, half_bytes, dres, it8 / 2, cus * 4, 256);
+        run<0, BUF4_SGPR>(buf, half_bytes, dres, it1, cus, 64);
+        run<0, BUF4_IMM>(buf, half_bytes, dres, it1, cus, 64);
+        run<0, GLB4_SADDR>(buf, half_bytes, dres, it1, cus, 64);
     }
     return 0;
 }
