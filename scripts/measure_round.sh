@@ -1,14 +1,17 @@
 #!/bin/bash
-# Round 4, final measurement session: store-WAR probe (all store forms), full GPU tests, smoke, bench (+ layer table), rocprofv3 kernel stats, PMC traffic
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r04; mkdir -p $OUT; cd $R
+# One measurement session on a GPU box (what the committed profiles/rNN_* set is made from): the two hardware probes, the full GPU test suite, smoke,
+# the driver's bench command (+ layer table), the rocprofv3 kernel trace + stats of it, and the PMC traffic passes (FETCH_SIZE / WRITE_SIZE, separate).
+# usage: /usr/local/graft/bin/gpurun --timeout 5400 -- 'bash scripts/measure_round.sh r05'   -> gpurun_out/r05/*; copy what is to be judged into profiles/
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r04}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
-echo "== 1. store WAR probe, every store form"; timeout 600 scripts/bin/vmem_store_war_probe 300 > $OUT/store_war_probe_forms.txt 2>&1; echo "exit $?"; cut -c1-250 $OUT/store_war_probe_forms.txt | head -45
+echo "== 1. hardware probes: store data write-after-read per store form, LDS-DMA completion order"; timeout 600 scripts/bin/vmem_store_war_probe 300 > $OUT/store_war_probe_forms.txt 2>&1; echo "exit $?"; cut -c1-250 $OUT/store_war_probe_forms.txt | head -45
+timeout 300 scripts/bin/ldsdma_order_probe 1500 > $OUT/ldsdma_order_probe.txt 2>&1; echo "exit $?"; cut -c1-250 $OUT/ldsdma_order_probe.txt | head -10
 echo "== 2. pytest -m gpu"; timeout 2700 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu_final.log 2>&1; echo "pytest exit $?"; tail -4 $OUT/pytest_gpu_final.log
 echo "== 3. smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -2 $OUT/smoke.log
 echo "== 4. bench (driver command) + layer table"; timeout 1500 python bench.py --steps 20 --warmup 4 --layer-table > $OUT/bench_final.json 2> $OUT/bench_final_layers.txt; echo "bench exit $?"
-python - <<'PY'
+python - $OUT/bench_final.json <<'PY'
 import json
-d=json.load(open('gpurun_out/r04/bench_final.json'))
+import sys; d=json.load(open(sys.argv[1]))
 r=d['roofline']
 print(d['value'], d['ms_per_step'], 'frac', r['frac'], 'issued', r.get('frac_issued'), 'trunk', r.get('frac_trunk_only'), 'conv ms', r.get('ms_per_step'))
 print('mfma', r['mfma_bound_launches']['frac'], r['mfma_bound_launches']['ms_per_step'], 'hbm', r['hbm_bound_launches']['frac'], r['hbm_bound_launches']['ms_per_step'])
