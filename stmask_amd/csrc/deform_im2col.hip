@@ -836,6 +836,146 @@ __global__ __launch_bounds__(256) void dcn_sample_planar_kernel(const SampleArgs
 }
 
 
+// ---- round 4: the same sampler written straight-line for the fp16 two-plane columns the inference graph uses.  The kernel above carries its
+// plane format, its store policy and the liveness of a pixel group as RUN-TIME branches inside the unrolled tap loop (~10 branches and exec-mask
+// rebuilds per tap) and keeps one tap of loads in flight; this one fixes them at compile time (FMT = 1, nontemporal stores, dead groups masked by
+// the exec mask of the stores only), takes the range check out of the loop (one running maximum, tested once), broadcasts a tap's coefficients
+// with a DPP row share where a pixel's lane group is one row of 16 lanes (C = 128: no LDS crossbar instruction), and -- PIPE = 1 -- issues tap
+// k + 1's eight corner loads before tap k is blended (96-110 VGPRs: 4 waves per SIMD instead of 8, two taps of loads in flight per wave).
+// Same bilerp(), same split: columns bit-identical to the kernel above.  DS_ABL (make variant ... VFLAGS=-DDS_ABL=n, RESULTS ARE WRONG):
+// 1 no column stores, 2 corners not loaded (constants), 4 every corner reads the tap's first corner (L1-resident gathers).
+#ifndef DS_ABL
+#define DS_ABL 0
+#endif
+template <int LPP, int K, bool MASK, int PIPE>
+__global__ __launch_bounds__(256) void dcn_sample_planar_f16x2_kernel(const SampleArgs a)
+{
+    constexpr int PPW = 64 / LPP;
+    static_assert(K <= LPP, "one sub-lane per tap");
+    const int lane = threadIdx.x & 63, sl = lane % LPP;
+    int bid = blockIdx.x;
+    if (a.xcd) {
+        bid = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= a.per_xcd) return;
+    }
+    const int m = (bid * 4 + (threadIdx.x >> 6)) * PPW + lane / LPP;
+    if (bid * 4 * PPW >= a.M) return;
+    const bool live = m < a.M;
+    const int mm = live ? m : a.M - 1;
+    const int b = mm / (a.Ho * a.Wo);
+    const int rem = mm - b * (a.Ho * a.Wo);
+    const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    const float* xb = a.x + (size_t)b * a.H * a.W * a.x_ld + sl * 8;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    f32x4v pf = {0.f, 0.f, 0.f, 0.f};
+    if (a.prefetch) {
+        const int cy = min(max(ho * a.sh - a.ph + a.dh, 0), a.H - 1), cx = min(max(wo * a.sw - a.pw + a.dw, 0), a.W - 1);
+        pf = *reinterpret_cast<const f32x4v*>(xb + (size_t)(cy * a.W + cx) * a.x_ld);
+    }
+    float cw1 = 0.f, cw2 = 0.f, cw3 = 0.f, cw4 = 0.f;
+    int ca1 = 0, ca2 = 0, ca3 = 0, ca4 = 0;
+    if (sl < K) {
+        const int i = sl / a.kw, j = sl - a.kw * i;
+        const float* omp = a.om + (size_t)mm * a.om_ld;
+        const float dy = omp[2 * sl], dx = omp[2 * sl + 1];
+        const float mk = MASK ? sigmoidf_dev(omp[2 * K + sl]) : 1.0f;
+        const float fy = (float)(ho * a.sh - a.ph + i * a.dh) + dy;
+        const float fx = (float)(wo * a.sw - a.pw + j * a.dw) + dx;
+        if (fy > -1.0f && fx > -1.0f && fy < (float)a.H && fx < (float)a.W) {
+            const float fl_y = floorf(fy), fl_x = floorf(fx);
+            const int h_low = (int)fl_y, w_low = (int)fl_x, h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = fy - fl_y, lw = fx - fl_x, hh = 1.0f - lh, hw = 1.0f - lw;
+            const bool t = h_low >= 0, l = w_low >= 0, bt = h_high <= a.H - 1, r = w_high <= a.W - 1;
+            const int hl = max(h_low, 0), wl = max(w_low, 0), hh_i = min(h_high, a.H - 1), wh_i = min(w_high, a.W - 1);
+            cw1 = (t && l) ? hh * hw * mk : 0.f;
+            cw2 = (t && r) ? hh * lw * mk : 0.f;
+            cw3 = (bt && l) ? lh * hw * mk : 0.f;
+            cw4 = (bt && r) ? lh * lw * mk : 0.f;
+            ca1 = (hl * a.W + wl) * a.x_ld;
+            ca2 = (hl * a.W + wh_i) * a.x_ld;
+            ca3 = (hh_i * a.W + wl) * a.x_ld;
+            ca4 = (hh_i * a.W + wh_i) * a.x_ld;
+        }
+    }
+    // a tap's coefficient from the sub-lane that prepared it: a DPP row share where the lane group IS a row of 16 lanes, else the crossbar
+    auto bcast_i = [&](int v, int k) -> int {
+        if constexpr (LPP == 16) {
+            switch (k) {      // (the DPP control is an immediate)
+#define STM_RS(n_) case n_: return __builtin_amdgcn_update_dpp(0, v, 0x150 + n_, 0xf, 0xf, false);
+                STM_RS(0) STM_RS(1) STM_RS(2) STM_RS(3) STM_RS(4) STM_RS(5) STM_RS(6) STM_RS(7) STM_RS(8) STM_RS(9) STM_RS(10) STM_RS(11) STM_RS(12)
+                STM_RS(13) STM_RS(14) STM_RS(15)
+#undef STM_RS
+                default: return v;
+            }
+        } else {
+            return __shfl(v, k, LPP);
+        }
+    };
+    auto bcast_f = [&](float v, int k) { return __builtin_bit_cast(float, bcast_i(__builtin_bit_cast(int, v), k)); };
+    struct Tap { f32x4v q[4][2]; };
+    auto load_tap = [&](int k, Tap& t) {
+        const int a1 = bcast_i(ca1, k), a2 = bcast_i(ca2, k), a3 = bcast_i(ca3, k), a4 = bcast_i(ca4, k);
+        const int ad[4] = {a1, (DS_ABL & 4) ? a1 : a2, (DS_ABL & 4) ? a1 : a3, (DS_ABL & 4) ? a1 : a4};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (DS_ABL & 2) t.q[c][h] = f32x4v{1.f + c, 2.f, 3.f + h, 4.f};
+                else t.q[c][h] = *reinterpret_cast<const f32x4v*>(xb + ad[c] + 4 * h);
+            }
+    };
+    unsigned mag = 0;
+    const bool nt = a.nt != 0;
+    auto blend_store = [&](int k, const Tap& t) {
+        const float w1 = bcast_f(cw1, k), w2 = bcast_f(cw2, k), w3 = bcast_f(cw3, k), w4 = bcast_f(cw4, k);
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * h + e] = bilerp(w1, w2, w3, w4, t.q[0][h][e], t.q[1][h][e], t.q[2][h][e], t.q[3][h][e]);
+        unsigned q0[4], q1[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mag = max(mag, __builtin_bit_cast(unsigned, v[e]) & 0x7fffffffu);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2_planes_f16(v[2 * e], v[2 * e + 1], q0[e], q1[e]);
+        const u32x4v p0 = {q0[0], q0[1], q0[2], q0[3]}, p1 = {q1[0], q1[1], q1[2], q1[3]};
+        const int kc = k * a.C + sl * 8;
+        uint8_t* o = a.out + (((size_t)(kc >> 5) * a.out_np + a.out_pix0 + mm) * 32 + (kc & 31)) * 2;
+        if (DS_ABL & 1) { asm volatile("" ::"v"(p0), "v"(p1)); return; }
+        if (live) {
+            if (nt) {
+                __builtin_nontemporal_store(p0, reinterpret_cast<u32x4v*>(o));
+                __builtin_nontemporal_store(p1, reinterpret_cast<u32x4v*>(o + a.out_pstride));
+            } else {
+                *reinterpret_cast<u32x4v*>(o) = p0;
+                *reinterpret_cast<u32x4v*>(o + a.out_pstride) = p1;
+            }
+        }
+    };
+    if constexpr (PIPE) {
+        Tap t0, t1;
+        load_tap(0, t0);
+#pragma unroll
+        for (int k = 0; k < K; k += 2) {
+            if (k + 1 < K) load_tap(k + 1, t1);
+            blend_store(k, t0);
+            if (k + 2 < K) load_tap(k + 2, t0);
+            if (k + 1 < K) blend_store(k + 1, t1);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            Tap t;
+            load_tap(k, t);
+            blend_store(k, t);
+        }
+    }
+    if (mag > 0x477fe000u && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;   // > 65504, inf, nan: no fp16 plane representation
+    asm volatile("" ::"v"(pf));
+}
+
+
 // ---- LDS-staged form of the planar sampler (the form BASELINE.json's north star names: "deformable im2col with LDS-staged input
 // tiles and coalesced HBM offset reads").  The register-gather kernel above fetches every bilinear corner through the vector-memory
 // path: 4 corners x 9 taps x C x 4 B = 18 KB per output pixel at C = 128 for 4.6 KB of columns, at the 64 B/clk a CU's L1 moves --
@@ -1113,6 +1253,21 @@ extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const floa
         }
     }
     const dim3 grid(a.xcd ? 8 * a.per_xcd : nblk);
+    // STM_DCN_VARIANT: 0 = the run-time-format kernel (rounds 1-3: 64 registers, 8 waves per SIMD); the straight-line fp16x2 kernel: 1 = registers as
+    // the compiler likes (116: 4 waves per SIMD, it hoists the next taps' loads by itself), 2 = explicit one-tap look-ahead (143: 3 waves).  Default
+    // (-1): form 2 on the stride-2 layers of 256 / 512 channels, form 0 elsewhere -- profiles/r04_dcn_sampler_forms.txt: 123 vs 127 us and 65 vs 77 us
+    // there, 20-50 % slower on the stride-1 layers; forms capped to 6 / 8 waves per SIMD spilled (148 / 220 B per lane) and ran at half the rate.
+    int variant = STM_ENV_INT("STM_DCN_VARIANT", -1);
+    if (variant < 0) variant = (g->sh == 2 && g->C >= 256) ? 2 : 0;
+    if (variant && fmt == 1 && has_mask && K == 9 && (g->C == 128 || g->C == 256 || g->C == 512)) {
+#define STM_DSV(LPP_) \
+        if (variant == 2) hipLaunchKernelGGL((dcn_sample_planar_f16x2_kernel<LPP_, 9, true, 1>), grid, dim3(256), 0, stm_hs(stream), a); \
+        else hipLaunchKernelGGL((dcn_sample_planar_f16x2_kernel<LPP_, 9, true, 0>), grid, dim3(256), 0, stm_hs(stream), a);
+        if (g->C == 128) { STM_DSV(16) } else if (g->C == 256) { STM_DSV(32) } else { STM_DSV(64) }
+#undef STM_DSV
+        STM_CHECK_LAUNCH("dcn_sample_planar_f16x2_kernel");
+        return STM_OK;
+    }
     if (!has_mask && K == 15) hipLaunchKernelGGL((dcn_sample_planar_kernel<32, 15, false>), grid, dim3(256), 0, stm_hs(stream), a);
     else if (!has_mask) hipLaunchKernelGGL((dcn_sample_planar_kernel<32, 9, false>), grid, dim3(256), 0, stm_hs(stream), a);
     else if (g->C == 128) hipLaunchKernelGGL((dcn_sample_planar_kernel<16>), grid, dim3(256), 0, stm_hs(stream), a);
