@@ -110,9 +110,32 @@ class workspace_scope:
         return False
 
 
+_ws_branch = ""    # suffix of every workspace tag while a side branch of the trunk runs (workspace_branch)
+
+
+class workspace_branch:
+    """`with workspace_branch("proto"):` -- scratch requested inside gets its own buffers (tag + suffix).  PlanarGraph runs independent parts of the
+    trunk on a second stream while a HIP graph is captured; inside a workspace_scope scratch is keyed by tag, not by stream, so two branches that
+    both park split-K partial sums would otherwise share one buffer."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _ws_branch
+        self.saved, _ws_branch = _ws_branch, "/" + self.name
+        return self
+
+    def __exit__(self, *exc):
+        global _ws_branch
+        _ws_branch = self.saved
+        return False
+
+
 def _workspace(nbytes, device, tag="ws"):
     """Grow-only scratch buffer per (device, stream, tag) -- or per (device, tag) of the active workspace_scope
     (cols buffers are GBs at large batch: never allocated per call)."""
+    tag = tag + _ws_branch
     if _ws_scope is not None:
         key = (device.index, tag)
         buf = _ws_scope.get(key)

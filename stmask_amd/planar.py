@@ -45,6 +45,12 @@ STEM_FUSED = os.environ.get("STM_STEM_FUSED", "1") != "0"    # conv1 + ReLU + ma
 CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 layers on the kx-reuse kernel (csrc/conv_kxr.hip)
 TN_BORDER = os.environ.get("STM_TN_BORDER", "1") != "0"     # TemporalNet's 3x3 layers as nine window launches without the zero taps of the RoI borders
 CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"
+# Independent parts of the trunk on a second stream while a HIP graph is being captured (PlanarGraph.run): 0 off (default), 1 proto-net beside the
+# shared head, 2 also the P5 -> P6 -> P7 convolutions beside the finer FPN levels; only batches of at most BRANCH_MAX_IMAGES frames.  Bit-equal, and
+# SLOWER at every batch size it was meant for (profiles/r04_trunk_branches_ab.txt: 1 clip 478 -> 426-442 frames/s, 2 clips 728 -> 640-694, 4 clips
+# 1034 -> 960-990, 8 clips 1284 -> 1206-1223): a fork / join pair in a replayed HIP graph costs more than the small grids it lets overlap.
+TRUNK_BRANCHES = int(os.environ.get("STM_TRUNK_BRANCHES", "0"))
+BRANCH_MAX_IMAGES = int(os.environ.get("STM_BRANCH_MAX_IMAGES", "16"))
 # bit 0 = the projection form (a stage's first block); bit 1 = the kernel also computes the NEXT block's conv1 (z); bit 2 (diagnostics) = z is
 # computed but not used.  Round 3 shipped 1 because the z-producing instantiation (conv_chain_kernel<true, .>) gave wrong y / z beside a
 # second process on the GPU.  Round 4 found why (csrc/conv_chain.hip, store16: a 16-byte buffer store with an SGPR soffset reads its data
@@ -440,7 +446,9 @@ class PlanarGraph:
         feat = torch.empty(NP, nf // 32, ntot, 32, device=dev, dtype=pdt)   # P3..P7, all levels, planar
         feat32 = torch.empty(ntot, nf, device=dev, dtype=torch.float32) if not self.head_planar else None
         fpn_outs = [None] * len(sizes)
-        for i, conv in enumerate(self.fpn_pred):
+
+        def pred_level(i):
+            conv = self.fpn_pred[i]
             j = n - 1 - i
             h, w = sizes[j]
             xp = latp[j] if latp[j] is not None else _split(_nhwc(lat[j]), self.fmt)
@@ -453,51 +461,83 @@ class PlanarGraph:
                 fpn_outs[j] = y32.view(B, h, w, nf).permute(0, 3, 1, 2)
             else:
                 conv(xp, ("img", B, h, w), out="planes", out_planes=feat, out_off=starts[j])
-        for i, conv in enumerate(self.fpn_down):
-            j = n + i
-            h, w = sizes[j - 1]
-            if feat32 is not None:
-                conv(feat, ("img", B, h, w), out="both", x_off=starts[j - 1], out_planes=feat, out_f32=feat32, out_off=starts[j])
-                fpn_outs[j] = feat32[starts[j]:starts[j + 1]].view(B, *sizes[j], nf).permute(0, 3, 1, 2)
-            else:
-                conv(feat, ("img", B, h, w), out="planes", x_off=starts[j - 1], out_planes=feat, out_off=starts[j])
+
+        def down_levels():
+            for i, conv in enumerate(self.fpn_down):
+                j = n + i
+                h, w = sizes[j - 1]
+                if feat32 is not None:
+                    conv(feat, ("img", B, h, w), out="both", x_off=starts[j - 1], out_planes=feat, out_f32=feat32, out_off=starts[j])
+                    fpn_outs[j] = feat32[starts[j]:starts[j + 1]].view(B, *sizes[j], nf).permute(0, 3, 1, 2)
+                else:
+                    conv(feat, ("img", B, h, w), out="planes", x_off=starts[j - 1], out_planes=feat, out_off=starts[j])
+
+        # Second-stream branches (TRUNK_BRANCHES), only while a HIP graph is captured: the graph then holds parallel paths, and on small batches --
+        # where a launch fills a fraction of the 256 CUs -- the GPU runs them side by side.  Same kernels on the same data: bit-equal to the plain order.
+        side = self._side_stream(dev, B)
+        if side is not None and TRUNK_BRANCHES >= 2 and len(self.fpn_down) > 0:
+            # coarsest level first on the main stream, then P6 / P7 (which only need it) on the side stream beside the finer levels
+            pred_level(0)
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side), ops.workspace_branch("fpn_down"):
+                down_levels()
+            for i in range(1, len(self.fpn_pred)):
+                pred_level(i)
+            main.wait_stream(side)
+        else:
+            for i in range(len(self.fpn_pred)):
+                pred_level(i)
+            down_levels()
         if feat32 is None and self.cor_idx is not None and fpn_outs[self.cor_idx] is None:
             # fp32 NCHW view of the correlation level, rebuilt from its planes (exact)
             j = self.cor_idx
             fpn_outs[j] = ops.planes_to_f32(feat[:, :, starts[j]:starts[j + 1]]).view(B, *sizes[j], nf).permute(0, 3, 1, 2)
 
         toc("fpn_pred_down")
+
         # ---- proto-net on P3 (mask_proto_src) ------------------------------------------------------------------
-        src = net.proto_src
-        h, w = sizes[src]
-        xp, x_off, cur = feat, starts[src], None
-        n_layers = len(self.proto)
-        for li, layer in enumerate(self.proto):
-            last = li == n_layers - 1
-            if isinstance(layer, PlanarConv):
-                nxt_is_interp = (not last) and not isinstance(self.proto[li + 1], PlanarConv)
-                if cur is not None:            # fp32 NHWC tensor pending a split
-                    xp, x_off = _split(cur, self.fmt), 0
-                    cur = None
-                if last or nxt_is_interp:
-                    y = layer(xp, ("img", B, h, w), out="f32", x_off=x_off)
-                    cur = y.view(B, h, w, layer.O)
-                else:
-                    xp, x_off = layer(xp, ("img", B, h, w), out="planes", x_off=x_off), 0
-            else:                              # bilinear upsample
-                kw = layer.kwargs
-                sf = kw.get("scale_factor")
-                nxt_conv = (not last) and isinstance(self.proto[li + 1], PlanarConv)
-                if (nxt_conv and not layer.args and kw.get("mode") == "bilinear" and not kw.get("align_corners", False)
-                        and isinstance(sf, (int, float)) and float(sf).is_integer() and set(kw) <= {"scale_factor", "mode", "align_corners"}):
-                    # ... straight into the next convolution's planes (no fp32 upsampled tensor)
-                    h, w = h * int(sf), w * int(sf)
-                    xp, x_off, cur = ops.resize_bilinear_planes(cur, (h, w), self.fmt), 0, None
-                else:
-                    t = layer(cur.permute(0, 3, 1, 2))
-                    h, w = t.shape[2:]
-                    cur = _nhwc(t)
-        proto = cur                            # [B, 2h, 2w, 32], ReLU applied by the last layer (STMask.py:227)
+        def proto_net():
+            src = net.proto_src
+            h, w = sizes[src]
+            xp, x_off, cur = feat, starts[src], None
+            n_layers = len(self.proto)
+            for li, layer in enumerate(self.proto):
+                last = li == n_layers - 1
+                if isinstance(layer, PlanarConv):
+                    nxt_is_interp = (not last) and not isinstance(self.proto[li + 1], PlanarConv)
+                    if cur is not None:            # fp32 NHWC tensor pending a split
+                        xp, x_off = _split(cur, self.fmt), 0
+                        cur = None
+                    if last or nxt_is_interp:
+                        y = layer(xp, ("img", B, h, w), out="f32", x_off=x_off)
+                        cur = y.view(B, h, w, layer.O)
+                    else:
+                        xp, x_off = layer(xp, ("img", B, h, w), out="planes", x_off=x_off), 0
+                else:                              # bilinear upsample
+                    kw = layer.kwargs
+                    sf = kw.get("scale_factor")
+                    nxt_conv = (not last) and isinstance(self.proto[li + 1], PlanarConv)
+                    if (nxt_conv and not layer.args and kw.get("mode") == "bilinear" and not kw.get("align_corners", False)
+                            and isinstance(sf, (int, float)) and float(sf).is_integer() and set(kw) <= {"scale_factor", "mode", "align_corners"}):
+                        # ... straight into the next convolution's planes (no fp32 upsampled tensor)
+                        h, w = h * int(sf), w * int(sf)
+                        xp, x_off, cur = ops.resize_bilinear_planes(cur, (h, w), self.fmt), 0, None
+                    else:
+                        t = layer(cur.permute(0, 3, 1, 2))
+                        h, w = t.shape[2:]
+                        cur = _nhwc(t)
+            return cur                         # [B, 2h, 2w, 32], ReLU applied by the last layer (STMask.py:227)
+
+        proto_side = side is not None and TRUNK_BRANCHES >= 1 and self.head_planar
+        if proto_side:
+            # proto-net and the shared head both start from `feat` and meet in the detection stage: proto-net on the side stream, joined at the end
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side), ops.workspace_branch("proto"):
+                proto = proto_net()
+        else:
+            proto = proto_net()
         toc("proto_net")
 
         keys = ("mask_coeff", "priors", "loc", "T2S_feat", "centerness", "conf", "track")
@@ -609,8 +649,21 @@ class PlanarGraph:
             pred["centerness"] = torch.tanh(torch.cat(cen, 1))
         pred["T2S_feat"] = t2s
         pred["proto"] = proto
+        if proto_side:
+            torch.cuda.current_stream().wait_stream(side)
         toc("head_assemble")
         return fpn_outs, pred
+
+    def _side_stream(self, dev, n_images):
+        """The second stream of run()'s branches, or None: branches exist only inside a HIP-graph capture (eager passes keep the plain order: tensors
+        crossing streams would need allocator bookkeeping there, and the eager path is not the one that is timed) and only for small batches."""
+        if TRUNK_BRANCHES <= 0 or n_images > BRANCH_MAX_IMAGES or self.timer is not None and self.timer.on:
+            return None
+        if not torch.cuda.is_current_stream_capturing():
+            return None
+        if getattr(self, "_side", None) is None or self._side.device != torch.device(dev):
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
 
 # (row class, column class, first / end kernel row, first / end kernel column) of the nine border classes of a 3x3 / pad-1 convolution

@@ -402,3 +402,29 @@ def test_pipeline_is_bit_reproducible_run_to_run():
     assert len(keeps[0]) == 8
     for t, (a, b) in enumerate(zip(*keeps)):
         assert torch.equal(a, b), f"step {t}: max abs diff {(a - b).abs().max().item()}"
+
+
+def test_trunk_branches_in_the_graph_are_bit_equal_to_the_plain_order(monkeypatch):
+    """PlanarGraph.run puts proto-net beside the shared head and P6 / P7 beside the finer FPN levels on a second stream while the trunk's HIP graph
+    is captured (small batches only: planar.TRUNK_BRANCHES).  Same kernels on the same data, separate split-K scratch per branch: the detection
+    blocks of every step must equal those of the plain order bit for bit."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from stmask_amd import planar
+    args = bench.parse_args(["--clips", "2", "--steps", "6", "--warmup", "3"])
+    dev = torch.device("cuda:0")
+    net = bench.build_net(args, dev)
+    keeps = []
+    for branches in (0, 2):
+        monkeypatch.setattr(planar, "TRUNK_BRANCHES", branches)
+        run = bench.Runner(args, dev, 0, 1, 2, net=net)
+        run.keep = []
+        run.timed(args.warmup, args.steps)
+        torch.cuda.synchronize()
+        assert run.pipe.graph_active, "the trunk was not replayed from a graph: the branches were not exercised"
+        keeps.append([k.clone() for k in run.keep])
+        del run
+    assert len(keeps[0]) == 9
+    for t, (a, b) in enumerate(zip(*keeps)):
+        assert torch.equal(a, b), f"step {t}: max abs diff {(a - b).abs().max().item()}"
