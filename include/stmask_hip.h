@@ -32,6 +32,7 @@
  *     stm_stem_fused_f32; the bottleneck chain stm_chain_tail_weight_bytes(_proj) / stm_chain_pack_tail(_proj)_f32 /
  *     stm_bottleneck_chain(_proj)_f32; stm_detect_cc_logits_f32; stm_corr_patch_nhwc_f32 / stm_roi_align_planes_nhwc_f32).
  *     stm_struct_bytes(which) lets a client check its layout of EVERY struct of this header against the library.
+ *     Added since without a version change (new entry points only): stm_conv2d_planar_windows_pool_f32, stm_temporal_pool_fc_f32.
  */
 #ifndef STMASK_HIP_H_
 #define STMASK_HIP_H_
@@ -338,6 +339,22 @@ typedef struct stm_conv_geom {
 typedef struct stm_conv_window { int kh, kw, ph, pw, Ho, Wo, y0, x0; } stm_conv_window;
 int stm_conv2d_planar_windows_f32(const void* x_planes, const void* const* packed_weights, const stm_conv_window* windows, int n_windows,
                                   const float* bias, float* out_f32, void* out_planes, const stm_conv_geom* g, int relu, stm_stream_t stream);
+
+/* The same window set with ReLU and an average pool over each whole output image folded into the epilogue -- TemporalNet's conv3 -> ReLU ->
+ * AvgPool2d((7, 7)) (track_to_segment_head.py:30-33) without the per-pixel tensor.  pool_fix [B][Cout] (unsigned 64-bit, 32.32 fixed point, 8-byte
+ * aligned) receives, ADDED to what it holds, the sum over the image's win_h x win_w pixels of relu(conv + bias): zero it before the first use;
+ * stm_temporal_pool_fc_f32 zeroes what it consumes.  The accumulation is integer (each workgroup converts its fp32 partial sum exactly), so the
+ * result does not depend on the order in which workgroups finish.  A partial sum of 2^32 or more (or NaN) raises the device's range flag.
+ * g as for stm_conv2d_planar_windows_f32, Cout a multiple of 128; the out_* fields are ignored. */
+int stm_conv2d_planar_windows_pool_f32(const void* x_planes, const void* const* packed_weights, const stm_conv_window* windows, int n_windows,
+                                       const float* bias, unsigned long long* pool_fix, const stm_conv_geom* g, stm_stream_t stream);
+
+/* TemporalNet's tail (track_to_segment_head.py:33-37): mean[b][c] = pool_fix[b][c] / 2^32 / npix, y[b][o] = bias[o] + sum_c mean[b][c] weight[o][c]
+ * for o < n_out -- weight [n_out][C] row-major is the reference's fc and fc_coeff stacked (4 + 32 rows), bias [n_out] or NULL.  Rows o < n_first
+ * go to out [n][n_first], the others to out2 [n][n_out - n_first] (out2 NULL: everything to out [n][n_out]).  pooled_out [n][C] (optional)
+ * receives the means.  clear != 0 zeroes the rows of pool_fix it has read.  One fixed summation order: run-to-run identical. */
+int stm_temporal_pool_fc_f32(unsigned long long* pool_fix, int n, int C, int npix, const float* weight, const float* bias, int n_out, int n_first,
+                             float* out, float* out2, float* pooled_out, int clear, stm_stream_t stream);
 
 /* Two-source 1x1 convolution on the planar kernel: y = W [x1 ; x2 (stride s2)] + bias (+ residual) (+ ReLU) -- the last 1x1 convolution of
  * a ResNet stage's first bottleneck and its projection shortcut (backbone.py:38-58: out = bn3(conv3(out)); out += downsample(x); relu)

@@ -117,6 +117,10 @@ struct PlanarArgs {
 // its own: half a KB more of kernel arguments on EVERY convolution launch cost the single-stream step 0.1 ms.)
 struct PlanarArgsCls : PlanarArgs {
     int n_cls, cls_tiles;
+    // pooled output (stm_conv2d_planar_windows_pool_f32): instead of writing its pixels the launch adds relu(conv + bias) of every output image's pixels
+    // into pool[image][channel] as unsigned 32.32 fixed point -- integer sums, so the order in which the classes' workgroups arrive does not matter
+    unsigned long long* pool;
+    int pool_ld;
     struct Cls { const uint8_t* wp; int kh, kw, ph, pw, Ho, Wo, M, slabs, win_off, tile0; float inv_hw, inv_w; } cls[9];
 };
 
@@ -827,6 +831,38 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const typename std:
     __syncthreads();                                   // all fragment reads of the last slab are done
     constexpr float LS = DT == 1 ? 1.0f / STM_F16_LOW_SCALE : 1.0f;   // fp16 planes: the corrections carry the low-plane scale
     park16<NJ>(acc16, accl16, smem, wave, lane, LS);
+    if constexpr (CLS && NJ == 2) {
+        if (a_in.pool) {
+            // AvgPool2d over the whole output image folded into the epilogue (TemporalNet: track_to_segment_head.py:30-33).  The wave owns 64 class
+            // pixels x 64 channels: lane = channel, the rows are walked once; the pixels of one image are consecutive rows of a class (hw of them), so
+            // the running sum is flushed whenever the image index advances, and at the end of the block (an image cut by a block or class boundary
+            // arrives in several pieces).  Each piece is an fp32 sum in row order, converted exactly to 32.32 fixed point and added with an integer
+            // atomic: the total does not depend on the order of arrival.
+            constexpr int EP_LD = 32 * NJ + 4;
+            const float* park = park_base<NJ>(smem, wave);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int hw = a.Ho * a.Wo;
+            const int mw = m0 + wm * 64;
+            const int rows = min(64, a.M - mw);
+            int b = mw / hw, r = mw - b * hw;
+            const int col = nt * BN + wn * 64 + lane;
+            const float bias = a.bias ? a.bias[col] : 0.0f;
+            float sum = 0.0f;
+            for (int row = 0; row < rows; ++row) {
+                sum += __builtin_fmaxf(__builtin_fmaf(park[row * EP_LD + lane], a.out_scale, bias), 0.0f);
+                if (++r == hw || row == rows - 1) {
+                    if (!(sum < 4.0e9f) && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;     // (also NaN)
+                    const unsigned hi = (unsigned)sum;
+                    const unsigned lo = (unsigned)((sum - (float)hi) * 4294967296.0f);
+                    __hip_atomic_fetch_add(a_in.pool + (size_t)b * a_in.pool_ld + col, ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    sum = 0.0f;
+                    if (r == hw) { r = 0; ++b; }
+                }
+            }
+            return;
+        }
+    }
     if (a.splitk > 1) {
         // raw fp32 partial sums of this K range; planar_splitk_finish_kernel adds the parts and runs the epilogue
         constexpr int EP_LD = 32 * NJ + 4, LPR = 4 * NJ;
@@ -1391,7 +1427,7 @@ extern "C" int stm_stem_rows_planes_f32(const float* x, void* planes, int B, int
 }
 
 namespace {
-struct WinSet { const void* const* packed; const stm_conv_window* win; int n; };
+struct WinSet { const void* const* packed; const stm_conv_window* win; int n; unsigned long long* pool; };
 struct DualSrc { const void* x2; int C2, H2, W2, s2; long long x2_np, x2_plane_stride; };
 int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
                        const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,
@@ -1441,8 +1477,31 @@ extern "C" int stm_conv2d_planar_windows_f32(const void* x_planes, const void* c
     stm_conv_geom g0 = *g;                       // window 0 stands in for the common checks and fields
     g0.kh = windows[0].kh; g0.kw = windows[0].kw; g0.ph = windows[0].ph; g0.pw = windows[0].pw;
     g0.Ho = windows[0].Ho; g0.Wo = windows[0].Wo; g0.win_y0 = windows[0].y0; g0.win_x0 = windows[0].x0;
-    WinSet ws{packed_weights, windows, n_windows};
+    WinSet ws{packed_weights, windows, n_windows, nullptr};
     return conv2d_planar_impl(x_planes, packed_weights[0], bias, nullptr, nullptr, out_f32, out_planes, &g0, relu, nullptr, 0, stream, nullptr, &ws);
+}
+
+// The same window set with ReLU and the average pool over each output image folded into the epilogue (TemporalNet's conv3 + ReLU + AvgPool2d((7, 7)):
+// track_to_segment_head.py:30-33): nothing is written per pixel; pool_fix[image][channel] (row length Cout, unsigned 64-bit, 32.32 fixed point)
+// receives the SUM over the image's win_h x win_w pixels of relu(conv + bias), added to what it holds -- the caller zeroes it (stm_temporal_pool_fc_f32
+// does, when it consumes it).  Integer accumulation: the result does not depend on the order in which the workgroups finish.  Sums must stay below
+// 2^32 (the per-device range flag is raised otherwise, as for an fp16 overflow).
+extern "C" int stm_conv2d_planar_windows_pool_f32(const void* x_planes, const void* const* packed_weights, const stm_conv_window* windows, int n_windows,
+                                                  const float* bias, unsigned long long* pool_fix, const stm_conv_geom* g, stm_stream_t stream)
+{
+    const char* who = "stm_conv2d_planar_windows_pool_f32";
+    STM_REQUIRE(packed_weights && windows && g && pool_fix, STM_ENULL, "%s: NULL argument", who);
+    STM_REQUIRE(n_windows >= 1 && n_windows <= 9, STM_EINVAL, "%s: 1 .. 9 windows", who);
+    STM_REQUIRE(g->win_w > 0 && g->win_h > 0 && g->fmt == 1 && g->sh == 1 && g->sw == 1 && (g->groups <= 1) && g->n_levels <= 0 &&
+                (g->tile_n == 0 || g->tile_n == 128) && g->Cout % 128 == 0, STM_EUNSUPPORTED,
+                "%s: fp16x2 planes, stride 1, one group, whole 128-channel tiles, win_h / win_w set", who);
+    STM_REQUIRE((uintptr_t)pool_fix % 8 == 0, STM_EINVAL, "%s: pool_fix must be 8-byte aligned", who);
+    for (int i = 0; i < n_windows; ++i) STM_REQUIRE(packed_weights[i], STM_ENULL, "%s: packed weight %d is NULL", who, i);
+    stm_conv_geom g0 = *g;
+    g0.kh = windows[0].kh; g0.kw = windows[0].kw; g0.ph = windows[0].ph; g0.pw = windows[0].pw;
+    g0.Ho = windows[0].Ho; g0.Wo = windows[0].Wo; g0.win_y0 = windows[0].y0; g0.win_x0 = windows[0].x0;
+    WinSet ws{packed_weights, windows, n_windows, pool_fix};
+    return conv2d_planar_impl(x_planes, packed_weights[0], bias, nullptr, nullptr, nullptr, nullptr, &g0, 1, nullptr, 0, stream, nullptr, &ws);
 }
 
 namespace {
@@ -1451,7 +1510,7 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
                        int relu, void* workspace, size_t workspace_bytes, stm_stream_t stream, const DualSrc* dual, const WinSet* wset)
 {
     const char* who = dual ? "stm_conv2d_planar_dual_f32" : "stm_conv2d_planar_f32";
-    STM_REQUIRE(x_planes && packed_weight && (out_f32 || out_planes), STM_ENULL,
+    STM_REQUIRE(x_planes && packed_weight && (out_f32 || out_planes || (wset && wset->pool)), STM_ENULL,
                 "%s: x_planes/packed_weight and at least one output must be non-NULL", who);
     STM_REQUIRE(g, STM_ENULL, "%s: geometry is NULL", who);
     const int groups = g->groups > 0 ? g->groups : 1;
@@ -1603,6 +1662,8 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
         PlanarArgsCls ac;
         static_cast<PlanarArgs&>(ac) = a;
         ac.n_cls = wset->n;
+        ac.pool = wset->pool;
+        ac.pool_ld = g->Cout;
         int t0 = 0;
         for (int i = 0; i < wset->n; ++i) {
             const stm_conv_window& w = wset->win[i];

@@ -596,6 +596,49 @@ def conv2d_planar_windows(xp, packed_list, windows, bias, B, H, W, C, O, out_h, 
     return out_f32 if out_f32 is not None else out_planes
 
 
+def conv2d_planar_windows_pool(xp, packed_list, windows, bias, B, H, W, C, O, out_h, out_w, out_scale, pool_fix):
+    """stm_conv2d_planar_windows_pool_f32: the window set of conv2d_planar_windows with ReLU and the average pool over each out_h x out_w image in
+    the epilogue: pool_fix [>= B, O] int64 (32.32 fixed point, zero before the first use) receives the pooled SUMS; nothing is written per pixel."""
+    _dev(xp)
+    if pool_fix.dtype != torch.int64 or pool_fix.dim() != 2 or pool_fix.shape[0] < B or pool_fix.shape[1] != O or not pool_fix.is_contiguous():
+        raise StmError("conv2d_planar_windows_pool: pool_fix must be a contiguous int64 [>= B, O] tensor")
+    n = len(windows)
+    g = _lib.ConvGeom()
+    g.B, g.H, g.W, g.C, g.Cout, g.sh, g.sw, g.planes, g.fmt, g.tile_n = B, H, W, C, O, 1, 1, 2, 1, 128
+    g.kh, g.kw, g.Ho, g.Wo = windows[0][0], windows[0][1], windows[0][4], windows[0][5]
+    g.win_h, g.win_w = out_h, out_w
+    g.out_scale = out_scale
+    g.x_np, g.x_plane_stride = xp.shape[2], xp.shape[1] * xp.shape[2] * 32
+    wins = (_lib.ConvWindow * n)()
+    for i, wv in enumerate(windows):
+        wins[i].kh, wins[i].kw, wins[i].ph, wins[i].pw, wins[i].Ho, wins[i].Wo, wins[i].y0, wins[i].x0 = wv
+    ptrs = (ctypes.c_void_p * n)(*[p.data_ptr() for p in packed_list])
+    check(_lib.lib().stm_conv2d_planar_windows_pool_f32(_p(xp), ptrs, wins, c_i(n), _p(bias) if bias is not None else None, _p(pool_fix),
+                                                        ctypes.byref(g), _stream()), "stm_conv2d_planar_windows_pool_f32")
+    return pool_fix
+
+
+def temporal_pool_fc(pool_fix, n, npix, weight, bias, n_first=None, clear=True, want_pooled=False):
+    """stm_temporal_pool_fc_f32: mean = pool_fix / 2^32 / npix, y = mean @ weight.t() + bias for the first n rows of pool_fix [>= n, C] (int64
+    fixed-point sums of conv2d_planar_windows_pool); zeroes the consumed rows when clear.  Returns y [n, n_out] -- or, with n_first, the two
+    contiguous blocks (y[:, :n_first], y[:, n_first:]) -- and the means [n, C] when want_pooled."""
+    C, n_out = pool_fix.shape[1], weight.shape[0]
+    weight = _f32c(weight)
+    dev = pool_fix.device
+    nf = n_out if n_first is None else int(n_first)
+    out = torch.empty(n, nf, device=dev, dtype=torch.float32)
+    out2 = torch.empty(n, n_out - nf, device=dev, dtype=torch.float32) if n_first is not None else None
+    pooled = torch.empty(n, C, device=dev, dtype=torch.float32) if want_pooled else None
+    check(_lib.lib().stm_temporal_pool_fc_f32(_p(pool_fix), c_i(n), c_i(C), c_i(npix), _p(weight), _p(_f32c(bias)) if bias is not None else None,
+                                              c_i(n_out), c_i(nf), _p(out), _p(out2) if out2 is not None else None,
+                                              _p(pooled) if pooled is not None else None, c_i(1 if clear else 0), _stream()),
+          "stm_temporal_pool_fc_f32")
+    res = (out, out2) if n_first is not None else (out,)
+    if want_pooled:
+        res = res + (pooled,)
+    return res if len(res) > 1 else res[0]
+
+
 def conv_kxr_supported(O, C, kh, kw, stride, padding, groups, group_cout, fmt, max_tiles=4):
     """Layers the kx-reuse narrow-output kernel (csrc/conv_kxr.hip, stm_conv2d_planar_kxr_f32) takes: stride 1, same padding,
     kw = 3 or 5, fp16 plane formats, at most 16 * max_tiles real output channels per group, at most 4 groups, and a three-stage

@@ -44,6 +44,7 @@ C3DS_FUSED = os.environ.get("STM_C3DS_FUSED", "1") != "0"    # conv3 + projectio
 STEM_FUSED = os.environ.get("STM_STEM_FUSED", "1") != "0"    # conv1 + ReLU + max-pool as one kernel (csrc/stem_fused.hip)
 CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 layers on the kx-reuse kernel (csrc/conv_kxr.hip)
 TN_BORDER = os.environ.get("STM_TN_BORDER", "1") != "0"     # TemporalNet's 3x3 layers as nine window launches without the zero taps of the RoI borders
+TN_POOL = os.environ.get("STM_TN_POOL", "1") != "0"         # ... and its AvgPool2d in conv3's epilogue, fc + fc_coeff as one launch (needs TN_BORDER)
 CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"
 # Independent parts of the trunk on a second stream while a HIP graph is being captured (PlanarGraph.run): 0 off (default), 1 proto-net beside the
 # shared head, 2 also the P5 -> P6 -> P7 convolutions beside the finer FPN levels; only batches of at most BRANCH_MAX_IMAGES frames.  Bit-equal, and
@@ -721,6 +722,11 @@ class PlanarTemporalNet:
                 and all(tuple(_pair(c.padding)) == (1, 1) and tuple(_pair(c.stride)) == (1, 1) for c in (tn.conv1, tn.conv2, tn.conv3))):
             self.border = [{"w": w.float().contiguous(), "b": (b.detach().float().contiguous() if b is not None else None), "frac": frac, "packed": None}
                            for w, b, frac in ws]
+        # tail (track_to_segment_head.py:33-37): fc (4 rows) and fc_coeff stacked, for stm_temporal_pool_fc_f32
+        self.w_tail = torch.cat([tn.fc.weight.detach().float(), tn.fc_coeff.weight.detach().float()], 0).contiguous()
+        self.b_tail = torch.cat([tn.fc.bias.detach().float(), tn.fc_coeff.bias.detach().float()], 0).contiguous()
+        self.n_fc = tn.fc.weight.shape[0]
+        self._pool = None            # int64 [capacity, 1024] fixed-point pooled sums: zero between steps (the tail kernel clears what it reads)
 
     def __call__(self, roi_feats):
         """roi_feats [n, 633, 7, 7] fp32 -> (loc shift [n, 4], coeff shift [n, 32])."""
@@ -743,6 +749,8 @@ class PlanarTemporalNet:
         dev = xp.device
         out_planes = torch.empty(2, O // 32, n * h * w, 32, device=dev, dtype=torch.float16) if out == "planes" else None
         out_f32 = torch.empty(n * h * w, O, device=dev, dtype=torch.float32) if out == "f32" else None
+        if out == "pool" and (self._pool is None or self._pool.shape[0] < n or self._pool.shape[1] != O or self._pool.device != dev):
+            self._pool = torch.zeros(max(n, 2 * (self._pool.shape[0] if self._pool is not None else 0)), O, device=dev, dtype=torch.int64)
         wins, packed, macs = [], [], 0
         for ci, win in border_windows(h, w):
             wins.append(win)
@@ -752,22 +760,30 @@ class PlanarTemporalNet:
         if timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        ops.conv2d_planar_windows(xp, packed, wins, L["b"], n, h, w, C, O, h, w, L["out_scale"], relu=True, out_f32=out_f32, out_planes=out_planes)
+        if out == "pool":
+            ops.conv2d_planar_windows_pool(xp, packed, wins, L["b"], n, h, w, C, O, h, w, L["out_scale"], self._pool)
+        else:
+            ops.conv2d_planar_windows(xp, packed, wins, L["b"], n, h, w, C, O, h, w, L["out_scale"], relu=True, out_f32=out_f32, out_planes=out_planes)
         if timing is not None:
             e1.record()
             M = n * h * w
-            nbytes = M * C * 4 + M * O * 4 + L["w"].numel() * 4
+            nbytes = M * C * 4 + (n * O * 8 if out == "pool" else M * O * 4) + L["w"].numel() * 4
             # algorithmic flops as for every other layer: the reference's 2 M Cout Cin kh kw (its padded taps included), priced against the
             # format's peak (3 MFMA products per fp32 product); 8th field: share of those products that is actually issued (361 / 441 on 7x7)
             timing.append((e0, e1, 2.0 * M * 9 * O * C * L["frac"], (M, C, O, 3, 1, 1, -2), 3, "temporal", float(nbytes), macs / (h * w * 9.0)))
-        return out_planes if out == "planes" else out_f32
+        return out_planes if out == "planes" else (self._pool if out == "pool" else out_f32)
 
     def forward_planes(self, xp, n, h=7, w=7):
         """xp: the RoI features as planes [P, cpad/32, n*h*w, 32] in this object's channel order (ops.roi_align_planes)."""
         shape = ("img", n, h, w)
         # (under ~16 000 pixels the classes' partial tiles cost what their skipped taps save: 114 RoIs = 28 tiles x 7 taps against 22 x 9)
         if self.border is not None and h >= 3 and w >= 3 and n * h * w >= 16384:
-            y = self._border_layer(2, self._border_layer(1, self._border_layer(0, xp, n, h, w, "planes"), n, h, w, "planes"), n, h, w, "f32")
+            x2 = self._border_layer(1, self._border_layer(0, xp, n, h, w, "planes"), n, h, w, "planes")
+            if TN_POOL:
+                # conv3 + ReLU + AvgPool2d in one launch (pooled sums, no [n*49, 1024] tensor), then mean -> fc / fc_coeff in one more
+                pool = self._border_layer(2, x2, n, h, w, "pool")
+                return ops.temporal_pool_fc(pool, n, h * w, self.w_tail, self.b_tail, n_first=self.n_fc)
+            y = self._border_layer(2, x2, n, h, w, "f32")
         else:
             y = self.c3(self.c2(self.c1(xp, shape), shape), shape, out="f32")                # [n*h*w, 1024]
         pooled = y.view(n, h * w, -1).mean(dim=1)                                        # AvgPool2d((7, 7)) on a 7x7 map

@@ -918,3 +918,48 @@ def test_temporalnet_border_classes_equal_the_three_launches():
     finally:
         planar.FMT = old_fmt
     assert (a_loc - b_loc).abs().max().item() < 1e-6 and (a_co - b_co).abs().max().item() < 1e-6
+
+
+def test_temporalnet_pooled_epilogue_equals_pool_of_the_written_tensor(monkeypatch):
+    """conv3 + ReLU + AvgPool2d as one launch (stm_conv2d_planar_windows_pool_f32: pooled sums in 32.32 fixed point, integer atomics) and the
+    fc / fc_coeff tail (stm_temporal_pool_fc_f32) against the same layers writing the [n * 49, O] tensor, torch.mean and torch linear layers:
+    the means agree to fp32 rounding of a 49-term sum, the tail to 1e-6; two runs of the pooled path are bit-equal (the accumulation is integer:
+    arrival order cannot matter); the pooled sums are back to zero afterwards."""
+    from stmask_amd import planar
+    import types
+    tn = types.SimpleNamespace()
+    g = torch.Generator().manual_seed(9)
+    mk = lambda o, c: torch.nn.Conv2d(c, o, 3, padding=1)
+    tn.conv1, tn.conv2, tn.conv3 = mk(128, 96), mk(128, 128), mk(256, 128)
+    tn.fc, tn.fc_coeff = torch.nn.Linear(256, 4), torch.nn.Linear(256, 32)
+    for m in (tn.conv1, tn.conv2, tn.conv3, tn.fc, tn.fc_coeff):
+        m.to(DEV)
+    monkeypatch.setattr(planar, "FMT", 1)
+    net = planar.PlanarTemporalNet(tn, corr_channels=32)
+    assert net.border is not None
+    n = 347                                                       # 17 003 pixels: the classes' last tiles are partial, RoIs straddle 64-row blocks
+    feats = torch.randn(n, 96, 7, 7, generator=g).to(DEV)
+    monkeypatch.setattr(planar, "TN_POOL", True)
+    a_loc, a_co = net(feats)
+    assert a_loc.shape == (n, 4) and a_co.shape == (n, 32) and a_loc.is_contiguous() and a_co.is_contiguous()
+    assert int(net._pool.abs().max()) == 0                        # consumed and cleared
+    a2_loc, a2_co = net(feats)
+    assert torch.equal(a_loc, a2_loc) and torch.equal(a_co, a2_co)
+    monkeypatch.setattr(planar, "TN_POOL", False)
+    b_loc, b_co = net(feats)
+    assert (a_loc - b_loc).abs().max().item() < 1e-6 and (a_co - b_co).abs().max().item() < 1e-6
+    # the pooled means themselves, against the mean of conv3's written output
+    x = F.pad(feats.index_select(1, net.perm.to(feats.device)).permute(0, 2, 3, 1), (0, net.cpad - 96)).contiguous()
+    xp = ops.split_planes(x, 1)
+    x2 = net._border_layer(1, net._border_layer(0, xp, n, 7, 7, "planes"), n, 7, 7, "planes")
+    y = net._border_layer(2, x2, n, 7, 7, "f32").view(n, 49, -1)
+    pool = net._border_layer(2, x2, n, 7, 7, "pool")
+    sums = pool[:n].double() / 4294967296.0
+    assert (sums - y.double().sum(1)).abs().max().item() <= 49 * 2.0 ** -32 + 4e-6 * y.abs().sum(1).max().item()
+    (out, pooled) = ops.temporal_pool_fc(pool, n, 49, net.w_tail, net.b_tail, want_pooled=True)
+    assert (pooled - y.mean(1)).abs().max().item() <= 2e-6 * max(1.0, y.abs().max().item())
+    ref = torch.cat([tn.fc(y.mean(1)), tn.fc_coeff(y.mean(1))], 1)
+    assert (out - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    assert int(pool.abs().max()) == 0
+    with pytest.raises(StmError):
+        ops.conv2d_planar_windows_pool(xp, [], [], None, n, 7, 7, 96, 256, 7, 7, 1.0, torch.zeros(n, 256, device=DEV))   # not int64
