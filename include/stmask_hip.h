@@ -32,7 +32,8 @@
  *     stm_stem_fused_f32; the bottleneck chain stm_chain_tail_weight_bytes(_proj) / stm_chain_pack_tail(_proj)_f32 /
  *     stm_bottleneck_chain(_proj)_f32; stm_detect_cc_logits_f32; stm_corr_patch_nhwc_f32 / stm_roi_align_planes_nhwc_f32).
  *     stm_struct_bytes(which) lets a client check its layout of EVERY struct of this header against the library.
- *     Added since without a version change (new entry points only): stm_conv2d_planar_windows_pool_f32, stm_temporal_pool_fc_f32.
+ *     Added since without a version change (new entry points only): stm_conv2d_planar_windows_pool_f32, stm_temporal_pool_fc_f32,
+ *     stm_debug_launch_count.
  */
 #ifndef STMASK_HIP_H_
 #define STMASK_HIP_H_
@@ -65,6 +66,9 @@ size_t stm_struct_bytes(int which);
 /* Diagnostics: the STM_* environment switches are read once per process; this makes the next call read them again (tests, A/B
  * scripts).  Not needed in production. */
 void stm_debug_reload_tunables(void);
+/* Diagnostics: launches of an optional kernel form since the process started (tests check that the form they compare really ran):
+ * which = 0 conv_planar_kx3_kernel (kx-reuse staging of the 256 x 128 ring tiles); -1 for anything else. */
+long long stm_debug_launch_count(int which);
 
 /* ---------------------------------------------------------------------------------------------------
  * Deformable convolution.

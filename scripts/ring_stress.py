@@ -166,7 +166,10 @@ def main():
             shapes += [("conv_kxr_kernel<3,2> 256->41 3x3", 256, 48, 3, 3, 48, 80, None), ("conv_kxr_kernel<5,2> 256->41 3x5", 256, 48, 3, 5, 48, 80, None),
                        ("conv_kxr_kernel<3,2> 256->41 5x3", 256, 48, 5, 3, 48, 80, None)]
         if "planar" in which:
-            shapes += [("conv_planar_kernel ring 256x128 256->256 3x3 (head tower)", 256, 256, 3, 3, 48, 80, 128),
+            # (the 3x3 tower runs on conv_planar_kx3_kernel -- kx-reuse staging, round 4 -- where its grid takes 256-pixel tiles, i.e. at 32 clips, and on
+            # the 128 x 128 ring tiles of conv_planar_kernel at 4; the 1x1 DCN GEMM keeps conv_planar_kernel's 256 x 128 ring at 32 clips)
+            shapes += [("conv_planar_kx3_kernel / conv_planar_kernel ring 256->256 3x3 (head tower)", 256, 256, 3, 3, 48, 80, 128),
+                       ("conv_planar_kernel ring 256x128 1152->128 1x1 (DCN GEMM)", 1152, 128, 1, 1, 48, 80, 128),
                        ("conv_planar_kernel ring 128x64 256->64 1x1 (bottleneck conv1, two-buffer/ring rule)", 256, 64, 1, 1, 96, 160, 64),
                        ("conv_planar_kernel 128x64 64->256 1x1 + residual (bottleneck conv3)", 64, 256, 1, 1, 96, 160, 64)]
         for name, C, O, kh, kw, h, w, tile in shapes:

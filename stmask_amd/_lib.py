@@ -15,7 +15,7 @@ c_i, c_l, c_f, c_p, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.
 # every symbol include/stmask_hip.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_VERSION = 3   # include/stmask_hip.h STM_ABI_VERSION
 ABI_SYMBOLS = [
-    "stm_version", "stm_last_error_string", "stm_struct_bytes", "stm_debug_reload_tunables", "stm_conv_kxr_packed_bytes", "stm_conv_pack_weights_kxr_f32", "stm_conv2d_planar_kxr_f32", "stm_conv2d_planar_dual_f32", "stm_conv2d_planar_windows_f32", "stm_conv2d_planar_windows_pool_f32", "stm_temporal_pool_fc_f32", "stm_stem_packed_weight_bytes", "stm_stem_pack_weights_f32", "stm_stem_fused_f32", "stm_chain_tail_weight_bytes", "stm_chain_tail_weight_bytes_proj", "stm_chain_pack_tail_f32", "stm_chain_pack_tail_proj_f32", "stm_bottleneck_chain_f32", "stm_bottleneck_chain_proj_f32", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
+    "stm_version", "stm_last_error_string", "stm_struct_bytes", "stm_debug_reload_tunables", "stm_debug_launch_count", "stm_conv_kxr_packed_bytes", "stm_conv_pack_weights_kxr_f32", "stm_conv2d_planar_kxr_f32", "stm_conv2d_planar_dual_f32", "stm_conv2d_planar_windows_f32", "stm_conv2d_planar_windows_pool_f32", "stm_temporal_pool_fc_f32", "stm_stem_packed_weight_bytes", "stm_stem_pack_weights_f32", "stm_stem_fused_f32", "stm_chain_tail_weight_bytes", "stm_chain_tail_weight_bytes_proj", "stm_chain_pack_tail_f32", "stm_chain_pack_tail_proj_f32", "stm_bottleneck_chain_f32", "stm_bottleneck_chain_proj_f32", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
     "stm_deform_conv_fwd_f32", "stm_gemm_bias_f32", "stm_gemm_workspace_bytes", "stm_gemm_bias_ws_f32", "stm_fcb_ali_offsets_f32", "stm_corr_patch_f32", "stm_corr_patch_nhwc_f32",
     "stm_roi_align_avg_f32", "stm_decode_boxes_f32", "stm_generate_candidates_f32", "stm_cc_fast_nms_f32",
     "stm_detect_cc_workspace_bytes", "stm_detect_cc_f32", "stm_detect_cc_logits_f32", "stm_fast_nms_workspace_bytes", "stm_fast_nms_f32",
@@ -78,6 +78,7 @@ def lib():
             getattr(_lib, name).restype = c_sz
         _lib.stm_struct_bytes.restype = c_sz
         _lib.stm_debug_reload_tunables.restype = None
+        _lib.stm_debug_launch_count.restype = ctypes.c_longlong
         # this binding and the library must describe the same structs (a stale .so would read garbage past a shorter struct)
         if _lib.stm_version() != ABI_VERSION or _lib.stm_struct_bytes(0) != ctypes.sizeof(DeformGeom) or \
                 _lib.stm_struct_bytes(1) != ctypes.sizeof(ConvGeom) or _lib.stm_struct_bytes(2) != ctypes.sizeof(ConvWindow) or \

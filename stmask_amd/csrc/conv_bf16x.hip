@@ -885,6 +885,269 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const typename std:
 #endif
 }
 
+// ---- kx-reuse staging inside the ring loop (round 4, third attempt: see DESIGN section 4 item 3 for the two that lost) --------------------------
+// For a stride-1 convolution with kw = 3 the 256 x 128 ring kernel above stages the activation tile once per TAP: three of the nine (or 3 kh)
+// K-slabs of a channel slab fetch the same BM pixels shifted by one.  Here a STAGE is one (channel slab, ky): the BM + 2 consecutive pixels of the flat
+// pixel run m0 - 1 .. m0 + BM (each at its own row oy + ky - ph) are staged ONCE, into one of two 34-KB buffers, and serve kx = 0, 1, 2: tap kx of
+// tile pixel r is staged row r + kx.  Where that neighbour is in another image row (ox + kx - 1 outside [0, W)) the lane's read address points at an
+// always-zero staged row instead (rows 258 .. 271 of a buffer are filled by out-of-range DMAs): no masking instruction in the loop.  Weights keep
+// the three-slot ring, one slot per tap (slot = kx).  Per wave and tap: 11 / 3 LDS-DMA instructions instead of 6, 1 / 2.8 of the activation bytes.
+// What is different from the two earlier attempts: the three taps of a stage are unrolled with their read offsets in three register sets (the ring
+// kernel turned out to use 213 registers, not 256: the twelve offsets fit), so there is no per-tap register rotation and no run-time tap index; a
+// stage's DMAs are issued in the first half of taps 0 and 1 and are older than the weight slab the barrier of tap 2 waits for, so the counted waits
+// stay compile-time constants (5, 4, 2); every wave issues the same number of DMAs (the 17th row group is fetched by every wave: same bytes, same place).
+// Same products in the same order as conv_planar_kernel<2, 2, 2, 1, 3>: bit-equal outputs (tests/test_gpu_conv.py).
+constexpr int KX3_XROWS = 272, KX3_XPL = KX3_XROWS * 64, KX3_ABUF = 2 * KX3_XPL, KX3_WBUF = 2 * 128 * 64, KX3_W0 = 2 * KX3_ABUF;
+constexpr int KX3_ZROW = 260;
+constexpr int KX3_LDS_LOOP = KX3_W0 + 3 * KX3_WBUF;
+#ifndef KX3_SCHED
+#define KX3_SCHED 24     // 0: no schedule hints (experiment)
+#endif
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr int NJ = 2, BM = 256, BN = 128, WPL = BN * 64;
+    const int tiles = a.m_tiles * a.n_tiles;
+    const int per_xcd = (tiles + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= tiles) return;
+    const int mt = a.n_tiles == 1 ? logical : (a.n_tiles == 2 ? logical >> 1 : (a.n_tiles == 4 ? logical >> 2 : logical / a.n_tiles));
+    const int nt = logical - mt * a.n_tiles;
+    const int m0 = mt * BM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int grp = a.groups == 1 ? 0 : nt / a.ntpg;
+    const int n0g = (nt - grp * a.ntpg) * BN;
+    const int cslabs = a.C / CV_BK;
+
+    // pixel m of the launch's pixel axis -> (valid, first pixel of its level, image, row, column, level size)
+    auto decode = [&](int m, int& first, int& b, int& oy, int& ox, int& H, int& W) -> bool {
+        const bool ok = m >= 0 && m < a.M;
+        const int mm = ok ? m : 0;
+        H = a.H; W = a.W; first = 0;
+        int local = mm;
+        if (a.n_levels > 0) {
+#pragma unroll
+            for (int l = 0; l < 8; ++l)
+                if (l < a.n_levels && mm >= a.lvl_start[l]) { first = a.lvl_start[l]; H = a.lvl_h[l]; W = a.lvl_w[l]; }
+            local = mm - first;
+            b = local / (H * W);
+            const int rem = local - b * (H * W);
+            oy = rem / W;
+            ox = rem - oy * W;
+        } else {
+            const int hw = H * W;
+            b = (int)((float)local * a.inv_hw);
+            int rem = local - b * hw;
+            if (rem < 0) { --b; rem += hw; } else if (rem >= hw) { ++b; rem -= hw; }
+            oy = (int)((float)rem * a.inv_w);
+            int t = rem - oy * W;
+            if (t < 0) --oy; else if (t >= W) ++oy;
+            ox = rem - oy * W;
+        }
+        return ok;
+    };
+
+    // DMA duties of this lane: staged rows j = 16 q + (lane >> 2) of row groups q = wave, wave + 8 and 16; staged row j is launch pixel m0 - 1 + j
+    int base[3], wl64[3];
+    unsigned vmk[3];
+    const int slot = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int q = i == 0 ? wave : (i == 1 ? wave + 8 : 16);
+        const int j = q * 16 + (lane >> 2);
+        int first, b, oy, ox, H, W;
+        const bool ok = decode(m0 - 1 + j, first, b, oy, ox, H, W) && j < BM + 2;
+        unsigned vm = 0;
+        for (int ky = 0; ky < a.kh; ++ky)
+            if ((unsigned)(oy - a.ph + ky) < (unsigned)H) vm |= 1u << ky;
+        vmk[i] = ok ? vm : 0u;
+        wl64[i] = W * 64;
+        base[i] = (first + b * H * W + (oy - a.ph) * W + ox) * 64 + ((slot ^ swz(j)) << 4);
+    }
+    __amdgpu_buffer_rsrc_t xr[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
+    const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * KX3_WBUF;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+    // fragment read offsets: activation row tile i at tap kx = staged rows 64 wm + 16 i + r16 + kx, or the zero row where the tap leaves the image row
+    const int r16 = lane & 15, kc = lane >> 4;
+    int xo[3][4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wm * 64 + i * 16 + r16;
+        int first, b, oy, ox, H, W;
+        decode(m0 + r, first, b, oy, ox, H, W);
+        const int z = lds_off(KX3_ZROW, kc);
+        xo[0][i] = ox == 0 ? z : lds_off(r, kc);
+        xo[1][i] = lds_off(r + 1, kc);
+        xo[2][i] = ox == W - 1 ? z : lds_off(r + 2, kc);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) woff[j] = KX3_W0 + lds_off(wn * 64 + j * 16 + r16, kc);
+
+    // stage counters of the NEXT activation stage to issue: (channel slab, ky); stage index and its buffer
+    int st_c = 0, st_ky = 0, st_buf = 0;
+    auto dma_a = [&](int i, int p) {          // piece (row group of duty i, plane p) of the stage (st_c, st_ky) into buffer st_buf
+        const int q = i == 0 ? wave : (i == 1 ? wave + 8 : 16);
+        const unsigned oob = ((vmk[i] >> st_ky) & 1u) ^ 1u;
+        const unsigned off = (unsigned)(base[i] + st_ky * wl64[i] + (grp * cslabs + st_c) * (a.x_np * 64)) | (oob << 31);
+        if (!(ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(smem + st_buf * KX3_ABUF + p * KX3_XPL + q * 1024), 16, off, 0, 0, 0);
+    };
+    auto stage_advance = [&]() {
+        st_buf ^= 1;
+        if (++st_ky == a.kh) { st_ky = 0; ++st_c; }
+    };
+    auto dma_w = [&](int slab, int wslot) {
+        uint8_t* wb = smem + KX3_W0 + wslot * KX3_WBUF;
+        const uint8_t* wsrc = wtile + (size_t)slab * KX3_WBUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int wi = wave + 8 * j;
+            if (!(ABL & 1)) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + wi * 1024 + lane * 16), (lds_ptr)(wb + wi * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc16[4][4], accl16[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc16[i][j][r] = 0.0f; accl16[i][j][r] = 0.0f; }
+
+#define MM16(x_, y_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x_), __builtin_bit_cast(f16x8, y_), c_, 0, 0, 0)
+    const int S = a.slabs;                       // K-slabs = 3 taps x stages
+    // prologue: stage 0 whole, weight slabs 0 and 1
+    dma_a(0, 0); dma_a(0, 1); dma_a(1, 0); dma_a(1, 1); dma_a(2, wave & 1);
+    stage_advance();
+    dma_w(0, 0);
+    dma_w(min(1, S - 1), 1);
+    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    bf16x8 bf[4][2], af0[2][2], af1[2][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(smem + woff[j] + p * WPL);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + xo[0][i] + p * KX3_XPL);
+    int s = 0;                                   // K-slab of the tap being multiplied
+    // first half of tap KX_: row tiles 0, 1 (fragments in registers); reads the second half's activation fragments (same stage, same tap) and issues
+    // this tap's DMAs: the next stage's pieces (taps 0 and 1 only), then weight slab s + 2 into the slot tap KX_ - 1 just left
+#define KX3_HALF0(KX_)                                                                                                              \
+    {                                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
+            _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                           \
+                if (!(ABL & 4)) af1[i][p] = *reinterpret_cast<const bf16x8*>(smem + xo[KX_][2 + i] + p * KX3_XPL);                 \
+        if (KX_ == 0) { dma_a(0, 0); dma_a(0, 1); dma_a(1, 0); }                                                                    \
+        if (KX_ == 1) { dma_a(1, 1); dma_a(2, wave & 1); stage_advance(); }                                                         \
+        dma_w(min(s + 2, S - 1), (KX_ + 2) % 3);                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                             \
+            const f32x4 c0 = MM16(af0[0][1], bf[j][0], accl16[0][j]);                                                               \
+            const f32x4 c1 = MM16(af0[1][1], bf[j][0], accl16[1][j]);                                                               \
+            acc16[0][j] = MM16(af0[0][0], bf[j][0], acc16[0][j]);                                                                   \
+            accl16[0][j] = MM16(af0[0][0], bf[j][1], c0);                                                                           \
+            acc16[1][j] = MM16(af0[1][0], bf[j][0], acc16[1][j]);                                                                   \
+            accl16[1][j] = MM16(af0[1][0], bf[j][1], c1);                                                                           \
+        }                                                                                                                           \
+        constexpr int ND = KX_ == 0 ? 5 : (KX_ == 1 ? 4 : 2);                                                                       \
+        _Pragma("unroll") for (int k = 0; k < KX3_SCHED; ++k) {                                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                      \
+            if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                           \
+            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                                                                      \
+            if (k % (24 / ND) == 24 / ND - 1 && k / (24 / ND) < ND) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              \
+        }                                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+    }
+    // second half: row tiles 2, 3; with PRE_ the fragments of the next tap replace this tap's as they retire: activation rows 0, 1 at the next tap's
+    // shift (the offsets already point into the next stage's buffer when KX_ = 2), weight fragments from the next tap's slot
+#define KX3_HALF1(KX_, PRE_)                                                                                                        \
+    {                                                                                                                               \
+        if (PRE_ && !(ABL & 4)) {                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                       \
+                    af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + xo[(KX_ + 1) % 3][i] + p * KX3_XPL);                        \
+        }                                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                             \
+            const f32x4 c0 = MM16(af1[0][1], bf[j][0], accl16[2][j]);                                                               \
+            const f32x4 c1 = MM16(af1[1][1], bf[j][0], accl16[3][j]);                                                               \
+            acc16[2][j] = MM16(af1[0][0], bf[j][0], acc16[2][j]);                                                                   \
+            accl16[2][j] = MM16(af1[0][0], bf[j][1], c0);                                                                           \
+            acc16[3][j] = MM16(af1[1][0], bf[j][0], acc16[3][j]);                                                                   \
+            accl16[3][j] = MM16(af1[1][0], bf[j][1], c1);                                                                           \
+            if (PRE_ && !(ABL & 4)) {                                                                                               \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                       \
+                    bf[j][p] = *reinterpret_cast<const bf16x8*>(smem + woff[j] + ((KX_ + 1) % 3) * KX3_WBUF + p * WPL);             \
+            }                                                                                                                       \
+        }                                                                                                                           \
+        if (PRE_) {                                                                                                                 \
+            _Pragma("unroll") for (int k = 0; k < KX3_SCHED; ++k) {                                                                        \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                  \
+                if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                       \
+                else if (k >= 6 && ((k - 6) % 6) < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+            }                                                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        }                                                                                                                           \
+    }
+#define KX3_BARRIER(N_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory")
+    const int T = S / 3;                          // stages
+    KX3_HALF0(0);
+#ifdef KX3_TEST1
+    for (int t = 0; t < T; ++t) { KX3_BARRIER(5); KX3_HALF1(0, true); ++s; KX3_HALF0(0); }
+#else
+#define KX3_FLIP(T_)                                                                      \
+        {                                                                                 \
+            const int d = ((T_) & 1) ? -KX3_ABUF : KX3_ABUF;                              \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k)                                 \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) xo[k][i] += d;              \
+        }
+    for (int t = 0; t < T - 1; ++t) {
+        KX3_BARRIER(5);
+        KX3_HALF1(0, true);
+        ++s;
+        KX3_HALF0(1);
+        KX3_BARRIER(4);
+        KX3_HALF1(1, true);
+        ++s;
+        KX3_HALF0(2);
+        // the activation fragments of this stage are all in registers: from here on the read offsets address the other buffer
+        KX3_FLIP(t);
+        KX3_BARRIER(2);
+        KX3_HALF1(2, true);
+        ++s;
+        KX3_HALF0(0);
+    }
+    KX3_BARRIER(5);
+    KX3_HALF1(0, true);
+    ++s;
+    KX3_HALF0(1);
+    KX3_BARRIER(4);
+    KX3_HALF1(1, true);
+    ++s;
+    KX3_HALF0(2);
+    KX3_BARRIER(2);
+#undef KX3_FLIP
+#endif
+    KX3_HALF1(2, false);
+#undef KX3_HALF0
+#undef KX3_HALF1
+#undef KX3_BARRIER
+#undef MM16
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage and the weight slabs issued past the end must land before the epilogue reuses the LDS
+    __syncthreads();
+    park16<NJ>(acc16, accl16, smem, wave, lane, 1.0f / STM_F16_LOW_SCALE);
+    planar_epilogue_tail<NJ, 1>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
+#endif
+}
+
 // Streaming kernels below: workgroup ids are dealt round-robin to the 8 XCDs; a launch of 8 * per_xcd workgroups maps id ->
 // (id & 7) * per_xcd + (id >> 3), so each XCD works on a contiguous run of pixels (neighbouring rows share input lines in
 // one L2 instead of eight).  Returns -1 for the padding workgroups.
@@ -1176,6 +1439,7 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
 
 // Launch tunables: read from the environment ONCE (first launch), never per launch.  Defaults are the measured best (DESIGN.md
 // section 9); the variables exist for A/B runs.  stm_debug_reload_tunables() (capi.hip) makes the next launch re-read them.
+std::atomic<long long> g_kx3_launches{0};      // stm_debug_launch_count(0)
 struct ConvTunables {
     int ring = 3;          // STM_CONV_RING: 2 = two-buffer loop on the 128-wide tiles, 3 = three-buffer ring (fp16 formats)
     int ring64_small = 512; // STM_CONV_RING64_SMALL: grids up to this many workgroups take the ring on 128 x 64 tiles whatever K
@@ -1188,6 +1452,7 @@ struct ConvTunables {
     int scalar_epilogue = 0;   // STM_CONV_SCALAR_EPILOGUE: element-wise epilogue stores (tests)
     int abl = 0;           // STM_CONV_ABL (builds with -DSTM_ABLATE only)
     int nsub = 0;          // STM_CONV_NSUB: 2 / 4 = channel tiles of a pixel tile that share an XCD's L2 at one time (tile map of conv_planar_kernel)
+    int kx3 = 1;           // STM_CONV_KX3: 0 = stride-1 kw = 3 layers on the 256 x 128 ring tiles stay on conv_planar_kernel (1: conv_planar_kx3_kernel, kx-reuse staging)
 };
 ConvTunables read_tunables()
 {
@@ -1202,6 +1467,7 @@ ConvTunables read_tunables()
     t.mg = (int)geti("STM_CONV_MG", 0);
     t.nt_mb = geti("STM_CONV_NT", 0);
     t.scalar_epilogue = (int)geti("STM_CONV_SCALAR_EPILOGUE", 0);
+    t.kx3 = (int)geti("STM_CONV_KX3", t.kx3);
     t.abl = (int)geti("STM_CONV_ABL", 0);
     t.nsub = (int)geti("STM_CONV_NSUB", 0);
     return t;
@@ -1748,6 +2014,23 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
         return rc != STM_OK ? rc : finish_splitk();
     }
 #endif
+    if (tn.kx3 && a.fmt == 1 && ring && mg == 2 && !dual && !win && a.splitk == 1 && a.kw == 3 && a.pw == 1 && a.sh == 1 && a.sw == 1 &&
+        a.slabs % 3 == 0 && a.kh <= 8 && full) {
+        // kx-reuse staging (conv_planar_kx3_kernel): one staged run of BM + 2 pixels per (channel slab, ky) serves the three taps of a kernel row
+        static std::atomic<bool> kx3_reserved[STM_MAX_DEVICES];
+        constexpr size_t lds = 8 * 64 * (64 + 4) * sizeof(float) > (size_t)KX3_LDS_LOOP ? 8 * 64 * (64 + 4) * sizeof(float) : (size_t)KX3_LDS_LOOP;
+        int dev = 0;
+        const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STM_MAX_DEVICES;
+        if (!have_dev || !kx3_reserved[dev].load(std::memory_order_relaxed)) {
+            STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kx3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
+                            hipSuccess, STM_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
+            if (have_dev) kx3_reserved[dev].store(true, std::memory_order_relaxed);
+        }
+        hipLaunchKernelGGL((conv_planar_kx3_kernel<0>), dim3(8 * stm_cdiv(tiles, 8)), dim3(512), lds, stm_hs(stream), a);
+        STM_CHECK_LAUNCH("conv_planar_kx3_kernel");
+        g_kx3_launches.fetch_add(1, std::memory_order_relaxed);
+        return STM_OK;
+    }
     if (dual) {      // (the 128-wide tiles of the fp16 formats always take the ring loop here)
         if (a.fmt == 2) rc = mg == 2 ? launch_planar<1, 2, 2, 1, 3, 0, true>(a, tiles, stream) : launch_planar<1, 1, 2, 1, 3, 0, true>(a, tiles, stream);
         else rc = mg == 2 ? launch_planar<2, 2, 2, 1, 3, 0, true>(a, tiles, stream) : launch_planar<2, 1, 2, 1, 3, 0, true>(a, tiles, stream);
@@ -1762,6 +2045,8 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
     return rc != STM_OK ? rc : finish_splitk();
 }
 }  // namespace
+
+extern "C" long long stm_debug_launch_count(int which) { return which == 0 ? g_kx3_launches.load(std::memory_order_relaxed) : -1; }
 
 extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
                                      const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,

@@ -12,6 +12,8 @@ import torch.nn.functional as F
 
 import oracle
 from stmask_amd import ops
+from ctypes import c_int
+
 from stmask_amd._lib import StmError
 
 pytestmark = pytest.mark.gpu
@@ -963,3 +965,47 @@ def test_temporalnet_pooled_epilogue_equals_pool_of_the_written_tensor(monkeypat
     assert int(pool.abs().max()) == 0
     with pytest.raises(StmError):
         ops.conv2d_planar_windows_pool(xp, [], [], None, n, 7, 7, 96, 256, 7, 7, 1.0, torch.zeros(n, 256, device=DEV))   # not int64
+
+
+KX3_CASES = [
+    # B, sizes (levels) or one (H, W), C per group, O, groups, kh, residual
+    ("img 48x80", 8, [(48, 80)], 128, 256, 1, 3, False),
+    ("img 37x53 odd, residual, partial last tile", 19, [(37, 53)], 64, 128, 1, 3, True),
+    ("levels, grouped towers", 6, [(24, 40), (12, 20), (6, 10), (3, 5), (2, 3)], 64, 512, 4, 3, False),
+    ("levels 5x3 kernel", 5, [(24, 40), (12, 20), (6, 10), (3, 5), (2, 3)], 64, 128, 1, 5, False),
+    ("1x3 kernel", 4, [(40, 64)], 96, 128, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", KX3_CASES, ids=[c[0] for c in KX3_CASES])
+def test_conv_planar_kx3_staging_is_bit_equal_to_the_ring_kernel(case, tunables):
+    """conv_planar_kx3_kernel (STM_CONV_KX3=1: one staged run of BM + 2 pixels per (channel slab, ky) serves the three taps of a kernel row, the
+    image-row borders read an always-zero staged row) multiplies the same fragments in the same order as the ring kernel that stages every tap:
+    bit-equal fp32 and plane outputs -- single image size with odd widths and a partial last tile, the concatenated-levels pixel axis of the shared
+    head (tiles that span two levels), grouped layers, kh = 1 / 3 / 5, residual + ReLU; and against the fp64 oracle on the plain case."""
+    from stmask_amd import _lib
+    from stmask_amd.planar import PlanarConv
+    name, B, sizes, C, O, groups, kh, with_res = case
+    x = torch.cat([rnd(B, h, w, C * groups, seed=7 + i).reshape(-1, C * groups) for i, (h, w) in enumerate(sizes)], 0)      # [M, C] concatenated levels
+    M = x.shape[0]
+    w = rnd(O, C, kh, 3, seed=3, scale=(C * kh * 3) ** -0.5)
+    b = rnd(O, seed=4)
+    conv = PlanarConv(w.to(DEV), b.to(DEV), 1, (kh // 2, 1), relu=True, groups=groups, tile_n=128, fmt=1)
+    xp = ops.split_planes(x.to(DEV), 1)
+    res = ops.split_planes(rnd(M, O, seed=5).to(DEV), 1) if with_res else None
+    shape = ("levels", B, sizes) if len(sizes) > 1 else ("img", B, sizes[0][0], sizes[0][1])
+    outs = []
+    for kx3 in ("0", "1"):
+        tunables.set(STM_CONV_KX3=kx3, STM_CONV_MG="2", STM_CONV_SPLITK="1")     # (256-pixel tiles and no split along K whatever the pixel count)
+        n0 = _lib.lib().stm_debug_launch_count(c_int(0))
+        y32, ypl = conv(xp, shape, out="both", residual=res)
+        torch.cuda.synchronize()
+        assert _lib.lib().stm_debug_launch_count(c_int(0)) - n0 == (1 if kx3 == "1" else 0), "the kx-reuse kernel did not take this layer"
+        outs.append((y32.clone(), ypl.clone()))
+        tunables.clear("STM_CONV_KX3", "STM_CONV_MG", "STM_CONV_SPLITK")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    if name == "img 48x80":
+        xi = x.view(B, sizes[0][0], sizes[0][1], C)
+        ref = oracle.conv2d_nhwc(xi, w, b, None, padding=(1, 1), relu=True)
+        mag = oracle.conv2d_nhwc(xi.abs(), w.abs(), b.abs(), None, padding=(1, 1))
+        assert ((outs[1][0].cpu().view(ref.shape) - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
