@@ -233,8 +233,8 @@ def conv_roofline(conv_t, steps, planes, traffic=None, traffic_src=None, timed_i
                        "with residual, stem): inputs, residual, outputs and weights once, in their stored formats"}
     obj = dict(allo)
     obj.update({"bound": "mfma",
-                "kernel": f"conv_planar_kernel ({planes} planes: stem, backbone 1x1/3x3 and DCN GEMMs, FPN, proto-net, shared head, "
-                          "TemporalNet; all launches of " + timed_in + ")",
+                "kernel": f"conv_planar_kernel / conv_planar_kx3_kernel / conv_kxr_kernel / conv_chain_kernel ({planes} planes: stem, backbone 1x1/3x3 and DCN "
+                          "GEMMs, FPN, proto-net, shared head, TemporalNet; all launches of " + timed_in + ")",
                 "traffic": traffic,
                 "traffic_source": (f"profiles/{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
                                    "correction); average over all launches") if traffic_src else None,

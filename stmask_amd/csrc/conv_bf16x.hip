@@ -896,12 +896,25 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const typename std:
 // kernel turned out to use 213 registers, not 256: the twelve offsets fit), so there is no per-tap register rotation and no run-time tap index; a
 // stage's DMAs are issued in the first half of taps 0 and 1 and are older than the weight slab the barrier of tap 2 waits for, so the counted waits
 // stay compile-time constants (5, 4, 2); every wave issues the same number of DMAs (the 17th row group is fetched by every wave: same bytes, same place).
+// And the loop is written as `for (t < T - 1) { three taps } + last stage` -- with `for (;;) { ...; if (++t == T) break; ... }` around the same macros
+// the register allocator spilled 660 bytes per lane (fragments hoisted over the exit edge); this form takes 250 registers and no scratch.
 // Same products in the same order as conv_planar_kernel<2, 2, 2, 1, 3>: bit-equal outputs (tests/test_gpu_conv.py).
+// Measured (profiles/r04_kx3_ab.txt, r04_kx3_ablations.txt): the 3x3 layers -6 % (1417 -> 1335 us proto-net layer, 1801 -> 1683 us tower layer at batch 32),
+// the step 22.2 -> 21.8 ms.  Timing ablations of THIS kernel: no DMA at all 870 us, weight DMAs only 960 us, plus the stage's 40 pieces 1335 us -- and with
+// those 40 pieces reading hot weight lines instead of activations still 1257 us: what the staging costs is the DMA INSTRUCTIONS a wave issues between
+// its MFMAs (a marginal piece costs four times what the first 16 per tap and CU cost), not the bytes, their source, or HBM latency (all stages reading
+// channel slab 0: same time).
 constexpr int KX3_XROWS = 272, KX3_XPL = KX3_XROWS * 64, KX3_ABUF = 2 * KX3_XPL, KX3_WBUF = 2 * 128 * 64, KX3_W0 = 2 * KX3_ABUF;
 constexpr int KX3_ZROW = 260;
 constexpr int KX3_LDS_LOOP = KX3_W0 + 3 * KX3_WBUF;
 #ifndef KX3_SCHED
 #define KX3_SCHED 24     // 0: no schedule hints (experiment)
+#endif
+#ifndef KX3_SPREAD
+#define KX3_SPREAD 0     // 1: a stage's pieces spread over three halves (2 + 2 + 1) instead of two (3 + 2): at most 4 DMAs per half (experiment)
+#endif
+#ifndef KX3_ABL
+#define KX3_ABL 0        // timing builds (RESULTS WRONG): 1 no DMA at all, 2 no activation DMA, 4 no fragment reads, 8 every stage stages channel slab 0 (L2-resident rows), 16 activation pieces read weight bytes instead (same count of DMAs, hot lines)
 #endif
 template <int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArgs a)
@@ -997,8 +1010,11 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     auto dma_a = [&](int i, int p) {          // piece (row group of duty i, plane p) of the stage (st_c, st_ky) into buffer st_buf
         const int q = i == 0 ? wave : (i == 1 ? wave + 8 : 16);
         const unsigned oob = ((vmk[i] >> st_ky) & 1u) ^ 1u;
-        const unsigned off = (unsigned)(base[i] + st_ky * wl64[i] + (grp * cslabs + st_c) * (a.x_np * 64)) | (oob << 31);
-        if (!(ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(smem + st_buf * KX3_ABUF + p * KX3_XPL + q * 1024), 16, off, 0, 0, 0);
+        const unsigned off = (unsigned)(base[i] + st_ky * wl64[i] + (grp * cslabs + ((ABL & 8) ? 0 : st_c)) * (a.x_np * 64)) | (oob << 31);
+        if constexpr ((ABL & 16) != 0) {        // the same number of DMAs into the same LDS places, but reading weight-tile bytes the way dma_w does
+            __builtin_amdgcn_global_load_lds((glb_ptr)(wtile + (size_t)(q & 15) * 1024 + lane * 16), (lds_ptr)(smem + st_buf * KX3_ABUF + p * KX3_XPL + q * 1024), 16, 0, 0);
+        } else
+        if (!(ABL & 3)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(smem + st_buf * KX3_ABUF + p * KX3_XPL + q * 1024), 16, off, 0, 0, 0);
     };
     auto stage_advance = [&]() {
         st_buf ^= 1;
@@ -1047,8 +1063,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
             _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                           \
                 if (!(ABL & 4)) af1[i][p] = *reinterpret_cast<const bf16x8*>(smem + xo[KX_][2 + i] + p * KX3_XPL);                 \
-        if (KX_ == 0) { dma_a(0, 0); dma_a(0, 1); dma_a(1, 0); }                                                                    \
-        if (KX_ == 1) { dma_a(1, 1); dma_a(2, wave & 1); stage_advance(); }                                                         \
+        if (KX_ == 0) { dma_a(0, 0); dma_a(0, 1); if (!KX3_SPREAD) dma_a(1, 0); }                                                   \
+        if (KX_ == 1) { if (!KX3_SPREAD) dma_a(1, 1); dma_a(2, wave & 1); stage_advance(); }                                        \
         dma_w(min(s + 2, S - 1), (KX_ + 2) % 3);                                                                                    \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                             \
             const f32x4 c0 = MM16(af0[0][1], bf[j][0], accl16[0][j]);                                                               \
@@ -1058,7 +1074,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
             acc16[1][j] = MM16(af0[1][0], bf[j][0], acc16[1][j]);                                                                   \
             accl16[1][j] = MM16(af0[1][0], bf[j][1], c1);                                                                           \
         }                                                                                                                           \
-        constexpr int ND = KX_ == 0 ? 5 : (KX_ == 1 ? 4 : 2);                                                                       \
+        constexpr int ND = KX3_SPREAD ? (KX_ == 0 ? 4 : (KX_ == 1 ? 3 : 2)) : (KX_ == 0 ? 5 : (KX_ == 1 ? 4 : 2));                  \
         _Pragma("unroll") for (int k = 0; k < KX3_SCHED; ++k) {                                                                            \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                      \
             if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                           \
@@ -1071,6 +1087,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     // shift (the offsets already point into the next stage's buffer when KX_ = 2), weight fragments from the next tap's slot
 #define KX3_HALF1(KX_, PRE_)                                                                                                        \
     {                                                                                                                               \
+        if (KX3_SPREAD && KX_ == 0) { dma_a(1, 0); dma_a(1, 1); }                                                                   \
         if (PRE_ && !(ABL & 4)) {                                                                                                   \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
                 _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                       \
@@ -1093,16 +1110,17 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                  \
                 if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                       \
                 else if (k >= 6 && ((k - 6) % 6) < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+                if (KX3_SPREAD && KX_ == 0) {                                                                                       \
+                    __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                                                              \
+                    if (k == 9 || k == 21) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                       \
+                }                                                                                                                   \
             }                                                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                                      \
         }                                                                                                                           \
     }
-#define KX3_BARRIER(N_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N_) : "memory")
+#define KX3_BARRIER(N_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((ABL & 2) ? 2 : (N_)) : "memory")     // (ABL 2: only the weight slab s + 2 is in flight)
     const int T = S / 3;                          // stages
     KX3_HALF0(0);
-#ifdef KX3_TEST1
-    for (int t = 0; t < T; ++t) { KX3_BARRIER(5); KX3_HALF1(0, true); ++s; KX3_HALF0(0); }
-#else
 #define KX3_FLIP(T_)                                                                      \
         {                                                                                 \
             const int d = ((T_) & 1) ? -KX3_ABUF : KX3_ABUF;                              \
@@ -1110,11 +1128,11 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) xo[k][i] += d;              \
         }
     for (int t = 0; t < T - 1; ++t) {
-        KX3_BARRIER(5);
+        KX3_BARRIER(KX3_SPREAD ? 4 : 5);
         KX3_HALF1(0, true);
         ++s;
         KX3_HALF0(1);
-        KX3_BARRIER(4);
+        KX3_BARRIER(KX3_SPREAD ? 5 : 4);
         KX3_HALF1(1, true);
         ++s;
         KX3_HALF0(2);
@@ -1125,17 +1143,16 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         ++s;
         KX3_HALF0(0);
     }
-    KX3_BARRIER(5);
+    KX3_BARRIER(KX3_SPREAD ? 4 : 5);
     KX3_HALF1(0, true);
     ++s;
     KX3_HALF0(1);
-    KX3_BARRIER(4);
+    KX3_BARRIER(KX3_SPREAD ? 5 : 4);
     KX3_HALF1(1, true);
     ++s;
     KX3_HALF0(2);
     KX3_BARRIER(2);
 #undef KX3_FLIP
-#endif
     KX3_HALF1(2, false);
 #undef KX3_HALF0
 #undef KX3_HALF1
@@ -2022,11 +2039,11 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
         int dev = 0;
         const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STM_MAX_DEVICES;
         if (!have_dev || !kx3_reserved[dev].load(std::memory_order_relaxed)) {
-            STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kx3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
+            STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kx3_kernel<KX3_ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
                             hipSuccess, STM_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
             if (have_dev) kx3_reserved[dev].store(true, std::memory_order_relaxed);
         }
-        hipLaunchKernelGGL((conv_planar_kx3_kernel<0>), dim3(8 * stm_cdiv(tiles, 8)), dim3(512), lds, stm_hs(stream), a);
+        hipLaunchKernelGGL((conv_planar_kx3_kernel<KX3_ABL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(512), lds, stm_hs(stream), a);
         STM_CHECK_LAUNCH("conv_planar_kx3_kernel");
         g_kx3_launches.fetch_add(1, std::memory_order_relaxed);
         return STM_OK;
