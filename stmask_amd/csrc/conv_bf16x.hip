@@ -911,7 +911,10 @@ constexpr int KX3_LDS_LOOP = KX3_W0 + 3 * KX3_WBUF;
 #define KX3_SCHED 24     // 0: no schedule hints (experiment)
 #endif
 #ifndef KX3_SPREAD
-#define KX3_SPREAD 0     // 1: a stage's pieces spread over three halves (2 + 2 + 1) instead of two (3 + 2): at most 4 DMAs per half (experiment)
+#define KX3_SPREAD 0     // experiments: 1 = a stage's pieces spread over three halves (2 + 2 + 1) instead of two (3 + 2); 2 = weight slab s + 3 issued in the second half of tap s (activation pieces alone in the first halves)
+#endif
+#ifndef KX3_WBUFFER
+#define KX3_WBUFFER 1    // weight pieces as buffer loads (scalar offset + 16 lane: 242 registers, -0.8 %); 0 = global_load_lds with a 64-bit per-lane address
 #endif
 #ifndef KX3_ABL
 #define KX3_ABL 0        // timing builds (RESULTS WRONG): 1 no DMA at all, 2 no activation DMA, 4 no fragment reads, 8 every stage stages channel slab 0 (L2-resident rows), 16 activation pieces read weight bytes instead (same count of DMAs, hot lines)
@@ -965,8 +968,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     };
 
     // DMA duties of this lane: staged rows j = 16 q + (lane >> 2) of row groups q = wave, wave + 8 and 16; staged row j is launch pixel m0 - 1 + j
-    int base[3], wl64[3];
-    unsigned vmk[3];
+    int base[3], wlv[3];          // wlv = row pitch in bytes (a multiple of 64) | one validity bit per ky in the low six bits
     const int slot = lane & 3;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -977,8 +979,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         unsigned vm = 0;
         for (int ky = 0; ky < a.kh; ++ky)
             if ((unsigned)(oy - a.ph + ky) < (unsigned)H) vm |= 1u << ky;
-        vmk[i] = ok ? vm : 0u;
-        wl64[i] = W * 64;
+        wlv[i] = W * 64 + (int)(ok ? vm : 0u);
         base[i] = (first + b * H * W + (oy - a.ph) * W + ox) * 64 + ((slot ^ swz(j)) << 4);
     }
     __amdgpu_buffer_rsrc_t xr[2];
@@ -991,7 +992,9 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
 
     // fragment read offsets: activation row tile i at tap kx = staged rows 64 wm + 16 i + r16 + kx, or the zero row where the tap leaves the image row
     const int r16 = lane & 15, kc = lane >> 4;
-    int xo[3][4], woff[4];
+    // (row tiles 16 apart share their chunk swizzle -- it depends on bits 2, 3 of the row -- so tile i / column tile j is a constant 1 KB further:
+    // one register for the weight fragments and one for the unmasked middle tap instead of four each)
+    int xo[3][4], woff0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = wm * 64 + i * 16 + r16;
@@ -999,18 +1002,17 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         decode(m0 + r, first, b, oy, ox, H, W);
         const int z = lds_off(KX3_ZROW, kc);
         xo[0][i] = ox == 0 ? z : lds_off(r, kc);
-        xo[1][i] = lds_off(r + 1, kc);
+        xo[1][i] = lds_off(r + 1, kc);           // (= xo[1][0] + 1024 i: only xo[1][0] stays live)
         xo[2][i] = ox == W - 1 ? z : lds_off(r + 2, kc);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) woff[j] = KX3_W0 + lds_off(wn * 64 + j * 16 + r16, kc);
+    woff0 = KX3_W0 + lds_off(wn * 64 + r16, kc);
 
     // stage counters of the NEXT activation stage to issue: (channel slab, ky); stage index and its buffer
     int st_c = 0, st_ky = 0, st_buf = 0;
     auto dma_a = [&](int i, int p) {          // piece (row group of duty i, plane p) of the stage (st_c, st_ky) into buffer st_buf
         const int q = i == 0 ? wave : (i == 1 ? wave + 8 : 16);
-        const unsigned oob = ((vmk[i] >> st_ky) & 1u) ^ 1u;
-        const unsigned off = (unsigned)(base[i] + st_ky * wl64[i] + (grp * cslabs + ((ABL & 8) ? 0 : st_c)) * (a.x_np * 64)) | (oob << 31);
+        const unsigned oob = (((unsigned)wlv[i] >> st_ky) & 1u) ^ 1u;
+        const unsigned off = (unsigned)(base[i] + st_ky * (wlv[i] & ~63) + (grp * cslabs + ((ABL & 8) ? 0 : st_c)) * (a.x_np * 64)) | (oob << 31);
         if constexpr ((ABL & 16) != 0) {        // the same number of DMAs into the same LDS places, but reading weight-tile bytes the way dma_w does
             __builtin_amdgcn_global_load_lds((glb_ptr)(wtile + (size_t)(q & 15) * 1024 + lane * 16), (lds_ptr)(smem + st_buf * KX3_ABUF + p * KX3_XPL + q * 1024), 16, 0, 0);
         } else
@@ -1020,13 +1022,19 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         st_buf ^= 1;
         if (++st_ky == a.kh) { st_ky = 0; ++st_c; }
     };
+    // weight pieces as buffer loads: per-lane part of the address = 16 lane (one loop-invariant register), the rest in the scalar offset
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wtile), 0, a.slabs * KX3_WBUF, 0x00020000);
+    const int lane16 = lane * 16;
     auto dma_w = [&](int slab, int wslot) {
         uint8_t* wb = smem + KX3_W0 + wslot * KX3_WBUF;
-        const uint8_t* wsrc = wtile + (size_t)slab * KX3_WBUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int wi = wave + 8 * j;
-            if (!(ABL & 1)) __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + wi * 1024 + lane * 16), (lds_ptr)(wb + wi * 1024), 16, 0, 0);
+#if KX3_WBUFFER
+            if (!(ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(wb + wi * 1024), 16, lane16, slab * KX3_WBUF + wi * 1024, 0, 0);
+#else
+            if (!(ABL & 1)) __builtin_amdgcn_global_load_lds((glb_ptr)(wtile + (size_t)slab * KX3_WBUF + wi * 1024 + lane16), (lds_ptr)(wb + wi * 1024), 16, 0, 0);
+#endif
         }
     };
 
@@ -1038,6 +1046,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc16[i][j][r] = 0.0f; accl16[i][j][r] = 0.0f; }
 
+#define KX3_XO(K_, I_) ((K_) == 1 ? xo[1][0] + (I_) * 1024 : xo[K_][I_])
 #define MM16(x_, y_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x_), __builtin_bit_cast(f16x8, y_), c_, 0, 0, 0)
     const int S = a.slabs;                       // K-slabs = 3 taps x stages
     // prologue: stage 0 whole, weight slabs 0 and 1
@@ -1045,16 +1054,17 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     stage_advance();
     dma_w(0, 0);
     dma_w(min(1, S - 1), 1);
-    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    if (KX3_SPREAD == 2) dma_w(min(2, S - 1), 2);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KX3_SPREAD == 2 ? 4 : 2) : "memory");
     bf16x8 bf[4][2], af0[2][2], af1[2][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(smem + woff[j] + p * WPL);
+        for (int p = 0; p < 2; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(smem + woff0 + j * 1024 + p * WPL);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + xo[0][i] + p * KX3_XPL);
+        for (int p = 0; p < 2; ++p) af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + KX3_XO(0, i) + p * KX3_XPL);
     int s = 0;                                   // K-slab of the tap being multiplied
     // first half of tap KX_: row tiles 0, 1 (fragments in registers); reads the second half's activation fragments (same stage, same tap) and issues
     // this tap's DMAs: the next stage's pieces (taps 0 and 1 only), then weight slab s + 2 into the slot tap KX_ - 1 just left
@@ -1062,10 +1072,10 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     {                                                                                                                               \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
             _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                           \
-                if (!(ABL & 4)) af1[i][p] = *reinterpret_cast<const bf16x8*>(smem + xo[KX_][2 + i] + p * KX3_XPL);                 \
-        if (KX_ == 0) { dma_a(0, 0); dma_a(0, 1); if (!KX3_SPREAD) dma_a(1, 0); }                                                   \
-        if (KX_ == 1) { if (!KX3_SPREAD) dma_a(1, 1); dma_a(2, wave & 1); stage_advance(); }                                        \
-        dma_w(min(s + 2, S - 1), (KX_ + 2) % 3);                                                                                    \
+                if (!(ABL & 4)) af1[i][p] = *reinterpret_cast<const bf16x8*>(smem + KX3_XO(KX_, 2 + i) + p * KX3_XPL);                 \
+        if (KX_ == 0) { dma_a(0, 0); dma_a(0, 1); if (KX3_SPREAD != 1) dma_a(1, 0); }                                                 \
+        if (KX_ == 1) { if (KX3_SPREAD != 1) dma_a(1, 1); dma_a(2, wave & 1); stage_advance(); }                                      \
+        if (KX3_SPREAD != 2) dma_w(min(s + 2, S - 1), (KX_ + 2) % 3);                                                               \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                             \
             const f32x4 c0 = MM16(af0[0][1], bf[j][0], accl16[0][j]);                                                               \
             const f32x4 c1 = MM16(af0[1][1], bf[j][0], accl16[1][j]);                                                               \
@@ -1074,7 +1084,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
             acc16[1][j] = MM16(af0[1][0], bf[j][0], acc16[1][j]);                                                                   \
             accl16[1][j] = MM16(af0[1][0], bf[j][1], c1);                                                                           \
         }                                                                                                                           \
-        constexpr int ND = KX3_SPREAD ? (KX_ == 0 ? 4 : (KX_ == 1 ? 3 : 2)) : (KX_ == 0 ? 5 : (KX_ == 1 ? 4 : 2));                  \
+        constexpr int ND = KX3_SPREAD == 2 ? (KX_ == 0 ? 3 : (KX_ == 1 ? 2 : 1)) : KX3_SPREAD ? (KX_ == 0 ? 4 : (KX_ == 1 ? 3 : 2)) : (KX_ == 0 ? 5 : (KX_ == 1 ? 4 : 2)); \
         _Pragma("unroll") for (int k = 0; k < KX3_SCHED; ++k) {                                                                            \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                      \
             if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                           \
@@ -1087,11 +1097,11 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     // shift (the offsets already point into the next stage's buffer when KX_ = 2), weight fragments from the next tap's slot
 #define KX3_HALF1(KX_, PRE_)                                                                                                        \
     {                                                                                                                               \
-        if (KX3_SPREAD && KX_ == 0) { dma_a(1, 0); dma_a(1, 1); }                                                                   \
+        if (KX3_SPREAD == 1 && KX_ == 0) { dma_a(1, 0); dma_a(1, 1); }                                                              \
         if (PRE_ && !(ABL & 4)) {                                                                                                   \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
                 _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                       \
-                    af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + xo[(KX_ + 1) % 3][i] + p * KX3_XPL);                        \
+                    af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + KX3_XO((KX_ + 1) % 3, i) + p * KX3_XPL);                        \
         }                                                                                                                           \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                             \
             const f32x4 c0 = MM16(af1[0][1], bf[j][0], accl16[2][j]);                                                               \
@@ -1102,17 +1112,18 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
             accl16[3][j] = MM16(af1[1][0], bf[j][1], c1);                                                                           \
             if (PRE_ && !(ABL & 4)) {                                                                                               \
                 _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                       \
-                    bf[j][p] = *reinterpret_cast<const bf16x8*>(smem + woff[j] + ((KX_ + 1) % 3) * KX3_WBUF + p * WPL);             \
+                    bf[j][p] = *reinterpret_cast<const bf16x8*>(smem + woff0 + j * 1024 + ((KX_ + 1) % 3) * KX3_WBUF + p * WPL);             \
             }                                                                                                                       \
         }                                                                                                                           \
+        if (KX3_SPREAD == 2) dma_w(min(s + 3, S - 1), KX_);          /* weight slab s + 3 into the slot tap s has left (after the reads in source order: the compiler orders LDS reads against an LDS-DMA) */ \
         if (PRE_) {                                                                                                                 \
             _Pragma("unroll") for (int k = 0; k < KX3_SCHED; ++k) {                                                                        \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                  \
                 if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                       \
                 else if (k >= 6 && ((k - 6) % 6) < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-                if (KX3_SPREAD && KX_ == 0) {                                                                                       \
+                if ((KX3_SPREAD == 1 && KX_ == 0) || KX3_SPREAD == 2) {                                                             \
                     __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                                                              \
-                    if (k == 9 || k == 21) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                       \
+                    if (k == (KX3_SPREAD == 2 ? 20 : 9) || k == (KX3_SPREAD == 2 ? 23 : 21)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
                 }                                                                                                                   \
             }                                                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                                      \
@@ -1125,14 +1136,14 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         {                                                                                 \
             const int d = ((T_) & 1) ? -KX3_ABUF : KX3_ABUF;                              \
             _Pragma("unroll") for (int k = 0; k < 3; ++k)                                 \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) xo[k][i] += d;              \
+                _Pragma("unroll") for (int i = 0; i < (k == 1 ? 1 : 4); ++i) xo[k][i] += d; \
         }
     for (int t = 0; t < T - 1; ++t) {
-        KX3_BARRIER(KX3_SPREAD ? 4 : 5);
+        KX3_BARRIER(KX3_SPREAD == 2 ? 5 : KX3_SPREAD ? 4 : 5);
         KX3_HALF1(0, true);
         ++s;
         KX3_HALF0(1);
-        KX3_BARRIER(KX3_SPREAD ? 5 : 4);
+        KX3_BARRIER(KX3_SPREAD == 2 ? 7 : KX3_SPREAD ? 5 : 4);
         KX3_HALF1(1, true);
         ++s;
         KX3_HALF0(2);
@@ -1143,17 +1154,18 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         ++s;
         KX3_HALF0(0);
     }
-    KX3_BARRIER(KX3_SPREAD ? 4 : 5);
+    KX3_BARRIER(KX3_SPREAD == 2 ? 5 : KX3_SPREAD ? 4 : 5);
     KX3_HALF1(0, true);
     ++s;
     KX3_HALF0(1);
-    KX3_BARRIER(KX3_SPREAD ? 5 : 4);
+    KX3_BARRIER(KX3_SPREAD == 2 ? 7 : KX3_SPREAD ? 5 : 4);
     KX3_HALF1(1, true);
     ++s;
     KX3_HALF0(2);
     KX3_BARRIER(2);
 #undef KX3_FLIP
     KX3_HALF1(2, false);
+#undef KX3_XO
 #undef KX3_HALF0
 #undef KX3_HALF1
 #undef KX3_BARRIER
@@ -2032,7 +2044,7 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
     }
 #endif
     if (tn.kx3 && a.fmt == 1 && ring && mg == 2 && !dual && !win && a.splitk == 1 && a.kw == 3 && a.pw == 1 && a.sh == 1 && a.sw == 1 &&
-        a.slabs % 3 == 0 && a.kh <= 8 && full) {
+        a.slabs % 3 == 0 && a.kh <= 6 && full) {
         // kx-reuse staging (conv_planar_kx3_kernel): one staged run of BM + 2 pixels per (channel slab, ky) serves the three taps of a kernel row
         static std::atomic<bool> kx3_reserved[STM_MAX_DEVICES];
         constexpr size_t lds = 8 * 64 * (64 + 4) * sizeof(float) > (size_t)KX3_LDS_LOOP ? 8 * 64 * (64 + 4) * sizeof(float) : (size_t)KX3_LDS_LOOP;
