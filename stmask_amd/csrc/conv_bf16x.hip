@@ -910,9 +910,6 @@ constexpr int KX3_LDS_LOOP = KX3_W0 + 3 * KX3_WBUF;
 #ifndef KX3_SCHED
 #define KX3_SCHED 24     // 0: no schedule hints (experiment)
 #endif
-#ifndef KX3_SPREAD
-#define KX3_SPREAD 0     // experiments: 1 = a stage's pieces spread over three halves (2 + 2 + 1) instead of two (3 + 2); 2 = weight slab s + 3 issued in the second half of tap s (activation pieces alone in the first halves)
-#endif
 #ifndef KX3_WBUFFER
 #define KX3_WBUFFER 1    // weight pieces as buffer loads (scalar offset + 16 lane: 242 registers, -0.8 %); 0 = global_load_lds with a 64-bit per-lane address
 #endif
@@ -1054,8 +1051,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     stage_advance();
     dma_w(0, 0);
     dma_w(min(1, S - 1), 1);
-    if (KX3_SPREAD == 2) dma_w(min(2, S - 1), 2);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KX3_SPREAD == 2 ? 4 : 2) : "memory");
+    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
     bf16x8 bf[4][2], af0[2][2], af1[2][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1073,9 +1069,9 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
             _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                           \
                 if (!(ABL & 4)) af1[i][p] = *reinterpret_cast<const bf16x8*>(smem + KX3_XO(KX_, 2 + i) + p * KX3_XPL);                 \
-        if (KX_ == 0) { dma_a(0, 0); dma_a(0, 1); if (KX3_SPREAD != 1) dma_a(1, 0); }                                                 \
-        if (KX_ == 1) { if (KX3_SPREAD != 1) dma_a(1, 1); dma_a(2, wave & 1); stage_advance(); }                                      \
-        if (KX3_SPREAD != 2) dma_w(min(s + 2, S - 1), (KX_ + 2) % 3);                                                               \
+        if (KX_ == 0) { dma_a(0, 0); dma_a(0, 1); dma_a(1, 0); }                                                 \
+        if (KX_ == 1) { dma_a(1, 1); dma_a(2, wave & 1); stage_advance(); }                                      \
+        dma_w(min(s + 2, S - 1), (KX_ + 2) % 3);                                                               \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                             \
             const f32x4 c0 = MM16(af0[0][1], bf[j][0], accl16[0][j]);                                                               \
             const f32x4 c1 = MM16(af0[1][1], bf[j][0], accl16[1][j]);                                                               \
@@ -1084,7 +1080,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
             acc16[1][j] = MM16(af0[1][0], bf[j][0], acc16[1][j]);                                                                   \
             accl16[1][j] = MM16(af0[1][0], bf[j][1], c1);                                                                           \
         }                                                                                                                           \
-        constexpr int ND = KX3_SPREAD == 2 ? (KX_ == 0 ? 3 : (KX_ == 1 ? 2 : 1)) : KX3_SPREAD ? (KX_ == 0 ? 4 : (KX_ == 1 ? 3 : 2)) : (KX_ == 0 ? 5 : (KX_ == 1 ? 4 : 2)); \
+        constexpr int ND = KX_ == 0 ? 5 : (KX_ == 1 ? 4 : 2);                                                                       \
         _Pragma("unroll") for (int k = 0; k < KX3_SCHED; ++k) {                                                                            \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                      \
             if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                           \
@@ -1097,7 +1093,6 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     // shift (the offsets already point into the next stage's buffer when KX_ = 2), weight fragments from the next tap's slot
 #define KX3_HALF1(KX_, PRE_)                                                                                                        \
     {                                                                                                                               \
-        if (KX3_SPREAD == 1 && KX_ == 0) { dma_a(1, 0); dma_a(1, 1); }                                                              \
         if (PRE_ && !(ABL & 4)) {                                                                                                   \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
                 _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                       \
@@ -1115,16 +1110,11 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
                     bf[j][p] = *reinterpret_cast<const bf16x8*>(smem + woff0 + j * 1024 + ((KX_ + 1) % 3) * KX3_WBUF + p * WPL);             \
             }                                                                                                                       \
         }                                                                                                                           \
-        if (KX3_SPREAD == 2) dma_w(min(s + 3, S - 1), KX_);          /* weight slab s + 3 into the slot tap s has left (after the reads in source order: the compiler orders LDS reads against an LDS-DMA) */ \
         if (PRE_) {                                                                                                                 \
             _Pragma("unroll") for (int k = 0; k < KX3_SCHED; ++k) {                                                                        \
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                  \
                 if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                       \
                 else if (k >= 6 && ((k - 6) % 6) < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-                if ((KX3_SPREAD == 1 && KX_ == 0) || KX3_SPREAD == 2) {                                                             \
-                    __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                                                              \
-                    if (k == (KX3_SPREAD == 2 ? 20 : 9) || k == (KX3_SPREAD == 2 ? 23 : 21)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-                }                                                                                                                   \
             }                                                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                                      \
         }                                                                                                                           \
@@ -1139,11 +1129,11 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
                 _Pragma("unroll") for (int i = 0; i < (k == 1 ? 1 : 4); ++i) xo[k][i] += d; \
         }
     for (int t = 0; t < T - 1; ++t) {
-        KX3_BARRIER(KX3_SPREAD == 2 ? 5 : KX3_SPREAD ? 4 : 5);
+        KX3_BARRIER(5);
         KX3_HALF1(0, true);
         ++s;
         KX3_HALF0(1);
-        KX3_BARRIER(KX3_SPREAD == 2 ? 7 : KX3_SPREAD ? 5 : 4);
+        KX3_BARRIER(4);
         KX3_HALF1(1, true);
         ++s;
         KX3_HALF0(2);
@@ -1154,11 +1144,11 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         ++s;
         KX3_HALF0(0);
     }
-    KX3_BARRIER(KX3_SPREAD == 2 ? 5 : KX3_SPREAD ? 4 : 5);
+    KX3_BARRIER(5);
     KX3_HALF1(0, true);
     ++s;
     KX3_HALF0(1);
-    KX3_BARRIER(KX3_SPREAD == 2 ? 7 : KX3_SPREAD ? 5 : 4);
+    KX3_BARRIER(4);
     KX3_HALF1(1, true);
     ++s;
     KX3_HALF0(2);
