@@ -44,9 +44,12 @@ def main():
             return None
         return {"launches": nf, "fetch_bytes_per_launch": fb / nf, "write_bytes_per_launch": wb / nw, "traffic_bytes_per_launch": fb / nf + wb / nw}
 
-    g = group_any(("conv_planar_kernel", "conv_kxr_kernel"))
+    g = group_any(("conv_planar_kernel", "conv_planar_kx3_kernel", "conv_kxr_kernel"))
     if g:
-        doc["conv_planar"] = {"kernel": "conv_planar_kernel<*> + conv_kxr_kernel<*> (all launches of bench.py at batch 32, fp16x2 plane format)", **g}
+        doc["conv_planar"] = {"kernel": "conv_planar_kernel<*> + conv_planar_kx3_kernel + conv_kxr_kernel<*> (all launches of bench.py at batch 32, fp16x2 plane format)", **g}
+    g = group("conv_planar_kx3_kernel")
+    if g:
+        doc["conv_planar_kx3"] = {"kernel": "conv_planar_kx3_kernel (stride-1 kw = 3 layers on 256-pixel tiles: head towers, proto-net, FPN 3x3; kx-reuse staging)", **g}
     g = group("conv_chain_kernel")
     if g:
         doc["conv_chain"] = {"kernel": "conv_chain_kernel<*> (layer1's three bottlenecks at batch 32: conv2 3x3 -> conv3 + shortcut -> the next block's conv1; "

@@ -20,6 +20,7 @@ sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
 
 def cat(name):
     n = name
+    if "conv_planar_kx3_kernel" in n: return "ours: conv_planar_kx3_kernel (plane-split dense conv, kx-reuse staging)"
     if "conv_planar_kernel" in n: return "ours: conv_planar_kernel (plane-split dense conv)"
     if "conv_kxr_kernel" in n: return "ours: conv_kxr_kernel (narrow layers, kx-reuse)"
     if "conv_bf16x" in n: return "ours: conv_bf16x (register-staged variant)"
