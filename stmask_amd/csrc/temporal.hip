@@ -362,35 +362,52 @@ extern "C" int stm_roi_align_avg_f32(const float* feat, const float* rois, float
 }
 
 // ---- TemporalNet's tail: AvgPool2d((7, 7)) + fc + fc_coeff (track_to_segment_head.py:33-37) -------------------------------------------------
-// Input: the pooled SUMS stm_conv2d_planar_windows_pool_f32 accumulated (pool_fix[n][C], unsigned 32.32 fixed point).  One workgroup per RoI:
+// Input: the pooled SUMS stm_conv2d_planar_windows_pool_f32 accumulated (pool_fix[n][C], unsigned 32.32 fixed point).  One workgroup per eight RoIs:
 // mean = sum / npix (one rounding, in double), kept in LDS; output o = bias[o] + sum_k mean[k] w[o][k]: a lane adds its k = lane, lane + 64, ... in
 // order, the 64 lane sums are folded by a butterfly -- a fixed order, the same on every run.  With `clear` the consumed sums are zeroed for the
 // next step (no separate memset launch).
 namespace {
-__global__ __launch_bounds__(256) void temporal_pool_fc_kernel(unsigned long long* __restrict__ pool_fix, int C, double inv, const float* __restrict__ w,
+constexpr int TPF_R = 8;      // RoIs per workgroup: a row of the stacked weight matrix is read once per 8 RoIs
+__global__ __launch_bounds__(256) void temporal_pool_fc_kernel(unsigned long long* __restrict__ pool_fix, int n, int C, double inv, const float* __restrict__ w,
                                                               const float* __restrict__ bias, int n_out, int n_first, float* __restrict__ out,
                                                               float* __restrict__ out2, float* __restrict__ pooled_out, int clear)
 {
-    extern __shared__ float mean[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long* row = pool_fix + (size_t)b * C;
-    for (int c = tid; c < C; c += 256) {
-        const float m = (float)((double)row[c] * inv);
-        mean[c] = m;
-        if (pooled_out) pooled_out[(size_t)b * C + c] = m;
-        if (clear) row[c] = 0ull;
+    extern __shared__ float mean[];                       // [TPF_R][C]
+    const int b0 = blockIdx.x * TPF_R, nr = min(TPF_R, n - b0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long* rows = pool_fix + (size_t)b0 * C;
+    for (int idx = tid; idx < nr * C; idx += 256) {       // (the RoIs' rows are contiguous: one linear sweep)
+        const float m = (float)((double)rows[idx] * inv);
+        mean[idx] = m;
+        if (pooled_out) pooled_out[(size_t)b0 * C + idx] = m;
+        if (clear) rows[idx] = 0ull;
     }
+    for (int idx = nr * C + tid; idx < TPF_R * C; idx += 256) mean[idx] = 0.0f;
     __syncthreads();
     for (int o = wave; o < n_out; o += 4) {
         const float* wr = w + (size_t)o * C;
-        float s = 0.0f;
-        for (int k = lane; k < C; k += 64) s = __builtin_fmaf(mean[k], wr[k], s);
+        float s[TPF_R];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        for (int r = 0; r < TPF_R; ++r) s[r] = 0.0f;
+        for (int k = lane; k < C; k += 64) {
+            const float wv = wr[k];
+#pragma unroll
+            for (int r = 0; r < TPF_R; ++r) s[r] = __builtin_fmaf(mean[r * C + k], wv, s[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < TPF_R; ++r) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) s[r] += __shfl_xor(s[r], d, 64);
+        }
         if (lane == 0) {
-            const float v = s + (bias ? bias[o] : 0.0f);
-            if (o < n_first) out[(size_t)b * n_first + o] = v;
-            else out2[(size_t)b * (n_out - n_first) + (o - n_first)] = v;
+            const float bo = bias ? bias[o] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < TPF_R; ++r) {
+                if (r >= nr) break;
+                const float v = s[r] + bo;
+                if (o < n_first) out[(size_t)(b0 + r) * n_first + o] = v;
+                else out2[(size_t)(b0 + r) * (n_out - n_first) + (o - n_first)] = v;
+            }
         }
     }
 }
@@ -403,10 +420,10 @@ extern "C" int stm_temporal_pool_fc_f32(unsigned long long* pool_fix, int n, int
     STM_REQUIRE(n >= 0, STM_EINVAL, "%s: n=%d", who, n);
     if (n == 0) return STM_OK;
     STM_REQUIRE(pool_fix && weight && out, STM_ENULL, "%s: pool_fix / weight / out must be non-NULL", who);
-    STM_REQUIRE(C > 0 && C <= 16384 && npix > 0 && n_out > 0, STM_EINVAL, "%s: C (%d, at most 16384), npix (%d), n_out (%d)", who, C, npix, n_out);
+    STM_REQUIRE(C > 0 && C <= 2048 && npix > 0 && n_out > 0, STM_EINVAL, "%s: C (%d, at most 2048), npix (%d), n_out (%d)", who, C, npix, n_out);
     if (!out2) n_first = n_out;
     STM_REQUIRE(n_first >= 0 && n_first <= n_out, STM_EINVAL, "%s: n_first (%d) must lie in [0, n_out]", who, n_first);
-    hipLaunchKernelGGL(temporal_pool_fc_kernel, dim3(n), dim3(256), (size_t)C * sizeof(float), stm_hs(stream), pool_fix, C,
+    hipLaunchKernelGGL(temporal_pool_fc_kernel, dim3(stm_cdiv(n, TPF_R)), dim3(256), (size_t)TPF_R * C * sizeof(float), stm_hs(stream), pool_fix, n, C,
                        1.0 / (4294967296.0 * (double)npix), weight, bias, n_out, n_first, out, out2, pooled_out, clear);
     STM_CHECK_LAUNCH("temporal_pool_fc_kernel");
     return STM_OK;
