@@ -566,14 +566,24 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const typename std:
             if (++s_ky == a.kh) { s_ky = 0; s_t = 0; ++s_c; }
         }
     };
+    // weight pieces as buffer loads: the per-lane part of the address is 16 lane (one loop-invariant register), slab and piece go into the scalar offset
+    // (round 4, measured on conv_planar_kx3_kernel: -0.8 % against global_load_lds with a 64-bit per-lane address; CV_WBUFFER=0 restores that form)
+#ifndef CV_WBUFFER
+#define CV_WBUFFER 1
+#endif
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wtile), 0, a.slabs * WBUF, 0x00020000);
+    const int lane16 = lane * 16;
     auto dma_w = [&](int slab, int buf) {
         uint8_t* wb = smem + buf * BUF + XBUF;
-        const uint8_t* wsrc = wtile + (size_t)slab * WBUF;
 #pragma unroll
         for (int j = 0; j < WDMA; ++j) {
             const int wi = wave + NWAVES * j;
             // (default cache policy: the nontemporal hint on this stream, which every CU re-reads from L2, measured -1.5 %)
-            __builtin_amdgcn_global_load_lds((glb_ptr)(wsrc + wi * 1024 + lane * 16), (lds_ptr)(wb + wi * 1024), 16, 0, 0);
+#if CV_WBUFFER
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(wb + wi * 1024), 16, lane16, slab * WBUF + wi * 1024, 0, 0);
+#else
+            __builtin_amdgcn_global_load_lds((glb_ptr)(wtile + (size_t)slab * WBUF + wi * 1024 + lane16), (lds_ptr)(wb + wi * 1024), 16, 0, 0);
+#endif
         }
     };
 
