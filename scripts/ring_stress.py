@@ -192,12 +192,36 @@ def main():
             out.append((f"{name} B={B}", launch, fresh, None))
         return out
 
+    def window_cases(B):
+        """TemporalNet's border-class window set (stm_conv2d_planar_windows_f32): the kw = 3 classes on conv_planar_kx3_kernel<WIN>, the others on
+        conv_planar_kernel<CLS>, one 3x3 layer 512 -> 512 on 7x7 RoI maps, 112 RoIs per clip."""
+        from stmask_amd.planar import border_windows, _BORDER_CLASSES
+        n, C, O, h, w = 112 * B, 512, 512, 7, 7
+        wt, bs = rnd(O, C, 3, 3, scale=(C * 9) ** -0.5).to(dev), rnd(O, scale=0.3).to(dev)
+        wsc = ops._pow2_wscale(wt)
+        wins, packed = [], []
+        for ci, win in border_windows(h, w):
+            _, _, k0y, k1y, k0x, k1x = _BORDER_CLASSES[ci]
+            wins.append(win)
+            packed.append(ops.conv_pack_weights(wt[:, :, k0y:k1y, k0x:k1x].contiguous(), tile_n=128, fmt=1, wscale=wsc)[0])
+        sets = [ops.split_planes(rnd(n * h * w, C).abs().to(dev), 1) for _ in range(args.sets)]
+
+        def launch(k, outs):
+            ops.conv2d_planar_windows(sets[k], packed, wins, bs, n, h, w, C, O, h, w, 1.0 / wsc, relu=True, out_planes=outs[0])
+
+        def fresh():
+            return (torch.empty(2, O // 32, n * h * w, 32, device=dev, dtype=torch.float16), None)
+
+        return [(f"window set 3x3 512->512 on 7x7 maps (conv_planar_kx3_kernel<WIN> + conv_planar_kernel<CLS>) B={B}", launch, fresh, None)]
+
     which = args.cases.split(",")
     cases = []
     for B in [int(b) for b in args.clips.split(",")]:
         if "chain" in which:
             cases += chain_cases(B)
         cases += conv_cases(B, which)
+        if "planar" in which:
+            cases += window_cases(B)
 
     # ------------------------------------------------------------------------------------------------------------------ solo references
     NAN16 = float("nan")

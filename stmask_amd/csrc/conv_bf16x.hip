@@ -356,6 +356,34 @@ __global__ __launch_bounds__(256) void planar_splitk_finish_kernel(const PlanarA
 // ABL (builds with -DSTM_ABLATE only): timing ablations of the ring loop, RESULTS ARE WRONG -- 1 no DMA, 2 no barrier, 4 no
 // fragment reads, 8 no wait for the DMAs, 16 activation DMA on every third slab only (the traffic of a kx-reuse staging), 32 no
 // activation DMA, 64 no weight DMA.
+// AvgPool2d over the whole output image folded into the epilogue of a window-set launch (TemporalNet: track_to_segment_head.py:30-33).  The wave owns 64
+// class pixels x 64 channels, parked in LDS: lane = channel, the rows are walked once; the pixels of one image are consecutive rows of a class (hw of
+// them), so the running sum is flushed whenever the image index advances, and at the end of the block (an image cut by a block or class boundary arrives
+// in several pieces).  Each piece is an fp32 sum in row order, converted exactly to 32.32 fixed point and added with an integer atomic: the total does
+// not depend on the order of arrival.  mw = first class pixel of the wave's rows, col = the lane's output channel.
+__device__ __forceinline__ void pooled_epilogue(const PlanarArgs& a, unsigned long long* pool, int pool_ld, uint8_t* smem, int wave, int lane, int mw, int col)
+{
+    constexpr int EP_LD = 32 * 2 + 4;
+    const float* park = park_base<2>(smem, wave);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int hw = a.Ho * a.Wo;
+    const int rows = min(64, a.M - mw);
+    int b = mw / hw, r = mw - b * hw;
+    const float bias = a.bias ? a.bias[col] : 0.0f;
+    float sum = 0.0f;
+    for (int row = 0; row < rows; ++row) {
+        sum += __builtin_fmaxf(__builtin_fmaf(park[row * EP_LD + lane], a.out_scale, bias), 0.0f);
+        if (++r == hw || row == rows - 1) {
+            if (!(sum < 4.0e9f) && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;     // (also NaN)
+            const unsigned hi = (unsigned)sum;
+            const unsigned lo = (unsigned)((sum - (float)hi) * 4294967296.0f);
+            __hip_atomic_fetch_add(pool + (size_t)b * pool_ld + col, ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum = 0.0f;
+            if (r == hw) { r = 0; ++b; }
+        }
+    }
+}
+
 // (Tried and removed, round 2: loading the residual planes of a 64-channel tile BEFORE the K loop -- no change on the HBM-bound
 // expanding 1x1 convolutions, 337 vs 345 us, for 32 more live registers and one wave per SIMD less; and resident workgroups
 // walking the tiles instead of one workgroup per tile -- 404 -> 451 us.  Neither the epilogue's second memory round trip nor
@@ -843,33 +871,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kernel(const typename std:
     park16<NJ>(acc16, accl16, smem, wave, lane, LS);
     if constexpr (CLS && NJ == 2) {
         if (a_in.pool) {
-            // AvgPool2d over the whole output image folded into the epilogue (TemporalNet: track_to_segment_head.py:30-33).  The wave owns 64 class
-            // pixels x 64 channels: lane = channel, the rows are walked once; the pixels of one image are consecutive rows of a class (hw of them), so
-            // the running sum is flushed whenever the image index advances, and at the end of the block (an image cut by a block or class boundary
-            // arrives in several pieces).  Each piece is an fp32 sum in row order, converted exactly to 32.32 fixed point and added with an integer
-            // atomic: the total does not depend on the order of arrival.
-            constexpr int EP_LD = 32 * NJ + 4;
-            const float* park = park_base<NJ>(smem, wave);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int hw = a.Ho * a.Wo;
-            const int mw = m0 + wm * 64;
-            const int rows = min(64, a.M - mw);
-            int b = mw / hw, r = mw - b * hw;
-            const int col = nt * BN + wn * 64 + lane;
-            const float bias = a.bias ? a.bias[col] : 0.0f;
-            float sum = 0.0f;
-            for (int row = 0; row < rows; ++row) {
-                sum += __builtin_fmaxf(__builtin_fmaf(park[row * EP_LD + lane], a.out_scale, bias), 0.0f);
-                if (++r == hw || row == rows - 1) {
-                    if (!(sum < 4.0e9f) && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;     // (also NaN)
-                    const unsigned hi = (unsigned)sum;
-                    const unsigned lo = (unsigned)((sum - (float)hi) * 4294967296.0f);
-                    __hip_atomic_fetch_add(a_in.pool + (size_t)b * a_in.pool_ld + col, ((unsigned long long)hi << 32) | lo, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                    sum = 0.0f;
-                    if (r == hw) { r = 0; ++b; }
-                }
-            }
+            pooled_epilogue(a, a_in.pool, a_in.pool_ld, smem, wave, lane, m0 + wm * 64, nt * BN + wn * 64 + lane);
             return;
         }
     }
@@ -926,18 +928,44 @@ constexpr int KX3_LDS_LOOP = KX3_W0 + 3 * KX3_WBUF;
 #ifndef KX3_ABL
 #define KX3_ABL 0        // timing builds (RESULTS WRONG): 1 no DMA at all, 2 no activation DMA, 4 no fragment reads, 8 every stage stages channel slab 0 (L2-resident rows), 16 activation pieces read weight bytes instead (same count of DMAs, hot lines)
 #endif
-template <int ABL = 0>
-__global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArgs a)
+template <int ABL = 0, bool WIN = false>
+__global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const typename std::conditional<WIN, PlanarArgsCls, PlanarArgs>::type a_in)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int NJ = 2, BM = 256, BN = 128, WPL = BN * 64;
-    const int tiles = a.m_tiles * a.n_tiles;
-    const int per_xcd = (tiles + 7) >> 3;
-    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (logical >= tiles) return;
-    const int mt = a.n_tiles == 1 ? logical : (a.n_tiles == 2 ? logical >> 1 : (a.n_tiles == 4 ? logical >> 2 : logical / a.n_tiles));
-    const int nt = logical - mt * a.n_tiles;
+    // staged rows per activation buffer: BM + 2 (17 row groups of 16) -- or, WIN, the kw = 3 classes of a window set (TemporalNet's border classes with
+    // all three column taps: the 5-pixel-wide windows of a 7x7 map): a tile's 256 class pixels are at most 53 window rows, each staged as its Wo + 2 input
+    // pixels (371 rows, 24 groups), and tap kx of pixel (window row q, ox) is staged row (Wo + 2) q + ox + kx -- every tap inside the map, no zero row
+    constexpr int XROWS = WIN ? 384 : KX3_XROWS, XPL = XROWS * 64, ABUF = 2 * XPL, W0 = 2 * ABUF;
+    int logical, n_tiles_ = a_in.n_tiles, cls_c = 0;
+    if constexpr (WIN) {
+        // tile -> class, as conv_planar_kernel<..., CLS>: pixel tiles dealt round-robin to the XCDs, each with all its channel tiles
+        const int j = blockIdx.x >> 3;
+        const int jm = j / n_tiles_, nt_ = j - jm * n_tiles_;
+        logical = (jm * 8 + (int)(blockIdx.x & 7)) * n_tiles_ + nt_;
+        if (logical >= a_in.cls_tiles) return;
+#pragma unroll
+        for (int i = 1; i < 9; ++i)
+            if (i < a_in.n_cls && logical >= a_in.cls[i].tile0) cls_c = i;
+        logical -= a_in.cls[cls_c].tile0;
+    } else {
+        const int tiles = a_in.m_tiles * n_tiles_;
+        const int per_xcd = (tiles + 7) >> 3;
+        logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (logical >= tiles) return;
+    }
+    const PlanarArgs& a = a_in;
+    // the fields a class replaces, as scalars (the class-adjusted copy of the whole argument block is only built for the epilogue, after the loop: kept
+    // live across the loop it went to scratch memory)
+    int KH = a.kh, PH = a.ph, PW = a.pw, HO = a.Ho, WO = a.Wo, MM = a.M, SLABS = a.slabs;
+    const uint8_t* WP = a.wp;
+    if constexpr (WIN) {
+        KH = a_in.cls[cls_c].kh; PH = a_in.cls[cls_c].ph; PW = a_in.cls[cls_c].pw; HO = a_in.cls[cls_c].Ho; WO = a_in.cls[cls_c].Wo;
+        MM = a_in.cls[cls_c].M; SLABS = a_in.cls[cls_c].slabs; WP = a_in.cls[cls_c].wp;
+    }
+    const int mt = n_tiles_ == 1 ? logical : (n_tiles_ == 2 ? logical >> 1 : (n_tiles_ == 4 ? logical >> 2 : logical / n_tiles_));
+    const int nt = logical - mt * n_tiles_;
     const int m0 = mt * BM;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -948,7 +976,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
 
     // pixel m of the launch's pixel axis -> (valid, first pixel of its level, image, row, column, level size)
     auto decode = [&](int m, int& first, int& b, int& oy, int& ox, int& H, int& W) -> bool {
-        const bool ok = m >= 0 && m < a.M;
+        const bool ok = m >= 0 && m < MM;
         const int mm = ok ? m : 0;
         H = a.H; W = a.W; first = 0;
         int local = mm;
@@ -974,26 +1002,37 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         return ok;
     };
 
-    // DMA duties of this lane: staged rows j = 16 q + (lane >> 2) of row groups q = wave, wave + 8 and 16; staged row j is launch pixel m0 - 1 + j
+    // DMA duties of this lane: staged rows j = 16 q + (lane >> 2) of row groups q = wave, wave + 8 and 16 (WIN: wave + 16); staged row j is launch pixel
+    // m0 - 1 + j -- WIN: input pixel xi - pw of window row wr0 + j / Ws, xi = j mod Ws
     int base[3], wlv[3];          // wlv = row pitch in bytes (a multiple of 64) | one validity bit per ky in the low six bits
     const int slot = lane & 3;
+    const int Ws = WO + 2, wr0 = WIN ? m0 / WO : 0;        // (WIN) staged pixels per window row; first window row of the tile
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int q = i == 0 ? wave : (i == 1 ? wave + 8 : 16);
+        const int q = i == 0 ? wave : (i == 1 ? wave + 8 : (WIN ? wave + 16 : 16));
         const int j = q * 16 + (lane >> 2);
-        int first, b, oy, ox, H, W;
-        const bool ok = decode(m0 - 1 + j, first, b, oy, ox, H, W) && j < BM + 2;
-        unsigned vm = 0;
-        for (int ky = 0; ky < a.kh; ++ky)
-            if ((unsigned)(oy - a.ph + ky) < (unsigned)H) vm |= 1u << ky;
-        wlv[i] = W * 64 + (int)(ok ? vm : 0u);
-        base[i] = (first + b * H * W + (oy - a.ph) * W + ox) * 64 + ((slot ^ swz(j)) << 4);
+        if constexpr (WIN) {
+            const int qr = j / Ws, xi = j - qr * Ws;
+            const int wr = wr0 + qr;                             // window row (image b, window line oy) of this staged pixel
+            const bool ok = wr * WO < MM;
+            const int b = wr / HO, oy = wr - b * HO;
+            wlv[i] = a.W * 64 + (ok ? 63 : 0);                   // every tap of a class lies inside the map
+            base[i] = ((b * a.H + oy - PH) * a.W + (xi - PW)) * 64 + ((slot ^ swz(j)) << 4);
+        } else {
+            int first, b, oy, ox, H, W;
+            const bool ok = decode(m0 - 1 + j, first, b, oy, ox, H, W) && j < BM + 2;
+            unsigned vm = 0;
+            for (int ky = 0; ky < KH; ++ky)
+                if ((unsigned)(oy - PH + ky) < (unsigned)H) vm |= 1u << ky;
+            wlv[i] = W * 64 + (int)(ok ? vm : 0u);
+            base[i] = (first + b * H * W + (oy - PH) * W + ox) * 64 + ((slot ^ swz(j)) << 4);
+        }
     }
     __amdgpu_buffer_rsrc_t xr[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
         xr[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.xp) + (size_t)p * a.x_pstride, 0, (int)a.plane_bytes, 0x00020000);
-    const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * KX3_WBUF;
+    const uint8_t* wtile = WP + (size_t)nt * SLABS * KX3_WBUF;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
 
@@ -1005,35 +1044,42 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = wm * 64 + i * 16 + r16;
-        int first, b, oy, ox, H, W;
-        decode(m0 + r, first, b, oy, ox, H, W);
-        const int z = lds_off(KX3_ZROW, kc);
-        xo[0][i] = ox == 0 ? z : lds_off(r, kc);
-        xo[1][i] = lds_off(r + 1, kc);           // (= xo[1][0] + 1024 i: only xo[1][0] stays live)
-        xo[2][i] = ox == W - 1 ? z : lds_off(r + 2, kc);
+        if constexpr (WIN) {
+            const int m = m0 + r;
+            const int wr = m / WO, ox = m - wr * WO;
+            const int sr = (wr - wr0) * Ws + ox;                 // staged row of tap 0
+            xo[0][i] = lds_off(sr, kc); xo[1][i] = lds_off(sr + 1, kc); xo[2][i] = lds_off(sr + 2, kc);
+        } else {
+            int first, b, oy, ox, H, W;
+            decode(m0 + r, first, b, oy, ox, H, W);
+            const int z = lds_off(KX3_ZROW, kc);
+            xo[0][i] = ox == 0 ? z : lds_off(r, kc);
+            xo[1][i] = lds_off(r + 1, kc);           // (= xo[1][0] + 1024 i: only xo[1][0] stays live)
+            xo[2][i] = ox == W - 1 ? z : lds_off(r + 2, kc);
+        }
     }
-    woff0 = KX3_W0 + lds_off(wn * 64 + r16, kc);
+    woff0 = W0 + lds_off(wn * 64 + r16, kc);
 
     // stage counters of the NEXT activation stage to issue: (channel slab, ky); stage index and its buffer
     int st_c = 0, st_ky = 0, st_buf = 0;
     auto dma_a = [&](int i, int p) {          // piece (row group of duty i, plane p) of the stage (st_c, st_ky) into buffer st_buf
-        const int q = i == 0 ? wave : (i == 1 ? wave + 8 : 16);
+        const int q = i == 0 ? wave : (i == 1 ? wave + 8 : (WIN ? wave + 16 : 16));
         const unsigned oob = (((unsigned)wlv[i] >> st_ky) & 1u) ^ 1u;
         const unsigned off = (unsigned)(base[i] + st_ky * (wlv[i] & ~63) + (grp * cslabs + ((ABL & 8) ? 0 : st_c)) * (a.x_np * 64)) | (oob << 31);
         if constexpr ((ABL & 16) != 0) {        // the same number of DMAs into the same LDS places, but reading weight-tile bytes the way dma_w does
-            __builtin_amdgcn_global_load_lds((glb_ptr)(wtile + (size_t)(q & 15) * 1024 + lane * 16), (lds_ptr)(smem + st_buf * KX3_ABUF + p * KX3_XPL + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(wtile + (size_t)(q & 15) * 1024 + lane * 16), (lds_ptr)(smem + st_buf * ABUF + p * XPL + q * 1024), 16, 0, 0);
         } else
-        if (!(ABL & 3)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(smem + st_buf * KX3_ABUF + p * KX3_XPL + q * 1024), 16, off, 0, 0, 0);
+        if (!(ABL & 3)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(smem + st_buf * ABUF + p * XPL + q * 1024), 16, off, 0, 0, 0);
     };
     auto stage_advance = [&]() {
         st_buf ^= 1;
-        if (++st_ky == a.kh) { st_ky = 0; ++st_c; }
+        if (++st_ky == KH) { st_ky = 0; ++st_c; }
     };
     // weight pieces as buffer loads: per-lane part of the address = 16 lane (one loop-invariant register), the rest in the scalar offset
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wtile), 0, a.slabs * KX3_WBUF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wtile), 0, SLABS * KX3_WBUF, 0x00020000);
     const int lane16 = lane * 16;
     auto dma_w = [&](int slab, int wslot) {
-        uint8_t* wb = smem + KX3_W0 + wslot * KX3_WBUF;
+        uint8_t* wb = smem + W0 + wslot * KX3_WBUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int wi = wave + 8 * j;
@@ -1053,11 +1099,12 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc16[i][j][r] = 0.0f; accl16[i][j][r] = 0.0f; }
 
-#define KX3_XO(K_, I_) ((K_) == 1 ? xo[1][0] + (I_) * 1024 : xo[K_][I_])
+#define KX3_XO(K_, I_) ((K_) == 1 && !WIN ? xo[1][0] + (I_) * 1024 : xo[K_][I_])
 #define MM16(x_, y_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x_), __builtin_bit_cast(f16x8, y_), c_, 0, 0, 0)
-    const int S = a.slabs;                       // K-slabs = 3 taps x stages
+    const int S = SLABS;                       // K-slabs = 3 taps x stages
     // prologue: stage 0 whole, weight slabs 0 and 1
-    dma_a(0, 0); dma_a(0, 1); dma_a(1, 0); dma_a(1, 1); dma_a(2, wave & 1);
+    dma_a(0, 0); dma_a(0, 1); dma_a(1, 0); dma_a(1, 1);
+    if (WIN) { dma_a(2, 0); dma_a(2, 1); } else dma_a(2, wave & 1);
     stage_advance();
     dma_w(0, 0);
     dma_w(min(1, S - 1), 1);
@@ -1070,7 +1117,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + KX3_XO(0, i) + p * KX3_XPL);
+        for (int p = 0; p < 2; ++p) af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + KX3_XO(0, i) + p * XPL);
     int s = 0;                                   // K-slab of the tap being multiplied
     // first half of tap KX_: row tiles 0, 1 (fragments in registers); reads the second half's activation fragments (same stage, same tap) and issues
     // this tap's DMAs: the next stage's pieces (taps 0 and 1 only), then weight slab s + 2 into the slot tap KX_ - 1 just left
@@ -1078,9 +1125,9 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     {                                                                                                                               \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                               \
             _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                           \
-                if (!(ABL & 4)) af1[i][p] = *reinterpret_cast<const bf16x8*>(smem + KX3_XO(KX_, 2 + i) + p * KX3_XPL);                 \
+                if (!(ABL & 4)) af1[i][p] = *reinterpret_cast<const bf16x8*>(smem + KX3_XO(KX_, 2 + i) + p * XPL);                 \
         if (KX_ == 0) { dma_a(0, 0); dma_a(0, 1); dma_a(1, 0); }                                                 \
-        if (KX_ == 1) { dma_a(1, 1); dma_a(2, wave & 1); stage_advance(); }                                      \
+        if (KX_ == 1) { dma_a(1, 1); if (WIN) { dma_a(2, 0); dma_a(2, 1); } else dma_a(2, wave & 1); stage_advance(); }                                      \
         dma_w(min(s + 2, S - 1), (KX_ + 2) % 3);                                                               \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                             \
             const f32x4 c0 = MM16(af0[0][1], bf[j][0], accl16[0][j]);                                                               \
@@ -1090,7 +1137,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
             acc16[1][j] = MM16(af0[1][0], bf[j][0], acc16[1][j]);                                                                   \
             accl16[1][j] = MM16(af0[1][0], bf[j][1], c1);                                                                           \
         }                                                                                                                           \
-        constexpr int ND = KX_ == 0 ? 5 : (KX_ == 1 ? 4 : 2);                                                                       \
+        constexpr int ND = KX_ == 0 ? 5 : (KX_ == 1 ? (WIN ? 5 : 4) : 2);                                                                       \
         _Pragma("unroll") for (int k = 0; k < KX3_SCHED; ++k) {                                                                            \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                      \
             if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                           \
@@ -1106,7 +1153,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
         if (PRE_ && !(ABL & 4)) {                                                                                                   \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                           \
                 _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                       \
-                    af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + KX3_XO((KX_ + 1) % 3, i) + p * KX3_XPL);                        \
+                    af0[i][p] = *reinterpret_cast<const bf16x8*>(smem + KX3_XO((KX_ + 1) % 3, i) + p * XPL);                        \
         }                                                                                                                           \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                             \
             const f32x4 c0 = MM16(af1[0][1], bf[j][0], accl16[2][j]);                                                               \
@@ -1134,16 +1181,16 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     KX3_HALF0(0);
 #define KX3_FLIP(T_)                                                                      \
         {                                                                                 \
-            const int d = ((T_) & 1) ? -KX3_ABUF : KX3_ABUF;                              \
+            const int d = ((T_) & 1) ? -ABUF : ABUF;                              \
             _Pragma("unroll") for (int k = 0; k < 3; ++k)                                 \
-                _Pragma("unroll") for (int i = 0; i < (k == 1 ? 1 : 4); ++i) xo[k][i] += d; \
+                _Pragma("unroll") for (int i = 0; i < (k == 1 && !WIN ? 1 : 4); ++i) xo[k][i] += d; \
         }
     for (int t = 0; t < T - 1; ++t) {
         KX3_BARRIER(5);
         KX3_HALF1(0, true);
         ++s;
         KX3_HALF0(1);
-        KX3_BARRIER(4);
+        KX3_BARRIER(WIN ? 5 : 4);
         KX3_HALF1(1, true);
         ++s;
         KX3_HALF0(2);
@@ -1158,7 +1205,7 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     KX3_HALF1(0, true);
     ++s;
     KX3_HALF0(1);
-    KX3_BARRIER(4);
+    KX3_BARRIER(WIN ? 5 : 4);
     KX3_HALF1(1, true);
     ++s;
     KX3_HALF0(2);
@@ -1173,7 +1220,15 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const PlanarArg
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage and the weight slabs issued past the end must land before the epilogue reuses the LDS
     __syncthreads();
     park16<NJ>(acc16, accl16, smem, wave, lane, 1.0f / STM_F16_LOW_SCALE);
-    planar_epilogue_tail<NJ, 1>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
+    if constexpr (WIN) {
+        PlanarArgs a_cls = static_cast<const PlanarArgs&>(a_in);
+        a_cls.Ho = HO; a_cls.Wo = WO; a_cls.M = MM;
+        a_cls.win_off = a_in.cls[cls_c].win_off; a_cls.inv_hw = a_in.cls[cls_c].inv_hw; a_cls.inv_w = a_in.cls[cls_c].inv_w;
+        if (a_in.pool) pooled_epilogue(a_cls, a_in.pool, a_in.pool_ld, smem, wave, lane, m0 + wm * 64, nt * BN + wn * 64 + lane);
+        else planar_epilogue_tail<NJ, 1>(a_cls, smem, wave, lane, m0, n0g, grp, wm, wn);
+    } else {
+        planar_epilogue_tail<NJ, 1>(a, smem, wave, lane, m0, n0g, grp, wm, wn);
+    }
 #endif
 }
 
@@ -1954,12 +2009,16 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
     };
     if (wset) {
         STM_REQUIRE(bn == 128 && a.fmt == 1 && !dual && win, STM_EUNSUPPORTED, "%s: window sets run on the 256 x 128 ring tiles of the fp16x2 format", who);
-        PlanarArgsCls ac;
-        static_cast<PlanarArgs&>(ac) = a;
-        ac.n_cls = wset->n;
-        ac.pool = wset->pool;
-        ac.pool_ld = g->Cout;
-        int t0 = 0;
+        // Two grids: the windows whose sub-kernel has all three column taps inside the map (kw = 3: the interior-column border classes, 79 % of the
+        // products of a 3x3 layer on 7x7 maps) take conv_planar_kx3_kernel<., WIN> -- one staged run per (channel slab, ky) and window row serves the
+        // three taps -- the others (two column taps: the left / right columns) stay on conv_planar_kernel<..., CLS>.  Disjoint output rows.
+        PlanarArgsCls ac[2];
+        int t0[2] = {0, 0}, ncls[2] = {0, 0};
+        for (int k = 0; k < 2; ++k) {
+            static_cast<PlanarArgs&>(ac[k]) = a;
+            ac[k].pool = wset->pool;
+            ac[k].pool_ld = g->Cout;
+        }
         for (int i = 0; i < wset->n; ++i) {
             const stm_conv_window& w = wset->win[i];
             STM_REQUIRE(w.kh > 0 && w.kw > 0 && w.kh * w.kw <= 32 && w.Ho > 0 && w.Wo > 0 && w.y0 >= 0 && w.x0 >= 0 && w.y0 + w.Ho <= g->win_h &&
@@ -1968,21 +2027,49 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
             STM_REQUIRE((uintptr_t)wset->packed[i] % 16 == 0, STM_EINVAL, "%s: packed weight %d is not 16-byte aligned", who, i);
             const int64_t Mc = (int64_t)g->B * w.Ho * w.Wo;
             STM_REQUIRE(Mc < ((int64_t)1 << 24), STM_EUNSUPPORTED, "%s: more than 2^24 output pixels in one window", who);
-            PlanarArgsCls::Cls& c = ac.cls[i];
+            // kx-reuse form: every tap inside the input map (no zero fill to stage), and a tile's window rows with their two halo pixels fit 384 staged rows
+            const bool taps_inside = -w.ph >= 0 && -w.ph + (w.Ho - 1) + (w.kh - 1) <= g->H - 1 && -w.pw >= 0 && -w.pw + (w.Wo - 1) + (w.kw - 1) <= g->W - 1;
+            const int k = (tn.kx3 && w.kw == 3 && w.kh <= 6 && taps_inside && (255 / w.Wo + 2) * (w.Wo + 2) <= 384) ? 1 : 0;
+            PlanarArgsCls::Cls& c = ac[k].cls[ncls[k]++];
             c.wp = static_cast<const uint8_t*>(wset->packed[i]);
             c.kh = w.kh; c.kw = w.kw; c.ph = w.ph; c.pw = w.pw; c.Ho = w.Ho; c.Wo = w.Wo; c.M = (int)Mc;
-            c.slabs = w.kh * w.kw * (g->C / CV_BK); c.win_off = w.y0 * g->win_w + w.x0; c.tile0 = t0;
+            c.slabs = w.kh * w.kw * (g->C / CV_BK); c.win_off = w.y0 * g->win_w + w.x0; c.tile0 = t0[k];
             c.inv_hw = 1.0f / (float)(w.Ho * w.Wo); c.inv_w = 1.0f / (float)w.Wo;
-            t0 += stm_cdiv(Mc, 2 * CV_BM) * a.n_tiles;
+            t0[k] += stm_cdiv(Mc, 2 * CV_BM) * a.n_tiles;
         }
-        for (int i = wset->n; i < 9; ++i) ac.cls[i] = ac.cls[0];
-        ac.cls_tiles = t0;
-        ac.m_tiles = 0;
-        ac.nsub = ((tn.nsub == 2 || tn.nsub == 4) && a.n_tiles > tn.nsub && a.n_tiles % tn.nsub == 0 && g->groups == 1) ? tn.nsub : 0;
-        // (grid: every XCD gets the same number of pixel tiles x all channel tiles -- a multiple of 32 / nsub of them under the regrouped tile
-        // map, so that its groups are whole; ids past the last tile leave at once)
-        const int pg = ac.nsub ? 32 / ac.nsub : 1;
-        return launch_planar<2, 2, 2, 1, 3, 0, false, true>(ac, stm_cdiv(stm_cdiv(t0 / a.n_tiles, 8), pg) * pg * 8 * a.n_tiles, stream);
+        for (int k = 0; k < 2; ++k) {
+            if (!ncls[k]) continue;
+            for (int i = ncls[k]; i < 9; ++i) ac[k].cls[i] = ac[k].cls[0];
+            ac[k].n_cls = ncls[k];
+            ac[k].cls_tiles = t0[k];
+            ac[k].m_tiles = 0;
+            ac[k].nsub = 0;
+            if (k == 0) {
+                ac[0].nsub = ((tn.nsub == 2 || tn.nsub == 4) && a.n_tiles > tn.nsub && a.n_tiles % tn.nsub == 0 && g->groups == 1) ? tn.nsub : 0;
+                // (grid: every XCD gets the same number of pixel tiles x all channel tiles -- a multiple of 32 / nsub of them under the regrouped tile
+                // map, so that its groups are whole; ids past the last tile leave at once)
+                const int pg = ac[0].nsub ? 32 / ac[0].nsub : 1;
+#ifndef CLS_ABL
+#define CLS_ABL 0     // timing build (RESULTS WRONG): 16 = the window-set kernel issues its activation DMAs on every third K-slab only
+#endif
+                const int rc0 = launch_planar<2, 2, 2, 1, 3, CLS_ABL, false, true>(ac[0], stm_cdiv(stm_cdiv(t0[0] / a.n_tiles, 8), pg) * pg * 8 * a.n_tiles, stream);
+                if (rc0 != STM_OK) return rc0;
+            } else {
+                static std::atomic<bool> kx3w_reserved[STM_MAX_DEVICES];
+                constexpr size_t lds = 2 * 2 * 384 * 64 + 3 * KX3_WBUF;      // two 48-KB activation buffers + the weight ring (the epilogue's park needs less)
+                int dev = 0;
+                const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STM_MAX_DEVICES;
+                if (!have_dev || !kx3w_reserved[dev].load(std::memory_order_relaxed)) {
+                    STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kx3_kernel<KX3_ABL, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)lds) == hipSuccess, STM_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
+                    if (have_dev) kx3w_reserved[dev].store(true, std::memory_order_relaxed);
+                }
+                hipLaunchKernelGGL((conv_planar_kx3_kernel<KX3_ABL, true>), dim3(stm_cdiv(t0[1] / a.n_tiles, 8) * 8 * a.n_tiles), dim3(512), lds, stm_hs(stream), ac[1]);
+                STM_CHECK_LAUNCH("conv_planar_kx3_kernel<WIN>");
+                g_kx3_launches.fetch_add(1, std::memory_order_relaxed);
+            }
+        }
+        return STM_OK;
     }
     int rc;
     if (bn == 64) {
@@ -2051,11 +2138,11 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
         int dev = 0;
         const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STM_MAX_DEVICES;
         if (!have_dev || !kx3_reserved[dev].load(std::memory_order_relaxed)) {
-            STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kx3_kernel<KX3_ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
+            STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_planar_kx3_kernel<KX3_ABL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
                             hipSuccess, STM_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
             if (have_dev) kx3_reserved[dev].store(true, std::memory_order_relaxed);
         }
-        hipLaunchKernelGGL((conv_planar_kx3_kernel<KX3_ABL>), dim3(8 * stm_cdiv(tiles, 8)), dim3(512), lds, stm_hs(stream), a);
+        hipLaunchKernelGGL((conv_planar_kx3_kernel<KX3_ABL, false>), dim3(8 * stm_cdiv(tiles, 8)), dim3(512), lds, stm_hs(stream), a);
         STM_CHECK_LAUNCH("conv_planar_kx3_kernel");
         g_kx3_launches.fetch_add(1, std::memory_order_relaxed);
         return STM_OK;

@@ -37,5 +37,5 @@ def test_chain_kernels_are_bit_stable_beside_a_second_process(tmp_path):
 
 def test_kxr_and_planar_rings_are_bit_stable_beside_a_second_process(tmp_path):
     rc, res, tail = _run("kxr,planar", 240, tmp_path)
-    assert len(res) == 14 and all(r["launches"] >= 200 for r in res)        # (3 kxr + 4 planar shapes, the 3x3 one on conv_planar_kx3_kernel at 32 clips) x 2 batch sizes
+    assert len(res) == 16 and all(r["launches"] >= 200 for r in res)        # (3 kxr + 4 planar shapes + TemporalNet's window set: conv_planar_kx3_kernel, its WIN form, the CLS ring) x 2 batch sizes
     assert rc == 0 and all(r["differing_outputs"] == 0 for r in res), tail
