@@ -104,52 +104,129 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const float* __restrict_
     if (lane == 0) bits[(int64_t)i * words + word] = bal;
 }
 
-// grid: n1 workgroups; row i of the first set staged in LDS.  A wave takes the columns j in chunks of 64: a lane checks one column's group (the clip a
-// mask belongs to in the batched pipeline: pairs of different groups are never compared by the caller, their IoU is left at 0 and their words are not
-// read) and writes the zeros; for every column of row i's group the whole wave then walks that column's words -- lane t reads word t, t + 64, ...: one
-// coalesced run per column instead of 256 threads striding 1 920 bytes apart (round 4: 191 -> ~10 us at 32 clips) -- and folds intersection and
-// column area, packed into one 32-bit sum, with one butterfly.  Integer counts: the same IoU bits as the one-thread-per-column form.
+// grid: ceil(n1 / R) workgroups; R <= 8 rows of the first set staged in LDS, so a column's words are fetched once for eight pairs (one row per
+// workgroup read 1.1 GB through L2 per step for 17 MB of masks).  A wave takes the columns j in chunks of 64: a lane checks one column's group against
+// the rows' groups (the clip a mask belongs to in the batched pipeline: pairs of different groups are never compared by the caller, their IoU is 0 and
+// their words are not read), writes the zeros of the unmatched pairs and lists the matched columns; those are then dealt to the waves FOUR at a time, one per DPP
+// row of 16 lanes: lane s of a row reads words s, s + 16, ... of its column (128 contiguous bytes per row and step), counts the eight intersections
+// against the staged rows (the same LDS word for all four rows: a broadcast) and the column's area, and the nine counts are summed over the row's 16
+// lanes with DPP moves (no LDS round trips: with __shfl butterflies over 64 lanes the reductions were most of the kernel).  Integer counts: the same
+// IoU bits as a one-thread-per-pair loop.
+constexpr int MIOU_R = 8, MIOU_LIST = 2048;
 __global__ __launch_bounds__(256) void mask_iou_pairs_kernel(const unsigned long long* __restrict__ b1,
-                                                             const unsigned long long* __restrict__ b2, int n2, int words,
+                                                             const unsigned long long* __restrict__ b2, int n1, int n2, int words,
                                                              float* __restrict__ out, const int* __restrict__ g1,
-                                                             const int* __restrict__ g2)
+                                                             const int* __restrict__ g2, int R)
 {
-    extern __shared__ unsigned long long arow[];
-    __shared__ int a1_part[4];
-    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gi = g1 ? g1[i] : 0;
-    int pa = 0;
-    for (int t = tid; t < words; t += 256) {
-        const unsigned long long a = b1[(int64_t)i * words + t];
-        arow[t] = a;
-        pa += __popcll(a);
+    extern __shared__ unsigned long long arow[];               // [R][words]
+    __shared__ int a1_s[MIOU_R], gi_s[MIOU_R];
+    const int i0 = blockIdx.x * R, nr = min(R, n1 - i0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < MIOU_R; r += 4) {                   // a wave stages two rows and counts their bits
+        unsigned pa = 0;
+        for (int t = lane; t < words && r < nr; t += 64) {
+            const unsigned long long a = b1[(int64_t)(i0 + r) * words + t];
+            arow[r * words + t] = a;
+            pa += (unsigned)__popcll(a);
+        }
+        pa = stm_row16_sum(pa);
+        const int tot = stm_wave_sum_rows(pa);
+        if (lane == 0) { a1_s[r] = tot; gi_s[r] = r < nr ? (g1 ? g1[i0 + r] : 0) : -0x7fffffff; }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) pa += __shfl_xor(pa, d, 64);
-    if (lane == 0) a1_part[wave] = pa;
     __syncthreads();
-    const float a1 = (float)(a1_part[0] + a1_part[1] + a1_part[2] + a1_part[3]);
-    float* orow = out + (int64_t)i * n2;
-    for (int j0 = wave * 64; j0 < n2; j0 += 256) {
-        const int j = j0 + lane;
-        const bool mine = j < n2 && (!g2 || g2[j] == gi);
-        if (j < n2 && !mine) orow[j] = 0.0f;
-        unsigned long long todo = __ballot(mine);
-        while (todo) {
-            const int l = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const unsigned long long* q = b2 + (int64_t)(j0 + l) * words;
-            unsigned acc = 0;                                   // intersection << 16 | column area: both below 2^16 per lane (words / 64 * 64 bits)
-            for (int t = lane; t < words; t += 64) {
-                const unsigned long long b = q[t];
-                acc += ((unsigned)__popcll(arow[t] & b) << 16) + (unsigned)__popcll(b);
-            }
-            unsigned hi = acc >> 16, lo = acc & 0xffffu;        // (summed apart: 64 lanes of up to 2^16 would overflow the packed halves)
+    int gi[MIOU_R];
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { hi += __shfl_xor(hi, d, 64); lo += __shfl_xor(lo, d, 64); }
-            if (lane == 0) {
-                const float fi = (float)hi, uni = (a1 + (float)lo) - fi;
-                orow[j0 + l] = (uni == 0.0f) ? 0.0f : fi / uni;
+    for (int r = 0; r < MIOU_R; ++r) gi[r] = gi_s[r];
+    const int q = lane >> 4, sl = lane & 15;                   // DPP row of the lane (= which of the four columns of a pass), lane within the row
+    // pass 1: every column's group against the rows' groups; zeros for the unmatched pairs; the matched columns (with their match bits) are appended to
+    // a list in LDS -- chunk by chunk in column order, each wave's chunk at the offset the workgroup's running count gives it: a deterministic order
+    __shared__ int list_j[MIOU_LIST], list_m[MIOU_LIST], chunk_n[4], list_n;
+    if (tid == 0) list_n = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n2; j0 += 256) {
+        const int j = j0 + tid;
+        const int gj = j < n2 ? (g2 ? g2[j] : 0) : 0x7fffffff;
+        unsigned match = 0;                                    // bit r: row r and column j are of one group
+#pragma unroll
+        for (int r = 0; r < MIOU_R; ++r) match |= (unsigned)(r < nr && gj == gi[r]) << r;
+        if (j < n2) {
+#pragma unroll
+            for (int r = 0; r < MIOU_R; ++r)
+                if (r < nr && !((match >> r) & 1u)) out[(int64_t)(i0 + r) * n2 + j] = 0.0f;
+        }
+        const unsigned long long mb = __ballot(match != 0);
+        if (lane == 0) chunk_n[wave] = __popcll(mb);
+        __syncthreads();
+        int base = list_n;
+        for (int w = 0; w < wave; ++w) base += chunk_n[w];
+        if (match) {
+            const int pos = base + __popcll(mb & ((1ull << lane) - 1ull));
+            if (pos < MIOU_LIST) { list_j[pos] = j; list_m[pos] = (int)match; }
+        }
+        __syncthreads();
+        if (tid == 0) list_n += chunk_n[0] + chunk_n[1] + chunk_n[2] + chunk_n[3];
+        __syncthreads();
+    }
+    const int nlist = min(list_n, MIOU_LIST);
+    // pass 2: the matched columns, four per wave and pass (one per DPP row), dealt round-robin to the waves; all of a column's words of a lane in flight
+    for (int p0 = wave * 4; p0 < nlist; p0 += 16) {
+        const int pi = min(p0 + q, nlist - 1);
+        const int jq = list_j[pi];
+        const unsigned mq = (unsigned)list_m[pi];
+        const unsigned long long* col = b2 + (int64_t)jq * words;
+        unsigned hi[MIOU_R], lo = 0;
+#pragma unroll
+        for (int r = 0; r < MIOU_R; ++r) hi[r] = 0;
+        for (int t0 = sl; t0 < words; t0 += 16 * 16) {
+            unsigned long long c[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c[u] = t0 + 16 * u < words ? col[t0 + 16 * u] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int t = t0 + 16 * u;
+                if (t < words) {
+                    lo += (unsigned)__popcll(c[u]);
+#pragma unroll
+                    for (int r = 0; r < MIOU_R; ++r)
+                        if (r < nr) hi[r] += (unsigned)__popcll(arow[r * words + t] & c[u]);
+                }
+            }
+        }
+        lo = stm_row16_sum(lo);
+#pragma unroll
+        for (int r = 0; r < MIOU_R; ++r) hi[r] = stm_row16_sum(hi[r]);
+        // lane r of DPP row q writes pair (row r, this row's column) if they are of one group
+        if (sl < MIOU_R && p0 + q < nlist) {
+            unsigned h = 0;
+#pragma unroll
+            for (int r = 0; r < MIOU_R; ++r)
+                if (sl == r) h = hi[r];
+            if (sl < nr && ((mq >> sl) & 1u)) {
+                const float fi = (float)h, uni = ((float)a1_s[sl] + (float)lo) - fi;
+                out[(int64_t)(i0 + sl) * n2 + jq] = (uni == 0.0f) ? 0.0f : fi / uni;
+            }
+        }
+    }
+    // (more matched columns than the list holds -- over 2 048 masks of one group against a block of rows: the rest one column per pass, in column order)
+    if (list_n > MIOU_LIST) {
+        for (int j = 0, seen = 0; j < n2; ++j) {
+            const int gj = g2 ? g2[j] : 0;
+            unsigned match = 0;
+#pragma unroll
+            for (int r = 0; r < MIOU_R; ++r) match |= (unsigned)(r < nr && gj == gi[r]) << r;
+            if (!match) continue;
+            if (seen++ < MIOU_LIST) continue;
+            if (wave != 0) continue;
+            const unsigned long long* col = b2 + (int64_t)j * words;
+            for (int r = 0; r < nr; ++r) {
+                if (!((match >> r) & 1u)) continue;
+                unsigned h = 0, o = 0;
+                for (int t = lane; t < words; t += 64) { const unsigned long long c = col[t]; o += (unsigned)__popcll(c); h += (unsigned)__popcll(arow[r * words + t] & c); }
+                const int hs = stm_wave_sum_rows(stm_row16_sum(h)), os = stm_wave_sum_rows(stm_row16_sum(o));
+                if (lane == 0) {
+                    const float fi = (float)hs, uni = ((float)a1_s[r] + (float)os) - fi;
+                    out[(int64_t)(i0 + r) * n2 + j] = (uni == 0.0f) ? 0.0f : fi / uni;
+                }
             }
         }
     }
@@ -221,15 +298,17 @@ extern "C" int stm_mask_iou_grouped_f32(const float* m1, int n1, const float* m2
     STM_REQUIRE(workspace && workspace_bytes >= stm_mask_iou_workspace_bytes(n1, n2, hw), STM_EWORKSPACE,
                 "stm_mask_iou_f32: workspace too small");
     STM_REQUIRE(n1 <= 65535 && n2 <= 65535, STM_EINVAL, "stm_mask_iou_f32: too many masks");
-    STM_REQUIRE(hw <= 60000 * 64, STM_EUNSUPPORTED, "stm_mask_iou_f32: masks of more than 3.8 M pixels (per-lane counts are kept in 16 bits)");
+
     const int words = (hw + 63) / 64;
     unsigned long long* b1 = reinterpret_cast<unsigned long long*>(workspace);
     unsigned long long* b2 = b1 + (size_t)n1 * words;
     hipLaunchKernelGGL(mask_pack_kernel, dim3(stm_cdiv(words, 4), n1), dim3(256), 0, stm_hs(stream), m1, b1, hw, words, thr);
     hipLaunchKernelGGL(mask_pack_kernel, dim3(stm_cdiv(words, 4), n2), dim3(256), 0, stm_hs(stream), m2, b2, hw, words, thr);
     STM_CHECK_LAUNCH("mask_pack_kernel");
-    hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(n1), dim3(256), (size_t)words * 8, stm_hs(stream), b1,
-                       b2, n2, words, out, group1, group2);
+    const int rows_wg = std::min(MIOU_R, (60 * 1024) / (words * 8));
+    STM_REQUIRE(rows_wg >= 1, STM_EUNSUPPORTED, "stm_mask_iou_f32: a mask row of %d words does not fit the 60 KB of LDS the kernel stages rows in", words);
+    hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n1, rows_wg)), dim3(256), (size_t)rows_wg * words * 8, stm_hs(stream), b1,
+                       b2, n1, n2, words, out, group1, group2, rows_wg);
     STM_CHECK_LAUNCH("mask_iou_pairs_kernel");
     return STM_OK;
 }
@@ -243,11 +322,13 @@ extern "C" int stm_mask_iou_bits_f32(const uint64_t* bits1, int n1, const uint64
     if (n1 == 0 || n2 == 0) return STM_OK;
     STM_REQUIRE(bits1 && bits2 && out, STM_ENULL, "stm_mask_iou_bits_f32: bits1/bits2/out must be non-NULL");
     STM_REQUIRE(n1 <= 65535 && n2 <= 65535, STM_EINVAL, "stm_mask_iou_bits_f32: too many masks");
-    STM_REQUIRE(hw <= 60000 * 64, STM_EUNSUPPORTED, "stm_mask_iou_bits_f32: masks of more than 3.8 M pixels (per-lane counts are kept in 16 bits)");
+
     const int words = (hw + 63) / 64;
-    hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(n1), dim3(256), (size_t)words * 8, stm_hs(stream),
-                       reinterpret_cast<const unsigned long long*>(bits1), reinterpret_cast<const unsigned long long*>(bits2), n2, words, out, group1,
-                       group2);
+    const int rows_wg = std::min(MIOU_R, (60 * 1024) / (words * 8));
+    STM_REQUIRE(rows_wg >= 1, STM_EUNSUPPORTED, "stm_mask_iou_bits_f32: a mask row of %d words does not fit the 60 KB of LDS the kernel stages rows in", words);
+    hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n1, rows_wg)), dim3(256), (size_t)rows_wg * words * 8, stm_hs(stream),
+                       reinterpret_cast<const unsigned long long*>(bits1), reinterpret_cast<const unsigned long long*>(bits2), n1, n2, words, out, group1,
+                       group2, rows_wg);
     STM_CHECK_LAUNCH("mask_iou_pairs_kernel");
     return STM_OK;
 }

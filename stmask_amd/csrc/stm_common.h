@@ -120,3 +120,48 @@ __device__ __forceinline__ void stm_sanitize(float x1, float x2, int size, int p
     lo = l < 0.0f ? 0.0f : l;
     hi = h > (float)size ? (float)size : h;
 }
+
+// Sum over the 16 lanes of a DPP row (lanes 16 q .. 16 q + 15): four data-parallel-primitive moves at VALU speed, every lane of the row ends with the
+// row's sum -- quad_perm [1, 0, 3, 2], quad_perm [2, 3, 0, 1], row_half_mirror, row_mirror.  (__shfl_xor goes through ds_bpermute: an LDS round trip
+// per step; the tail kernels that fold many small sums spent most of their time there.)  One fixed order: run-to-run identical.
+// (The builtins exist only in the device pass; the host pass needs the names.)
+__device__ __forceinline__ float stm_row16_sum(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+#endif
+    return v;
+}
+__device__ __forceinline__ unsigned stm_row16_sum(unsigned v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);
+#endif
+    return v;
+}
+// ... and over the whole wave: the four row sums read from lanes 0, 16, 32, 48 and added in that order (wave-uniform result)
+__device__ __forceinline__ float stm_wave_sum(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = stm_row16_sum(v);
+    const int i = __builtin_bit_cast(int, v);
+    v = ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32))) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+#endif
+    return v;
+}
+__device__ __forceinline__ int stm_wave_sum_rows(unsigned row_sums)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readlane((int)row_sums, 0) + __builtin_amdgcn_readlane((int)row_sums, 16) + __builtin_amdgcn_readlane((int)row_sums, 32) +
+           __builtin_amdgcn_readlane((int)row_sums, 48);
+#else
+    return (int)row_sums;
+#endif
+}

@@ -364,7 +364,7 @@ extern "C" int stm_roi_align_avg_f32(const float* feat, const float* rois, float
 // ---- TemporalNet's tail: AvgPool2d((7, 7)) + fc + fc_coeff (track_to_segment_head.py:33-37) -------------------------------------------------
 // Input: the pooled SUMS stm_conv2d_planar_windows_pool_f32 accumulated (pool_fix[n][C], unsigned 32.32 fixed point).  One workgroup per eight RoIs:
 // mean = sum / npix (one rounding, in double), kept in LDS; output o = bias[o] + sum_k mean[k] w[o][k]: a lane adds its k = lane, lane + 64, ... in
-// order, the 64 lane sums are folded by a butterfly -- a fixed order, the same on every run.  With `clear` the consumed sums are zeroed for the
+// order, the 64 lane sums are folded row by row with DPP moves and the four row totals added -- a fixed order, the same on every run.  With `clear` the consumed sums are zeroed for the
 // next step (no separate memset launch).
 namespace {
 constexpr int TPF_R = 8;      // RoIs per workgroup: a row of the stacked weight matrix is read once per 8 RoIs
@@ -376,29 +376,46 @@ __global__ __launch_bounds__(256) void temporal_pool_fc_kernel(unsigned long lon
     const int b0 = blockIdx.x * TPF_R, nr = min(TPF_R, n - b0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* rows = pool_fix + (size_t)b0 * C;
-    for (int idx = tid; idx < nr * C; idx += 256) {       // (the RoIs' rows are contiguous: one linear sweep)
-        const float m = (float)((double)rows[idx] * inv);
-        mean[idx] = m;
-        if (pooled_out) pooled_out[(size_t)b0 * C + idx] = m;
-        if (clear) rows[idx] = 0ull;
+    // (the RoIs' rows are contiguous: one linear sweep, eight loads in flight per thread -- with the clearing store between two loads of the plain loop
+    // the compiler kept one load in flight and the sweep took most of the kernel's 59 us)
+    const int total = nr * C;
+    for (int i0 = tid; i0 < total; i0 += 8 * 256) {
+        unsigned long long x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = i0 + u * 256 < total ? rows[i0 + u * 256] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = i0 + u * 256;
+            if (idx < total) {
+                const float m = (float)((double)x[u] * inv);
+                mean[idx] = m;
+                if (pooled_out) pooled_out[(size_t)b0 * C + idx] = m;
+                if (clear) rows[idx] = 0ull;
+            }
+        }
     }
-    for (int idx = nr * C + tid; idx < TPF_R * C; idx += 256) mean[idx] = 0.0f;
+    for (int idx = total + tid; idx < TPF_R * C; idx += 256) mean[idx] = 0.0f;
     __syncthreads();
     for (int o = wave; o < n_out; o += 4) {
         const float* wr = w + (size_t)o * C;
         float s[TPF_R];
 #pragma unroll
         for (int r = 0; r < TPF_R; ++r) s[r] = 0.0f;
-        for (int k = lane; k < C; k += 64) {
-            const float wv = wr[k];
+        for (int k0 = lane; k0 < C; k0 += 64 * 8) {                   // eight weight loads in flight per lane (same order of the sums as a plain loop)
+            float wv[8];
 #pragma unroll
-            for (int r = 0; r < TPF_R; ++r) s[r] = __builtin_fmaf(mean[r * C + k], wv, s[r]);
+            for (int u = 0; u < 8; ++u) wv[u] = k0 + 64 * u < C ? wr[k0 + 64 * u] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 64 * u;
+                if (k < C) {
+#pragma unroll
+                    for (int r = 0; r < TPF_R; ++r) s[r] = __builtin_fmaf(mean[r * C + k], wv[u], s[r]);
+                }
+            }
         }
 #pragma unroll
-        for (int r = 0; r < TPF_R; ++r) {
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) s[r] += __shfl_xor(s[r], d, 64);
-        }
+        for (int r = 0; r < TPF_R; ++r) s[r] = stm_wave_sum(s[r]);        // (DPP row sums + four row totals: no LDS round trips)
         if (lane == 0) {
             const float bo = bias ? bias[o] : 0.0f;
 #pragma unroll

@@ -449,9 +449,9 @@ def mask_iou_bits(bits1, bits2, hw, group1=None, group2=None):
     """box_utils.py:435-447 on bit-packed binary masks (lincomb_sigmoid_crop_bits) -> [n1, n2]; groups as in mask_iou."""
     _dev(bits1, bits2, group1, group2)
     n1, n2 = bits1.shape[0], bits2.shape[0]
-    out = torch.zeros(n1, n2, dtype=torch.float32, device=bits1.device)
     if n1 == 0 or n2 == 0:
-        return out
+        return torch.zeros(n1, n2, dtype=torch.float32, device=bits1.device)
+    out = torch.empty(n1, n2, dtype=torch.float32, device=bits1.device)     # (the kernel writes every element: zeros for pairs of different groups)
     if bits1.dtype != torch.int64 or bits2.dtype != torch.int64 or bits1.shape[1] != (hw + 63) // 64 or bits2.shape[1] != bits1.shape[1]:
         raise StmError("mask_iou_bits: bit tables must be int64 [n, ceil(hw / 64)]")
     check(_lib.lib().stm_mask_iou_bits_f32(_p(bits1.contiguous()), c_i(n1), _p(bits2.contiguous()), c_i(n2), c_i(hw), _p(out),
