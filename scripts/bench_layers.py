@@ -44,6 +44,15 @@ EXP = [("64->256 +res planes (baseline)", 96, 160, 64, 256, 1, 1, True, "planes"
        ("256->1024 +res tile128", 24, 40, 256, 1024, 1, 1, True, "planes", 128)]
 
 
+# single-round grids at batch 32: 240 tiles of 256 pixels on 256 CUs (--set mg: run under STM_CONV_MG=1 / 2 to compare the pixel-tile sizes)
+MG = [("l3 conv1 1024->256 1x1 @24x40", 24, 40, 1024, 256, 1, 1, False, "planes"),
+      ("l3->l4 1024->512 1x1 @24x40", 24, 40, 1024, 512, 1, 1, False, "planes"),
+      ("fpn 256->256 3x3 @24x40", 24, 40, 256, 256, 3, 1, False, "planes"),
+      ("dcn gemm l3 2304->256 @24x40", 24, 40, 2304, 256, 1, 1, False, "planes"),
+      ("l4 conv1 2048->512 1x1 @12x20", 12, 20, 2048, 512, 1, 1, False, "planes"),
+      ("dcn gemm l4 4608->512 @12x20", 12, 20, 4608, 512, 1, 1, False, "planes")]
+
+
 def run(name, B, H, W, C, O, k, s, has_res, out, tile_n=None, fmt=1, reps=20, nbuf=4):
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
@@ -84,6 +93,6 @@ if __name__ == "__main__":
     planar.set_format(a.fmt if a.fmt != 2 else 1, backbone_fmt=2 if a.fmt == 2 else None)
     print(torch.cuda.get_device_name(0), "fmt", a.fmt, "batch", a.batch, flush=True)
     tot = 0.0
-    for name, *shape in (HBM if a.set in ("hbm", "all") else []) + (MFMA if a.set in ("mfma", "all") else []) + (EXP if a.set == "exp" else []) + (EXP[:1] if a.set == "one" else []):
+    for name, *shape in (HBM if a.set in ("hbm", "all") else []) + (MFMA if a.set in ("mfma", "all") else []) + (EXP if a.set == "exp" else []) + (MG if a.set == "mg" else []) + (EXP[:1] if a.set == "one" else []):
         tot += run(name, a.batch, *shape, fmt=a.fmt)
     print(f"sum {tot:.0f} us")
