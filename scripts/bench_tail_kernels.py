@@ -5,7 +5,7 @@ says little about its cost; alone they show their own time.  usage: bench_tail_k
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stmask_amd import ops
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32     # (fewer than 25 clips: under 4096 detection rows, the small-problem kernel)
 dev = "cuda"
 
 
@@ -50,7 +50,7 @@ pc = lambda x: torch.tensor([[bin(int(v) & (2**64 - 1)).count("1") for v in row]
 inter = torch.tensor([[sum(bin((int(x) & int(y)) & (2**64 - 1)).count("1") for x, y in zip(ra, rb)) for rb in b[:4].tolist()] for ra in a[:4].tolist()])
 uni = pc(a[:4]).view(-1, 1) + pc(b[:4]).view(1, -1) - inter
 assert torch.equal(out[:4, :4].cpu(), inter.float() / uni.float()), "mask_iou_bits differs from the host popcounts"
-assert float(out[:nd, npv:].abs().max()) == 0.0
+assert B == 1 or float(out[:nd, npv:].abs().max()) == 0.0
 print("mask_iou_bits %d x %d masks of %d px, %d clips: %.1f us" % (B * nd, B * npv, hw, B, us))
 n, C = B * npv, 1024
 pool = torch.randint(0, 2**40, (n, C), device=dev, dtype=torch.int64, generator=g)

@@ -104,6 +104,44 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const float* __restrict_
     if (lane == 0) bits[(int64_t)i * words + word] = bal;
 }
 
+// Small problems (fewer than MIOU_BIG_ROWS rows: single-stream and small-batch steps): grid (ceil(n2/256), n1), row i staged in LDS, one thread per
+// column j -- many tiny workgroups that finish in ~20-40 us whatever the batch, where the row-block kernel below needs a workgroup's ~100 us
+__global__ __launch_bounds__(256) void mask_iou_pairs_small_kernel(const unsigned long long* __restrict__ b1,
+                                                             const unsigned long long* __restrict__ b2, int n2, int words,
+                                                             float* __restrict__ out, const int* __restrict__ g1,
+                                                             const int* __restrict__ g2)
+{
+    extern __shared__ unsigned long long arow[];
+    const int i = blockIdx.y;
+    // group ids (the clip a mask belongs to in the batched pipeline): pairs of different groups are never compared by the
+    // caller -- their IoU is left at 0 and their words are not read.  A workgroup none of whose 256 columns belongs to row i's
+    // group leaves at once (rows sorted by group, as the pipeline keeps them, make that the common case; any order is correct).
+    const int gi = g1 ? g1[i] : 0;
+    if (g2) {
+        const int j = blockIdx.x * 256 + threadIdx.x;
+        const bool mine = j < n2 && g2[j] == gi;
+        if (!__syncthreads_or(mine ? 1 : 0)) {
+            if (j < n2) out[(int64_t)i * n2 + j] = 0.0f;
+            return;
+        }
+    }
+    for (int t = threadIdx.x; t < words; t += 256) arow[t] = b1[(int64_t)i * words + t];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n2) return;
+    if (g2 && g2[j] != gi) { out[(int64_t)i * n2 + j] = 0.0f; return; }
+    int inter = 0, a1 = 0, a2 = 0;
+    const unsigned long long* q = b2 + (int64_t)j * words;
+    for (int t = 0; t < words; ++t) {
+        unsigned long long a = arow[t], b = q[t];
+        inter += __popcll(a & b);
+        a1 += __popcll(a);
+        a2 += __popcll(b);
+    }
+    float fi = (float)inter, uni = ((float)a1 + (float)a2) - fi;
+    out[(int64_t)i * n2 + j] = (uni == 0.0f) ? 0.0f : fi / uni;
+}
+
 // grid: ceil(n1 / R) workgroups; R <= 8 rows of the first set staged in LDS, so a column's words are fetched once for eight pairs (one row per
 // workgroup read 1.1 GB through L2 per step for 17 MB of masks).  A wave takes the columns j in chunks of 64: a lane checks one column's group against
 // the rows' groups (the clip a mask belongs to in the batched pipeline: pairs of different groups are never compared by the caller, their IoU is 0 and
@@ -112,7 +150,7 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const float* __restrict_
 // against the staged rows (the same LDS word for all four rows: a broadcast) and the column's area, and the nine counts are summed over the row's 16
 // lanes with DPP moves (no LDS round trips: with __shfl butterflies over 64 lanes the reductions were most of the kernel).  Integer counts: the same
 // IoU bits as a one-thread-per-pair loop.
-constexpr int MIOU_R = 8, MIOU_LIST = 2048;
+constexpr int MIOU_R = 8, MIOU_LIST = 2048, MIOU_BIG_ROWS = 4096;
 __global__ __launch_bounds__(256) void mask_iou_pairs_kernel(const unsigned long long* __restrict__ b1,
                                                              const unsigned long long* __restrict__ b2, int n1, int n2, int words,
                                                              float* __restrict__ out, const int* __restrict__ g1,
@@ -307,8 +345,11 @@ extern "C" int stm_mask_iou_grouped_f32(const float* m1, int n1, const float* m2
     STM_CHECK_LAUNCH("mask_pack_kernel");
     const int rows_wg = std::min(MIOU_R, (60 * 1024) / (words * 8));
     STM_REQUIRE(rows_wg >= 1, STM_EUNSUPPORTED, "stm_mask_iou_f32: a mask row of %d words does not fit the 60 KB of LDS the kernel stages rows in", words);
-    hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n1, rows_wg)), dim3(256), (size_t)rows_wg * words * 8, stm_hs(stream), b1,
-                       b2, n1, n2, words, out, group1, group2, rows_wg);
+    if (n1 < MIOU_BIG_ROWS)
+        hipLaunchKernelGGL(mask_iou_pairs_small_kernel, dim3(stm_cdiv(n2, 256), n1), dim3(256), (size_t)words * 8, stm_hs(stream), b1, b2, n2, words, out, group1, group2);
+    else
+        hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n1, rows_wg)), dim3(256), (size_t)rows_wg * words * 8, stm_hs(stream), b1,
+                           b2, n1, n2, words, out, group1, group2, rows_wg);
     STM_CHECK_LAUNCH("mask_iou_pairs_kernel");
     return STM_OK;
 }
@@ -326,9 +367,13 @@ extern "C" int stm_mask_iou_bits_f32(const uint64_t* bits1, int n1, const uint64
     const int words = (hw + 63) / 64;
     const int rows_wg = std::min(MIOU_R, (60 * 1024) / (words * 8));
     STM_REQUIRE(rows_wg >= 1, STM_EUNSUPPORTED, "stm_mask_iou_bits_f32: a mask row of %d words does not fit the 60 KB of LDS the kernel stages rows in", words);
-    hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n1, rows_wg)), dim3(256), (size_t)rows_wg * words * 8, stm_hs(stream),
-                       reinterpret_cast<const unsigned long long*>(bits1), reinterpret_cast<const unsigned long long*>(bits2), n1, n2, words, out, group1,
-                       group2, rows_wg);
+    if (n1 < MIOU_BIG_ROWS)
+        hipLaunchKernelGGL(mask_iou_pairs_small_kernel, dim3(stm_cdiv(n2, 256), n1), dim3(256), (size_t)words * 8, stm_hs(stream),
+                           reinterpret_cast<const unsigned long long*>(bits1), reinterpret_cast<const unsigned long long*>(bits2), n2, words, out, group1, group2);
+    else
+        hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n1, rows_wg)), dim3(256), (size_t)rows_wg * words * 8, stm_hs(stream),
+                           reinterpret_cast<const unsigned long long*>(bits1), reinterpret_cast<const unsigned long long*>(bits2), n1, n2, words, out, group1,
+                           group2, rows_wg);
     STM_CHECK_LAUNCH("mask_iou_pairs_kernel");
     return STM_OK;
 }
