@@ -127,7 +127,9 @@ class PlanarConv:
         slabs = self.C * self.kh * self.kw // 32
         # (long K on a grid of about one 128 x 128 workgroup per CU -- layer4 at 32 clips -- is better off on the wide tiles:
         # 2048 -> 512 at M = 7 680: 58.4 -> 53.5 us, the 4608 -> 512 DCN product 118.1 -> 104.9; scripts/sweep_small_m.py)
-        if tiles128 < 400 and not (tiles128 >= 192 and slabs >= 64):
+        # (round 4, scripts/sweep_tile_small.py: the exception holds up to ONE workgroup per CU only -- the head towers at 1 clip, 320 wide tiles:
+        # 98 -> 81 us on the 64-wide ones; the `up` layer at 4 clips: 96 -> 77 us)
+        if tiles128 < 400 and not (192 <= tiles128 <= 256 and slabs >= 64):
             return 64
         # short K, wide output (the bottlenecks' expanding 1x1 convs with their residual): HBM-bound, and three resident
         # 128 x 64 workgroups per CU (48 KB each) keep more loads and stores in flight than one 256 x 128 workgroup:
