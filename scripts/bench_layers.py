@@ -93,6 +93,6 @@ if __name__ == "__main__":
     planar.set_format(a.fmt if a.fmt != 2 else 1, backbone_fmt=2 if a.fmt == 2 else None)
     print(torch.cuda.get_device_name(0), "fmt", a.fmt, "batch", a.batch, flush=True)
     tot = 0.0
-    for name, *shape in (HBM if a.set in ("hbm", "all") else []) + (MFMA if a.set in ("mfma", "all") else []) + (EXP if a.set == "exp" else []) + (MG if a.set == "mg" else []) + (EXP[:1] if a.set == "one" else []):
+    for name, *shape in (HBM if a.set in ("hbm", "all") else []) + (MFMA if a.set in ("mfma", "all") else []) + (EXP if a.set == "exp" else []) + (MG if a.set == "mg" else []) + (MFMA[:1] if a.set == "proto" else []) + (EXP[:1] if a.set == "one" else []):
         tot += run(name, a.batch, *shape, fmt=a.fmt)
     print(f"sum {tot:.0f} us")

@@ -926,7 +926,7 @@ constexpr int KX3_LDS_LOOP = KX3_W0 + 3 * KX3_WBUF;
 #define KX3_WBUFFER 1    // weight pieces as buffer loads (scalar offset + 16 lane: 242 registers, -0.8 %); 0 = global_load_lds with a 64-bit per-lane address
 #endif
 #ifndef KX3_ABL
-#define KX3_ABL 0        // timing builds (RESULTS WRONG): 1 no DMA at all, 2 no activation DMA, 4 no fragment reads, 8 every stage stages channel slab 0 (L2-resident rows), 16 activation pieces read weight bytes instead (same count of DMAs, hot lines)
+#define KX3_ABL 0        // timing builds (RESULTS WRONG): 1 no DMA at all, 2 no activation DMA, 4 no fragment reads, 8 every stage stages channel slab 0 (L2-resident rows), 16 activation pieces read weight bytes instead (same count of DMAs, hot lines), 32 activation pieces land behind the weight ring (another LDS region), 64 the ring pre-filled once with random fp16 values
 #endif
 template <int ABL = 0, bool WIN = false>
 __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const typename std::conditional<WIN, PlanarArgsCls, PlanarArgs>::type a_in)
@@ -1068,6 +1068,8 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const typename 
         const unsigned off = (unsigned)(base[i] + st_ky * (wlv[i] & ~63) + (grp * cslabs + ((ABL & 8) ? 0 : st_c)) * (a.x_np * 64)) | (oob << 31);
         if constexpr ((ABL & 16) != 0) {        // the same number of DMAs into the same LDS places, but reading weight-tile bytes the way dma_w does
             __builtin_amdgcn_global_load_lds((glb_ptr)(wtile + (size_t)(q & 15) * 1024 + lane * 16), (lds_ptr)(smem + st_buf * ABUF + p * XPL + q * 1024), 16, 0, 0);
+        } else if constexpr ((ABL & 32) != 0) { // the real activation pieces, landing in the spare LDS behind the weight ring instead of the activation buffers
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(smem + W0 + 3 * KX3_WBUF + ((q + 17 * p) & 15) * 1024), 16, off, 0, 0, 0);
         } else
         if (!(ABL & 3)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr[p], (lds_ptr)(smem + st_buf * ABUF + p * XPL + q * 1024), 16, off, 0, 0, 0);
     };
@@ -1102,6 +1104,17 @@ __global__ __launch_bounds__(512, 1) void conv_planar_kx3_kernel(const typename 
 #define KX3_XO(K_, I_) ((K_) == 1 && !WIN ? xo[1][0] + (I_) * 1024 : xo[K_][I_])
 #define MM16(x_, y_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x_), __builtin_bit_cast(f16x8, y_), c_, 0, 0, 0)
     const int S = SLABS;                       // K-slabs = 3 taps x stages
+    if constexpr ((ABL & 64) != 0) {
+        // timing build: the whole ring pre-filled ONCE with pseudo-random fp16 values in [0.5, 2) of both signs -- with ABL 1 | 64 the MFMAs then run on
+        // operands that look like data although nothing is staged (an LDS that is never written hands the matrix pipe constant fragments, and a pipe
+        // fed constants draws much less power: at the board's power limit that reads as a far faster loop)
+        for (int i = tid; i < (W0 + 3 * KX3_WBUF) / 4; i += 512) {
+            unsigned h = (unsigned)i * 2654435761u + (unsigned)blockIdx.x * 40503u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            reinterpret_cast<unsigned*>(smem)[i] = (h & 0x87ff87ffu) | 0x38003800u;
+        }
+        __syncthreads();
+    }
     // prologue: stage 0 whole, weight slabs 0 and 1
     dma_a(0, 0); dma_a(0, 1); dma_a(1, 0); dma_a(1, 1);
     if (WIN) { dma_a(2, 0); dma_a(2, 1); } else dma_a(2, wave & 1);
