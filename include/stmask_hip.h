@@ -33,7 +33,9 @@
  *     stm_bottleneck_chain(_proj)_f32; stm_detect_cc_logits_f32; stm_corr_patch_nhwc_f32 / stm_roi_align_planes_nhwc_f32).
  *     stm_struct_bytes(which) lets a client check its layout of EVERY struct of this header against the library.
  *     Added since without a version change (new entry points only): stm_conv2d_planar_windows_pool_f32, stm_temporal_pool_fc_f32,
- *     stm_debug_launch_count.
+ *     stm_debug_launch_count;
+ *      4: those three entry points are part of the version now (a library that lacks them must not pass for this ABI), plus the fused
+ *     deformable convolution stm_deform_conv_fused_planar_f32 / stm_deform_conv_fused_planar_supported; stm_debug_launch_count(1)).
  */
 #ifndef STMASK_HIP_H_
 #define STMASK_HIP_H_
@@ -45,7 +47,7 @@
 extern "C" {
 #endif
 
-#define STM_ABI_VERSION 3
+#define STM_ABI_VERSION 4
 
 enum stm_status {
     STM_OK = 0,
@@ -67,7 +69,8 @@ size_t stm_struct_bytes(int which);
  * scripts).  Not needed in production. */
 void stm_debug_reload_tunables(void);
 /* Diagnostics: launches of an optional kernel form since the process started (tests check that the form they compare really ran):
- * which = 0 conv_planar_kx3_kernel (kx-reuse staging of the 256 x 128 ring tiles); -1 for anything else. */
+ * which = 0 conv_planar_kx3_kernel (kx-reuse staging of the 256 x 128 ring tiles), 1 dcn_fused_kernel (the fused deformable
+ * convolution); -1 for anything else. */
 long long stm_debug_launch_count(int which);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -612,6 +615,24 @@ int stm_deform_sample_planar_f32(const float* x, int x_ld, const float* offsets,
 /* plane-format aware form (fmt as in stm_conv_geom: 0 = bf16 x 3, 1 = fp16 x 2) */
 int stm_dcn_sample_planar_fmt_f32(const float* x, const float* offset_mask, int om_ld, void* planes, int out_np,
                                   long long out_plane_stride, const stm_deform_geom* g, int fmt, stm_stream_t stream);
+
+/* ---- fused deformable convolution for the planar graph (rows a1 / a7): sampler + plane split + matrix product in ONE kernel ----
+ * Replaces the pair stm_deform_sample_planar_f32 (columns as planes, 78 % of a DCN layer's bytes) + stm_conv2d_planar_f32 over
+ * taps*C channels, i.e. dcn_v2.DCN.forward (backbone.py:20-26,45; has_mask = 1: 18 offsets then 9 mask logits per pixel, sigmoid
+ * applied here, bias, the bottleneck's ReLU) and mmcv.ops.DeformConv2d as FeatureAlign calls it (Featurealign.py:27-31,72;
+ * has_mask = 0, 3x3 / 3x5 / 5x3, no bias).  x fp32 pixel-major [B*H*W, x_ld >= C]; offsets fp32 [B*Ho*Wo, om_ld]; packed_weight =
+ * stm_conv_pack_weights_fmt_f32 of the ORIGINAL [Cout][C][kh][kw] weight at tile_n 128 in format fmt (1: fp16 x 2, 2: fp16 x 1),
+ * out_scale = 1 / its wscale; the output leaves as planes [P][Cout/32][out_np][32] in out_fmt (= fmt, or 1 under fmt 2) at pixels
+ * [out_pixel_offset, out_pixel_offset + B*Ho*Wo).  The sampled values are those of stm_deform_sample_planar_f32 bit for bit (same
+ * corner weights, same blend, same split); the products and their order per K-slab are those of stm_conv2d_planar_f32, with the K
+ * axis ordered channel-slab outer / tap inner.  No column buffer exists: algorithmic bytes = input + offsets + output + weights
+ * (fused form).  One deformable group, <= 15 taps (9 with mask), C % 64 == 0, Cout % 128 == 0
+ * (stm_deform_conv_fused_planar_supported says so without raising an error). */
+int stm_deform_conv_fused_planar_supported(const stm_deform_geom* g, int Cout, int has_mask, int fmt);
+int stm_deform_conv_fused_planar_f32(const float* x, int x_ld, const float* offsets, int om_ld, int has_mask, const void* packed_weight,
+                                     const float* bias, void* out_planes, int out_np, int out_pixel_offset, long long out_plane_stride,
+                                     int Cout, int relu, float out_scale, const stm_deform_geom* g, int fmt, int out_fmt,
+                                     stm_stream_t stream);
 
 #ifdef __cplusplus
 }

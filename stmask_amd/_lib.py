@@ -13,7 +13,7 @@ _lib = None
 c_i, c_l, c_f, c_p, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
 # every symbol include/stmask_hip.h declares (tests/test_abi.py checks the library exports all of them)
-ABI_VERSION = 3   # include/stmask_hip.h STM_ABI_VERSION
+ABI_VERSION = 4   # include/stmask_hip.h STM_ABI_VERSION
 ABI_SYMBOLS = [
     "stm_version", "stm_last_error_string", "stm_struct_bytes", "stm_debug_reload_tunables", "stm_debug_launch_count", "stm_conv_kxr_packed_bytes", "stm_conv_pack_weights_kxr_f32", "stm_conv2d_planar_kxr_f32", "stm_conv2d_planar_dual_f32", "stm_conv2d_planar_windows_f32", "stm_conv2d_planar_windows_pool_f32", "stm_temporal_pool_fc_f32", "stm_stem_packed_weight_bytes", "stm_stem_pack_weights_f32", "stm_stem_fused_f32", "stm_chain_tail_weight_bytes", "stm_chain_tail_weight_bytes_proj", "stm_chain_pack_tail_f32", "stm_chain_pack_tail_proj_f32", "stm_bottleneck_chain_f32", "stm_bottleneck_chain_proj_f32", "stm_deform_im2col_f32", "stm_deform_conv_workspace_bytes",
     "stm_deform_conv_fwd_f32", "stm_gemm_bias_f32", "stm_gemm_workspace_bytes", "stm_gemm_bias_ws_f32", "stm_fcb_ali_offsets_f32", "stm_corr_patch_f32", "stm_corr_patch_nhwc_f32",
@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "stm_conv_pack_weights_tiled_f32", "stm_preprocess_u8_f32", "stm_head_assemble_f32", "stm_conv2d_planar_ws_f32", "stm_dcn_sample_planar_f32", "stm_conv_pack_weights_fmt_f32", "stm_split_planes_fmt_f32", "stm_dcn_sample_planar_fmt_f32", "stm_planar_set_range_flag", "stm_resize_bilinear_planes_f32", "stm_bias_relu_maxpool_planes_f32", "stm_roi_align_planes_f32", "stm_roi_align_planes_nhwc_f32", "stm_deform_sample_planar_f32", "stm_stem_rows_planes_f32", "stm_mask_iou_grouped_f32", "stm_cc_fast_nms_workspace_bytes", "stm_cc_fast_nms_ws_f32",
     "stm_gather_detections_f32", "stm_shift_rois_f32", "stm_shift_apply_f32", "stm_match_scores_f32", "stm_match_scores_embed_f32", "stm_gather_rows2", "stm_pack_tracked_f32", "stm_pack_tracked_bits_f32",
     "stm_lincomb_sigmoid_crop_bits_f32", "stm_mask_iou_bits_f32", "stm_split_planes_f16", "stm_conv_pack_weights_f16", "stm_conv2d_planar_f16", "stm_dcn_sample_planar_f16",
+    "stm_deform_conv_fused_planar_supported", "stm_deform_conv_fused_planar_f32",
 ]
 
 
@@ -87,6 +88,10 @@ def lib():
             _lib = None
             raise StmError(f"{LIB_PATH} has ABI version {v}, this binding was written for {ABI_VERSION} (or a struct size "
                            "differs): rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
+        missing = [n for n in ABI_SYMBOLS if not hasattr(_lib, n)]
+        if missing:
+            _lib = None
+            raise StmError(f"{LIB_PATH} lacks {', '.join(missing)}: rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
     return _lib
 
 

@@ -2144,7 +2144,9 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
     }
 #endif
     if (tn.kx3 && a.fmt == 1 && ring && mg == 2 && !dual && !win && a.splitk == 1 && a.kw == 3 && a.pw == 1 && a.sh == 1 && a.sw == 1 &&
-        a.slabs % 3 == 0 && a.kh <= 6 && full) {
+        a.slabs % 3 == 0 && a.kh <= 6 && 2 * a.ph == a.kh - 1 && full) {
+        // ("same" padding in height too: the kernel decodes a pixel index ONCE and uses it for the output and the staged input rows alike, so
+        // Ho == H and Wo == W are part of its contract -- a 3x3 layer with padding (0, 1) stays on conv_planar_kernel)
         // kx-reuse staging (conv_planar_kx3_kernel): one staged run of BM + 2 pixels per (channel slab, ky) serves the three taps of a kernel row
         static std::atomic<bool> kx3_reserved[STM_MAX_DEVICES];
         constexpr size_t lds = 8 * 64 * (64 + 4) * sizeof(float) > (size_t)KX3_LDS_LOOP ? 8 * 64 * (64 + 4) * sizeof(float) : (size_t)KX3_LDS_LOOP;
@@ -2175,7 +2177,10 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
 }
 }  // namespace
 
-extern "C" long long stm_debug_launch_count(int which) { return which == 0 ? g_kx3_launches.load(std::memory_order_relaxed) : -1; }
+extern "C" long long stm_debug_launch_count(int which)
+{
+    return which == 0 ? g_kx3_launches.load(std::memory_order_relaxed) : (which == 1 ? stm_internal_fused_dcn_launches() : -1);
+}
 
 extern "C" int stm_conv2d_planar_f32(const void* x_planes, const void* packed_weight, const float* bias, const float* residual_f32,
                                      const void* residual_planes, float* out_f32, void* out_planes, const stm_conv_geom* g,

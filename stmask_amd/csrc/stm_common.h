@@ -40,7 +40,8 @@ int stm_env_int_uncached(const char* name, int dflt);
         return v_;                                                                       \
     }())
 
-int* stm_internal_range_flag();   // conv_bf16x.hip: the device flag registered with stm_planar_set_range_flag (or null)
+int* stm_internal_range_flag();
+long long stm_internal_fused_dcn_launches();   // dcn_fused.hip: launches of dcn_fused_kernel (stm_debug_launch_count(1))   // conv_bf16x.hip: the device flag registered with stm_planar_set_range_flag (or null)
 
 static inline hipStream_t stm_hs(stm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

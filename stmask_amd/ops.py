@@ -164,6 +164,17 @@ def im2col_timing(enable):
     return old
 
 
+_fused_dcn_timing = None  # when a list: (start_event, end_event, algorithmic bytes, algorithmic flops, MFMA products per product) per fused DCN launch
+
+
+def fused_dcn_timing(enable):
+    """bench.py: time every stm_deform_conv_fused_planar_f32 launch with HIP events on the launch stream (live roofline)."""
+    global _fused_dcn_timing
+    old = _fused_dcn_timing
+    _fused_dcn_timing = [] if enable else None
+    return old
+
+
 _conv_timing = None  # when a list: (start_event, end_event, algorithmic_flops) per planar-conv launch (bench.py roofline)
 
 
@@ -1121,6 +1132,75 @@ def head_assemble(small, trk, B, sizes, n_cls, mask_dim, embed_dim, group_pad):
     check(_lib.lib().stm_head_assemble_f32(sp, tp, ctypes.byref(L), _p(conf), _p(loc), _p(mask), _p(track), _p(cen), _stream()),
           "stm_head_assemble_f32")
     return conf, loc, mask, track, cen
+
+
+def deform_conv_fused_supported(C, O, kernel_size, has_mask, fmt, deformable_groups=1):
+    """True when stm_deform_conv_fused_planar_f32 takes this layer (one deformable group, <= 15 taps, 9 with mask, C % 64 == 0,
+    O % 128 == 0, an fp16 plane format)."""
+    kh, kw = _pair(kernel_size)
+    g = DeformGeom(1, C, 8, 8, kh, kw, 1, 1, kh // 2, kw // 2, 1, 1, deformable_groups, 8, 8)
+    return bool(_lib.lib().stm_deform_conv_fused_planar_supported(ctypes.byref(g), c_i(O), c_i(1 if has_mask else 0), c_i(fmt)))
+
+
+def deform_conv_fused_tiles(B, Ho, Wo, O):
+    """Workgroups stm_deform_conv_fused_planar_f32 launches for B images of Ho x Wo output pixels and O channels (patches of <= 128
+    pixels chosen as csrc/dcn_fused.hip pick_patch does: fewest wasted tile pixels, then the squarest) -- the callers' small-grid rule."""
+    best, bt, bper = -1.0, 1, 1 << 30
+    for tw in range(4, 129):
+        th = 128 // tw
+        if th < 1:
+            break
+        thc, twc = min(th, Ho), min(tw, Wo)
+        tiles = -(-Ho // thc) * -(-Wo // twc)
+        eff = Ho * Wo / (tiles * 128.0)
+        per = thc + twc
+        if eff > best + 1e-9 or (eff > best - 1e-9 and per < bper):
+            best, bt, bper = eff, tiles, per
+    return B * bt * (O // 128)
+
+
+def deform_conv_fused_planar(x_pix, B, H, W, C, om, packed, out_scale, bias, O, kernel_size=3, stride=1, padding=1, dilation=1, has_mask=True,
+                             relu=False, fmt=1, out_fmt=None, out=None, out_off=0):
+    """The whole deformable convolution of the planar graph as one kernel (csrc/dcn_fused.hip: sampler -> plane split -> MFMA product,
+    no column buffer): dcn_v2.DCN (backbone.py:20-26,45; has_mask, bias, ReLU) or mmcv DeformConv2d as FeatureAlign uses it
+    (Featurealign.py:27-31,72).  x_pix fp32 [B*H*W, ld >= C] pixel-major (unit channel stride), om fp32 [B*Ho*Wo, >= 2K (+K)] raw offsets
+    (and mask logits), packed = conv_pack_weights(weight [O, C, kh, kw], tile_n=128, fmt=fmt)[0] with out_scale its second value.
+    Returns / fills planes [P, O/32, N, 32] in out_fmt at pixels [out_off, out_off + B*Ho*Wo)."""
+    _dev(x_pix, om, packed)
+    if x_pix.dtype != torch.float32 or x_pix.dim() != 2 or x_pix.stride(1) != 1 or x_pix.shape[0] != B * H * W or x_pix.shape[1] != C:
+        raise StmError(f"deform_conv_fused_planar: x must be fp32 [B*H*W, C] with unit channel stride, got {tuple(x_pix.shape)} {x_pix.stride()}")
+    om = _f32c(om)
+    kh, kw = _pair(kernel_size)
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    Ho, Wo = conv_out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw)
+    M, K = B * Ho * Wo, kh * kw
+    if om.dim() != 2 or om.shape[0] != M or om.shape[1] < (3 if has_mask else 2) * K:
+        raise StmError(f"deform_conv_fused_planar: offsets {tuple(om.shape)} do not match {M} output pixels x {(3 if has_mask else 2) * K}")
+    out_fmt = fmt if out_fmt is None else out_fmt
+    if out is None:
+        out = _empty_planes(out_fmt, O // 32, M, x_pix.device)
+        out_off = 0
+    elif out.dim() != 4 or out.shape[1] * 32 != O or not out.is_contiguous() or out.shape[0] < plane_layout(out_fmt)[0]:
+        raise StmError(f"deform_conv_fused_planar: planes {tuple(out.shape)} do not hold {O} channels in format {out_fmt}")
+    if bias is not None:
+        _dev(bias)
+        bias = _f32c(bias)
+    g = DeformGeom(B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, 1, Ho, Wo)
+    timing = _fused_dcn_timing
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.lib().stm_deform_conv_fused_planar_f32(_p(x_pix), c_i(x_pix.stride(0)), _p(om), c_i(om.shape[1]), c_i(1 if has_mask else 0), _p(packed),
+                                                      _p(bias), _p(out), c_i(out.shape[2]), c_i(out_off), c_l(0), c_i(O), c_i(1 if relu else 0),
+                                                      c_f(out_scale), ctypes.byref(g), c_i(fmt), c_i(out_fmt), _stream()),
+          "stm_deform_conv_fused_planar_f32")
+    if timing is not None:
+        e1.record()
+        # SURVEY.md section 8(d), fused form: input once, offsets (+ mask) per output pixel, output planes, weights (as packed planes); no columns
+        npl, npo = plane_layout(fmt)[0], plane_layout(out_fmt)[0]
+        nbytes = 4 * B * C * H * W + 4 * (3 if has_mask else 2) * K * M + 2 * npo * O * M + 2 * npl * O * C * K
+        timing.append((e0, e1, float(nbytes), 2.0 * M * O * C * K, {1: 3, 2: 1}[fmt]))
+    return out
 
 
 def dcn_sample_planar(x_nhwc, om, stride=1, padding=1, dilation=1, fmt=0):

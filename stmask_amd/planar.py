@@ -46,6 +46,10 @@ CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 laye
 TN_BORDER = os.environ.get("STM_TN_BORDER", "1") != "0"     # TemporalNet's 3x3 layers as nine window launches without the zero taps of the RoI borders
 TN_POOL = os.environ.get("STM_TN_POOL", "1") != "0"         # ... and its AvgPool2d in conv3's epilogue, fc + fc_coeff as one launch (needs TN_BORDER)
 CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"
+# the deformable 3x3 layers (and the FCB class branch) as ONE kernel -- sampler -> plane split -> MFMA product, no column buffer (csrc/dcn_fused.hip) --
+# from DCN_FUSED_MIN_TILES workgroups on (below that the grid leaves CUs idle and the sampler + split-K product pair is faster); 0 = the pair everywhere
+DCN_FUSED = os.environ.get("STM_DCN_FUSED", "1") != "0"
+DCN_FUSED_MIN_TILES = int(os.environ.get("STM_DCN_FUSED_MIN_TILES", "200"))
 # Independent parts of the trunk on a second stream while a HIP graph is being captured (PlanarGraph.run): 0 off (default), 1 proto-net beside the
 # shared head, 2 also the P5 -> P6 -> P7 convolutions beside the finer FPN levels; only batches of at most BRANCH_MAX_IMAGES frames.  Bit-equal, and
 # SLOWER at every batch size it was meant for (profiles/r04_trunk_branches_ab.txt: 1 clip 478 -> 426-442 frames/s, 2 clips 728 -> 640-694, 4 clips
@@ -264,6 +268,14 @@ class PlanarConv:
                                                  ops._stream())
         check(rc, "stm_conv2d_planar_f32")
         return self._finish(timing, e0 if timing is not None else None, M, shape, g, NP, NPo, dt, out, out_f32, out_planes, residual)
+
+    def deform(self, x32, B, H, W, om, stride, padding, dilation, has_mask, out=None, out_off=0):
+        """This layer as a DEFORMABLE convolution in one kernel (ops.deform_conv_fused_planar, csrc/dcn_fused.hip): x32 fp32 pixel-major
+        [B*H*W, C] (a channel slice of a wider tensor is fine), om fp32 [B*Ho*Wo, 2K (+K)]; the weight is this layer's own kh x kw weight
+        packed for 128-channel tiles.  Bias and ReLU as configured; planes out."""
+        packed = self.packed(128)
+        return ops.deform_conv_fused_planar(x32, B, H, W, self.C, om, packed, self.out_scale, self.bias, self.O, (self.kh, self.kw), stride, padding,
+                                            dilation, has_mask=has_mask, relu=self.relu, fmt=self.fmt, out_fmt=self.out_fmt, out=out, out_off=out_off)
 
     def _finish(self, timing, e0, M, shape, g, NP, NPo, dt, out, out_f32, out_planes, residual):
         if timing is not None:
@@ -902,6 +914,9 @@ class PlanarBackbone:
                     if e["dcn_planar"]:
                         wk = c2.weight.detach().permute(0, 2, 3, 1).reshape(O, 9 * Cin, 1, 1)
                         e["dcn_conv"] = PlanarConv(wk, c2.bias, 1, 0, relu=True, fmt=fmt)
+                        # ... or the whole deformable convolution as one kernel: the ORIGINAL 3x3 weight packed channel-slab outer / tap inner
+                        if DCN_FUSED and fmt in (1, 2) and ops.deform_conv_fused_supported(Cin, O, 3, True, fmt):
+                            e["dcn_fused"] = PlanarConv(c2.weight, c2.bias, c2.stride, c2.padding, relu=True, fmt=fmt)
                 else:
                     e["c2"] = PlanarConv(c2.weight, c2.bias, c2.stride, c2.padding, relu=True, fmt=fmt)
                 if blk.downsample is not None:
@@ -982,8 +997,12 @@ class PlanarBackbone:
                         # [pixels, 27]; sampler -> planar columns; GEMM + bias + ReLU as a planar 1x1 convolution
                         t32, tpl = e["c1"](xp, shape, out="both")
                         om = e["om"](tpl, shape, out="f32")
-                        cols = ops.dcn_sample_planar(t32.view(B, H, W, -1), om, d.stride, d.padding, d.dilation, fmt=self.fmt)
-                        mid = e["dcn_conv"](cols, ("img", B, Ho, Wo))
+                        fz = e.get("dcn_fused")
+                        if fz is not None and ops.deform_conv_fused_tiles(B, Ho, Wo, fz.O) >= DCN_FUSED_MIN_TILES:
+                            mid = fz.deform(t32, B, H, W, om, d.stride, d.padding, d.dilation, has_mask=True)
+                        else:
+                            cols = ops.dcn_sample_planar(t32.view(B, H, W, -1), om, d.stride, d.padding, d.dilation, fmt=self.fmt)
+                            mid = e["dcn_conv"](cols, ("img", B, Ho, Wo))
                     elif B * Ho * Wo >= self.OM_PLANAR_MIN_PIXELS:
                         t32, tpl = e["c1"](xp, shape, out="both")
                         om = e["om"](tpl, shape, out="f32")[:, :e["n_om"]].reshape(B, Ho, Wo, -1).permute(0, 3, 1, 2).contiguous()

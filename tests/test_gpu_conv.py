@@ -1009,3 +1009,31 @@ def test_conv_planar_kx3_staging_is_bit_equal_to_the_ring_kernel(case, tunables)
         ref = oracle.conv2d_nhwc(xi, w, b, None, padding=(1, 1), relu=True)
         mag = oracle.conv2d_nhwc(xi.abs(), w.abs(), b.abs(), None, padding=(1, 1))
         assert ((outs[1][0].cpu().view(ref.shape) - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("kh,ph", [(3, 0), (5, 1), (3, 2)])
+def test_conv_planar_kx3_leaves_other_height_paddings_to_the_ring_kernel(kh, ph, tunables):
+    """The kx-reuse kernel decodes a pixel index once for the output and the staged input rows: it is only right for "same" padding in height as
+    well as in width.  A kw = 3 / pw = 1 layer whose height padding is NOT kh // 2 (Ho != H) must stay on conv_planar_kernel -- the launch counter
+    does not move, and the result equals the run with the kernel switched off and the fp64 oracle."""
+    from stmask_amd import _lib
+    from stmask_amd.planar import PlanarConv
+    B, H, W, C, O = 8, 48, 80, 64, 128
+    x = rnd(B, H, W, C, seed=11)
+    w = rnd(O, C, kh, 3, seed=12, scale=(C * kh * 3) ** -0.5)
+    b = rnd(O, seed=13)
+    conv = PlanarConv(w.to(DEV), b.to(DEV), 1, (ph, 1), relu=True, tile_n=128, fmt=1)
+    xp = ops.split_planes(x.to(DEV), 1)
+    outs = []
+    for kx3 in ("0", "1"):
+        tunables.set(STM_CONV_KX3=kx3, STM_CONV_MG="2", STM_CONV_SPLITK="1")
+        n0 = _lib.lib().stm_debug_launch_count(c_int(0))
+        y32 = conv(xp, ("img", B, H, W), out="f32")
+        torch.cuda.synchronize()
+        assert _lib.lib().stm_debug_launch_count(c_int(0)) == n0, "a layer without same padding in height went to the kx-reuse kernel"
+        outs.append(y32.clone())
+        tunables.clear("STM_CONV_KX3", "STM_CONV_MG", "STM_CONV_SPLITK")
+    assert torch.equal(outs[0], outs[1])
+    ref = oracle.conv2d_nhwc(x, w, b, None, padding=(ph, 1), relu=True)
+    mag = oracle.conv2d_nhwc(x.abs(), w.abs(), b.abs(), None, padding=(ph, 1))
+    assert ((outs[1].cpu().view(ref.shape) - ref).abs() / mag.clamp_min(1e-6)).max().item() < 2e-6
