@@ -233,8 +233,8 @@ def conv_roofline(conv_t, steps, planes, traffic=None, traffic_src=None, timed_i
                        "with residual, stem): inputs, residual, outputs and weights once, in their stored formats"}
     obj = dict(allo)
     obj.update({"bound": "mfma",
-                "kernel": f"conv_planar_kernel / conv_planar_kx3_kernel / conv_kxr_kernel / conv_chain_kernel ({planes} planes: stem, backbone 1x1/3x3 and DCN "
-                          "GEMMs, FPN, proto-net, shared head, TemporalNet; all launches of " + timed_in + ")",
+                "kernel": f"conv_planar_kernel / conv_planar_kx3_kernel / conv_kxr_kernel / conv_chain_kernel / dcn_fused_kernel ({planes} planes: stem, backbone 1x1/3x3 and the deformable "
+                          "convolutions, FPN, proto-net, shared head, TemporalNet; all launches of " + timed_in + ")",
                 "traffic": traffic,
                 "traffic_source": (f"profiles/{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
                                    "correction); average over all launches") if traffic_src else None,
@@ -400,6 +400,7 @@ class Runner:
         if collect:
             ops.im2col_timing(True)
             ops.conv_timing(True)
+            ops.fused_dcn_timing(True)
         self.tracked_sum, self.tracked_steps = 0.0, 0
         tm = getattr(self.pipe, "timer", None)
         if tm is not None and tm.on:
@@ -417,6 +418,8 @@ class Runner:
         elapsed = time.perf_counter() - t0
         timing = ops.im2col_timing(False) if collect else None
         conv_t = (ops.conv_timing(False) or []) if collect else None
+        if collect:
+            self.fused_t = ops.fused_dcn_timing(False) or []       # launches of the fused deformable convolution (csrc/dcn_fused.hip) of this pass
         return elapsed, out, timing, conv_t
 
 
@@ -639,6 +642,49 @@ def main():
                        "traffic_source": f"profiles/{src_s} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)" if src_s else None,
                        "launches": len(timing), "avg_launch_us": round(ker_ms * 1e3 / n_launch, 2),
                        "algorithmic_bytes_per_launch": int(ker_bytes / n_launch)}
+        fused_t = getattr(run, "fused_t", None) or []
+        if fused_t:
+            # the deformable layers as ONE kernel (sampler + plane split + MFMA product, no column buffer): priced both ways -- against the HBM peak
+            # with SURVEY 8(d)'s FUSED byte formula (input + offsets + output + weights; the 78 % of a DCN layer's bytes that were columns are gone,
+            # so this kernel is nowhere near HBM-bound) and against the matrix peak with the layer's reference flops
+            f_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in fused_t)
+            f_by, f_fl = sum(t[2] for t in fused_t), sum(t[3] for t in fused_t)
+            f_mf = sum(t[3] * t[4] for t in fused_t)
+            tr_f, src_f = pmc_traffic("dcn_fused") if default_wl else (None, None)
+            res["roofline_dcn_fused"] = {
+                "kernel": "dcn_fused_kernel (deformable convolution of the DCN layers: corner gathers, blend, fp16 plane split and the three plane products "
+                          "in one kernel; all launches of the pass the other roofline objects come from)",
+                "launches": len(fused_t), "avg_launch_us": round(f_ms * 1e3 / len(fused_t), 2), "ms_per_step": round(f_ms / args.steps, 3),
+                "bound": "mfma", "achieved": round(f_fl / (f_ms * 1e-3) / 1e12, 1), "peak": round(BF16_MFMA_PEAK_TF * f_fl / f_mf, 1), "unit": "TFLOP/s",
+                "frac": round(f_mf / (f_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4),
+                "hbm": {"bound": "hbm", "achieved": round(f_by / (f_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(f_by / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(f_by / len(fused_t)),
+                        "formula": "4 B (C H W + 27 Ho Wo) + planes (Cout Ho Wo + 9 C Cout): SURVEY 8(d), fused im2col + GEMM"},
+                "traffic": tr_f,
+                "traffic_source": f"profiles/{src_f} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)" if src_f else None,
+                "replaces": "dcn_sample_planar_kernel (roofline_im2col: 412 MB of columns per launch at 0.48-0.50 of the HBM peak) + the 1x1 product over 9C "
+                            "channels; what bounds the fused kernel instead: profiles/r05_dcn_fused_forms.txt"}
+            if not timing:
+                # the sampler the north star names did not run in that pass (every DCN layer took the fused kernel): its own figure from a short eager
+                # pass of the same pipeline with fusion switched off (same process, right after; nothing of it enters the headline)
+                from stmask_amd import planar as _plf
+                saved_mt, saved_g = _plf.DCN_FUSED_MIN_TILES, (run.pipe.use_graph if run.batched else None)
+                _plf.DCN_FUSED_MIN_TILES = 1 << 30
+                if run.batched:
+                    run.pipe.use_graph = False
+                try:
+                    _, _, timing, _ = run.timed(1, min(args.steps, 8), use_dist, collect=True)
+                finally:
+                    _plf.DCN_FUSED_MIN_TILES = saved_mt
+                    if run.batched:
+                        run.pipe.use_graph = saved_g
+                ker_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
+                ker_bytes = sum(b for _, _, b in timing)
+                n_launch = max(len(timing), 1)
+                achieved = ker_bytes / (ker_ms * 1e-3) / 1e9 if ker_ms > 0 else 0.0
+                im2col_roof.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4), "launches": len(timing),
+                                    "avg_launch_us": round(ker_ms * 1e3 / n_launch, 2), "algorithmic_bytes_per_launch": int(ker_bytes / n_launch),
+                                    "timed_in": "a short eager pass with STM_DCN_FUSED off right after the timed region (the timed region runs the fused kernel: roofline_dcn_fused)"})
         if conv_t:
             tr_c, src_c = pmc_traffic("conv_planar") if default_wl else (None, None)
             res["roofline"] = conv_roofline(conv_t, args.steps, args.planes, tr_c, src_c,

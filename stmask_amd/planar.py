@@ -50,6 +50,10 @@ CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"
 # from DCN_FUSED_MIN_TILES workgroups on (below that the grid leaves CUs idle and the sampler + split-K product pair is faster); 0 = the pair everywhere
 DCN_FUSED = os.environ.get("STM_DCN_FUSED", "1") != "0"
 DCN_FUSED_MIN_TILES = int(os.environ.get("STM_DCN_FUSED_MIN_TILES", "200"))
+# ... the FCB class branch (FeatureAlign's DeformConv2d, 256 -> 256 channels, 9 / 15 / 15 taps over five levels) on the same kernel: built and tested, OFF by
+# default -- two 128-channel tiles per pixel patch sample every pixel twice and the sampler + product pair wins (R50 FCB-ada at 32 clips: 918 frames/s with
+# the pair, 764 fused; profiles/r05_dcn_fused_forms.txt)
+FCB_FUSED = os.environ.get("STM_FCB_FUSED", "0") != "0"
 # Independent parts of the trunk on a second stream while a HIP graph is being captured (PlanarGraph.run): 0 off (default), 1 proto-net beside the
 # shared head, 2 also the P5 -> P6 -> P7 convolutions beside the finer FPN levels; only batches of at most BRANCH_MAX_IMAGES frames.  Bit-equal, and
 # SLOWER at every batch size it was meant for (profiles/r04_trunk_branches_ab.txt: 1 clip 478 -> 426-442 frames/s, 2 clips 728 -> 640-694, 4 clips
@@ -399,7 +403,11 @@ class PlanarGraph:
                 if ad.deform_groups == 1 and Cin == 256 and akh * akw in (9, 15):
                     wk = ad.weight.detach().permute(0, 2, 3, 1).reshape(O, akh * akw * Cin, 1, 1)
                     entry.append(PlanarConv(wk, None, 1, 0, relu=True))
+                    # ... or, level by level where the grid is large enough, the whole DeformConv2d + ReLU as one kernel (csrc/dcn_fused.hip)
+                    entry.append(PlanarConv(ad.weight, None, 1, fa.padding, relu=True)
+                                 if DCN_FUSED and FCB_FUSED and self.fmt in (1, 2) and ops.deform_conv_fused_supported(Cin, O, (akh, akw), False, self.fmt) else None)
                 else:
+                    entry.append(None)
                     entry.append(None)
             self.finals.append(tuple(entry))
         self.head = head
@@ -588,7 +596,7 @@ class PlanarGraph:
             # conf_x per level as NCHW fp32 (shared by the three kernel shapes)
             conf_x = None
             outs = []
-            for small, trk, fa, fconv, adconv in self.finals:
+            for small, trk, fa, fconv, adconv, adfused in self.finals:
                 buf = torch.empty(ntot, 3 * P, device=dev, dtype=torch.float32)   # [conf | centerness+bbox | mask] groups
                 small(t2, lv, out="f32", out_f32=buf, x_ch_off=cw, out_ch_off=P)
                 npri = head.num_priors
@@ -600,7 +608,15 @@ class PlanarGraph:
                     if fa.use_pred_offset:
                         off = bbox_pix @ fa.conv_offset.weight.view(2 * K, 4).t()   # Featurealign.py:40-43 (1x1 conv, no bias)
                     NP_, pdt_ = _planes_dtype(self.fmt)
-                    cols = torch.empty(NP_, K * cw // 32, ntot, 32, device=dev, dtype=pdt_)
+                    # levels whose grid fills the chip take the fused kernel (no columns); the coarser ones, contiguous at the end of the pixel axis,
+                    # share one column buffer and one 1x1 product as before -- both write the same feature planes
+                    n_fused = 0
+                    if adfused is not None:
+                        while n_fused < len(sizes) and ops.deform_conv_fused_tiles(B, sizes[n_fused][0], sizes[n_fused][1], adfused.O) >= DCN_FUSED_MIN_TILES:
+                            n_fused += 1
+                    c0 = starts[n_fused]                                         # first pixel of the column-buffer levels
+                    feat_pl = torch.empty(NP_, cw // 32, ntot, 32, device=dev, dtype=pdt_)
+                    cols = torch.empty(NP_, K * cw // 32, ntot - c0, 32, device=dev, dtype=pdt_) if ntot > c0 else None
                     for l, (hh, ww) in enumerate(sizes):
                         sl = slice(starts[l], starts[l + 1])
                         if fa.use_pred_offset:
@@ -608,8 +624,12 @@ class PlanarGraph:
                         else:
                             loc_l = bbox_pix[sl].reshape(B, hh, ww, 4).permute(0, 3, 1, 2).contiguous()
                             off_l = ops.fcb_ali_offsets(loc_l, kh, kw).permute(0, 2, 3, 1).reshape(-1, 2 * K)
-                        ops.deform_sample_planar(t2_32[sl, 0:cw], B, hh, ww, cw, off_l, (kh, kw), fa.padding, cols, starts[l], self.fmt)
-                    feat_pl = adconv(cols, ("img", 1, 1, ntot))                  # DeformConv2d's GEMM + ReLU
+                        if l < n_fused:
+                            adfused.deform(t2_32[sl, 0:cw], B, hh, ww, off_l, 1, fa.padding, 1, has_mask=False, out=feat_pl, out_off=starts[l])
+                        else:
+                            ops.deform_sample_planar(t2_32[sl, 0:cw], B, hh, ww, cw, off_l, (kh, kw), fa.padding, cols, starts[l] - c0, self.fmt)
+                    if cols is not None:
+                        adconv(cols, ("img", 1, 1, ntot - c0), out_planes=feat_pl, out_off=c0)      # DeformConv2d's GEMM + ReLU
                     fconv(feat_pl, lv, out="f32", out_f32=buf)                   # conf logits into columns [0, n_cls)
                     outs.append((buf, trk(t2, lv, out="f32", x_ch_off=3 * cw)))
                     continue

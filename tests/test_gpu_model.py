@@ -143,6 +143,45 @@ def test_planar_graph_matches_module_path_and_reference(name, tag, planes):
                     tol_rms=1e-4, tol_abs=2e-4)
 
 
+@pytest.mark.parametrize("name,tag", CASES[:3])
+def test_planar_graph_with_fused_deformable_layers_matches_reference(name, tag, monkeypatch):
+    """The same graph with every deformable convolution on the fused kernel (csrc/dcn_fused.hip: the DCN layers of the backbone and -- FCB
+    configs -- FeatureAlign's DeformConv2d on every FPN level; at the test's image size the small-grid rule would keep the sampler + product
+    pair, so the rule is switched off): module path, reference goldens and the clip's detections to the tolerances of the test above."""
+    from stmask_amd import planar, _lib
+    from stmask_amd.fuse import optimize_for_inference
+    monkeypatch.setattr(planar, "DCN_FUSED", True)
+    monkeypatch.setattr(planar, "FCB_FUSED", True)
+    monkeypatch.setattr(planar, "DCN_FUSED_MIN_TILES", 1)
+    g = load_golden(f"model_{tag}.npz")
+    h, w = [int(v) for v in g["frames_hw"]]
+    ref_net = build(name)
+    opt_net = build(name)
+    optimize_for_inference(opt_net, planar=True, planes="fp16x2")
+    opt_net = opt_net.to(memory_format=torch.channels_last)
+    opt_net.TemporalNet = opt_net.TemporalNet.to(memory_format=torch.contiguous_format)
+    frames = synthetic.synthetic_clip(int(g["n_frames"]), h, w, seed=0)
+    x = frames[:2].cuda()
+    n0 = _lib.lib().stm_debug_launch_count(1)
+    with torch.no_grad():
+        fa, a = ref_net.forward_single(x)
+        fb, b = opt_net.forward_single(x.contiguous(memory_format=torch.channels_last))
+    launched = _lib.lib().stm_debug_launch_count(1) - n0
+    assert launched >= 7 + (0 if tag == "r50_fca" else 15), launched          # 7 DCN layers (+ 3 kernel shapes x 5 levels of the class branch)
+    for k in ("loc", "conf", "mask_coeff", "centerness", "proto", "track"):
+        scale = max(1.0, a[k].abs().max().item())
+        assert (a[k] - b[k]).abs().max().item() < 5e-5 * scale, (k, (a[k] - b[k]).abs().max().item())
+    for k, gk in [("loc", "f0_loc"), ("conf", "f0_conf_logits"), ("mask_coeff", "f0_mask_coeff"),
+                  ("centerness", "f0_centerness"), ("proto", "f0_proto")]:
+        ref = g[gk]
+        assert (b[k][0].cpu() - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item()), k
+    from test_gpu_parity import check_frame
+    outs = run_clip(opt_net, frames.contiguous(memory_format=torch.channels_last), "cuda")
+    for t, det in enumerate(outs):
+        check_frame((tag, "fused", t), det, g[f"t{t}_box"], g[f"t{t}_class"], g[f"t{t}_mask"], min_frac=0.98, tol_box=3e-6,
+                    tol_rms=1e-4, tol_abs=2e-4)
+
+
 @pytest.mark.parametrize("fmt", [1, 0])
 def test_planar_temporalnet_matches_module(fmt):
     """PlanarTemporalNet (633 -> 640 zero-padded channels, any RoI count per launch) == the nn.Module TemporalNet."""
