@@ -556,7 +556,11 @@ def main():
         sys.stdout.flush()
         _RESULT_FD = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev if args.backend == "nccl" else None)
+        # NO device_id: with it torch binds the communicator eagerly at start-up, and on this stack that alone -- no collective issued -- costs a rank
+        # 1.3-1.5 ms of every 21-ms step (profiles/r05_launcher_overhead.txt: plain 21.19, eager communicator without any gather 22.56, lazy
+        # communicator with a gather every step 21.20).  The device is set above; barriers name it.  STM_PG_EAGER=1 restores the eager form (A/B).
+        dist.init_process_group(args.backend, rank=rank, world_size=world,
+                                device_id=dev if (args.backend == "nccl" and os.environ.get("STM_PG_EAGER", "0") != "0") else None)
 
     # MIOpen immediate mode (only --no-planar graphs reach the library at all)
     torch.backends.cudnn.benchmark = False
@@ -569,6 +573,17 @@ def main():
     elapsed, out, timing, conv_t = run.timed(args.warmup, args.steps, use_dist, collect=not graphed and not args.world2_one_gpu)
     if args.world2_one_gpu:
         sys.exit(world2_report(args, run, dev, rank, world, elapsed, use_dist))
+    coll_local = coll_delta = None
+    if use_dist and run.batched:
+        # the collective's report, taken HERE: the block this rank packed in the last timed step (before any further pass advances the pipeline), and
+        # the same K steps once more with the exchange switched off (the process group stays): what the all-gather costs a step
+        run.gatherer.wait()
+        coll_local = run.pipe._pack_outputs(dev).clone()
+        saved_mode = run.gatherer.mode
+        run.gatherer.mode = 2
+        el_nog, _, _, _ = run.timed(1, args.steps, use_dist)
+        run.gatherer.mode = saved_mode
+        coll_delta = (elapsed - el_nog) / args.steps * 1e3
     if graphed:
         # a graph replay cannot be bracketed kernel by kernel: the per-kernel HIP-event timing of the roofline objects comes from
         # a second, eager pass of the same K steps right after the timed region (same kernels, same shapes, same process)
@@ -623,8 +638,11 @@ def main():
             # at world size 1, where the gathered block must BE the local block -- whether the last one came back bit-equal
             g = run.gatherer
             run.gatherer.wait()
-            last_local = run.pipe._pack_outputs(dev) if run.batched else None
+            last_local = coll_local
             res["collective"] = {"backend": dist.get_backend(), "world_size": world, "all_gathers_on_comm_stream": g.n_collectives,
+                                 "ms_per_step_delta_vs_no_gather": round(coll_delta, 3) if coll_delta is not None else None,
+                                 "delta_note": "timed region minus the same K steps run right after it with the exchange switched off (process group kept); "
+                                               "profiles/r05_launcher_overhead.txt has the same-box runs against a plain process without any process group",
                                  "comm_stream": (g._comm is not None and g._comm != torch.cuda.default_stream(dev)),
                                  "gathered_shape": list(out.shape),
                                  "last_gather_equals_local_block": (bool(torch.equal(out[rank * args.clips:(rank + 1) * args.clips], last_local))

@@ -67,23 +67,43 @@ class DetectionGatherer:
     (or a device synchronisation) has returned."""
 
     def __init__(self, device=None):
+        import os
         self.device = device
         self._comm = None
         self._events = []
         self.n_collectives = 0          # all-gathers enqueued on the communication stream (the RCCL branch)
+        # diagnosis (scripts/ab_launcher_overhead.sh): 0 = as described above; 1 = two persistent output buffers, the packed block kept alive by a
+        # reference instead of record_stream; 2 = no collective at all (the process group exists, nothing is gathered); 3 = the collective on the
+        # CURRENT stream (no communication stream)
+        self.mode = int(os.environ.get("STM_GATHER_MODE", "0"))
+        self._outs, self._hold = [None, None], None
 
     def gather(self, packed):
         if not (dist.is_available() and dist.is_initialized()):
             return packed
         if not packed.is_cuda or dist.get_backend() == "gloo":
             return all_gather_detections(packed)
+        if self.mode == 2:
+            return packed
+        if self.mode == 3:
+            self.n_collectives += 1
+            return all_gather_detections(packed)
         if self._comm is None:
             self._comm = torch.cuda.Stream(device=packed.device)
         main = torch.cuda.current_stream()
         self._comm.wait_stream(main)
         with torch.cuda.stream(self._comm):
-            packed.record_stream(self._comm)
-            out = all_gather_detections(packed)
+            if self.mode == 1:
+                i = self.n_collectives & 1
+                shape = (dist.get_world_size() * packed.shape[0],) + tuple(packed.shape[1:])
+                if self._outs[i] is None or tuple(self._outs[i].shape) != shape:
+                    self._outs[i] = torch.empty(shape, dtype=packed.dtype, device=packed.device)
+                out = self._outs[i]
+                self._hold = packed.contiguous()
+                dist.all_gather_into_tensor(out, self._hold)
+            else:
+                packed.record_stream(self._comm)
+                out = all_gather_detections(packed)
             ev = torch.cuda.Event()
             ev.record()
         self._events = [ev]
