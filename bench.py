@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the parity block that needs it)")
     ap.add_argument("--no-extras", action="store_true", help="skip the 8-clip / 1-clip / bf16x3 side measurements")
-    ap.add_argument("--extras", default="realistic,clips8,clips1,bf16x3", help="which side measurements to run (comma-separated)")
+    ap.add_argument("--extras", default="realistic,clips8,clips1,bf16x3,per_class_nms,non_tf", help="which side measurements to run (comma-separated)")
     ap.add_argument("--nchw", dest="channels_last", action="store_false", help="keep the dense convs in NCHW")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="keep BatchNorm / bias / ReLU as separate kernels")
     ap.add_argument("--overlap", choices=("late", "early", "off"), default="late",
@@ -766,6 +766,30 @@ def main():
                     del r2
                     torch.cuda.empty_cache()
                 except Exception as e:  # a side measurement never takes the headline down
+                    extras[name] = {"error": repr(e)[:200]}
+            # rows a13 / a18 through the same batched pipeline: the reference's per-class Fast NMS variant (detection_TF.py:136-204: ONE launch pair
+            # for all clips) and the non-temporal-fusion flow Detect + Track (detection.py:98-137, track.py:56-179) on the headline's net and clips
+            for name in ("per_class_nms", "non_tf"):
+                if name not in args.extras.split(",") or args.max_instances:
+                    continue
+                try:
+                    r2 = Runner(args, dev, rank, world, args.clips, net=net)
+                    if name == "per_class_nms":
+                        net.Detect_TF.use_cross_class_nms = False
+                    else:
+                        r2.pipe.tf = False
+                    try:
+                        el, _, _, _ = r2.timed(args.warmup, args.steps)
+                    finally:
+                        net.Detect_TF.use_cross_class_nms = True
+                    extras[name] = {"value": round(args.clips * args.steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / args.steps * 1e3, 3),
+                                    "clips_per_gpu": args.clips, "steps": args.steps, "instances_per_clip_mean": round(r2.tracked_sum / max(r2.tracked_steps, 1), 1),
+                                    "what": ("Detect_TF.use_cross_class_nms = False: 40 class-wise Fast NMS per frame, top 100 (stm_fast_nms_batched_f32)"
+                                             if name == "per_class_nms" else
+                                             "no temporal fusion: Detect + Track (binary-mask tracker, track.py:162 update gate), the frame's detections as output")}
+                    del r2
+                    torch.cuda.empty_cache()
+                except Exception as e:
                     extras[name] = {"error": repr(e)[:200]}
             if "clips1" in extras and "value" in extras["clips1"]:
                 extras["clips1"]["context"] = "single-stream regime of the reference's own FPS table (README.md:102: 29.3 FPS on a 2080 Ti, batch 1)"

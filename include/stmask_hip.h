@@ -35,7 +35,8 @@
  *     Added since without a version change (new entry points only): stm_conv2d_planar_windows_pool_f32, stm_temporal_pool_fc_f32,
  *     stm_debug_launch_count;
  *      4: those three entry points are part of the version now (a library that lacks them must not pass for this ABI), plus the fused
- *     deformable convolution stm_deform_conv_fused_planar_f32 / stm_deform_conv_fused_planar_supported; stm_debug_launch_count(1)).
+ *     deformable convolution stm_deform_conv_fused_planar_f32 / stm_deform_conv_fused_planar_supported; stm_debug_launch_count(1); the batched per-class Fast NMS
+ *     stm_fast_nms_batched_f32 / stm_fast_nms_batched_workspace_bytes).
  */
 #ifndef STMASK_HIP_H_
 #define STMASK_HIP_H_
@@ -224,6 +225,17 @@ int stm_fast_nms_f32(const float* conf, const float* boxes, const float* centern
                      const int* k_dev, float iou_thr, int top_k, float conf_thresh, int max_det,
                      int64_t* idx_out, int64_t* cls_out, float* score_out, float* box_out, int* count_out,
                      void* workspace, size_t workspace_bytes, stm_stream_t stream);
+/* The same for B frames in ONE launch pair (ABI 4; the batched clip pipeline's use_cross_class_nms = False path): frame b reads the confidence rows
+ * conf + b * conf_bstride (ncls floats each), the COMPACTED candidate boxes boxes + b * 4 K (float4 rows, as stm_generate_candidates_f32 writes them),
+ * centerness + b * cen_bstride and its candidate count k_dev[b] (device, <= K = the capacity of a frame's candidate arrays).  row_index (optional,
+ * [B][K] int64): candidate row i of frame b is row row_index[b][i] of conf / centerness -- the candidate pass's keep list, so that the [N, ncls]
+ * confidence rows need not be gathered; idx_out then holds those row numbers (prior indices).  Outputs [B][max_det] (+ box [B][max_det][4]),
+ * count_out [B].  Each frame's LDS sort covers its own count, not K.  Scores, order and ties as the one-frame entry (which is this one with B = 1). */
+size_t stm_fast_nms_batched_workspace_bytes(int K, int ncls, int top_k, int B);
+int stm_fast_nms_batched_f32(const float* conf, int64_t conf_bstride, const int64_t* row_index, const float* boxes, const float* centerness,
+                             int64_t cen_bstride, int K, int ncls, const int* k_dev, float iou_thr, int top_k, float conf_thresh, int max_det,
+                             int B, int64_t* idx_out, int64_t* cls_out, float* score_out, float* box_out, int* count_out,
+                             void* workspace, size_t workspace_bytes, stm_stream_t stream);
 
 /* Pairwise box IoU.  Replaces: layers.box_utils.jaccard (box_utils.py:60-88), 2-D form, bit-exact. */
 int stm_jaccard_f32(const float* a, int na, const float* b, int nb, float* out, stm_stream_t stream);

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "stm_conv_pack_weights_tiled_f32", "stm_preprocess_u8_f32", "stm_head_assemble_f32", "stm_conv2d_planar_ws_f32", "stm_dcn_sample_planar_f32", "stm_conv_pack_weights_fmt_f32", "stm_split_planes_fmt_f32", "stm_dcn_sample_planar_fmt_f32", "stm_planar_set_range_flag", "stm_resize_bilinear_planes_f32", "stm_bias_relu_maxpool_planes_f32", "stm_roi_align_planes_f32", "stm_roi_align_planes_nhwc_f32", "stm_deform_sample_planar_f32", "stm_stem_rows_planes_f32", "stm_mask_iou_grouped_f32", "stm_cc_fast_nms_workspace_bytes", "stm_cc_fast_nms_ws_f32",
     "stm_gather_detections_f32", "stm_shift_rois_f32", "stm_shift_apply_f32", "stm_match_scores_f32", "stm_match_scores_embed_f32", "stm_gather_rows2", "stm_pack_tracked_f32", "stm_pack_tracked_bits_f32",
     "stm_lincomb_sigmoid_crop_bits_f32", "stm_mask_iou_bits_f32", "stm_split_planes_f16", "stm_conv_pack_weights_f16", "stm_conv2d_planar_f16", "stm_dcn_sample_planar_f16",
-    "stm_deform_conv_fused_planar_supported", "stm_deform_conv_fused_planar_f32",
+    "stm_deform_conv_fused_planar_supported", "stm_deform_conv_fused_planar_f32", "stm_fast_nms_batched_workspace_bytes", "stm_fast_nms_batched_f32",
 ]
 
 
@@ -75,7 +75,7 @@ def lib():
         _lib.stm_last_error_string.restype = ctypes.c_char_p
         _lib.stm_version.restype = c_i
         for name in ("stm_deform_conv_workspace_bytes", "stm_gemm_workspace_bytes", "stm_mask_rle_workspace_bytes", "stm_detect_cc_workspace_bytes", "stm_fast_nms_workspace_bytes",
-                     "stm_mask_iou_workspace_bytes", "stm_conv_packed_weight_bytes", "stm_conv_packed_weight_bytes_tiled", "stm_cc_fast_nms_workspace_bytes", "stm_conv_kxr_packed_bytes", "stm_stem_packed_weight_bytes", "stm_chain_tail_weight_bytes", "stm_chain_tail_weight_bytes_proj"):
+                     "stm_mask_iou_workspace_bytes", "stm_conv_packed_weight_bytes", "stm_conv_packed_weight_bytes_tiled", "stm_cc_fast_nms_workspace_bytes", "stm_conv_kxr_packed_bytes", "stm_stem_packed_weight_bytes", "stm_chain_tail_weight_bytes", "stm_chain_tail_weight_bytes_proj", "stm_fast_nms_batched_workspace_bytes"):
             getattr(_lib, name).restype = c_sz
         _lib.stm_struct_bytes.restype = c_sz
         _lib.stm_debug_reload_tunables.restype = None

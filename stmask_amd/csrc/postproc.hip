@@ -418,33 +418,47 @@ __global__ __launch_bounds__(NMS_THREADS) void cc_nms_kernel(const float* __rest
 // ------------------------------------------------------------------------------- per-class NMS
 // stage A: one workgroup per foreground class: sort conf[:,c]*centerness, top_k, IoU, keep & score > conf_thresh
 // workspace per class: float kscore[top_k], int krow[top_k]; counts[ncls-1]
+// Batched form (blockIdx.y = frame): frame b reads conf + b * conf_bs (rows of ncls), boxes + b * box_bs (float4 rows), centerness + b * cen_bs, its
+// candidate count k_dev[b], and writes workspace block b.  row_index (optional, + b * K_cap): candidate row i of the frame is row row_index[i] of
+// conf / centerness (the boxes are already compacted) -- the batched pipeline passes the candidate pass's keep list instead of gathering the
+// [N, ncls] confidence rows.  The LDS sort covers next_pow2(K) keys of the frame's OWN count, not the capacity: same order, a fraction of the passes.
 __global__ __launch_bounds__(NMS_THREADS) void pc_nms_class_kernel(const float* __restrict__ conf,
                                                                    const float* __restrict__ boxes,
                                                                    const float* __restrict__ centerness, int K_cap,
                                                                    int ncls, const int* __restrict__ k_dev, float iou_thr,
                                                                    int top_k, float conf_thresh, int Kp,
                                                                    float* __restrict__ ws_score, int* __restrict__ ws_row,
-                                                                   int* __restrict__ ws_count)
+                                                                   int* __restrict__ ws_count, const int64_t* __restrict__ row_index,
+                                                                   int64_t conf_bs, int64_t box_bs, int64_t cen_bs, int64_t ws_bs)
 {
     extern __shared__ unsigned long long keys[];  // same carve-up as cc_nms_kernel
     float4* sbox = reinterpret_cast<float4*>(keys + Kp);
     int* srow = reinterpret_cast<int*>(sbox + top_k);
     int* wave_cnt = srow + 2 * top_k;
     const int c = blockIdx.x;  // foreground class index 0..ncls-2
+    const int fb = blockIdx.y;  // frame
+    conf += fb * conf_bs;
+    boxes += fb * box_bs;
+    if (centerness) centerness += fb * cen_bs;
+    if (row_index) row_index += (int64_t)fb * K_cap;
+    ws_score += fb * ws_bs; ws_row += fb * ws_bs; ws_count += (int64_t)fb * ncls;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int K = K_cap;
-    if (k_dev) K = min(K_cap, max(k_dev[0], 0));
-    for (int i = tid; i < Kp; i += NMS_THREADS) {
+    if (k_dev) K = min(K_cap, max(k_dev[fb], 0));
+    int Ks = 2;
+    while (Ks < K) Ks <<= 1;                     // (<= Kp: K <= K_cap)
+    for (int i = tid; i < Ks; i += NMS_THREADS) {
         unsigned long long key = ~0ull;
         if (i < K) {
-            float s = conf[(int64_t)i * ncls + c + 1];
-            if (centerness) s = s * centerness[i];
+            const int64_t r = row_index ? row_index[i] : (int64_t)i;
+            float s = conf[r * ncls + c + 1];
+            if (centerness) s = s * centerness[r];
             key = ((unsigned long long)ord_desc(s) << 32) | (unsigned int)i;
         }
         keys[i] = key;
     }
     __syncthreads();
-    bitonic_sort_lds(keys, Kp, tid, NMS_THREADS);
+    bitonic_sort_lds(keys, Ks, tid, NMS_THREADS);
     const int n = min(K, top_k);
     const float4* b4 = reinterpret_cast<const float4*>(boxes);
     float sc = 0.0f;
@@ -483,12 +497,20 @@ __global__ __launch_bounds__(NMS_THREADS) void pc_nms_merge_kernel(const float* 
                                                                    int64_t* __restrict__ idx_out,
                                                                    int64_t* __restrict__ cls_out,
                                                                    float* __restrict__ score_out,
-                                                                   float* __restrict__ box_out, int* __restrict__ count_out)
+                                                                   float* __restrict__ box_out, int* __restrict__ count_out,
+                                                                   const int64_t* __restrict__ row_index, int K_cap, int64_t box_bs, int64_t ws_bs)
 {
     extern __shared__ unsigned long long keys[];  // [Kp] (low word = flattened position p) | int cls_start[ncls]
     int* cls_start = reinterpret_cast<int*>(keys + Kp);
     const int tid = threadIdx.x;
     const int nc = ncls - 1;
+    const int fb = blockIdx.x;                    // frame (batched form: see pc_nms_class_kernel)
+    boxes += fb * box_bs;
+    ws_score += fb * ws_bs; ws_row += fb * ws_bs; ws_count += (int64_t)fb * ncls;
+    idx_out += (int64_t)fb * max_det; cls_out += (int64_t)fb * max_det; score_out += (int64_t)fb * max_det;
+    if (box_out) box_out += (int64_t)fb * max_det * 4;
+    count_out += fb;
+    if (row_index) row_index += (int64_t)fb * K_cap;
     if (tid == 0) {
         int run = 0;
         for (int c = 0; c < nc; ++c) {
@@ -521,7 +543,7 @@ __global__ __launch_bounds__(NMS_THREADS) void pc_nms_merge_kernel(const float* 
             while (c + 1 < nc && cls_start[c + 1] <= p) ++c;
             int r = p - cls_start[c];
             int row = ws_row[(int64_t)c * top_k + r];
-            idx_out[t] = row;
+            idx_out[t] = row_index ? row_index[row] : (int64_t)row;       // (the caller's row numbering: prior index in the batched pipeline)
             cls_out[t] = c + 1;
             score_out[t] = ord_desc_inv((unsigned int)(keys[t] >> 32));
             if (bo) bo[t] = b4[row];
@@ -747,11 +769,31 @@ extern "C" size_t stm_fast_nms_workspace_bytes(int K, int ncls, int top_k)
     return (size_t)(ncls - 1) * top_k * 8 + (size_t)ncls * 4 + 256;
 }
 
+extern "C" int stm_fast_nms_batched_f32(const float* conf, int64_t conf_bstride, const int64_t* row_index, const float* boxes, const float* centerness,
+                                        int64_t cen_bstride, int K, int ncls, const int* k_dev, float iou_thr, int top_k, float conf_thresh, int max_det,
+                                        int B, int64_t* idx_out, int64_t* cls_out, float* score_out, float* box_out, int* count_out,
+                                        void* workspace, size_t workspace_bytes, stm_stream_t stream);
 extern "C" int stm_fast_nms_f32(const float* conf, const float* boxes, const float* centerness, int K, int ncls,
                                 const int* k_dev, float iou_thr, int top_k, float conf_thresh, int max_det,
                                 int64_t* idx_out, int64_t* cls_out, float* score_out, float* box_out, int* count_out,
                                 void* workspace, size_t workspace_bytes, stm_stream_t stream)
 {
+    return stm_fast_nms_batched_f32(conf, 0, nullptr, boxes, centerness, 0, K, ncls, k_dev, iou_thr, top_k, conf_thresh, max_det, 1, idx_out, cls_out,
+                                    score_out, box_out, count_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t stm_fast_nms_batched_workspace_bytes(int K, int ncls, int top_k, int B)
+{
+    if (B <= 0) return 0;
+    return (size_t)B * stm_fast_nms_workspace_bytes(K, ncls, top_k);
+}
+
+extern "C" int stm_fast_nms_batched_f32(const float* conf, int64_t conf_bstride, const int64_t* row_index, const float* boxes, const float* centerness,
+                                        int64_t cen_bstride, int K, int ncls, const int* k_dev, float iou_thr, int top_k, float conf_thresh, int max_det,
+                                        int B, int64_t* idx_out, int64_t* cls_out, float* score_out, float* box_out, int* count_out,
+                                        void* workspace, size_t workspace_bytes, stm_stream_t stream)
+{
+    STM_REQUIRE(B >= 1, STM_EINVAL, "stm_fast_nms_f32: B=%d", B);
     STM_REQUIRE(idx_out && cls_out && score_out && count_out, STM_ENULL, "stm_fast_nms_f32: outputs must be non-NULL");
     STM_REQUIRE(K >= 0 && ncls >= 2 && ncls <= 128, STM_EINVAL, "stm_fast_nms_f32: bad sizes K=%d ncls=%d", K, ncls);
     STM_REQUIRE(top_k > 0 && top_k <= NMS_MAX_TOPK && max_det > 0, STM_EINVAL, "stm_fast_nms_f32: top_k=%d max_det=%d",
@@ -759,26 +801,29 @@ extern "C" int stm_fast_nms_f32(const float* conf, const float* boxes, const flo
     STM_REQUIRE(K <= NMS_MAX_KEYS, STM_EUNSUPPORTED, "stm_fast_nms_f32: K=%d > %d candidates", K, NMS_MAX_KEYS);
     STM_REQUIRE((int64_t)(ncls - 1) * top_k <= NMS_MAX_KEYS, STM_EUNSUPPORTED, "stm_fast_nms_f32: (ncls-1)*top_k too large");
     if (K == 0) {
-        (void)hipMemsetAsync(count_out, 0, sizeof(int), stm_hs(stream));
+        (void)hipMemsetAsync(count_out, 0, sizeof(int) * B, stm_hs(stream));
         return STM_OK;
     }
     STM_REQUIRE(conf && boxes, STM_ENULL, "stm_fast_nms_f32: conf/boxes must be non-NULL");
-    STM_REQUIRE(workspace && workspace_bytes >= stm_fast_nms_workspace_bytes(K, ncls, top_k), STM_EWORKSPACE,
+    STM_REQUIRE(B == 1 || k_dev, STM_ENULL, "stm_fast_nms_batched_f32: the batched form takes the frames' candidate counts on the device");
+    STM_REQUIRE(workspace && workspace_bytes >= (size_t)B * stm_fast_nms_workspace_bytes(K, ncls, top_k), STM_EWORKSPACE,
                 "stm_fast_nms_f32: workspace too small");
+    // workspace: [B][(ncls - 1) * top_k] scores | the same of rows | [B][ncls] counts
+    const int64_t ws_bs = (int64_t)(ncls - 1) * top_k;
     float* ws_score = reinterpret_cast<float*>(workspace);
-    int* ws_row = reinterpret_cast<int*>(ws_score + (size_t)(ncls - 1) * top_k);
-    int* ws_count = ws_row + (size_t)(ncls - 1) * top_k;
+    int* ws_row = reinterpret_cast<int*>(ws_score + (size_t)B * ws_bs);
+    int* ws_count = ws_row + (size_t)B * ws_bs;
     const int Kp = next_pow2(K);
     size_t lds = nms_lds_bytes(Kp, top_k);
     allow_big_lds(pc_nms_class_kernel, lds);
-    hipLaunchKernelGGL(pc_nms_class_kernel, dim3(ncls - 1), dim3(NMS_THREADS), lds, stm_hs(stream), conf, boxes, centerness,
-                       K, ncls, k_dev, iou_thr, top_k, conf_thresh, Kp, ws_score, ws_row, ws_count);
+    hipLaunchKernelGGL(pc_nms_class_kernel, dim3(ncls - 1, B), dim3(NMS_THREADS), lds, stm_hs(stream), conf, boxes, centerness,
+                       K, ncls, k_dev, iou_thr, top_k, conf_thresh, Kp, ws_score, ws_row, ws_count, row_index, conf_bstride, (int64_t)K * 4, cen_bstride, ws_bs);
     STM_CHECK_LAUNCH("pc_nms_class_kernel");
     const int Kp2 = next_pow2((ncls - 1) * top_k);
     size_t lds2 = (size_t)Kp2 * 8 + (size_t)(ncls + 4) * 4;
     allow_big_lds(pc_nms_merge_kernel, lds2);
-    hipLaunchKernelGGL(pc_nms_merge_kernel, dim3(1), dim3(NMS_THREADS), lds2, stm_hs(stream), boxes, ncls, top_k, max_det,
-                       Kp2, ws_score, ws_row, ws_count, idx_out, cls_out, score_out, box_out, count_out);
+    hipLaunchKernelGGL(pc_nms_merge_kernel, dim3(B), dim3(NMS_THREADS), lds2, stm_hs(stream), boxes, ncls, top_k, max_det,
+                       Kp2, ws_score, ws_row, ws_count, idx_out, cls_out, score_out, box_out, count_out, row_index, K, (int64_t)K * 4, ws_bs);
     STM_CHECK_LAUNCH("pc_nms_merge_kernel");
     return STM_OK;
 }

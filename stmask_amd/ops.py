@@ -431,6 +431,31 @@ def fast_nms(conf, boxes, centerness, iou_thr=0.5, top_k=200, conf_thresh=0.05, 
     return idx, cls, sc, bx, cnt[0]
 
 
+def detect_pc(loc, priors, conf, centerness, conf_thresh=0.05, iou_thr=0.5, top_k=200, max_det=100):
+    """generate_candidate + per-class Fast NMS (detection_TF.py:136-204) for a whole frame batch with no host sync: the candidate pass
+    (stm_generate_candidates_f32) leaves keep lists, compacted boxes and counts on the device, and ONE launch pair of stm_fast_nms_batched_f32 runs
+    every frame's 40 class sorts through the keep lists.  loc [B,N,4], priors [N,4], conf [B,N,ncls] SOFT-MAXED, centerness [B,N] or [B,N,1] ->
+    (prior_idx [B,max_det], cls, score, box [B,max_det,4], count [B]), the layout detect_cc returns."""
+    _dev(loc, priors, conf, centerness)
+    loc, priors, conf = _f32c(loc), _f32c(priors), _f32c(conf)
+    B, N, ncls = conf.shape
+    cen = _f32c(centerness.reshape(B, N)) if centerness is not None else None
+    dev = conf.device
+    if N > NMS_LDS_KEYS:
+        raise StmError(f"detect_pc: {N} priors exceed the {NMS_LDS_KEYS} keys of the per-class LDS sort (use the per-frame layer API)")
+    keep_idx, cand_box, count = generate_candidates(loc, priors, conf, conf_thresh)
+    idx = torch.empty(B, max_det, dtype=torch.int64, device=dev)
+    cls = torch.empty(B, max_det, dtype=torch.int64, device=dev)
+    sc = torch.empty(B, max_det, dtype=torch.float32, device=dev)
+    bx = torch.empty(B, max_det, 4, dtype=torch.float32, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    ws = _workspace(_lib.lib().stm_fast_nms_batched_workspace_bytes(c_i(N), c_i(ncls), c_i(top_k), c_i(B)), dev, "pcnms_b")
+    check(_lib.lib().stm_fast_nms_batched_f32(_p(conf), c_l(N * ncls), _p(keep_idx), _p(cand_box), _p(cen), c_l(N), c_i(N), c_i(ncls), _p(count), c_f(iou_thr),
+                                              c_i(top_k), c_f(conf_thresh), c_i(max_det), c_i(B), _p(idx), _p(cls), _p(sc), _p(bx), _p(cnt), _p(ws),
+                                              c_sz(ws.numel()), _stream()), "stm_fast_nms_batched_f32")
+    return idx, cls, sc, bx, cnt
+
+
 def jaccard(a, b):
     """box_utils.py:60-88 (2-D form), bit-exact."""
     _dev(a, b)

@@ -130,8 +130,11 @@ class BatchedClipPipeline:
 
     def __init__(self, net, n_clips):
         self.net, self.cfg, self.B = net, net.cfg, n_clips
-        if not self.cfg.temporal_fusion_module:
-            raise NotImplementedError("BatchedClipPipeline drives the temporal-fusion configs")
+        # temporal-fusion configs: Detect_TF + Track_TF (CandidateShift, soft masks, the keep rule); without the module the reference runs
+        # Detect + Track (detection.py:98-137, track.py:56-179: binary masks, the (mask_ious > 0.3).sum() < 2 update gate, the frame's own
+        # detections as output) -- _step_nontf
+        self.tf = bool(self.cfg.temporal_fusion_module)
+        self._last = None           # non-TF: the last step's detections (rows, ids, clip ranges) for detections()
         self.t = 0
         self.prev = None            # dict of concatenated row tensors
         self.prev_n = [0] * n_clips  # tracked instances per clip
@@ -273,6 +276,40 @@ class BatchedClipPipeline:
             ev.record()
         self._pending = (next_frames, out, ev)
 
+    def _take_trunk(self, frames):
+        """(fpn_outs, pred) of `frames`: the trunk started for them on the side stream by the previous step, or a fresh one.  Third value: a
+        prefetched trunk of OTHER frames was dropped."""
+        net = self.net
+        pend, self._pending = self._pending, None
+        if pend is not None and pend[0] is frames:
+            fpn_outs, pred = pend[1]
+            torch.cuda.current_stream().wait_event(pend[2])
+            if not self.graph_active:                            # (graph outputs live in the graphs' own pool)
+                for t_ in list(pred.values()) + list(fpn_outs):  # allocated on the side stream, consumed on this one
+                    if torch.is_tensor(t_):
+                        t_.record_stream(torch.cuda.current_stream())
+                t2s_ = pred["T2S_feat"][net.correlation_selected_layer] if isinstance(pred.get("T2S_feat"), (list, tuple)) else None
+                if torch.is_tensor(t2s_):
+                    t2s_.record_stream(torch.cuda.current_stream())
+        else:
+            if pend is not None:
+                torch.cuda.current_stream().wait_event(pend[2])   # a trunk nobody asked for: let it finish, drop it
+            fpn_outs, pred = self._trunk(frames)
+        return fpn_outs, pred, (pend is not None and pend[0] is not frames)
+
+    def _detect(self, pred):
+        """Decode + confidence threshold + Fast NMS for every frame of the batch, no host sync -> (prior_idx [B, cap], cls, score, box, count [B]).
+        Cross-class Fast NMS (the default, detection_TF.py:85-134: cap = nms_top_k) or -- Detect_TF.use_cross_class_nms = False, the reference's
+        per-class variant (detection_TF.py:136-204, README "mAP*" column: cap = max_num_detections) -- one launch pair for all frames."""
+        cfg, net = self.cfg, self.net
+        priors = pred["priors"].squeeze(0)
+        det = net.Detect_TF if self.tf else net.detect
+        if getattr(det, "use_cross_class_nms", True):
+            # (the softmax of STMask.py:314 is taken per row inside the candidate pass: no pass over the [B, N, 41] logits of its own)
+            return ops.detect_cc(pred["loc"], priors, pred["conf"], pred["centerness"], cfg.eval_conf_thresh, cfg.nms_thresh, cfg.nms_top_k, logits=True)
+        return ops.detect_pc(pred["loc"], priors, F.softmax(pred["conf"], -1), pred["centerness"], cfg.eval_conf_thresh, cfg.nms_thresh, cfg.nms_top_k,
+                             cfg.max_num_detections)
+
     @torch.no_grad()
     def step(self, frames, is_first=None, next_frames=None):
         """frames [B,3,H,W] -> packed detections [B, top_k, 40] (stmask_amd.dist layout) without a final sync, plus the
@@ -288,26 +325,13 @@ class BatchedClipPipeline:
         tmr.tic()
         if getattr(net, "_planar", None) is not None and tmr.on:
             net._planar.timer = tmr      # finer stages inside the trunk
-        pend, self._pending = self._pending, None
-        if pend is not None and pend[0] is frames:
-            fpn_outs, pred = pend[1]
-            torch.cuda.current_stream().wait_event(pend[2])
-            if not self.graph_active:                            # (graph outputs live in the graphs' own pool)
-                for t_ in list(pred.values()) + list(fpn_outs):  # allocated on the side stream, consumed on this one
-                    if torch.is_tensor(t_):
-                        t_.record_stream(torch.cuda.current_stream())
-                t2s_ = pred["T2S_feat"][net.correlation_selected_layer]
-                if torch.is_tensor(t2s_):
-                    t2s_.record_stream(torch.cuda.current_stream())
-        else:
-            if pend is not None:
-                torch.cuda.current_stream().wait_event(pend[2])   # a trunk nobody asked for: let it finish, drop it
-            fpn_outs, pred = self._trunk(frames)
+        if not self.tf:
+            return self._step_nontf(frames, first, next_frames)
+        fpn_outs, pred, dropped = self._take_trunk(frames)
         tmr.toc("trunk")
         # A dropped prefetch under graph replay leaves the round-robin one slot ahead: the slot the NEXT replay overwrites is then
         # the one holding the previous frame's P4 / T2S, which CandidateShift below still reads -- so in that step the next trunk
         # must not start before _shift_prev is enqueued (the late position), whatever prefetch_early says.
-        dropped = pend is not None and pend[0] is not frames
         if self.prefetch_early and not (dropped and self.graph_active):
             # start the next trunk right away: it then also shares the GPU with this step's temporal-fusion convolutions
             # (more throughput, but kernels of the two streams stretch each other: per-kernel timings stop being clean)
@@ -324,16 +348,13 @@ class BatchedClipPipeline:
         if Pn:
             self._shift_prev(P4, T2S, proto, dev)
         self._prefetch_trunk(next_frames)
-        priors = pred["priors"].squeeze(0)
-        # (the softmax of STMask.py:314 is taken per row inside the candidate pass: no pass over the [B, N, 41] logits of its own)
-        idx, cls, score, box, cnt = ops.detect_cc(pred["loc"], priors, pred["conf"], pred["centerness"], cfg.eval_conf_thresh,
-                                                  cfg.nms_thresh, cfg.nms_top_k, logits=True)
+        idx, cls, score, box, cnt = self._detect(pred)
         if self.max_instances > 0:
             cnt = torch.clamp(cnt, max=self.max_instances)
         counts, host_scores = ops.counts_to_host(cnt, extra=score)  # host read 1: B counts + the fp16 range flag + the NMS scores
         tmr.toc("detect")
         D = sum(counts)
-        top_k = cfg.nms_top_k
+        top_k = idx.shape[1]                              # slots per frame of the detector's outputs (nms_top_k, or max_num_detections per class-wise NMS)
         # ---- detections of all clips, concatenated (rows sorted by clip): one gather kernel ------------------------------
         det = ops.gather_detections(idx, cls, score, box, cnt, pred["mask_coeff"], pred["track"], pred["centerness"], D)
         if D:
@@ -412,6 +433,111 @@ class BatchedClipPipeline:
         tmr.toc("pack")
         return out
 
+    def _step_nontf(self, frames, first, next_frames):
+        """One frame of every clip through Detect + Track (reference detection.py:98-137, track.py:56-179; STMask.py:323-325): the frame's own
+        detections leave with their object ids; the tracker keeps BINARY masks (their bit words here) and replaces a matched object's row only while
+        (mask_ious > 0.3).sum() < 2 (track.py:162).  All clips per launch; two host reads per step as the temporal-fusion path."""
+        from .dist import DET_COLS
+        net, cfg, B = self.net, self.cfg, self.B
+        dev = frames.device
+        if first:
+            self.prev, self.prev_n, self._bits = None, [0] * B, None
+        fpn_outs, pred, _ = self._take_trunk(frames)
+        self._prefetch_trunk(next_frames)
+        proto = pred["proto"]
+        mc = torch.tanh(pred["mask_coeff"])                               # STMask.py:324 (generate_mask applies tanh AGAIN on this path: reproduced)
+        idx, cls, score, box, cnt = self._detect(pred)
+        counts, host_scores = ops.counts_to_host(cnt, extra=score)       # host read 1
+        D, cap = sum(counts), idx.shape[1]
+        det = ops.gather_detections(idx, cls, score, box, cnt, mc, pred["track"], pred["centerness"], D)
+        if not cfg.train_track:
+            det["track"] = F.normalize(det["mask_coeff"], dim=1)
+        out = torch.zeros(B, cfg.nms_top_k, DET_COLS, device=dev)
+        if D == 0:
+            self._last = None
+            self.t += 1
+            return out
+        det_mask, det_bits = ops.lincomb_sigmoid_crop_bits(proto, det["mask_coeff"], det["box"], det["clip"])
+        det_scores = [float(host_scores[b * cap + j]) for b in range(B) for j in range(counts[b])]
+        Pn = sum(self.prev_n)
+        if Pn:
+            prev = self.prev
+            self._upload_offsets(dev)
+            miou = ops.mask_iou_bits(det_bits, self._bits, proto.shape[1] * proto.shape[2], group1=det["clip"], group2=prev["clip"])
+            match = ops.match_scores_embed(det["track"], prev["track"], miou, det["box"], prev["box"], det["score"], det["class"], prev["class"],
+                                           det["clip"], self._off_dev, cfg.match_coeff, 0.3)
+            host = torch.stack([match, (miou > 0.3).sum(1).to(torch.int32)]).tolist()   # host read 2: match ids + the update gate's counts
+            ids, n_over = host
+        else:
+            ids, n_over = [0] * D, [0] * D
+        plan, new_n, obj_ids = [], [], [-1] * D
+        p0 = d0 = 0
+        for b in range(B):
+            pn, dn = self.prev_n[b], counts[b]
+            src = list(range(p0, p0 + pn))
+            if pn == 0:
+                # (track.py:92-97: the first frame with detections -- they become the objects)
+                for j in range(dn):
+                    obj_ids[d0 + j] = j
+                    src.append(Pn + d0 + j)
+            else:
+                best_score, best_idx = [-1.0] * pn, [-1] * pn
+                for j in range(dn):
+                    mid = ids[d0 + j]
+                    if mid == 0:
+                        obj_ids[d0 + j] = len(src)
+                        src.append(Pn + d0 + j)
+                    else:
+                        obj = mid - 1 - p0
+                        if det_scores[d0 + j] > best_score[obj]:
+                            if best_idx[obj] != -1:
+                                obj_ids[d0 + best_idx[obj]] = -1
+                            obj_ids[d0 + j] = obj
+                            best_score[obj], best_idx[obj] = det_scores[d0 + j], j
+                            if n_over[d0 + j] < 2:                        # track.py:162
+                                src[obj] = Pn + d0 + j
+            plan += src
+            new_n.append(len(src))
+            p0 += pn
+            d0 += dn
+        # output rows: the frame's detections with an object id (remove_false_inst, track.py:172-179), in detection order
+        rows, dst_b, dst_j = [], [], []
+        d0 = 0
+        for b in range(B):
+            j_out = 0
+            for j in range(counts[b]):
+                if obj_ids[d0 + j] >= 0 or not cfg.remove_false_inst:
+                    rows.append(d0 + j); dst_b.append(b); dst_j.append(j_out)
+                    j_out += 1
+            d0 += counts[b]
+        meta = torch.tensor(plan + rows + dst_b + dst_j + [obj_ids[r] for r in rows], dtype=torch.int32).to(dev, non_blocking=True)
+        nP, nR = len(plan), len(rows)
+        plan_dev = meta[:nP]
+        r_dev, b_dev, j_dev, id_dev = (meta[nP + k * nR:nP + (k + 1) * nR].long() for k in range(4))
+        keys = ("box", "mask_coeff", "track", "class", "score", "clip")
+        pbits = self._bits if Pn else det_bits[:0]
+        a_rows = [self.prev[k] for k in keys] if Pn else [det[k][:0] for k in keys]
+        merged = ops.gather_rows2(a_rows + [pbits], [det[k] for k in keys] + [det_bits], plan_dev, Pn)
+        self.prev = dict(zip(keys, merged[:-1]))
+        self._bits = merged[-1]
+        self.prev_n = new_n
+        if nR:
+            out[b_dev, j_dev, 0:4] = det["box"][r_dev]
+            out[b_dev, j_dev, 4] = det["score"][r_dev]
+            out[b_dev, j_dev, 5] = det["class"][r_dev].float()
+            out[b_dev, j_dev, 6] = id_dev.float()
+            out[b_dev, j_dev, 7] = 1.0
+            out[b_dev, j_dev, 8:8 + det["mask_coeff"].shape[1]] = det["mask_coeff"][r_dev]
+        self._last = (det, det_mask, r_dev, b_dev, id_dev)
+        self.t += 1
+        return out
+
+    def _upload_offsets(self, dev):
+        off = [0]
+        for n in self.prev_n:
+            off.append(off[-1] + n)
+        self._off_dev = torch.tensor(off, dtype=torch.int32).to(dev, non_blocking=True)
+
     def _upload_meta(self, dev, plan):
         """One host -> device copy per step: [clip row offsets (B + 1) | frames-since-last-match counters | gather plan]."""
         off = [0]
@@ -436,6 +562,18 @@ class BatchedClipPipeline:
         """Reference-shaped per-clip detection dicts of the last step (host sync; for tests and users who want them)."""
         cfg, prev = self.cfg, self.prev
         outs = []
+        if not self.tf:
+            # the frame's own detections with their object ids; masks binary (track.py:88)
+            if self._last is None:
+                return [{} for _ in range(self.B)]
+            det, det_mask, r_dev, b_dev, id_dev = self._last
+            for b in range(self.B):
+                sel = r_dev[b_dev == b]
+                d = {k: det[k].index_select(0, sel) for k in ("box", "mask_coeff", "track", "class", "score")}
+                d["mask"] = det_mask.index_select(0, sel).gt(0.5).float()
+                d["box_ids"] = id_dev[b_dev == b]
+                outs.append(d)
+            return outs
         if prev is None:
             return [{} for _ in range(self.B)]
         dev = prev["box"].device

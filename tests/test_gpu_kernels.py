@@ -704,3 +704,35 @@ def test_detect_cc_on_logits_equals_softmax_then_detect():
             assert torch.equal(a[1][f, :n], b[1][f, :n]) and torch.equal(a[3][f, :n], b[3][f, :n])
             assert (a[2][f, :n] - b[2][f, :n]).abs().max().item() < 3e-7
     assert agree == B      # (a score within 1 ulp of the 0.05 threshold or of a neighbour in the sort could differ; not with this seed)
+
+
+def test_detect_pc_batched_equals_per_frame_per_class_nms():
+    """stm_fast_nms_batched_f32 through the candidate pass's keep lists (ops.detect_pc: one launch pair for all frames, each frame's sort sized by its
+    own candidate count) == stm_generate_candidates_f32 + stm_fast_nms_f32 frame by frame on gathered rows: indices, classes, scores, boxes, counts."""
+    g = torch.Generator().manual_seed(11)
+    B, N, ncls = 5, 3000, 41
+    priors = torch.rand(N, 4, generator=g) * 0.5 + 0.1
+    priors[:, 2:] = priors[:, 2:] * 0.3 + 0.02
+    loc = torch.randn(B, N, 4, generator=g) * 0.5
+    logits = torch.randn(B, N, ncls, generator=g)
+    logits[:, :, 0] += 9.0                                   # background wins everywhere ...
+    hot = torch.rand(B, N, generator=g) < torch.tensor([0.02, 0.2, 0.0, 0.6, 0.05]).view(B, 1)   # very different candidate counts, one empty frame
+    cls_hot = torch.randint(1, ncls, (B, N), generator=g)
+    logits[hot, cls_hot[hot]] += 8.0                         # ... but on the hot rows
+    conf = torch.softmax(logits, -1)
+    cen = torch.rand(B, N, generator=g)
+    d = lambda t: t.to(DEV)
+    idx, cls, sc, bx, cnt = ops.detect_pc(d(loc), d(priors), d(conf), d(cen), 0.05, 0.5, 200, 100)
+    keep_idx, cand_box, count = ops.generate_candidates(d(loc), d(priors), d(conf), 0.05)
+    counts = count.tolist()
+    assert counts[2] == 0 and max(counts) > 1000 and cnt.tolist()[2] == 0
+    for b in range(B):
+        k = counts[b]
+        if k == 0:
+            continue
+        rows = keep_idx[b, :k]
+        i1, c1, s1, b1, n1 = ops.fast_nms(d(conf)[b].index_select(0, rows), cand_box[b, :k], d(cen)[b].index_select(0, rows), 0.5, 200, 0.05, 100)
+        n = int(n1)
+        assert int(cnt[b]) == n and n > 0
+        assert torch.equal(idx[b, :n], rows[i1[:n]]) and torch.equal(cls[b, :n], c1[:n])
+        assert torch.equal(sc[b, :n], s1[:n]) and torch.equal(bx[b, :n], b1[:n])

@@ -82,6 +82,72 @@ def test_batched_pipeline_equals_per_clip_driver_on_gpu():
             assert torch.equal(un["box_ids"], r[b]["box_ids"][:200])
 
 
+def test_batched_pipeline_per_class_nms_equals_per_clip_driver():
+    """Row a13 through the batched pipeline: Detect_TF.use_cross_class_nms = False (detection_TF.py:136-204, the README's mAP* column) -- one
+    stm_fast_nms_batched_f32 launch pair for all clips -- against the reference-shaped per-clip driver with the same switch, frame by frame."""
+    from stmask_amd.dist import unpack_detections
+    from stmask_amd.pipeline import BatchedClipPipeline, ClipPipeline
+    net = build("STMask_plus_resnet50_config")
+    net.Detect_TF.use_cross_class_nms = False
+    clips = torch.stack([synthetic.synthetic_clip(4, 128, 192, seed=s) for s in (0, 5, 9)]).cuda()
+    fast, ref = BatchedClipPipeline(net, 3), ClipPipeline(net, 3)
+    seen = 0
+    for t in range(4):
+        packed = fast.step(clips[:, t].contiguous())
+        r = ref.step(clips[:, t].contiguous())
+        d = fast.detections()
+        for b in range(3):
+            assert torch.equal(d[b]["box_ids"], r[b]["box_ids"]), (t, b)
+            assert torch.equal(d[b]["class"], r[b]["class"])
+            assert (d[b]["box"] - r[b]["box"]).abs().max() < 1e-4
+            assert (d[b]["mask"] - r[b]["mask"]).abs().max() < 2e-5
+            un = unpack_detections(packed[b])
+            assert torch.equal(un["box_ids"], r[b]["box_ids"][:200])
+            seen += d[b]["box"].shape[0]
+    assert seen > 20
+
+
+def test_batched_pipeline_non_tf_equals_model_forward_and_reference():
+    """Row a18 through the batched pipeline: a config without the temporal-fusion module runs Detect + Track (detection.py:98-137,
+    track.py:56-179) -- binary masks, the (mask_ious > 0.3).sum() < 2 update gate, the frame's own detections with their object ids -- for all clips
+    per launch.  Against the module path (STMask.forward, one clip at a time) on three clips, and against the golden the reference's own
+    Detect.detect / Track.track produced (model_r50_fca_nontf.npz) on the golden's clip."""
+    from stmask_amd.dist import unpack_detections
+    from stmask_amd.pipeline import BatchedClipPipeline
+    from test_gpu_parity import build as build_p, match_instances
+    net = build_p("STMask_plus_resnet50_config", temporal_fusion=False)
+    g = load_golden("model_r50_fca_nontf.npz")
+    h, w = [int(v) for v in g["frames_hw"]]
+    T = int(g["n_frames"])
+    clips = torch.stack([synthetic.synthetic_clip(T, h, w, seed=s) for s in (0, 5, 9)]).cuda()
+    refs = [run_clip(net, clips[b], "cuda") for b in range(3)]                      # module path, clip by clip (fresh tracker state per clip: is_first)
+    pipe = BatchedClipPipeline(net, 3)
+    n_ids = 0
+    for t in range(T):
+        packed = pipe.step(clips[:, t].contiguous())
+        d = pipe.detections()
+        for b in range(3):
+            r = refs[b][t]
+            if r["box"].shape[0] == 0:
+                assert not d[b] or d[b]["box"].shape[0] == 0
+                continue
+            assert torch.equal(d[b]["box_ids"], r["box_ids"]), (t, b)
+            assert torch.equal(d[b]["class"], r["class"])
+            assert (d[b]["box"] - r["box"]).abs().max() < 1e-5 and (d[b]["score"] - r["score"]).abs().max() < 1e-6
+            assert torch.equal(d[b]["mask"], r["mask"])                              # binary masks of the same kernels on the same inputs
+            un = unpack_detections(packed[b])
+            assert torch.equal(un["box_ids"], r["box_ids"][:200]) and (un["box"] - r["box"][:200]).abs().max() < 1e-5
+            n_ids += r["box"].shape[0]
+        # clip 0 is the golden's clip: the reference's own after-NMS sets and ids
+        ref_box, ref_cls, ref_ids = g[f"t{t}_box"], g[f"t{t}_class"], g[f"t{t}_box_ids"]
+        gb, gc = d[0]["box"].cpu(), d[0]["class"].cpu()
+        gi, ri = match_instances(gb, gc, ref_box, ref_cls)
+        assert len(gi) >= 0.9 * ref_box.shape[0]
+        if gb.shape[0] == ref_box.shape[0] == len(gi):
+            assert d[0]["box_ids"].cpu()[gi].tolist() == ref_ids[ri].tolist(), t
+    assert n_ids > 20
+
+
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_optimized_inference_graph_on_gpu(channels_last):
     """fuse.optimize_for_inference (BN folded, one-pass conv epilogues, ReLU in the DCN GEMM) changes head outputs only
