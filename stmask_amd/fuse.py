@@ -135,17 +135,35 @@ def optimize_for_inference(net, planar=False, planes="fp16x2"):
         n_fused += 1
     net.fpn.pred_relu_fused = True
     if planar:
-        from . import planar as _planar
-        from .planar import PlanarBackbone, PlanarGraph, PlanarTemporalNet
-        if planes not in ("fp16x2", "bf16x3", "fp16x1"):
-            raise ValueError("planes must be 'fp16x2', 'bf16x3' or 'fp16x1'")
-        # fp16x1 (BASELINE config 5, "fp16 MFMA backbone convs"): the ResNet backbone's convolutions -- bottleneck 1x1 / 3x3,
-        # downsample projections, DCN offset convs and DCN GEMMs -- run on ONE fp16 plane (one MFMA product, fp32 accumulate);
-        # FPN, proto-net, heads and TemporalNet keep the fp32-equivalent fp16x2 format
-        _planar.set_format(0 if planes == "bf16x3" else 1, backbone_fmt=2 if planes == "fp16x1" else None)
-        net._planar = PlanarGraph(net)
-        net._planar_backbone = PlanarBackbone(net.backbone, selected=net.backbone_selected)
-        net._planar_backbone.planes_only = True     # the planar FPN laterals read the stage outputs as planes
-        if getattr(net, "TemporalNet", None) is not None:
-            net._planar_temporal = PlanarTemporalNet(net.TemporalNet)
+        attach_planar(net, build_planar(net, planes))
     return n_bn, n_fused
+
+
+def build_planar(net, planes):
+    """The planar inference graph of a net that optimize_for_inference has folded and fused, in the plane format `planes`: (PlanarGraph,
+    PlanarBackbone, PlanarTemporalNet or None, planes).  Leaves the module-level format of stmask_amd.planar set to it (the objects capture their
+    format at construction; helpers that split tensors read the module's)."""
+    from . import planar as _planar
+    from .planar import PlanarBackbone, PlanarGraph, PlanarTemporalNet
+    if planes not in ("fp16x2", "bf16x3", "fp16x1"):
+        raise ValueError("planes must be 'fp16x2', 'bf16x3' or 'fp16x1'")
+    # fp16x1 (BASELINE config 5, "fp16 MFMA backbone convs"): the ResNet backbone's convolutions -- bottleneck 1x1 / 3x3,
+    # downsample projections, DCN offset convs and DCN GEMMs -- run on ONE fp16 plane (one MFMA product, fp32 accumulate);
+    # FPN, proto-net, heads and TemporalNet keep the fp32-equivalent fp16x2 format
+    _planar.set_format(0 if planes == "bf16x3" else 1, backbone_fmt=2 if planes == "fp16x1" else None)
+    graph = PlanarGraph(net)
+    bb = PlanarBackbone(net.backbone, selected=net.backbone_selected)
+    bb.planes_only = True                           # the planar FPN laterals read the stage outputs as planes
+    tn = PlanarTemporalNet(net.TemporalNet) if getattr(net, "TemporalNet", None) is not None else None
+    return graph, bb, tn, planes
+
+
+def attach_planar(net, built):
+    """Make `built` (build_planar) the graph net.forward_single runs."""
+    from . import planar as _planar
+    graph, bb, tn, planes = built
+    _planar.set_format(0 if planes == "bf16x3" else 1, backbone_fmt=2 if planes == "fp16x1" else None)
+    net._planar, net._planar_backbone = graph, bb
+    if tn is not None:
+        net._planar_temporal = tn
+    net._planar_planes = planes

@@ -814,6 +814,11 @@ def planar_range_flag():
     return flag
 
 
+class RangeError(StmError):
+    """An activation left the range of the fp16 plane formats (the sticky device flag of stm_planar_set_range_flag was found set).  The batched
+    pipeline catches it, rebuilds the inference graph with bf16x3 planes (any fp32 range) and repeats the step."""
+
+
 RANGE_MESSAGE = ("an activation left the range of the fp16x2 planar format (|x| > 65504, inf or nan): results of this step are "
                  "invalid; build the graph with optimize_for_inference(net, planar=True, planes='bf16x3')")
 
@@ -823,7 +828,7 @@ def check_planar_range():
     flag = _range_flags.get(torch.cuda.current_device())
     if flag is not None and int(flag.item()):
         flag.zero_()
-        raise StmError(RANGE_MESSAGE)
+        raise RangeError(RANGE_MESSAGE)
 
 
 def counts_to_host(cnt, extra=None):
@@ -843,7 +848,7 @@ def counts_to_host(cnt, extra=None):
     n = cnt.numel()
     if flag is not None and int(host[n]):
         flag.zero_()
-        raise StmError(RANGE_MESSAGE)
+        raise RangeError(RANGE_MESSAGE)
     counts = host[:n].tolist()
     if extra is None:
         return counts

@@ -134,6 +134,8 @@ class BatchedClipPipeline:
         # Detect + Track (detection.py:98-137, track.py:56-179: binary masks, the (mask_ious > 0.3).sum() < 2 update gate, the frame's own
         # detections as output) -- _step_nontf
         self.tf = bool(self.cfg.temporal_fusion_module)
+        self.range_fallback = True  # an fp16 plane graph that leaves its range is replaced by the bf16x3 graph and the step repeated (see step)
+        self.fell_back = False
         self._last = None           # non-TF: the last step's detections (rows, ids, clip ranges) for detections()
         self.t = 0
         self.prev = None            # dict of concatenated row tensors
@@ -314,13 +316,63 @@ class BatchedClipPipeline:
     def step(self, frames, is_first=None, next_frames=None):
         """frames [B,3,H,W] -> packed detections [B, top_k, 40] (stmask_amd.dist layout) without a final sync, plus the
         per-clip tracked-instance counts (host ints).  next_frames (optional): the frames the NEXT call will be given;
-        their trunk is started on a second stream while this step's tracker logic runs."""
-        net, cfg, B = self.net, self.cfg, self.B
-        dev = frames.device
+        their trunk is started on a second stream while this step's tracker logic runs.
+
+        fp16 plane graphs carry |activation| <= 65504 only; their producers raise a sticky device flag beyond that, which arrives with the step's
+        first host read (ops.RangeError).  The step is then NOT lost: the tracker state it had touched is put back, the inference graph is rebuilt
+        with bf16x3 planes (fp32's range; weights repacked from the same modules, in-process), the step is repeated on it and the pipeline stays
+        there (`fell_back`; logged once on stderr).  range_fallback = False restores the raise."""
         first = (self.t == 0) if is_first is None else is_first
         if first:
-            self.prev, self.prev_n, self.prev_feat = None, [0] * B, None
-            self.tracked = [[] for _ in range(B)]
+            self.prev, self.prev_n, self.prev_feat = None, [0] * self.B, None
+            self.tracked = [[] for _ in range(self.B)]
+        snap = self._snapshot() if (self.range_fallback and self._range_guarded()) else None
+        try:
+            return self._step(frames, first, next_frames)
+        except ops.RangeError:
+            if snap is None:
+                raise
+            self._fall_back(snap)
+            return self._step(frames, first, next_frames)
+
+    def _range_guarded(self):
+        g = getattr(self.net, "_planar", None)
+        return g is not None and getattr(self.net, "_planar_planes", "bf16x3") != "bf16x3"
+
+    def _snapshot(self):
+        """What a step mutates IN PLACE before its first host read (CandidateShift's decode / coefficient shift / score decay on the tracked rows)
+        plus the host-side counters: enough to repeat the step."""
+        prev = self.prev
+        rows = None
+        if self.tf and prev is not None and sum(self.prev_n):
+            rows = tuple(prev[k].clone() for k in ("box", "mask_coeff", "score"))
+        return rows, [list(t) for t in self.tracked], self.t
+
+    def _fall_back(self, snap):
+        import sys
+        from . import fuse
+        net = self.net
+        pend, self._pending = self._pending, None
+        torch.cuda.synchronize()                      # nothing enqueued on the fp16 graph may raise the flag after it has been cleared
+        flag = ops._range_flags.get(torch.cuda.current_device())
+        if flag is not None:
+            flag.zero_()
+        sys.stderr.write(f"stmask_amd: step {self.t}: an activation left the range of the {getattr(net, '_planar_planes', 'fp16')} planar format (|x| > 65504); "
+                         "rebuilding the inference graph with bf16x3 planes, repeating the step and staying there (half the convolution rate)\n")
+        if getattr(net, "_planar_bf16x3", None) is None:
+            net._planar_bf16x3 = fuse.build_planar(net, "bf16x3")
+        fuse.attach_planar(net, net._planar_bf16x3)
+        self._graphs, self._graph_next, self.graph_active, self._graph_warm, self._graph_ws = [], 0, False, 0, {}
+        rows, tracked, t = snap
+        if rows is not None:
+            for k, v in zip(("box", "mask_coeff", "score"), rows):
+                self.prev[k].copy_(v)
+        self.tracked, self.t = tracked, t
+        self.fell_back = True
+
+    def _step(self, frames, first, next_frames):
+        net, cfg, B = self.net, self.cfg, self.B
+        dev = frames.device
         tmr = self.timer
         tmr.tic()
         if getattr(net, "_planar", None) is not None and tmr.on:

@@ -318,25 +318,52 @@ def test_batched_pipeline_trunk_overlap_is_transparent():
     assert (y1 - d.step(frames[1], is_first=False)).abs().max().item() < 1e-4
 
 
-def test_fp16_plane_graph_fails_loudly_out_of_range():
-    """The fp16x2 graph cannot carry |activation| > 65504: such an input must raise, never return detections computed
-    from inf / nan -- which a ReLU epilogue would turn into zeros, i.e. into plausible-looking wrong results (the bf16x3
-    graph has fp32's range and runs the same input)."""
+def test_fp16_plane_graph_out_of_range_falls_back_to_bf16x3():
+    """The fp16x2 graph cannot carry |activation| > 65504.  Such a step must never return detections computed from inf / nan (a ReLU epilogue
+    would turn them into zeros: plausible-looking wrong results) -- and it must not kill the run either: the pipeline puts back the tracker rows the
+    step had already shifted, rebuilds the graph with bf16x3 planes in-process, repeats the step and stays there.  Checked on a clip whose THIRD
+    frame leaves the range (so the repeated step has a tracked set to restore) against a pipeline that ran bf16x3 from the start, and on a net with
+    one layer's weights scaled to overflow; range_fallback = False keeps the loud failure."""
     from stmask_amd.pipeline import BatchedClipPipeline
     from stmask_amd.fuse import optimize_for_inference
     from stmask_amd.ops import StmError
-    frames = (synthetic.synthetic_clip(1, 128, 192, seed=2) * 1e5).cuda().contiguous(memory_format=torch.channels_last)
-    for planes in ("fp16x2", "bf16x3"):
+
+    def make(planes, scale_layer=False):
         net = build("STMask_plus_resnet50_config")
+        if scale_layer:
+            with torch.no_grad():
+                net.fpn.pred_layers[0].weight.mul_(3e5)              # P3's prediction conv: its outputs leave fp16's range, nothing upstream does
         optimize_for_inference(net, planar=True, planes=planes)
         net = net.to(memory_format=torch.channels_last)
         net.TemporalNet = net.TemporalNet.to(memory_format=torch.contiguous_format)
-        pipe = BatchedClipPipeline(net, 1)
-        if planes == "fp16x2":
-            with pytest.raises(StmError, match="range of the fp16x2 planar format"):
-                pipe.step(frames, is_first=True)
-        else:
-            pipe.step(frames, is_first=True)
+        return net, BatchedClipPipeline(net, 2)
+
+    clip = torch.stack([synthetic.synthetic_clip(4, 128, 192, seed=s) for s in (2, 7)]).cuda()
+    clip[:, 2] *= 1e5                                                 # frame 2 of both clips: |stem output| >> 65504
+    frames = [clip[:, t].contiguous(memory_format=torch.channels_last) for t in range(4)]
+    (net_a, a), (net_b, b) = make("fp16x2"), make("bf16x3")
+    seen = 0
+    for t in range(4):
+        pa, pb = a.step(frames[t], is_first=(t == 0)), b.step(frames[t], is_first=(t == 0))
+        assert a.fell_back == (t >= 2) and not b.fell_back
+        da, db = a.detections(), b.detections()
+        for c in range(2):
+            assert torch.equal(da[c]["box_ids"], db[c]["box_ids"]) and torch.equal(da[c]["class"], db[c]["class"]), (t, c)
+            if da[c]["box"].numel():
+                assert (da[c]["box"] - db[c]["box"]).abs().max() < 1e-4 and (da[c]["mask"] - db[c]["mask"]).abs().max() < 1e-3
+                seen += da[c]["box"].shape[0]
+        if t >= 2:
+            assert torch.isfinite(pa).all()
+    assert seen > 10 and net_a._planar.fmt == 0 and net_a._planar_planes == "bf16x3"
+    # one layer's weights out of range: same fallback on the first step, same results as the bf16x3 graph of the same weights
+    (_, a2), (_, b2) = make("fp16x2", True), make("bf16x3", True)
+    pa, pb = a2.step(frames[0], is_first=True), b2.step(frames[0], is_first=True)
+    assert a2.fell_back and torch.equal(pa, pb)
+    # the loud form
+    _, a3 = make("fp16x2")
+    a3.range_fallback = False
+    with pytest.raises(StmError, match="range of the fp16x2 planar format"):
+        a3.step(frames[2], is_first=True)
 
 
 @pytest.mark.parametrize("name,tag", [CASES[0], CASES[3]])
