@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the parity block that needs it)")
     ap.add_argument("--no-extras", action="store_true", help="skip the 8-clip / 1-clip / bf16x3 side measurements")
-    ap.add_argument("--extras", default="realistic,clips8,clips1,bf16x3,per_class_nms,non_tf", help="which side measurements to run (comma-separated)")
+    ap.add_argument("--extras", default="realistic,clips8,clips1,bf16x3,per_class_nms,non_tf,e2e", help="which side measurements to run (comma-separated)")
     ap.add_argument("--nchw", dest="channels_last", action="store_false", help="keep the dense convs in NCHW")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="keep BatchNorm / bias / ReLU as separate kernels")
     ap.add_argument("--overlap", choices=("late", "early", "off"), default="late",
@@ -421,6 +421,105 @@ class Runner:
         if collect:
             self.fused_t = ops.fused_dcn_timing(False) or []       # launches of the fused deformable convolution (csrc/dcn_fused.hip) of this pass
         return elapsed, out, timing, conv_t
+
+
+def e2e_block(args, dev, net, cap, steps, warmup=3):
+    """SURVEY 8(f) rows f3 + f1 around the step: uint8 720x1280 frames resident in HBM -> stm_preprocess_u8_f32 (resize to the test scale, normalise, pad
+    to /32, CHW; eval.py:703-717) -> the step -> keep rule -> stm_mask_resize_rle_f32 (un-pad, bilinear upsample to 720x1280, > 0.5, COCO run lengths;
+    output_utils.py:85-106) -> D2H of the run lengths -> RLE strings (library host function).  Wall-clock frames/s of the whole chain and per-stage GPU
+    time from HIP events; the next frame's pre-processing is enqueued before the step so that the step can start the next trunk beside its tracker tail."""
+    import numpy as np
+    from stmask_amd import ops, output_utils, synthetic
+    from stmask_amd.pipeline import BatchedClipPipeline
+    from stmask_amd.preprocess import MEANS, STD, preprocess_eval_frames
+    clips, T = args.clips, args.frames
+    img_h = {384: 360, 736: 720}.get(args.height, args.height)
+    img_w = args.width
+    OH, OW = 720, 1280
+    mean = torch.tensor(MEANS).view(1, 3, 1, 1)
+    std = torch.tensor(STD).view(1, 3, 1, 1)
+    u8 = []
+    clip_t = torch.stack([synthetic.synthetic_clip(T, args.height, args.width, seed=c) for c in range(clips)])      # [clips, T, 3, H, W], normalised
+    for t in range(T):
+        x = clip_t[:, t, :, :img_h, :img_w] * std + mean
+        x = x.round().clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1)                                          # [clips, img_h, img_w, 3]
+        if (img_h, img_w) != (OH, OW):
+            x = x.repeat_interleave(OH // img_h, 1).repeat_interleave(OW // img_w, 2)
+        u8.append(x.contiguous().to(dev))
+    del clip_t
+    fmt = torch.channels_last if args.channels_last else torch.contiguous_format
+
+    def pre(t):
+        x, _ = preprocess_eval_frames(u8[t % T], size=(img_w, img_h))
+        return x.contiguous(memory_format=fmt)
+
+    pipe = BatchedClipPipeline(net, clips)
+    pipe.max_instances = cap or 0
+    pipe.prefetch_early = args.overlap == "early"
+    thr = net.cfg.eval_conf_thresh
+    acc = {"pre": 0.0, "step": 0.0, "keep": 0.0, "rle": 0.0, "host": 0.0}
+    n_masks = n_bytes = 0
+    tracked_sum = 0.0
+    crop_h = crop_w = 0
+    x_next = pre(0)
+    torch.cuda.synchronize()
+    t0 = None
+    for t in range(warmup + steps):
+        if t == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        x, x_next = x_next, pre(t + 1)
+        ev[1].record()
+        pipe.step(x, is_first=(t % T == 0), next_frames=x_next if args.overlap != "off" else None)
+        ev[2].record()
+        prev = pipe.prev
+        n = 0
+        if prev is not None and sum(pipe.prev_n):
+            tm = torch.tensor([v for tr in pipe.tracked for v in tr], device=dev)
+            keep = (tm <= 10) & (prev["mask"].gt(0.5).sum([1, 2]) > 1) & (prev["score"] > thr)       # track_TF.py:158-165
+            masks = prev["mask"].index_select(0, torch.nonzero(keep).view(-1))
+            n = masks.shape[0]
+        ev[3].record()
+        th = time.perf_counter()
+        if n:
+            mh, mw = masks.shape[1:]
+            crop_h, crop_w = int(img_h / args.height * mh), int(img_w / args.width * mw)
+            counts, n_runs = ops.mask_resize_rle(masks, crop_h, crop_w, OH, OW)
+            ev[4].record()
+            nr = n_runs.cpu()
+            host = counts[:, :max(int(nr.max()), 1)].contiguous().cpu()
+            strings = output_utils.rle_strings(host, nr)
+        else:
+            ev[4].record()
+            strings = []
+        host_s = time.perf_counter() - th
+        if t >= warmup:
+            torch.cuda.synchronize()
+            acc["pre"] += ev[0].elapsed_time(ev[1]); acc["step"] += ev[1].elapsed_time(ev[2]); acc["keep"] += ev[2].elapsed_time(ev[3])
+            acc["rle"] += ev[3].elapsed_time(ev[4]); acc["host"] += host_s * 1e3
+            n_masks += n
+            n_bytes += sum(len(b) for b in strings)
+            tracked_sum += sum(pipe.prev_n) / clips
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    per = {k: v / steps for k, v in acc.items()}
+    nm = n_masks / steps
+    rle_bytes = nm * (crop_h * crop_w * 4 + 2 * OH * OW / 8) if n_masks else 0.0
+    return {"value": round(clips * steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 3), "clips_per_gpu": clips, "steps": steps,
+            "max_instances": cap or None, "frames_in": f"uint8 {OH}x{OW}x3 resident in HBM", "masks_per_step": round(nm, 1),
+            "tracked_instances_mean": round(tracked_sum / steps, 1),
+            "rle_bytes_per_mask": round(n_bytes / max(n_masks, 1), 1),
+            "stages_ms_per_step": {"preprocess_u8 (next frame: resize + normalise + pad + layout)": round(per["pre"], 3),
+                                   "step (trunk .. tracker, two host reads)": round(per["step"], 3),
+                                   "keep rule + mask gather": round(per["keep"], 3),
+                                   "mask_resize_rle kernels (resize_threshold_pack + rle_runs)": round(per["rle"], 3),
+                                   "D2H of run lengths + RLE strings (host wall clock, includes the wait for the kernels)": round(per["host"], 3)},
+            "preprocess_gbs": round(clips * (OH * OW * 3 + 3 * args.height * args.width * 4 * 3) / (per["pre"] * 1e-3) / 1e9, 1) if per["pre"] > 0 else None,
+            "mask_resize_rle_gpixel_s": round(nm * OH * OW / (per["rle"] * 1e-3) / 1e9, 1) if per["rle"] > 0 and nm else None,
+            "mask_resize_rle_gbs": round(rle_bytes / (per["rle"] * 1e-3) / 1e9, 1) if per["rle"] > 0 and nm else None,
+            "what": "frame bytes -> COCO RLE strings: the reference's FPS meter wraps the same span (eval.py:600-665, output_utils.py:85-106)"}
 
 
 def cpu_baseline(args, budget_s=25.0, n_frames=4):
@@ -791,6 +890,17 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as e:
                     extras[name] = {"error": repr(e)[:200]}
+            # frame bytes -> RLE strings around the same pipeline: the realistic regime (8 instances per clip) and the headline's tracked set
+            if "e2e" in args.extras.split(",") and not args.max_instances and args.pipeline == "batched":
+                try:
+                    extras["e2e"] = {"realistic": e2e_block(args, dev, net, 8, max(args.steps // 2, 5)),
+                                     "uncapped": e2e_block(args, dev, net, 0, max(args.steps // 2, 5)),
+                                     "note": "the frames are the headline's synthetic clips quantised to uint8 (values beyond 0..255 clipped), doubled to "
+                                             "720x1280 and zero-padded by the pre-processing: not bit-identical inputs, so the tracked set (and with it "
+                                             "TemporalNet's share of the step) differs from the headline's -- tracked_instances_mean says by how much"}
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    extras["e2e"] = {"error": repr(e)[:300]}
             if "clips1" in extras and "value" in extras["clips1"]:
                 extras["clips1"]["context"] = "single-stream regime of the reference's own FPS table (README.md:102: 29.3 FPS on a 2080 Ti, batch 1)"
             if "bf16x3" in extras and "value" in extras["bf16x3"]:

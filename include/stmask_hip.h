@@ -36,7 +36,7 @@
  *     stm_debug_launch_count;
  *      4: those three entry points are part of the version now (a library that lacks them must not pass for this ABI), plus the fused
  *     deformable convolution stm_deform_conv_fused_planar_f32 / stm_deform_conv_fused_planar_supported; stm_debug_launch_count(1); the batched per-class Fast NMS
- *     stm_fast_nms_batched_f32 / stm_fast_nms_batched_workspace_bytes).
+ *     stm_fast_nms_batched_f32 / stm_fast_nms_batched_workspace_bytes; the host-side stm_rle_strings_host).
  */
 #ifndef STMASK_HIP_H_
 #define STMASK_HIP_H_
@@ -293,6 +293,10 @@ int stm_bias_act_f32(float* y, const float* bias, const float* residual, int64_t
  *   (maskApi.c rleToString) is a few hundred bytes per mask and is done by the caller on the host.
  * ------------------------------------------------------------------------------------------------- */
 size_t stm_mask_rle_workspace_bytes(int n, int out_h, int out_w, int max_runs);
+/* HOST function (no device work): COCO compressed RLE strings (maskApi.c rleToString) of n masks' run lengths -- counts [n][ld] as
+ * stm_mask_resize_rle_f32 leaves them, copied to the host; row i holds n_runs[i] runs -- into out [n][out_ld] bytes, lengths in out_len [n].
+ * STM_EINVAL if a string needs more than out_ld bytes (out_len[i] then says how many).  ABI 4. */
+int stm_rle_strings_host(const uint32_t* counts, int ld, const int* n_runs, int n, char* out, int out_ld, int* out_len);
 int stm_mask_resize_rle_f32(const float* masks, int n, int mh, int mw, int crop_h, int crop_w, int out_h, int out_w,
                             float thr, uint32_t* counts, int max_runs, int* n_runs, void* workspace,
                             size_t workspace_bytes, stm_stream_t stream);

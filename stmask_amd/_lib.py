@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "stm_conv_pack_weights_tiled_f32", "stm_preprocess_u8_f32", "stm_head_assemble_f32", "stm_conv2d_planar_ws_f32", "stm_dcn_sample_planar_f32", "stm_conv_pack_weights_fmt_f32", "stm_split_planes_fmt_f32", "stm_dcn_sample_planar_fmt_f32", "stm_planar_set_range_flag", "stm_resize_bilinear_planes_f32", "stm_bias_relu_maxpool_planes_f32", "stm_roi_align_planes_f32", "stm_roi_align_planes_nhwc_f32", "stm_deform_sample_planar_f32", "stm_stem_rows_planes_f32", "stm_mask_iou_grouped_f32", "stm_cc_fast_nms_workspace_bytes", "stm_cc_fast_nms_ws_f32",
     "stm_gather_detections_f32", "stm_shift_rois_f32", "stm_shift_apply_f32", "stm_match_scores_f32", "stm_match_scores_embed_f32", "stm_gather_rows2", "stm_pack_tracked_f32", "stm_pack_tracked_bits_f32",
     "stm_lincomb_sigmoid_crop_bits_f32", "stm_mask_iou_bits_f32", "stm_split_planes_f16", "stm_conv_pack_weights_f16", "stm_conv2d_planar_f16", "stm_dcn_sample_planar_f16",
-    "stm_deform_conv_fused_planar_supported", "stm_deform_conv_fused_planar_f32", "stm_fast_nms_batched_workspace_bytes", "stm_fast_nms_batched_f32",
+    "stm_deform_conv_fused_planar_supported", "stm_deform_conv_fused_planar_f32", "stm_fast_nms_batched_workspace_bytes", "stm_fast_nms_batched_f32", "stm_rle_strings_host",
 ]
 
 

@@ -28,6 +28,24 @@ def test_rle_hand_vectors_and_round_trip():
     assert rle_counts_to_string(big.tolist()) == oracle.rle_to_string(big)
 
 
+def test_library_host_rle_string_packer_equals_oracle():
+    """stm_rle_strings_host (the library's host-side maskApi rleToString for a batch of masks: what output_utils.encode_masks calls) against the
+    oracle's string packer on ragged rows: empty rows, zero first runs, multi-chunk counts, negative deltas, a row that fills its width."""
+    from stmask_amd.output_utils import rle_strings
+    g = torch.Generator().manual_seed(5)
+    rows = [[], [6], [0, 4], [1, 4, 1], [0, 100000, 3, 70000, 1, 2, 900000]]
+    for _ in range(40):
+        k = int(torch.randint(1, 60, (1,), generator=g))
+        rows.append(torch.randint(0, 3000, (k,), generator=g).tolist())
+    width = max(len(r) for r in rows)
+    counts = torch.zeros(len(rows), width, dtype=torch.int32)
+    for i, r in enumerate(rows):
+        counts[i, :len(r)] = torch.tensor(r, dtype=torch.int32)
+    got = rle_strings(counts, torch.tensor([len(r) for r in rows], dtype=torch.int32))
+    for i, r in enumerate(rows):
+        assert got[i] == oracle.rle_to_string(torch.tensor(r, dtype=torch.int64)), i
+
+
 def test_resize_threshold_matches_aten_bilinear():
     g = torch.Generator().manual_seed(2)
     for (mh, mw, ch, cw, oh, ow) in [(24, 40, 22, 40, 90, 160), (96, 160, 90, 160, 360, 640), (12, 20, 12, 20, 50, 37)]:
