@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256) void mask_iou_pairs_small_kernel(const unsigne
 // lanes with DPP moves (no LDS round trips: with __shfl butterflies over 64 lanes the reductions were most of the kernel).  Integer counts: the same
 // IoU bits as a one-thread-per-pair loop.
 constexpr int MIOU_R = 8, MIOU_LIST = 2048, MIOU_BIG_ROWS = 4096;
+// staged rows (dynamic LDS) beside the kernel's 16.5 KB of static LDS (matched-column list) inside the 64 KB a kernel gets without an attribute:
+// long mask rows (config 5: 920 words) stage 6 rows per workgroup instead of 8.  STM_MIOU_BIG_ROWS (read once) moves the rule's threshold (tests).
+constexpr int MIOU_DYN_LDS = 46 * 1024;
 __global__ __launch_bounds__(256) void mask_iou_pairs_kernel(const unsigned long long* __restrict__ b1,
                                                              const unsigned long long* __restrict__ b2, int n1, int n2, int words,
                                                              float* __restrict__ out, const int* __restrict__ g1,
@@ -343,9 +346,9 @@ extern "C" int stm_mask_iou_grouped_f32(const float* m1, int n1, const float* m2
     hipLaunchKernelGGL(mask_pack_kernel, dim3(stm_cdiv(words, 4), n1), dim3(256), 0, stm_hs(stream), m1, b1, hw, words, thr);
     hipLaunchKernelGGL(mask_pack_kernel, dim3(stm_cdiv(words, 4), n2), dim3(256), 0, stm_hs(stream), m2, b2, hw, words, thr);
     STM_CHECK_LAUNCH("mask_pack_kernel");
-    const int rows_wg = std::min(MIOU_R, (60 * 1024) / (words * 8));
-    STM_REQUIRE(rows_wg >= 1, STM_EUNSUPPORTED, "stm_mask_iou_f32: a mask row of %d words does not fit the 60 KB of LDS the kernel stages rows in", words);
-    if (n1 < MIOU_BIG_ROWS)
+    const int rows_wg = std::min(MIOU_R, MIOU_DYN_LDS / (words * 8));
+    STM_REQUIRE(rows_wg >= 1, STM_EUNSUPPORTED, "stm_mask_iou_f32: a mask row of %d words does not fit the 46 KB of LDS the kernel stages rows in", words);
+    if (n1 < STM_ENV_INT("STM_MIOU_BIG_ROWS", MIOU_BIG_ROWS))
         hipLaunchKernelGGL(mask_iou_pairs_small_kernel, dim3(stm_cdiv(n2, 256), n1), dim3(256), (size_t)words * 8, stm_hs(stream), b1, b2, n2, words, out, group1, group2);
     else
         hipLaunchKernelGGL(mask_iou_pairs_kernel, dim3(stm_cdiv(n1, rows_wg)), dim3(256), (size_t)rows_wg * words * 8, stm_hs(stream), b1,
@@ -365,9 +368,9 @@ extern "C" int stm_mask_iou_bits_f32(const uint64_t* bits1, int n1, const uint64
     STM_REQUIRE(n1 <= 65535 && n2 <= 65535, STM_EINVAL, "stm_mask_iou_bits_f32: too many masks");
 
     const int words = (hw + 63) / 64;
-    const int rows_wg = std::min(MIOU_R, (60 * 1024) / (words * 8));
-    STM_REQUIRE(rows_wg >= 1, STM_EUNSUPPORTED, "stm_mask_iou_bits_f32: a mask row of %d words does not fit the 60 KB of LDS the kernel stages rows in", words);
-    if (n1 < MIOU_BIG_ROWS)
+    const int rows_wg = std::min(MIOU_R, MIOU_DYN_LDS / (words * 8));
+    STM_REQUIRE(rows_wg >= 1, STM_EUNSUPPORTED, "stm_mask_iou_bits_f32: a mask row of %d words does not fit the 46 KB of LDS the kernel stages rows in", words);
+    if (n1 < STM_ENV_INT("STM_MIOU_BIG_ROWS", MIOU_BIG_ROWS))
         hipLaunchKernelGGL(mask_iou_pairs_small_kernel, dim3(stm_cdiv(n2, 256), n1), dim3(256), (size_t)words * 8, stm_hs(stream),
                            reinterpret_cast<const unsigned long long*>(bits1), reinterpret_cast<const unsigned long long*>(bits2), n2, words, out, group1, group2);
     else

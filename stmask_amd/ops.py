@@ -658,6 +658,11 @@ def temporal_pool_fc(pool_fix, n, npix, weight, bias, n_first=None, clear=True, 
     """stm_temporal_pool_fc_f32: mean = pool_fix / 2^32 / npix, y = mean @ weight.t() + bias for the first n rows of pool_fix [>= n, C] (int64
     fixed-point sums of conv2d_planar_windows_pool); zeroes the consumed rows when clear.  Returns y [n, n_out] -- or, with n_first, the two
     contiguous blocks (y[:, :n_first], y[:, n_first:]) -- and the means [n, C] when want_pooled."""
+    _dev(pool_fix, weight)
+    if pool_fix.dtype != torch.int64 or pool_fix.dim() != 2 or not pool_fix.is_contiguous() or pool_fix.shape[0] < n or n < 0:
+        raise StmError(f"temporal_pool_fc: pool_fix must be contiguous int64 [>= {n}, C], got {pool_fix.dtype} {tuple(pool_fix.shape)}")
+    if weight.dim() != 2 or weight.shape[1] != pool_fix.shape[1] or (bias is not None and bias.numel() != weight.shape[0]):
+        raise StmError(f"temporal_pool_fc: weight {tuple(weight.shape)} / bias do not match C = {pool_fix.shape[1]}")
     C, n_out = pool_fix.shape[1], weight.shape[0]
     weight = _f32c(weight)
     dev = pool_fix.device

@@ -795,7 +795,12 @@ class PlanarTemporalNet:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if out == "pool":
-            ops.conv2d_planar_windows_pool(xp, packed, wins, L["b"], n, h, w, C, O, h, w, L["out_scale"], self._pool)
+            # the launch ADDS into the pooled sums and only the tail kernel re-zeroes them: a failure in between must not leave stale sums for the next step
+            try:
+                ops.conv2d_planar_windows_pool(xp, packed, wins, L["b"], n, h, w, C, O, h, w, L["out_scale"], self._pool)
+            except Exception:
+                self._pool.zero_()
+                raise
         else:
             ops.conv2d_planar_windows(xp, packed, wins, L["b"], n, h, w, C, O, h, w, L["out_scale"], relu=True, out_f32=out_f32, out_planes=out_planes)
         if timing is not None:
@@ -816,7 +821,11 @@ class PlanarTemporalNet:
             if TN_POOL:
                 # conv3 + ReLU + AvgPool2d in one launch (pooled sums, no [n*49, 1024] tensor), then mean -> fc / fc_coeff in one more
                 pool = self._border_layer(2, x2, n, h, w, "pool")
-                return ops.temporal_pool_fc(pool, n, h * w, self.w_tail, self.b_tail, n_first=self.n_fc)
+                try:
+                    return ops.temporal_pool_fc(pool, n, h * w, self.w_tail, self.b_tail, n_first=self.n_fc)
+                except Exception:
+                    self._pool.zero_()
+                    raise
             y = self._border_layer(2, x2, n, h, w, "f32")
         else:
             y = self.c3(self.c2(self.c1(xp, shape), shape), shape, out="f32")                # [n*h*w, 1024]

@@ -736,3 +736,29 @@ def test_detect_pc_batched_equals_per_frame_per_class_nms():
         assert int(cnt[b]) == n and n > 0
         assert torch.equal(idx[b, :n], rows[i1[:n]]) and torch.equal(cls[b, :n], c1[:n])
         assert torch.equal(sc[b, :n], s1[:n]) and torch.equal(bx[b, :n], b1[:n])
+
+
+def test_mask_iou_row_block_kernel_equals_small_kernel(tunables):
+    """mask_iou_pairs_kernel (the row-block form the library takes from 4 096 rows: eight staged rows per workgroup, matched-column list, DPP sums)
+    forced onto small problems (STM_MIOU_BIG_ROWS=1) against the one-thread-per-column kernel: same bits -- with and without groups, row counts that
+    leave a partial last block (n1 % 8 != 0), a group with more than 2 048 columns (the list's overflow path), empty groups, long rows (920 words:
+    six staged rows per workgroup)."""
+    g = torch.Generator().manual_seed(9)
+    cases = [(37, 700, 24, 40, 9), (13, 2600, 12, 20, 2), (5, 300, 184, 320, 3)]          # n1, n2, h, w, groups
+    for n1, n2, h, w, ng in cases:
+        m1, m2 = torch.rand(n1, h, w, generator=g).to(DEV), torch.rand(n2, h, w, generator=g).to(DEV)
+        g2 = torch.sort(torch.randint(0, ng, (n2,), generator=g)).values.to(torch.int32)
+        if ng > 4:
+            g2[g2 == 4] = 5                                    # an empty group
+        if ng == 2:
+            g2[:2300] = 0                                      # > 2 048 columns of one group against every block of group-0 rows
+        g1 = torch.randint(0, ng, (n1,), generator=g).to(torch.int32)
+        outs = {}
+        for big in ("100000", "1"):
+            tunables.set(STM_MIOU_BIG_ROWS=big)
+            outs[big] = (ops.mask_iou(m1, m2).cpu(), ops.mask_iou(m1, m2, group1=g1.to(DEV), group2=g2.to(DEV)).cpu())
+            tunables.clear("STM_MIOU_BIG_ROWS")
+        assert torch.equal(outs["1"][0], outs["100000"][0]), (n1, n2, "all pairs")
+        assert torch.equal(outs["1"][1], outs["100000"][1]), (n1, n2, "grouped")
+        same = g1[:, None] == g2[None, :]
+        assert torch.equal(outs["1"][1], torch.where(same, outs["1"][0], torch.zeros_like(outs["1"][0])))
