@@ -57,3 +57,27 @@ pool = torch.randint(0, 2**40, (n, C), device=dev, dtype=torch.int64, generator=
 w, bias = torch.randn(36, C, device=dev), torch.randn(36, device=dev)
 us = timeit(lambda: ops.temporal_pool_fc(pool, n, 49, w, bias, n_first=4, clear=False))
 print("temporal_pool_fc %d RoIs x %d channels -> 4 + 32: %.1f us" % (n, C, us))
+
+# RoI features of CandidateShift as TemporalNet's input planes (stm_roi_align_planes_nhwc_f32): the step's shapes -- P4 24 x 40, 256-channel T2S maps,
+# 121 correlation channels in rows of 128, 112 tracked instances per clip, boxes of ~0.1-0.4 of the frame -- both kernel forms (STM_ROI_TILED)
+from stmask_amd import _lib
+H, W, C1, Cc = 24, 40, 256, 121
+prev, cur = torch.randn(B, H, W, C1, device=dev, generator=g), torch.randn(B, H, W, C1, device=dev, generator=g)
+corr = torch.randn(B, H, W, 128, device=dev, generator=g)
+n = B * npv
+cx, cy = torch.rand(n, device=dev, generator=g) * W, torch.rand(n, device=dev, generator=g) * H
+bw, bh = (0.1 + 0.3 * torch.rand(n, device=dev, generator=g)) * W, (0.1 + 0.3 * torch.rand(n, device=dev, generator=g)) * H
+rois = torch.stack([torch.arange(B, device=dev).repeat_interleave(npv).float(), (cx - bw / 2).clamp(0, W), (cy - bh / 2).clamp(0, H),
+                    (cx + bw / 2).clamp(0, W), (cy + bh / 2).clamp(0, H)], 1).contiguous()
+outs = {}
+for tiled in ("0", "1"):
+    os.environ["STM_ROI_TILED"] = tiled
+    _lib.lib().stm_debug_reload_tunables()
+    us = timeit(lambda: ops.roi_align_planes(prev, cur, corr, rois, 7, fmt=1, corr_nhwc=Cc))
+    outs[tiled] = ops.roi_align_planes(prev, cur, corr, rois, 7, fmt=1, corr_nhwc=Cc)
+    nb = outs[tiled].numel() * 2 + (prev.numel() + cur.numel() + corr.numel()) * 4
+    print("roi_align_planes %s: %d RoIs -> %d pixels x 640 channels: %.1f us = %.2f TB/s of (inputs once + planes written)" % (
+        "tiled (16 pixels x all slabs per workgroup)" if tiled == "1" else "one pixel's channel groups per wave", n, n * 49, us, nb / us / 1e6))
+del os.environ["STM_ROI_TILED"]
+_lib.lib().stm_debug_reload_tunables()
+assert torch.equal(outs["0"], outs["1"]), "the two roi_align_planes forms differ"

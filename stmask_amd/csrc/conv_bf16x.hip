@@ -1469,6 +1469,98 @@ __global__ __launch_bounds__(256) void roi_align_planes_kernel(const RoiPlanesAr
     store_planes8(dst, plane_b, v, a.fmt, a.range_flag, false);
 }
 
+// The same, laid out for the memory system (round 5; channels-last correlation volume only).  The kernel above gives a wave 64 channel groups of ONE
+// pixel: its plane stores are sixteen 64-byte pieces in sixteen channel slabs per instruction, and nothing of what neighbouring bins share (the corners of
+// adjacent bins of a RoI are the same feature pixels) is reused inside a workgroup.  Here a workgroup owns 16 consecutive output pixels (two to three rows
+// of a 7 x 7 RoI grid) and every channel slab: lane = 4 pixel + chunk, wave w takes slabs w, w + 4, ... -- a plane store is 1 KB contiguous (16 pixels x
+// 64 B), a corner read 16 full 128-byte lines, and the five slabs of a lane share its RoI arithmetic.  Same expressions per output value: bit-equal.
+__global__ __launch_bounds__(256) void roi_align_planes_tiled_kernel(const RoiPlanesArgs a)
+{
+    const int64_t npix = (int64_t)a.n * a.PH * a.PW;
+    const int64_t blk = xcd_contiguous_block((npix + 15) >> 4);
+    if (blk < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pix_ = blk * 16 + (lane >> 2);
+    const bool live = pix_ < npix;
+    const int64_t pix = live ? pix_ : npix - 1;
+    const int ck = lane & 3;
+    const int ri = (int)(pix / (a.PH * a.PW));
+    const int pp = (int)(pix - (int64_t)ri * a.PH * a.PW);
+    const int py = pp / a.PW, px = pp - py * a.PW;
+    const float* roi = a.rois + 5 * ri;
+    const int b = (int)roi[0];
+    const float sw_ = roi[1] - 0.5f, sh_ = roi[2] - 0.5f, ew_ = roi[3] - 0.5f, eh_ = roi[4] - 0.5f;   // aligned, scale 1
+    const float rw = ew_ - sw_, rh = eh_ - sh_;
+    const float bh = rh / (float)a.PH, bw = rw / (float)a.PW;
+    const int gh = (int)ceilf(rh / (float)a.PH), gw = (int)ceilf(rw / (float)a.PW);
+    const float count = (float)max(gh * gw, 1);
+    const size_t plane_b = (size_t)npix * a.Cpad * 2;
+    const int nslabs = a.Cpad >> 5;
+    for (int s = wave; s < nslabs; s += 4) {
+        const int g = s * 4 + ck;
+        const int c0 = g * 8;
+        const bool from_prev = c0 < a.C1, from_cur = !from_prev && c0 < 2 * a.C1;
+        const float* nhwc = from_prev ? a.t2s_prev + (size_t)b * a.H * a.W * a.C1 + c0
+                                      : a.t2s + (size_t)b * a.H * a.W * a.C1 + (c0 - a.C1);
+        const int cc0 = c0 - 2 * a.C1;                             // first correlation channel of the lane
+        const float* cl = a.corr + (size_t)b * a.H * a.W * a.corr_ld + (cc0 > 0 ? cc0 : 0);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int iy = 0; iy < gh; ++iy) {
+            const float ys = sh_ + (float)py * bh + ((float)iy + 0.5f) * bh / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float xs = sw_ + (float)px * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                float y = ys, x = xs;
+                if (y < -1.0f || y > (float)a.H || x < -1.0f || x > (float)a.W) continue;     // the sample contributes 0
+                if (y <= 0.0f) y = 0.0f;
+                if (x <= 0.0f) x = 0.0f;
+                int y_low = (int)y, x_low = (int)x, y_high, x_high;
+                if (y_low >= a.H - 1) { y_high = y_low = a.H - 1; y = (float)y_low; } else y_high = y_low + 1;
+                if (x_low >= a.W - 1) { x_high = x_low = a.W - 1; x = (float)x_low; } else x_high = x_low + 1;
+                const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.0f - ly, hx = 1.0f - lx;
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                const int o1 = y_low * a.W + x_low, o2 = y_low * a.W + x_high, o3 = y_high * a.W + x_low, o4 = y_high * a.W + x_high;
+                float v1[8], v2[8], v3[8], v4[8];
+                if (from_prev || from_cur) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 q1 = *reinterpret_cast<const f32x4*>(nhwc + (size_t)o1 * a.C1 + 4 * h);
+                        const f32x4 q2 = *reinterpret_cast<const f32x4*>(nhwc + (size_t)o2 * a.C1 + 4 * h);
+                        const f32x4 q3 = *reinterpret_cast<const f32x4*>(nhwc + (size_t)o3 * a.C1 + 4 * h);
+                        const f32x4 q4 = *reinterpret_cast<const f32x4*>(nhwc + (size_t)o4 * a.C1 + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v1[4 * h + e] = q1[e]; v2[4 * h + e] = q2[e]; v3[4 * h + e] = q3[e]; v4[4 * h + e] = q4[e]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int hofs = cc0 + 4 * h < a.Cc ? 4 * h : -cc0;          // all-padding group: re-read channel 0 (masked below)
+                        const f32x4 q1 = *reinterpret_cast<const f32x4*>(cl + (size_t)o1 * a.corr_ld + hofs);
+                        const f32x4 q2 = *reinterpret_cast<const f32x4*>(cl + (size_t)o2 * a.corr_ld + hofs);
+                        const f32x4 q3 = *reinterpret_cast<const f32x4*>(cl + (size_t)o3 * a.corr_ld + hofs);
+                        const f32x4 q4 = *reinterpret_cast<const f32x4*>(cl + (size_t)o4 * a.corr_ld + hofs);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool real = cc0 + 4 * h + e < a.Cc;
+                            v1[4 * h + e] = real ? q1[e] : 0.0f; v2[4 * h + e] = real ? q2[e] : 0.0f;
+                            v3[4 * h + e] = real ? q3[e] : 0.0f; v4[4 * h + e] = real ? q4[e] : 0.0f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    acc[e] += w1 * fmaxf(v1[e], 0.0f) + w2 * fmaxf(v2[e], 0.0f) + w3 * fmaxf(v3[e], 0.0f) + w4 * fmaxf(v4[e], 0.0f);
+            }
+        }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[e] / count;
+        if (live) {
+            uint8_t* dst = a.planes + (((size_t)s * npix + pix) * 32 + ck * 8) * 2;
+            store_planes8(dst, plane_b, v, a.fmt, a.range_flag, false);
+        }
+    }
+}
+
 // Stem entry (backbone.py:73, the 7x7 / stride-2 convolution on the 3-channel frame): the kw * Cin = 21 values one kernel row
 // reads for output column ox are contiguous in the NHWC frame, starting at column sw*ox - pw.  This kernel lays them out as
 // the 32-channel slab of a planar tensor R[b][y][ox][32] (channels >= kw*Cin zero, columns outside the frame zero), which
@@ -1767,6 +1859,12 @@ extern "C" int stm_roi_align_planes_nhwc_f32(const float* t2s_prev, const float*
     a.n = n; a.H = H; a.W = W; a.C1 = C1; a.Cc = Cc; a.Cpad = (2 * C1 + Cc + 31) / 32 * 32; a.PH = PH; a.PW = PW; a.fmt = fmt;
     a.range_flag = current_range_flag();
     const int64_t threads = (int64_t)n * PH * PW * (a.Cpad / 8);
+    if (corr_ld > 0 && STM_ENV_INT("STM_ROI_TILED", 1)) {
+        const int64_t tiles = ((int64_t)n * PH * PW + 15) >> 4;
+        hipLaunchKernelGGL(roi_align_planes_tiled_kernel, dim3(8 * stm_cdiv(tiles, 8)), dim3(256), 0, stm_hs(stream), a);
+        STM_CHECK_LAUNCH("roi_align_planes_tiled_kernel");
+        return STM_OK;
+    }
     hipLaunchKernelGGL(roi_align_planes_kernel, dim3(8 * stm_cdiv(stm_cdiv(threads, 256), 8)), dim3(256), 0, stm_hs(stream), a);
     STM_CHECK_LAUNCH("roi_align_planes_kernel");
     return STM_OK;
