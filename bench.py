@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s meas
 DEFAULT_CLIPS = 32          # plateau of the throughput curve (999 frames/s at 8 clips, 1167 at 16, 1250-1280 at 32, 1300 at 64);
                             # SURVEY §8(d) names 8 clips/GPU: that line and the single-stream (1 clip) line ride along in `extras`
 CLIP_FRAMES = 16            # clips of T = 16 frames
-PMC_FILE = "r04_pmc_traffic.json"
+PMC_FILE = "r05_pmc_traffic.json"
 PARITY_MIN_MATCHED = 0.98   # bench.py exits 3 when its parity block finds fewer of the oracle's instances ...
 PARITY_MAX_MASK_L2 = 1e-4   # ... or a soft mask further than north_star's 1e-4 (RMS) from the oracle's
 
@@ -179,7 +179,7 @@ def launch_check(args, rank, world):
 def pmc_traffic(kernel):
     """HBM bytes per launch of the named kernel from the committed rocprofv3 PMC passes (bench.py cannot collect PMC counters
     about itself): profiles/r02_pmc_traffic.json, produced by `scripts/gpu_round.sh pmc` on this command and batch."""
-    for name in (PMC_FILE, "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in (PMC_FILE, "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 d = json.load(fh)

@@ -32,6 +32,10 @@ def main():
     g = group("dcn_sample_planar_kernel")
     if g:
         doc["dcn_sample_planar"] = {"kernel": "dcn_sample_planar_kernel (7 DCN layers of R50 at batch 32)", **g}
+    g = group("dcn_fused_kernel")
+    if g:
+        doc["dcn_fused"] = {"kernel": "dcn_fused_kernel (the 7 DCN layers of R50 at batch 32 as one kernel each: algorithmic bytes per launch 4 (C H W + 27 Ho Wo) "
+                                      "+ planes (Cout Ho Wo + 9 C Cout) = 128 MB on average, no column buffer)", **g}
     g = group("corr_patch_tiled")
     if g:
         doc["corr_patch"] = {"kernel": "corr_patch_tiled<11> (P4 24x40, 256 channels, batch 32: inputs 62.9 MB, output 14.9 MB)", **g}
@@ -44,7 +48,7 @@ def main():
             return None
         return {"launches": nf, "fetch_bytes_per_launch": fb / nf, "write_bytes_per_launch": wb / nw, "traffic_bytes_per_launch": fb / nf + wb / nw}
 
-    g = group_any(("conv_planar_kernel", "conv_planar_kx3_kernel", "conv_kxr_kernel"))
+    g = group_any(("conv_planar_kernel", "conv_planar_kx3_kernel", "conv_kxr_kernel"))   # (bench.py pmc_traffic("conv_planar"))
     if g:
         doc["conv_planar"] = {"kernel": "conv_planar_kernel<*> + conv_planar_kx3_kernel + conv_kxr_kernel<*> (all launches of bench.py at batch 32, fp16x2 plane format)", **g}
     g = group("conv_planar_kx3_kernel")
