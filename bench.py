@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the parity block that needs it)")
     ap.add_argument("--no-extras", action="store_true", help="skip the 8-clip / 1-clip / bf16x3 side measurements")
+    ap.add_argument("--no-sampler-pass", action="store_true",
+                    help="skip the short eager pass with the fused deformable convolution switched off that only serves roofline_im2col (kernel traces: one kind of step)")
     ap.add_argument("--extras", default="realistic,clips8,clips1,bf16x3,per_class_nms,non_tf,e2e", help="which side measurements to run (comma-separated)")
     ap.add_argument("--nchw", dest="channels_last", action="store_false", help="keep the dense convs in NCHW")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="keep BatchNorm / bias / ReLU as separate kernels")
@@ -233,8 +235,8 @@ def conv_roofline(conv_t, steps, planes, traffic=None, traffic_src=None, timed_i
                        "with residual, stem): inputs, residual, outputs and weights once, in their stored formats"}
     obj = dict(allo)
     obj.update({"bound": "mfma",
-                "kernel": f"conv_planar_kernel / conv_planar_kx3_kernel / conv_kxr_kernel / conv_chain_kernel / dcn_fused_kernel ({planes} planes: stem, backbone 1x1/3x3 and the deformable "
-                          "convolutions, FPN, proto-net, shared head, TemporalNet; all launches of " + timed_in + ")",
+                "kernel": f"conv_planar_kernel / conv_planar_kx3_kernel / conv_kxr_kernel / conv_chain_kernel ({planes} planes: stem, backbone 1x1/3x3 (the deformable layers: roofline_dcn_fused), "
+                          " FPN, proto-net, shared head, TemporalNet; all launches of " + timed_in + ")",
                 "traffic": traffic,
                 "traffic_source": (f"profiles/{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 "
                                    "correction); average over all launches") if traffic_src else None,
@@ -781,7 +783,7 @@ def main():
                 "traffic_source": f"profiles/{src_f} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)" if src_f else None,
                 "replaces": "dcn_sample_planar_kernel (roofline_im2col: 412 MB of columns per launch at 0.48-0.50 of the HBM peak) + the 1x1 product over 9C "
                             "channels; what bounds the fused kernel instead: profiles/r05_dcn_fused_forms.txt"}
-            if not timing:
+            if not timing and not args.no_sampler_pass:
                 # the sampler the north star names did not run in that pass (every DCN layer took the fused kernel): its own figure from a short eager
                 # pass of the same pipeline with fusion switched off (same process, right after; nothing of it enters the headline)
                 from stmask_amd import planar as _plf
@@ -807,6 +809,14 @@ def main():
             res["roofline"] = conv_roofline(conv_t, args.steps, args.planes, tr_c, src_c,
                                             "the timed region" if not graphed else "an eager pass of the same steps right after the timed region (which replays HIP graphs)")
             res["frac_trunk_only"] = res["roofline"]["frac_trunk_only"]
+            if fused_t:
+                # `roofline` keeps its definition of the earlier rounds -- the plane-split dense-convolution kernels -- so the deformable layers' products,
+                # which those kernels ran until round 4 (0.25 TFLOP per step), left it together with their time; the same figure WITH the fused kernel's
+                # launches (whose time also holds the sampling the old sampler kernel did outside any roofline object):
+                ro = res["roofline"]
+                c_ms, c_fl = ro["ms_per_step"] * args.steps + f_ms, ro["tflop_per_step"] * args.steps * 1e12 + f_fl
+                ro["with_dcn_fused"] = {"achieved": round(c_fl / (c_ms * 1e-3) / 1e12, 1), "frac": round(c_fl / (c_ms * 1e-3) / 1e12 / ro["peak"], 4),
+                                        "ms_per_step": round(c_ms / args.steps, 3), "tflop_per_step": round(c_fl / args.steps / 1e12, 3)}
             res["roofline_im2col"] = im2col_roof
             if args.layer_table:
                 # per-layer-shape table of the dominant kernel (stderr; the JSON line stays alone on stdout)

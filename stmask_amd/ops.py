@@ -1221,7 +1221,7 @@ def deform_conv_fused_planar(x_pix, B, H, W, C, om, packed, out_scale, bias, O, 
         _dev(bias)
         bias = _f32c(bias)
     g = DeformGeom(B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, 1, Ho, Wo)
-    timing = _fused_dcn_timing if _fused_dcn_timing is not None else ([] if _conv_timing is not None else None)
+    timing = _fused_dcn_timing
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -1235,10 +1235,6 @@ def deform_conv_fused_planar(x_pix, B, H, W, C, om, packed, out_scale, bias, O, 
         npl, npo = plane_layout(fmt)[0], plane_layout(out_fmt)[0]
         nbytes = 4 * B * C * H * W + 4 * (3 if has_mask else 2) * K * M + 2 * npo * O * M + 2 * npl * O * C * K
         timing.append((e0, e1, float(nbytes), 2.0 * M * O * C * K, {1: 3, 2: 1}[fmt]))
-        if _conv_timing is not None:
-            # the launch is also one of the step's dense-convolution launches (the product the sampler + 1x1 pair ran on conv_planar_kernel):
-            # same record as PlanarConv._finish makes, layer key tile -3 = dcn_fused_kernel
-            _conv_timing.append((e0, e1, 2.0 * M * O * C * K, (M, C, O, kh, sh, 1, -3), {1: 3, 2: 1}[fmt], "trunk", float(nbytes)))
     return out
 
 
