@@ -70,14 +70,15 @@ bw, bh = (0.1 + 0.3 * torch.rand(n, device=dev, generator=g)) * W, (0.1 + 0.3 * 
 rois = torch.stack([torch.arange(B, device=dev).repeat_interleave(npv).float(), (cx - bw / 2).clamp(0, W), (cy - bh / 2).clamp(0, H),
                     (cx + bw / 2).clamp(0, W), (cy + bh / 2).clamp(0, H)], 1).contiguous()
 outs = {}
-for tiled in ("0", "1"):
+for tiled in ("0", "1", "2"):
     os.environ["STM_ROI_TILED"] = tiled
     _lib.lib().stm_debug_reload_tunables()
     us = timeit(lambda: ops.roi_align_planes(prev, cur, corr, rois, 7, fmt=1, corr_nhwc=Cc))
     outs[tiled] = ops.roi_align_planes(prev, cur, corr, rois, 7, fmt=1, corr_nhwc=Cc)
     nb = outs[tiled].numel() * 2 + (prev.numel() + cur.numel() + corr.numel()) * 4
     print("roi_align_planes %s: %d RoIs -> %d pixels x 640 channels: %.1f us = %.2f TB/s of (inputs once + planes written)" % (
-        "tiled (16 pixels x all slabs per workgroup)" if tiled == "1" else "one pixel's channel groups per wave", n, n * 49, us, nb / us / 1e6))
+        {"0": "one pixel's channel groups per wave", "1": "tiled (16 pixels x all slabs per workgroup)", "2": "the RoI's patch in LDS (one workgroup per RoI)"}[tiled],
+        n, n * 49, us, nb / us / 1e6))
 del os.environ["STM_ROI_TILED"]
 _lib.lib().stm_debug_reload_tunables()
-assert torch.equal(outs["0"], outs["1"]), "the two roi_align_planes forms differ"
+assert torch.equal(outs["0"], outs["1"]) and torch.equal(outs["0"], outs["2"]), "the roi_align_planes forms differ"

@@ -1561,6 +1561,129 @@ __global__ __launch_bounds__(256) void roi_align_planes_tiled_kernel(const RoiPl
     }
 }
 
+// ... and with the RoI's feature patch in LDS (round 5; STM_ROI_TILED=2: built, bit-equal, NOT faster -- kept as the measured alternative).  The bins of a RoI sample the same few feature pixels over
+// and over (49 bins x gh gw samples x 4 corners over a patch of a few dozen pixels): through L1 that is 7 GB of gathers per step for 82 MB of feature
+// maps.  One workgroup per RoI: per 32-channel slab the patch (rows / columns any sample of the RoI can touch, ReLU applied, channels past Cc zero) is
+// copied into LDS once -- 144-byte rows: consecutive pixels start 4 banks apart -- and the 49 bins x 4 chunks gather from there; the output pixels of a
+// RoI are consecutive, so a slab's 49 x 64 B leave as one 3-KB run.  Same expressions in the same order per output value (relu(v) is taken when the
+// patch is staged instead of at every use: the same value): bit-equal to the kernels above.  RoIs whose patch exceeds RP_MAX pixels (a tenth of the
+// frame or more at 24 x 40) take the tiled kernel's direct loads inside the same launch.
+constexpr int RP_MAX = 288, RP_PITCH = 144;
+__global__ __launch_bounds__(256) void roi_align_planes_lds_kernel(const RoiPlanesArgs a)
+{
+    extern __shared__ __align__(16) uint8_t rp_smem[];
+    const int64_t blk = xcd_contiguous_block(a.n);
+    if (blk < 0) return;
+    const int ri = (int)blk;
+    const int tid = threadIdx.x;
+    const int64_t npix = (int64_t)a.n * a.PH * a.PW;
+    const int nb = a.PH * a.PW;                                       // bins (output pixels) of the RoI
+    const float* roi = a.rois + 5 * ri;
+    const int b = (int)roi[0];
+    const float sw_ = roi[1] - 0.5f, sh_ = roi[2] - 0.5f, ew_ = roi[3] - 0.5f, eh_ = roi[4] - 0.5f;   // aligned, scale 1
+    const float rw = ew_ - sw_, rh = eh_ - sh_;
+    const float bh = rh / (float)a.PH, bw = rw / (float)a.PW;
+    const int gh = (int)ceilf(rh / (float)a.PH), gw = (int)ceilf(rw / (float)a.PW);
+    const float count = (float)max(gh * gw, 1);
+    // feature rows / columns a sample of this RoI can read: samples lie in [sh_, eh_] x [sw_, ew_], are clamped to [0, H - 1] x [0, W - 1]
+    // and read (low, low + 1)
+    const int y0 = min(max((int)floorf(fminf(sh_, eh_)), 0), a.H - 1), y1 = min(max((int)floorf(fmaxf(sh_, eh_)) + 1, y0), a.H - 1);
+    const int x0 = min(max((int)floorf(fminf(sw_, ew_)), 0), a.W - 1), x1 = min(max((int)floorf(fmaxf(sw_, ew_)) + 1, x0), a.W - 1);
+    const int ph = y1 - y0 + 1, pw = x1 - x0 + 1;
+    const bool staged = ph * pw <= RP_MAX;                            // (uniform over the workgroup)
+    const int pp = tid >> 2, ck = tid & 3;                            // bin and 8-channel chunk of the compute phase
+    const int py = pp / a.PW, px = pp - py * a.PW;
+    const size_t plane_b = (size_t)npix * a.Cpad * 2;
+    const int nslabs = a.Cpad >> 5;
+    for (int s = 0; s < nslabs; ++s) {
+        const int c0s = s * 32;                                       // first channel of the slab
+        const bool from_prev = c0s < a.C1, from_cur = !from_prev && c0s < 2 * a.C1;
+        const int cc0s = c0s - 2 * a.C1;                              // first correlation channel of the slab
+        const float* src = from_prev ? a.t2s_prev + (size_t)b * a.H * a.W * a.C1 + c0s
+                         : from_cur ? a.t2s + (size_t)b * a.H * a.W * a.C1 + (c0s - a.C1)
+                                    : a.corr + (size_t)b * a.H * a.W * a.corr_ld + cc0s;
+        const int ld = (from_prev || from_cur) ? a.C1 : a.corr_ld;
+        if (staged) {
+            __syncthreads();                                          // the previous slab's gathers are done
+            for (int i = tid; i < ph * pw * 8; i += 256) {
+                const int q = i >> 3, c4 = i & 7;                     // patch pixel, 4-channel piece
+                const int qy = q / pw, qx = q - qy * pw;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                const int ch = c4 * 4;
+                if (from_prev || from_cur || cc0s + ch < a.Cc) {      // (a piece wholly past Cc is not loaded: it may lie beyond the padded row)
+                    v = *reinterpret_cast<const f32x4*>(src + (size_t)((y0 + qy) * a.W + x0 + qx) * ld + ch);
+                    if (!(from_prev || from_cur)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (cc0s + ch + e >= a.Cc) v[e] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                *reinterpret_cast<f32x4*>(rp_smem + q * RP_PITCH + c4 * 16) = v;
+            }
+            __syncthreads();
+        }
+        if (pp < nb) {
+            const int c0 = c0s + ck * 8, cc0 = c0 - 2 * a.C1;
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int iy = 0; iy < gh; ++iy) {
+                const float ys = sh_ + (float)py * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float xs = sw_ + (float)px * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                    float y = ys, x = xs;
+                    if (y < -1.0f || y > (float)a.H || x < -1.0f || x > (float)a.W) continue;     // the sample contributes 0
+                    if (y <= 0.0f) y = 0.0f;
+                    if (x <= 0.0f) x = 0.0f;
+                    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+                    if (y_low >= a.H - 1) { y_high = y_low = a.H - 1; y = (float)y_low; } else y_high = y_low + 1;
+                    if (x_low >= a.W - 1) { x_high = x_low = a.W - 1; x = (float)x_low; } else x_high = x_low + 1;
+                    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.0f - ly, hx = 1.0f - lx;
+                    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                    float v1[8], v2[8], v3[8], v4[8];
+                    if (staged) {
+                        const uint8_t* r1 = rp_smem + ((y_low - y0) * pw + x_low - x0) * RP_PITCH + ck * 32;
+                        const uint8_t* r2 = rp_smem + ((y_low - y0) * pw + x_high - x0) * RP_PITCH + ck * 32;
+                        const uint8_t* r3 = rp_smem + ((y_high - y0) * pw + x_low - x0) * RP_PITCH + ck * 32;
+                        const uint8_t* r4 = rp_smem + ((y_high - y0) * pw + x_high - x0) * RP_PITCH + ck * 32;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x4 q1 = *reinterpret_cast<const f32x4*>(r1 + 16 * h), q2 = *reinterpret_cast<const f32x4*>(r2 + 16 * h);
+                            const f32x4 q3 = *reinterpret_cast<const f32x4*>(r3 + 16 * h), q4 = *reinterpret_cast<const f32x4*>(r4 + 16 * h);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v1[4 * h + e] = q1[e]; v2[4 * h + e] = q2[e]; v3[4 * h + e] = q3[e]; v4[4 * h + e] = q4[e]; }
+                        }
+                    } else {
+                        const int o1 = y_low * a.W + x_low, o2 = y_low * a.W + x_high, o3 = y_high * a.W + x_low, o4 = y_high * a.W + x_high;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int chh = ck * 8 + 4 * h;
+                            const bool skip = !(from_prev || from_cur) && cc0 + 4 * h >= a.Cc;
+                            const int hofs = skip ? 0 : chh;
+                            const f32x4 q1 = *reinterpret_cast<const f32x4*>(src + (size_t)o1 * ld + hofs), q2 = *reinterpret_cast<const f32x4*>(src + (size_t)o2 * ld + hofs);
+                            const f32x4 q3 = *reinterpret_cast<const f32x4*>(src + (size_t)o3 * ld + hofs), q4 = *reinterpret_cast<const f32x4*>(src + (size_t)o4 * ld + hofs);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const bool real = from_prev || from_cur || cc0 + 4 * h + e < a.Cc;
+                                v1[4 * h + e] = real ? fmaxf(q1[e], 0.0f) : 0.0f; v2[4 * h + e] = real ? fmaxf(q2[e], 0.0f) : 0.0f;
+                                v3[4 * h + e] = real ? fmaxf(q3[e], 0.0f) : 0.0f; v4[4 * h + e] = real ? fmaxf(q4[e], 0.0f) : 0.0f;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+                }
+            }
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[e] / count;
+            const int64_t pix = (int64_t)ri * nb + pp;
+            uint8_t* dst = a.planes + (((size_t)s * npix + pix) * 32 + ck * 8) * 2;
+            store_planes8(dst, plane_b, v, a.fmt, a.range_flag, false);
+        }
+    }
+}
+
 // Stem entry (backbone.py:73, the 7x7 / stride-2 convolution on the 3-channel frame): the kw * Cin = 21 values one kernel row
 // reads for output column ox are contiguous in the NHWC frame, starting at column sw*ox - pw.  This kernel lays them out as
 // the 32-channel slab of a planar tensor R[b][y][ox][32] (channels >= kw*Cin zero, columns outside the frame zero), which
@@ -1859,7 +1982,15 @@ extern "C" int stm_roi_align_planes_nhwc_f32(const float* t2s_prev, const float*
     a.n = n; a.H = H; a.W = W; a.C1 = C1; a.Cc = Cc; a.Cpad = (2 * C1 + Cc + 31) / 32 * 32; a.PH = PH; a.PW = PW; a.fmt = fmt;
     a.range_flag = current_range_flag();
     const int64_t threads = (int64_t)n * PH * PW * (a.Cpad / 8);
-    if (corr_ld > 0 && STM_ENV_INT("STM_ROI_TILED", 1)) {
+    // STM_ROI_TILED: 0 the first kernel (one pixel's channel groups per wave), 1 (default) the tiled kernel, 2 the RoI's patch in LDS -- bit-equal,
+    // and slower: 399 vs 272 us at 32 clips, 149 vs 80 at 8 (twenty slabs of stage / barrier / gather / barrier per workgroup, 196 of 256 lanes at work)
+    const int roi_form = STM_ENV_INT("STM_ROI_TILED", 1);
+    if (corr_ld > 0 && roi_form == 2 && PH * PW * 4 <= 256 && C1 % 32 == 0 && corr_ld % 32 == 0 && a.Cpad == 2 * C1 + corr_ld) {
+        hipLaunchKernelGGL(roi_align_planes_lds_kernel, dim3(8 * stm_cdiv(n, 8)), dim3(256), (size_t)RP_MAX * RP_PITCH, stm_hs(stream), a);
+        STM_CHECK_LAUNCH("roi_align_planes_lds_kernel");
+        return STM_OK;
+    }
+    if (corr_ld > 0 && roi_form) {
         const int64_t tiles = ((int64_t)n * PH * PW + 15) >> 4;
         hipLaunchKernelGGL(roi_align_planes_tiled_kernel, dim3(8 * stm_cdiv(tiles, 8)), dim3(256), 0, stm_hs(stream), a);
         STM_CHECK_LAUNCH("roi_align_planes_tiled_kernel");

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void mask_iou_pairs_small_kernel(const unsigne
 // against the staged rows (the same LDS word for all four rows: a broadcast) and the column's area, and the nine counts are summed over the row's 16
 // lanes with DPP moves (no LDS round trips: with __shfl butterflies over 64 lanes the reductions were most of the kernel).  Integer counts: the same
 // IoU bits as a one-thread-per-pair loop.
-constexpr int MIOU_R = 8, MIOU_LIST = 2048, MIOU_BIG_ROWS = 4096;
+constexpr int MIOU_R = 8, MIOU_LIST = 2048, MIOU_BIG_ROWS = 3072;   // (crossover of the two kernels at 110 detections per clip: 124 vs 111 us at 3 520 rows, 92 vs 108 at 2 640; scripts/sweep_miou_rule.py)
 // staged rows (dynamic LDS) beside the kernel's 16.5 KB of static LDS (matched-column list) inside the 64 KB a kernel gets without an attribute:
 // long mask rows (config 5: 920 words) stage 6 rows per workgroup instead of 8.  STM_MIOU_BIG_ROWS (read once) moves the rule's threshold (tests).
 constexpr int MIOU_DYN_LDS = 46 * 1024;

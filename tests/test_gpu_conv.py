@@ -473,6 +473,36 @@ def test_roi_align_planes_equals_cat_relu_roialign_split(fmt):
     assert torch.equal(pl2.cpu(), pl.cpu())
 
 
+def test_roi_align_planes_forms_agree_bitwise(tunables):
+    """The three kernels behind stm_roi_align_planes_nhwc_f32 -- one pixel's channel groups per wave (STM_ROI_TILED=0), 16 pixels x all slabs per
+    workgroup (1), the RoI's feature patch staged in LDS (2, the default when the channel counts are whole slabs) -- write the same planes: boxes
+    inside, across the borders, outside the map, degenerate, a tenth of the map, and the WHOLE map (960 pixels: beyond the staged patch, the
+    workgroup's direct-load path); correlation channels 41 of a 64-float row (the slab holds real channels, masked channels and padding)."""
+    B, H, W, C1, Cc, ld = 3, 24, 40, 64, 41, 64
+    g = torch.Generator().manual_seed(7)
+    prev, cur = rnd(B, H, W, C1, seed=1).to(DEV), rnd(B, H, W, C1, seed=2).to(DEV)
+    cl = torch.full((B, H, W, ld), float("nan"))
+    cl[..., :Cc] = rnd(B, H, W, Cc, seed=3)
+    n = 64
+    x1 = torch.rand(n, generator=g) * W * 1.2 - 3.0
+    y1 = torch.rand(n, generator=g) * H * 1.2 - 3.0
+    bw = torch.rand(n, generator=g) ** 2 * W * 0.6
+    bh = torch.rand(n, generator=g) ** 2 * H * 0.6
+    rois = torch.stack([torch.randint(0, B, (n,), generator=g).float(), x1, y1, x1 + bw, y1 + bh], 1)
+    rois[0, 1:] = torch.tensor([3.0, 4.0, 3.0, 4.0])                      # empty box
+    rois[1, 1:] = torch.tensor([0.0, 0.0, float(W), float(H)])            # whole map
+    rois[2, 1:] = torch.tensor([-9.0, -7.0, -2.5, -1.5])                  # outside
+    rois[3, 1:] = torch.tensor([W - 0.5, H - 0.5, W + 6.0, H + 5.0])      # hanging over the far corner
+    rois[4, 1:] = torch.tensor([5.0, 2.0, 31.0, 20.0])                    # 27 x 19 pixels: beyond the staged patch too
+    outs = []
+    for form in ("0", "1", "2"):
+        tunables.set(STM_ROI_TILED=form)
+        outs.append(ops.roi_align_planes(prev, cur, cl.to(DEV), rois.to(DEV), 7, fmt=1, corr_nhwc=Cc).clone())
+        tunables.clear("STM_ROI_TILED")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.isfinite(ops.planes_to_f32(outs[2])).all()
+
+
 @pytest.mark.parametrize("fmt", [1, 0])
 def test_stem_row_patches_plus_planar_conv_equals_7x7_stride2(fmt):
     """stm_stem_rows_planes_f32 + a (7 x 1), stride (2, 1) planar convolution over the row-patch tensor == the stem's 7x7 /
