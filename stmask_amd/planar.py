@@ -50,6 +50,9 @@ CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"
 # from DCN_FUSED_MIN_TILES workgroups on (below that the grid leaves CUs idle and the sampler + split-K product pair is faster); 0 = the pair everywhere
 DCN_FUSED = os.environ.get("STM_DCN_FUSED", "1") != "0"
 DCN_FUSED_MIN_TILES = int(os.environ.get("STM_DCN_FUSED_MIN_TILES", "200"))
+# which layers: 0 = every layer whose grid is large enough; 1 = only where the fused kernel wins in isolation (profiles/r05_dcn_fused_forms.txt section 0): one
+# 128-channel tile per pixel patch, or two at stride 2 -- with more channel tiles every tile samples the patch again
+DCN_FUSED_RULE = int(os.environ.get("STM_DCN_FUSED_RULE", "0"))   # (in the step both rules measure the same within 0.1 ms on R50 and R101: profiles/r05_dcn_fused_forms.txt)
 # ... the FCB class branch (FeatureAlign's DeformConv2d, 256 -> 256 channels, 9 / 15 / 15 taps over five levels) on the same kernel: built and tested, OFF by
 # default -- two 128-channel tiles per pixel patch sample every pixel twice and the sampler + product pair wins (R50 FCB-ada at 32 clips: 918 frames/s with
 # the pair, 764 fused; profiles/r05_dcn_fused_forms.txt)
@@ -1027,7 +1030,8 @@ class PlanarBackbone:
                         t32, tpl = e["c1"](xp, shape, out="both")
                         om = e["om"](tpl, shape, out="f32")
                         fz = e.get("dcn_fused")
-                        if fz is not None and ops.deform_conv_fused_tiles(B, Ho, Wo, fz.O) >= DCN_FUSED_MIN_TILES:
+                        if (fz is not None and ops.deform_conv_fused_tiles(B, Ho, Wo, fz.O) >= DCN_FUSED_MIN_TILES
+                                and (DCN_FUSED_RULE == 0 or fz.O <= 128 or (fz.O <= 256 and _pair(d.stride)[0] == 2))):
                             mid = fz.deform(t32, B, H, W, om, d.stride, d.padding, d.dilation, has_mask=True)
                         else:
                             cols = ops.dcn_sample_planar(t32.view(B, H, W, -1), om, d.stride, d.padding, d.dilation, fmt=self.fmt)
