@@ -65,6 +65,18 @@ def start_hammer(mode, seconds):
 def main():
     args = parse()
     hammer = start_hammer(args.hammer, args.seconds)           # before this process touches the GPU
+    try:
+        return run(args, hammer)
+    finally:                                                   # an exception while the cases are prepared must not leave the neighbour (and the pipes it
+        if hammer is not None and hammer[0].poll() is None:    # inherited) behind: a caller reading our stdout would wait for the hammer's whole lifetime
+            open(hammer[1]["stop"], "w").write("stop\n")
+            try:
+                hammer[0].wait(timeout=60)
+            except subprocess.TimeoutExpired:
+                hammer[0].kill()
+
+
+def run(args, hammer):
     import torch
     from stmask_amd import _lib, ops
     from stmask_amd.planar import PlanarConv
@@ -214,6 +226,27 @@ def main():
 
         return [(f"window set 3x3 512->512 on 7x7 maps (conv_planar_kx3_kernel<WIN> + conv_planar_kernel<CLS>) B={B}", launch, fresh, None)]
 
+    def dcn_cases(B):
+        """dcn_fused_kernel (round 5): weight ring by LDS-DMA + operand ring written by producer waves, read by consumer waves across counted barriers --
+        the 128-channel stride-1 layer and the 256-channel stride-2 layer (two channel tiles per patch) of the R50 backbone, bench-like offsets."""
+        out = []
+        for name, C, H, W, st in (("dcn_fused_kernel 128ch 48x80 stride 1", 128, 48, 80, 1), ("dcn_fused_kernel 256ch 48x80 stride 2", 256, 48, 80, 2)):
+            Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+            M = B * Ho * Wo
+            wt, bs = rnd(C, C, 3, 3, scale=(9 * C) ** -0.5).to(dev), rnd(C, scale=0.3).to(dev)
+            conv = PlanarConv(wt, bs, st, 1, relu=True, fmt=1)
+            om = torch.cat([torch.rand(1, 18, device=dev) * 4 - 2 + 0.05 * rnd(M, 18), rnd(M, 9), torch.zeros(M, 5, device=dev)], 1).contiguous()
+            sets = [rnd(B * H * W, C).abs().to(dev) for _ in range(args.sets)]
+
+            def launch(k, outs, conv=conv, sets=sets, B=B, H=H, W=W, om=om, st=st):
+                conv.deform(sets[k], B, H, W, om, st, 1, 1, has_mask=True, out=outs[0])
+
+            def fresh(M=M, C=C):
+                return (torch.empty(2, C // 32, M, 32, device=dev, dtype=torch.float16), None)
+
+            out.append((f"{name} B={B}", launch, fresh, None))
+        return out
+
     which = args.cases.split(",")
     cases = []
     for B in [int(b) for b in args.clips.split(",")]:
@@ -222,6 +255,8 @@ def main():
         cases += conv_cases(B, which)
         if "planar" in which:
             cases += window_cases(B)
+        if "dcn" in which:
+            cases += dcn_cases(B)
 
     # ------------------------------------------------------------------------------------------------------------------ solo references
     NAN16 = float("nan")
@@ -338,12 +373,6 @@ def main():
                         "waves_stalled": stalled if dbg is not None else None, "seconds": round(dt, 1)})
         total_bad += n_bad
         del bufs
-    if hammer is not None:
-        open(hammer[1]["stop"], "w").write("stop\n")
-        try:
-            hammer[0].wait(timeout=60)
-        except subprocess.TimeoutExpired:
-            hammer[0].kill()
     if args.json:
         with open(args.json, "w") as f:
             json.dump({"hammer": args.hammer, "library": _lib.LIB_PATH, "results": results}, f, indent=1)

@@ -39,3 +39,12 @@ def test_kxr_and_planar_rings_are_bit_stable_beside_a_second_process(tmp_path):
     rc, res, tail = _run("kxr,planar", 240, tmp_path)
     assert len(res) == 16 and all(r["launches"] >= 200 for r in res)        # (3 kxr + 4 planar shapes + TemporalNet's window set: conv_planar_kx3_kernel, its WIN form, the CLS ring) x 2 batch sizes
     assert rc == 0 and all(r["differing_outputs"] == 0 for r in res), tail
+
+
+def test_fused_dcn_kernel_is_bit_stable_beside_a_second_process(tmp_path):
+    """dcn_fused_kernel (round 5: an LDS-DMA weight ring and a producer-written operand ring, consumers reading both one phase ahead across counted
+    barriers) under the same stress: two layer shapes x two batch sizes, >= 200 launches each beside the pipeline neighbour, every output bit-equal to
+    its solo launch."""
+    rc, res, tail = _run("dcn", 240, tmp_path)
+    assert len(res) == 4 and all(r["launches"] >= 200 for r in res)
+    assert rc == 0 and all(r["differing_outputs"] == 0 for r in res), tail
