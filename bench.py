@@ -50,6 +50,15 @@ PARITY_MIN_MATCHED = 0.98   # bench.py exits 3 when its parity block finds fewer
 PARITY_MAX_MASK_L2 = 1e-4   # ... or a soft mask further than north_star's 1e-4 (RMS) from the oracle's
 
 
+def barrier():
+    """dist.barrier() that names this rank's GPU under the RCCL backend: the process group is created WITHOUT device_id (see main), so the first
+    collective -- usually this barrier -- is what creates the communicator, and it must not have to guess the device."""
+    if dist.get_backend() == "nccl" and torch.cuda.is_available():
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier()
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,7 +157,7 @@ def launch_check(args, rank, world):
     for t in range(args.warmup):
         sdist.all_gather_detections(rows(t))
     if dist.is_initialized():
-        dist.barrier()
+        barrier()
     t0 = time.perf_counter()
     for t in range(args.warmup, args.warmup + args.steps):
         full = sdist.all_gather_detections(rows(t))
@@ -157,7 +166,7 @@ def launch_check(args, rank, world):
             want = torch.tensor([r + c * world for c in range(args.clips)], dtype=torch.float32)
             ok = ok and bool((blk[:, 0, 0] == want).all()) and bool((blk[:, 0, 1] == t).all())
     if dist.is_initialized():
-        dist.barrier()
+        barrier()
     elapsed = time.perf_counter() - t0
     if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64)
@@ -263,7 +272,7 @@ def world2_report(args, run, dev, rank, world, elapsed, use_dist):
         tmax = tmax.to(dev) if dist.get_backend() == "nccl" else tmax
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        dist.barrier()
+        barrier()
     rc = 0
     if rank == 0:
         from stmask_amd import dist as sdist
@@ -304,7 +313,7 @@ def world2_report(args, run, dev, rank, world, elapsed, use_dist):
         emit(json.dumps(res))
         rc = 0 if ok else 4
     if use_dist:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
     return rc
 
@@ -398,7 +407,7 @@ class Runner:
             self.step(t)
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            barrier()
         if collect:
             ops.im2col_timing(True)
             ops.conv_timing(True)
@@ -415,7 +424,7 @@ class Runner:
         self.gatherer.wait()
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         timing = ops.im2col_timing(False) if collect else None
@@ -934,7 +943,7 @@ def main():
                 sys.stderr.write(f"bench.py: PARITY FAILED against the CPU oracle: {json.dumps(par)[:400]}\n")
                 rc_final = 3
     if use_dist:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
     sys.exit(rc_final)
 

@@ -99,6 +99,26 @@ def test_fused_deform_conv_vs_oracle_and_pair(case):
         assert ((got - two).abs() / (mag + 1e-3)).max().item() < 2e-6   # same values and products, another summation order
 
 
+def test_fused_deform_conv_dilation_two():
+    """dilation 2 (the geometry struct's dh / dw; the reference's DCN keeps dilation 1, mmcv's DeformConv2d takes any): fused kernel vs the fp64 oracle."""
+    B, C, H, W, O, s, pad, dil = 2, 64, 11, 14, 128, 1, (2, 2), 2
+    Ho, Wo = ops.conv_out_hw(H, W, 3, 3, s, s, pad[0], pad[1], dil, dil)
+    x = rnd(B, C, H, W, seed=3)
+    off = rnd(B, 18, Ho, Wo, seed=4, scale=1.5)
+    logit = rnd(B, 9, Ho, Wo, seed=5)
+    w = rnd(O, C, 3, 3, seed=11, scale=(C * 9) ** -0.5)
+    bias = rnd(O, seed=12)
+    ref = oracle.deform_conv(x, off, torch.sigmoid(logit), w, bias, s, pad, dil, 1).permute(0, 2, 3, 1).reshape(-1, O)
+    mag = oracle.deform_conv(x.abs(), off, torch.sigmoid(logit), w.abs(), bias.abs(), s, pad, dil, 1).permute(0, 2, 3, 1).reshape(-1, O)
+    x_pix = x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().to(DEV)
+    om = torch.cat([off, logit], 1).permute(0, 2, 3, 1).reshape(-1, 27).contiguous().to(DEV)
+    packed, out_scale = ops.conv_pack_weights(w.to(DEV), tile_n=128, fmt=1)
+    pl = ops.deform_conv_fused_planar(x_pix, B, H, W, C, om, packed, out_scale, bias.to(DEV), O, (3, 3), s, pad, dil, has_mask=True, relu=False, fmt=1)
+    got = ops.planes_to_f32(pl).cpu()
+    assert got.shape == ref.shape
+    assert ((got - ref).abs() / (mag + 1e-3)).max().item() < 4e-6
+
+
 @pytest.mark.parametrize("fmt", [1, 2])
 def test_fused_deform_conv_planes_formats(fmt):
     """fp16 x 1 (BASELINE config 5's backbone format): one plane, one product, stated tolerance 1e-3 of sum |x w|; a format-2 layer may hand
