@@ -1,12 +1,13 @@
 #!/bin/bash
 # One measurement session on a GPU box (what the committed profiles/rNN_* set is made from): the two hardware probes, the full GPU test suite, smoke,
 # the driver's bench command (+ layer table), the rocprofv3 kernel trace + stats of it, and the PMC traffic passes (FETCH_SIZE / WRITE_SIZE, separate).
-# usage: /usr/local/graft/bin/gpurun --timeout 5400 -- 'bash scripts/measure_round.sh r05'   -> gpurun_out/r05/*; copy what is to be judged into profiles/
+# usage: /usr/local/graft/bin/gpurun --timeout 5400 -- 'bash scripts/measure_round.sh r05 [first step, default 1; 3 = skip the probes and the test suite]'   -> gpurun_out/r05/*; copy what is to be judged into profiles/
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r05}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
-echo "== 1. hardware probes: store data write-after-read per store form, LDS-DMA completion order"; timeout 600 scripts/bin/vmem_store_war_probe 300 > $OUT/store_war_probe_forms.txt 2>&1; echo "exit $?"; cut -c1-250 $OUT/store_war_probe_forms.txt | head -45
-timeout 300 scripts/bin/ldsdma_order_probe 1500 > $OUT/ldsdma_order_probe.txt 2>&1; echo "exit $?"; cut -c1-250 $OUT/ldsdma_order_probe.txt | head -10
-echo "== 2. pytest -m gpu"; timeout 2700 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu_final.log 2>&1; echo "pytest exit $?"; tail -4 $OUT/pytest_gpu_final.log
+FROM=${2:-1}
+[ "$FROM" -le 2 ] && { echo "== 1. hardware probes: store data write-after-read per store form, LDS-DMA completion order"; timeout 600 scripts/bin/vmem_store_war_probe 300 > $OUT/store_war_probe_forms.txt 2>&1; echo "exit $?"; cut -c1-250 $OUT/store_war_probe_forms.txt | head -45; }
+[ "$FROM" -le 2 ] && { timeout 300 scripts/bin/ldsdma_order_probe 1500 > $OUT/ldsdma_order_probe.txt 2>&1; echo "exit $?"; cut -c1-250 $OUT/ldsdma_order_probe.txt | head -10; }
+[ "$FROM" -le 2 ] && { echo "== 2. pytest -m gpu"; timeout 2700 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu_final.log 2>&1; echo "pytest exit $?"; tail -4 $OUT/pytest_gpu_final.log; }
 echo "== 3. smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -2 $OUT/smoke.log
 echo "== 4. bench (driver command) + layer table"; timeout 1500 python bench.py --steps 20 --warmup 4 --layer-table > $OUT/bench_final.json 2> $OUT/bench_final_layers.txt; echo "bench exit $?"
 python - $OUT/bench_final.json <<'PY'
@@ -36,5 +37,5 @@ cd /tmp
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1; echo "pmc write exit $?"
 cd $R; python scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt | cut -c1-200 | head -30
-cp profiles/r04_pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null; python scripts/make_pmc_json.py $OUT $OUT/pmc_traffic.json | head -40
+cp profiles/${TAG}_pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null; python scripts/make_pmc_json.py $OUT $OUT/pmc_traffic.json | head -40
 find $OUT/pmc_fetch $OUT/pmc_write -name '*.csv' -size +8M -delete
