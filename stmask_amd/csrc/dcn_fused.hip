@@ -376,6 +376,19 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.0f; accl[i][j][r] = 0.0f; }
 #define DF_MM(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a_), __builtin_bit_cast(f16x8, b_), c_, 0, 0, 0)
+#define DF_MM32(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_), __builtin_bit_cast(f16x8, b_), c_, 0, 0, 0)
+        // (DF_ABL & 64, timing only: the same flops as 6 v_mfma_f32_32x32x16_f16 per phase instead of 12 v_mfma_f32_16x16x32_f16, on whatever the fragment
+        // registers hold -- does the matrix instruction's shape change what the producer waves on the same SIMDs get of the issue port?)
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        f32x16 acc32[2][2], accl32[2][2];
+        if (DF_ABL & 64) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc32[i][j][r] = 0.0f; accl32[i][j][r] = 0.0f; }
+        }
         // Fragments are read one phase ahead of the MFMAs that use them, across the barriers: a step = four phases (channel tiles), each 12 MFMAs;
         // phase i reads the weight fragments of channel tile i + 1 (of the NEXT slab in the last phase) into the other of two fragment slots, and
         // two of the next slab's eight operand fragments into the other operand set.  (Read at the top of the step -- barrier, 16 reads, wait,
@@ -398,7 +411,11 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
         // channel tile I_ (fragments in slot I_ & 1) against the four pixel tiles: the four x_l w_h products, the four x_h w_h, then the four
         // x_h w_l, each 8 MFMAs behind the product whose accumulator it continues -- conv_planar_kernel's sums in its order per accumulator
 #define DF_TILE(I_, BH_, BL_)                                                                                                      \
-        if (!(DF_ABL & 4)) {                                                                                                       \
+        if (DF_ABL & 64) {                                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) accl32[(I_) >> 1][j] = DF_MM32(ah[(I_) & 1], BL_[j], accl32[(I_) >> 1][j]); \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc32[(I_) >> 1][j] = DF_MM32(ah[(I_) & 1], BH_[j], acc32[(I_) >> 1][j]);   \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) accl32[(I_) >> 1][j] = DF_MM32(al[(I_) & 1], BH_[j], accl32[(I_) >> 1][j]); \
+        } else if (!(DF_ABL & 4)) {                                                                                                \
             if constexpr (NPL == 2) {                                                                                              \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) accl[I_][j] = DF_MM(ah[(I_) & 1], BL_[j], accl[I_][j]);              \
             }                                                                                                                      \
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
         constexpr int RPP = NPL == 2 ? 6 : 3;                        // LDS reads per phase: one weight tile, two operand tiles (x planes)
 #define DF_PHASE_SCHED()                                                                                                           \
         __builtin_amdgcn_sched_group_barrier(0x100, RPP, 0);                                                                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, NPL == 2 ? 12 : 4, 0);                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, (DF_ABL & 64) ? 6 : NPL == 2 ? 12 : 4, 0);                                     \
         __builtin_amdgcn_sched_barrier(0);
         // step: slab s in operand set (BHC_, BLC_) and weight slot 0 (tile 0); slab s + 1 (certified by the barrier that opened the step) is
         // prefetched into (BHN_, BLN_)
@@ -428,12 +445,12 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
             DF_RD_A(1, ws, 3);                                                                                                     \
             DF_TILE(2, BHC_, BLC_);                                                                                                \
             __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);                                                                   \
-            __builtin_amdgcn_sched_group_barrier(0x008, NPL == 2 ? 12 : 4, 0);                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, (DF_ABL & 64) ? 6 : NPL == 2 ? 12 : 4, 0);                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                                     \
             DF_RD_A(0, wn, 0);                                                                                                     \
             DF_TILE(3, BHC_, BLC_);                                                                                                \
             __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);                                                                   \
-            __builtin_amdgcn_sched_group_barrier(0x008, NPL == 2 ? 12 : 4, 0);                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, (DF_ABL & 64) ? 6 : NPL == 2 ? 12 : 4, 0);                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                                     \
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                        \
             cur = nxt; nxt = nxt == 2 ? 0 : nxt + 1;                                                                               \
@@ -449,6 +466,15 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
             DF_CSTEP(bhA, blA, bhB, blB);
             DF_CSTEP(bhB, blB, bhA, blA);
         }
+        if (DF_ABL & 64) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc[i][j][r & 3] += acc32[i][j][r]; accl[i][j][r & 3] += accl32[i][j][r]; }
+        }
+#undef DF_MM32
 #undef DF_CSTEP
 #undef DF_PHASE_SCHED
 #undef DF_TILE

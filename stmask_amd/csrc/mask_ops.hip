@@ -17,6 +17,9 @@ namespace {
 constexpr int LC_DCHUNK = 32;  // most detections per workgroup (it holds the prototypes of its 256 pixels in registers and walks its rows:
                                // every chunk re-reads them, 128 B per pixel -- 880 MB per launch at 8 rows per chunk and 3 600 rows)
 
+#ifndef LC_ABL
+#define LC_ABL 0      // timing ablations (RESULTS WRONG): 1 no prototype loads, 2 no mask stores, 4 no bit words
+#endif
 template <int M>
 __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ proto, const float* __restrict__ coeff,
                                                       const float* __restrict__ boxes, float* __restrict__ out, int h,
@@ -48,27 +51,56 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ 
         sb[threadIdx.x * 4 + 2] = y1;
         sb[threadIdx.x * 4 + 3] = y2;
     }
+    // Which rows' crop rectangles touch this workgroup's 256 pixels at all.  The tracked sets of a 32-clip step are ~3 600 rows whose boxes cover ~12 %
+    // of the frame: four waves walking every row pixel by pixel issued ~40 instructions per wave and row to store zeros (80 of the launch's 108 us with
+    // every store removed).  Rows that miss the workgroup's pixel span are zero-filled by ONE 16-byte store per lane (a wave covers the whole 256-pixel
+    // segment of a row; the waves take such rows in turn) and skipped by the pixel loop below.
+    __shared__ int hit[LC_DCHUNK];
+    const int p0 = blockIdx.x * 256;
+    const bool vec_ok = (hw & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;       // row bases are then 16-byte aligned and a quad never straddles the end of a row
+    if (threadIdx.x < nd) {
+        const int d = threadIdx.x;
+        const int pl = min(p0 + 255, hw - 1);
+        const int ya = p0 / w, yb = pl / w;
+        const float fya = (float)ya, fyb = (float)yb;
+        bool touch = (d0 + d < n_valid) && fyb >= sb[d * 4 + 2] && fya < sb[d * 4 + 3];
+        if (touch && ya == yb) {                             // one image row: the x span decides too
+            const float fxa = (float)(p0 - ya * w), fxb = (float)(pl - ya * w);
+            touch = fxb >= sb[d * 4] && fxa < sb[d * 4 + 1];
+        }
+        hit[d] = (touch || !vec_ok) ? 1 : 0;
+    }
     __syncthreads();
     // bits != null: also the binarised mask (v > bits_thr) as 64-pixel words [n][ceil(hw / 64)] -- what mask IoU consumes
     // (box_utils.py:435-447 on m.gt(0.5)); a wave is 64 consecutive pixels, so the word is one ballot.  Waves that lie
     // entirely past the last pixel leave; lanes past it inside the last wave stay for the ballot and vote 0.
     const bool live = pix < hw;
+    const int words = (hw + 63) >> 6;
+    if (p0 < hw) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int q = p0 + 4 * lane;                         // this lane's quad of the 256-pixel segment
+        for (int d = wv; d < nd; d += 4) {
+            if (hit[d]) continue;
+            if (q < hw && !(LC_ABL & 2)) *reinterpret_cast<float4*>(out + (int64_t)(d0 + d) * hw + q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bits && lane < 4 && (p0 >> 6) + lane < words && !(LC_ABL & 4)) bits[(int64_t)(d0 + d) * words + (p0 >> 6) + lane] = 0ull;
+        }
+    }
     if (!bits && !live) return;
     if (bits && ((pix & ~63) >= hw)) return;
-    const int words = (hw + 63) >> 6;
 
     float p[M];
     int cur = -1;  // prototype set currently held in registers (rows of several frames may share one launch)
     const int y = pix / w, x = pix - y * w;
     const float fx = (float)x, fy = (float)y;
     for (int d = 0; d < nd; ++d) {
+        if (!hit[d]) continue;                               // zero-filled above
         const int want = row_proto ? row_proto[d0 + d] : 0;  // wave-uniform
         if (want != cur && live) {
             cur = want;
             const float4* pr = reinterpret_cast<const float4*>(proto + ((int64_t)cur * hw + pix) * M);
 #pragma unroll
             for (int q = 0; q < M / 4; ++q) {
-                float4 v = pr[q];
+                float4 v = (LC_ABL & 1) ? make_float4(0.01f * q, 0.02f, 0.03f, 0.04f) : pr[q];
                 p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
             }
         }
@@ -81,8 +113,8 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ 
             for (int k = 0; k < M; ++k) acc = fmaf(p[k], sc[d * M + k], acc);
             v = 1.0f / (1.0f + expf(-acc));
         }
-        if (live) out[(int64_t)(d0 + d) * hw + pix] = v;
-        if (bits) {
+        if (live && (!(LC_ABL & 2) || v == 12345.678f)) out[(int64_t)(d0 + d) * hw + pix] = v;
+        if (bits && !(LC_ABL & 4)) {
             const unsigned long long bal = __ballot(v > bits_thr);
             if ((threadIdx.x & 63) == 0) bits[(int64_t)(d0 + d) * words + (pix >> 6)] = bal;
         }

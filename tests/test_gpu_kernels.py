@@ -553,6 +553,41 @@ def test_generate_mask_big_tracked_set_takes_32_row_chunks():
         assert (big[r].cpu() - ref[0]).abs().max() < 5e-6
 
 
+@pytest.mark.parametrize("hw", [(96, 160), (23, 41), (24, 40)])
+def test_generate_mask_rows_that_miss_a_pixel_block_are_zero_filled(hw):
+    """lincomb_kernel zero-fills the rows whose crop rectangle misses a workgroup's 256 pixels with 16-byte stores instead of walking them (h*w a
+    multiple of 4; any other size keeps the pixel loop): small boxes, the output buffers poisoned first (torch.empty re-uses the freed block), soft
+    masks against the oracle and the bit words against the binarised soft masks."""
+    H, W = hw
+    gen = torch.Generator().manual_seed(21)
+    n, P = 90, 3
+    protos = torch.relu(torch.randn(P, H, W, 32, generator=gen))
+    coeff = torch.randn(n, 32, generator=gen)
+    c = torch.rand(n, 2, generator=gen)
+    wh = torch.rand(n, 2, generator=gen) * 0.25
+    box = torch.cat([c - wh / 2, c + wh / 2], 1)
+    box[7] = torch.tensor([0.0, 0.0, 1.0, 1.0])          # one row covering everything
+    box[8] = torch.tensor([0.3, 0.3, 0.3, 0.3])          # one degenerate box
+    rp = torch.sort(torch.randint(0, P, (n,), generator=gen)).values.to(torch.int32)
+    words = (H * W + 63) // 64
+    poison_m = torch.full((n, H, W), float("nan"), device=DEV)
+    poison_b = torch.full((n, words), -1, dtype=torch.int64, device=DEV)
+    del poison_m, poison_b
+    got, bits = ops.lincomb_sigmoid_crop_bits(protos.to(DEV), coeff.to(DEV), box.to(DEV), rp.to(DEV))
+    got, bits = got.cpu(), bits.cpu()
+    assert not torch.isnan(got).any()
+    for pi in range(P):
+        sel = torch.nonzero(rp == pi).view(-1)
+        ref = oracle.generate_mask(protos[pi], coeff[sel], box[sel])
+        assert (got[sel] - ref).abs().max() < 5e-6 and torch.equal(got[sel] == 0, ref == 0)
+    flat = (got.view(n, -1) > 0.5)
+    pad = torch.zeros(n, words * 64, dtype=torch.bool)
+    pad[:, :H * W] = flat
+    weights = (torch.ones(64, dtype=torch.int64) << torch.arange(64, dtype=torch.int64))      # bit i of a word = pixel 64 word + i
+    want = (pad.view(n, words, 64).to(torch.int64) * weights).sum(-1)
+    assert torch.equal(bits, want)
+
+
 @pytest.mark.parametrize("p", CASES)
 def test_mask_iou_bit_exact(golden_postproc, p):
     m = golden_postproc[p + "masks"]
