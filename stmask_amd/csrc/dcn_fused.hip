@@ -35,11 +35,23 @@ namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DF_TP = 128;            // pixels per tile (8 waves x 16)
-constexpr int DF_BN = 128;            // output channels per tile
-constexpr int DF_NS = 3;              // weight ring slots
-constexpr int DF_PARK_LD = 132;       // floats per parked pixel row
+constexpr int DF_NS = 3;              // ring slots
 constexpr int DF_KMAX = 15;           // taps the coefficient tables hold (3x3, 3x5, 5x3)
+// Two tile shapes.  NARROW: 128 pixels x 128 channels (two 16-pixel units per producer wave, consumer waves 2 (channel halves) x 2 (pixel halves)).
+// WIDE, for layers with Cout a multiple of 256: 64 pixels x 256 channels (one unit per producer wave, the four consumer waves take 64 channels each of
+// all 64 pixels).  A 256-channel layer on narrow tiles samples every pixel TWICE (once per channel tile) -- gathers, blend and split are the larger
+// half of the kernel's time -- while its weight slabs cross L2 -> LDS once per 128 pixels; wide tiles sample once and stream the weights once per 64
+// pixels: 2.4 MB less on-chip traffic per 128 pixels of a 256-channel layer, and half the blend arithmetic.
+template <int WIDE>
+struct DfShape {
+    static constexpr int TP = WIDE ? 64 : 128;        // pixels per tile
+    static constexpr int BN = WIDE ? 256 : 128;       // output channels per tile
+    static constexpr int NU = WIDE ? 1 : 2;           // 16-pixel units per producer wave
+    static constexpr int NH = WIDE ? 2 : 1;           // 128-channel weight tiles (stm_conv_pack_weights_fmt_f32, tile_n 128) per K-slab
+    static constexpr int PARK_LD = BN + 4;            // floats per parked pixel row
+    static constexpr int COEFA = DF_KMAX * TP * 16;   // bytes of one coefficient table
+    static constexpr int RING = 2 * COEFA;            // first byte behind the two tables
+};
 
 struct FusedArgs {
     const float* x;        // [B, H, W, x_ld >= C] fp32, pixel-major
@@ -91,18 +103,18 @@ __device__ __forceinline__ void blend_part(const f32x4 (&X)[4][2], const f32x4 w
 
 // Coefficients of a tile: (pixel, tap) -> four corner weights (mask folded in), four corner byte offsets into x.  Expressions and their order are
 // dcn_sample_planar_kernel's (deform_im2col.hip): same weights, same clamped corners, bit for bit.  All 512 threads of the workgroup.
-template <bool MASK>
+template <bool MASK, int TP>
 __device__ __forceinline__ void df_coefficients(const FusedArgs& a, int b, int oy0, int ox0, uint8_t* coefW, uint8_t* coefA, int tid)
 {
     const int K = a.K;
     const int tp = a.TH * a.TW;
     // the (up to four) items of a thread: their offset / mask loads all issued before the first is used -- one memory round trip per tile, not one per item
-    constexpr int NIT = (DF_KMAX * DF_TP + 511) / 512;
+    constexpr int NIT = (DF_KMAX * TP + 511) / 512;
     float dyv[NIT], dxv[NIT], mkv[NIT];
 #pragma unroll
     for (int n = 0; n < NIT; ++n) {
         const int it = tid + n * 512;
-        const int t = it & (DF_TP - 1), k = it >> 7;
+        const int t = it & (TP - 1), k = it / TP;
         const int ty = t / a.TW, tx = t - ty * a.TW;
         const int ho = oy0 + ty, wo = ox0 + tx;
         dyv[n] = dxv[n] = mkv[n] = 0.0f;
@@ -116,7 +128,7 @@ __device__ __forceinline__ void df_coefficients(const FusedArgs& a, int b, int o
 #pragma unroll
     for (int n = 0; n < NIT; ++n) {
         const int it = tid + n * 512;
-        const int t = it & (DF_TP - 1), k = it >> 7;
+        const int t = it & (TP - 1), k = it / TP;
         if (k >= K) break;
         const int ty = t / a.TW, tx = t - ty * a.TW;
         const int ho = oy0 + ty, wo = ox0 + tx;
@@ -145,17 +157,21 @@ __device__ __forceinline__ void df_coefficients(const FusedArgs& a, int b, int o
                 ca4 = (((rowb + hh_i) * a.W + wh_i) * a.x_ld) * 4;
             }
         }
-        *reinterpret_cast<f32x4*>(coefW + (k * DF_TP + t) * 16) = f32x4{cw1, cw2, cw3, cw4};
-        *reinterpret_cast<i32x4*>(coefA + (k * DF_TP + t) * 16) = i32x4{ca1, ca2, ca3, ca4};
+        *reinterpret_cast<f32x4*>(coefW + (k * TP + t) * 16) = f32x4{cw1, cw2, cw3, cw4};
+        *reinterpret_cast<i32x4*>(coefA + (k * TP + t) * 16) = i32x4{ca1, ca2, ca3, ca4};
     }
 }
 
-// Output pass of a tile: the 128 pixels x 128 channels parked in LDS as fp32 [pixel][DF_PARK_LD] (pixel = tile-linear index) -> out_scale, bias, ReLU,
-// plane split, 16-byte stores.  Wave w writes pixels 16 w .. 16 w + 15, one 32-channel slab per pass: 1-KB runs where the pixels are one image row.
+// Output pass of a tile: the TP pixels x BN channels parked in LDS as fp32 [pixel][PARK_LD] (pixel = tile-linear index) -> out_scale, bias, ReLU,
+// plane split, 16-byte stores.  Narrow: wave w writes pixels 16 w .. 16 w + 15; wide: pixels 16 (w & 3) .. + 15 of channel half w >> 2.  One 32-channel
+// slab per pass: 1-KB runs where the pixels are one image row.
+template <int WIDE>
 __device__ __forceinline__ void df_store_tile(const FusedArgs& a, const float* park_all, int wave, int lane, int b, int oy0, int ox0, int nt)
 {
+    constexpr int DF_PARK_LD = DfShape<WIDE>::PARK_LD, DF_BN = DfShape<WIDE>::BN;
     const int px = lane >> 2, cs = lane & 3;
-    const int t = wave * 16 + px;
+    const int t = (WIDE ? (wave & 3) : wave) * 16 + px;
+    const int ch0 = WIDE ? (wave >> 2) * 128 : 0;
     const int ty = t / a.TW, tx = t - ty * a.TW;
     const int ho = oy0 + ty, wo = ox0 + tx;
     const bool live = t < a.TH * a.TW && ho < a.Ho && wo < a.Wo;
@@ -163,7 +179,7 @@ __device__ __forceinline__ void df_store_tile(const FusedArgs& a, const float* p
     const float* park = park_all + t * DF_PARK_LD;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int ch = 32 * i + 8 * cs;
+        const int ch = ch0 + 32 * i + 8 * cs;
         const int co = nt * DF_BN + ch;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(park + ch);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(park + ch + 4);
@@ -203,14 +219,15 @@ __device__ __forceinline__ void df_store_tile(const FusedArgs& a, const float* p
 
 // LDS map (bytes): coefficient tables [15 taps][128 pixels] x 16 B weights, then offsets; the weight ring; the operand ring (sampled planes of a
 // K-slab: [plane][128 pixel rows][64 B], the planar kernels' chunk swizzle).  The parked output tile (67.6 KB) overlays it all after the K loop.
-constexpr int DF_COEFA = DF_KMAX * DF_TP * 16, DF_RING = 2 * DF_COEFA;
-
-template <int NPL, bool MASK>
+template <int NPL, bool MASK, int WIDE>
 __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __align__(16) uint8_t smem[];
-    constexpr int WPL = DF_BN * 64, WBUF = NPL * WPL;          // bytes of one weight plane / of one K-slab of weights
+    typedef DfShape<WIDE> S;
+    constexpr int DF_TP = S::TP, NU = S::NU, DF_COEFA = S::COEFA, DF_RING = S::RING, DF_PARK_LD = S::PARK_LD;
+    constexpr int WPL = 128 * 64, WT = NPL * WPL;              // bytes of one plane of a 128-channel weight tile's K-slab / of the tile's K-slab
+    constexpr int WBUF = S::NH * WT;                           // ... of one K-slab of weights in the ring: [128-channel tile][plane][128 rows][64 B]
     constexpr int BPL = DF_TP * 64, BBUF = NPL * BPL;          // ... of one sampled plane / of one K-slab of sampled values
     constexpr int BRING = DF_RING + DF_NS * WBUF;
     constexpr int NPW = WBUF / 1024 / 4;                       // weight DMA pieces (1 KB) per producer wave and slab
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
     // the other: LDS fragment reads 36 us + weight DMA 20 + MFMA 54 + gathers 64 = the 171 us it took per layer; profiles/r05_dcn_fused_forms.txt).
     // One barrier per K-slab for all eight waves: at barrier s the operand slab s and the weight slab s are complete (producers wrote / landed them
     // one to two slabs ago) and ring slot (s + 2) % 3 is free (the consumers have drained their reads of slab s - 1).
-    df_coefficients<MASK>(a, b, oy0, ox0, coefW, coefA, tid);
+    df_coefficients<MASK, DF_TP>(a, b, oy0, ox0, coefW, coefA, tid);
     __syncthreads();
 
     f32x4 acc[4][4], accl[4][4];                                  // consumer: [channel tile][pixel tile], main / correction products
@@ -256,33 +273,35 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
         const int gp = lane >> 2, gq = lane & 3;
         const int gq16 = gq * 16;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-        const uint8_t* wtile = a.wp + (size_t)nt * a.slabs * WBUF;
-        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wtile), 0, a.slabs * WBUF, 0x00020000);
+        const uint8_t* wtile = a.wp + (size_t)(nt * S::NH) * a.slabs * WT;          // this tile's NH consecutive 128-channel weight tiles
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wtile), 0, S::NH * a.slabs * WT, 0x00020000);
         const int lane16 = lane * 16;
         auto dma_w = [&](int slab, int slot) {
             if constexpr ((DF_ABL & 8) != 0) return;
             uint8_t* wb = smem + DF_RING + slot * WBUF;
 #pragma unroll
             for (int j = 0; j < NPW; ++j) {
-                const int wi = pw + 4 * j;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(wb + wi * 1024), 16, lane16, slab * WBUF + wi * 1024, 0, 0);
+                const int wi = pw + 4 * j;                                        // 1-KB piece of the ring slot
+                const int wh_ = wi / (WT / 1024), wp_ = wi - wh_ * (WT / 1024);   // weight tile, piece inside its K-slab
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(wb + wi * 1024), 16, lane16, (wh_ * a.slabs + slab) * WT + wp_ * 1024, 0, 0);
             }
         };
-        const int cpix0 = (pw * 32 + gp) * 16, cpix1 = cpix0 + 16 * 16;          // the lane's pixel of unit 0 / 1 inside a tap's coefficient block
+        const int cpix0 = (pw * 16 * NU + gp) * 16, cpix1 = cpix0 + 16 * 16;     // the lane's pixel of unit 0 / 1 inside a tap's coefficient block
         // operand-ring row of the lane's pixel (unit 0; unit 1 = + 16 rows), channels 4 gq (+ 16 h): chunk 2 h + (gq >> 1), second half for odd gq
-        const int row0 = pw * 32 + gp;
+        const int row0 = pw * 16 * NU + gp;
         const int st_w0 = BRING + lds_off(row0, gq >> 1) + 8 * (gq & 1), st_w1 = BRING + lds_off(row0, 2 + (gq >> 1)) + 8 * (gq & 1);
-        f32x4 XA[2][4][2], XB[2][4][2];                             // corner values [unit][corner][half], two sets
-        f32x4 WA[2], WB[2];                                         // corner weights [unit] of the sets
+        f32x4 XA[NU][4][2], XB[NU][4][2];                           // corner values [unit][corner][half], two sets
+        f32x4 WA[NU], WB[NU];                                       // corner weights [unit] of the sets
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < NU; ++u) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) { XA[u][c][0] = XA[u][c][1] = XB[u][c][0] = XB[u][c][1] = f32x4{0, 0, 0, 0}; }
-        WA[0] = WA[1] = WB[0] = WB[1] = f32x4{0, 0, 0, 0};
+            WA[u] = WB[u] = f32x4{0, 0, 0, 0};
+        }
         int g_tap = 0, g_soff = 0;                                  // tap and channel-slab byte offset of the next slab to gather
 #define DF_GATHER(X_, W_)                                                                                                          \
         {                                                                                                                          \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                        \
+            _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                                       \
                 W_[u] = *reinterpret_cast<const f32x4*>(coefW + g_tap * (DF_TP * 16) + (u ? cpix1 : cpix0));                       \
                 const i32x4 ca_ = *reinterpret_cast<const i32x4*>(coefA + g_tap * (DF_TP * 16) + (u ? cpix1 : cpix0));             \
                 if (!(DF_ABL & 1)) {                                                                                               \
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
         if (!(DF_ABL & 2)) {                                                                                                       \
             typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));                                                           \
             uint8_t* const bs_ = smem + (SLOT_) * BBUF;                                                                            \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                        \
+            _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                                       \
                 unsigned ph[4], pl[4];                                                                                             \
                 blend_part<NPL, 0>(X_[u], W_[u], ph, pl, rmax);                                                                    \
                 blend_part<NPL, 1>(X_[u], W_[u], ph, pl, rmax);                                                                    \
@@ -327,14 +346,14 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
             /* the gathers dealt out between the blend's arithmetic: issued as a block they fill the texture unit's queue, the wave stalls at   \
                issue behind them, and its ~110 vector instructions only start when the queue has drained */                        \
             if (DF_PSCHED) {                                                                                                       \
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                                 \
-                _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NU, 0);                                                            \
+                _Pragma("unroll") for (int k = 0; k < 8 * NU; ++k) {                                                                   \
                     __builtin_amdgcn_sched_group_barrier(0x002, DF_PSCHED, 0);                                                     \
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                             \
                 }                                                                                                                  \
             }                                                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                                                     \
-            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                              \
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(8 * NU) : "memory");                                  \
             slot2 = slot2 == 2 ? 0 : slot2 + 1;                                                                                    \
         }
         // prologue = iterations -3, -2, -1: G(0) | W(0), G(1), blend 0 | W(1), G(2), blend 1; barrier 0 certifies slabs 0 and 1
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
         DF_GATHER(XA, WA);
         DF_BLEND(XB, WB, 1);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(8 * NU) : "memory");
         int slot2 = 2;
         for (int i = 0; i < a.slabs; i += 2) {
             DF_PROD(i, XB, WB, XA, WA);
@@ -365,9 +384,9 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
         // ================================================ consumer =======================================================================
         if (DF_CPRIO) __builtin_amdgcn_s_setprio(DF_CPRIO);
         const int cw = wave - 4;
-        const int chh = cw & 1, pxh = cw >> 1;                       // 64-channel half, 64-pixel half of the tile
+        const int chh = cw & 1, pxh = WIDE ? 0 : cw >> 1, wh = WIDE ? cw >> 1 : 0;   // 64-channel half of weight tile wh, 64-pixel half of the tile
         const int p = lane & 15, q = lane >> 4;                      // fragment row (channel of a weight tile / pixel of an operand tile), K chunk
-        const int aoff = DF_RING + lds_off(p, q) + chh * (64 * 64);  // + i * 1024: channel tile i of this wave
+        const int aoff = DF_RING + wh * WT + lds_off(p, q) + chh * (64 * 64);  // + i * 1024: channel tile i of this wave
         const int boff = BRING + lds_off(p, q) + pxh * (64 * 64);    // + j * 1024: pixel tile j of this wave
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -487,7 +506,7 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
     __syncthreads();                                                // nobody reads or fills the rings or the coefficient tables any more
     float* const park_all = reinterpret_cast<float*>(smem);
     if (wave >= 4) {
-        const int cw = wave - 4, chh = cw & 1, pxh = cw >> 1, p = lane & 15, g = lane >> 4;
+        const int cw = wave - 4, chh = (WIDE ? cw : cw & 1), pxh = WIDE ? 0 : cw >> 1, p = lane & 15, g = lane >> 4;
         constexpr float LS = 1.0f / STM_F16_LOW_SCALE;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -499,16 +518,16 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
             }
     }
     __syncthreads();
-    df_store_tile(a, park_all, wave, lane, b, oy0, ox0, nt);
+    df_store_tile<WIDE>(a, park_all, wave, lane, b, oy0, ox0, nt);
 #endif
 }
 
 // tile patch TH x TW (<= 128 pixels) of a Ho x Wo output image: the one that wastes the fewest tile pixels, then the squarest
-void pick_patch(int Ho, int Wo, int& TH, int& TW)
+void pick_patch(int Ho, int Wo, int& TH, int& TW, int DF_TP)
 {
     double best = -1.0;
     int bth = 8, btw = 16, bper = 1 << 30;
-    for (int tw = 4; tw <= 128; ++tw) {
+    for (int tw = 4; tw <= DF_TP; ++tw) {
         const int th = DF_TP / tw;
         if (th < 1) break;
         const int thc = th > Ho ? Ho : th, twc = tw > Wo ? Wo : tw;
@@ -518,6 +537,23 @@ void pick_patch(int Ho, int Wo, int& TH, int& TW)
         if (eff > best + 1e-9 || (eff > best - 1e-9 && per < bper)) { best = eff; bth = thc; btw = twc; bper = per; }
     }
     TH = bth; TW = btw;
+}
+
+template <int NPL, bool MASK, int WIDE>
+int df_launch(const FusedArgs& a, size_t lds, hipStream_t stream, const char* who)
+{
+    static std::atomic<int> reserved[32];
+    int dev = 0;
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32;
+    if (!have_dev || reserved[dev].load(std::memory_order_relaxed) < (int)lds) {
+        STM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_fused_kernel<NPL, MASK, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
+                        hipSuccess, STM_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
+        if (have_dev) reserved[dev].store((int)lds, std::memory_order_relaxed);
+    }
+    const dim3 grid(8 * stm_cdiv((int64_t)a.m_tiles * a.n_tiles, 8));
+    hipLaunchKernelGGL((dcn_fused_kernel<NPL, MASK, WIDE>), grid, dim3(512), lds, stream, a);
+    STM_CHECK_LAUNCH("dcn_fused_kernel");
+    return STM_OK;
 }
 
 std::atomic<long long> g_fused_launches{0};
@@ -530,7 +566,7 @@ extern "C" int stm_deform_conv_fused_planar_supported(const stm_deform_geom* g, 
 {
     if (!g) return 0;
     const int K = g->kh * g->kw;
-    if (g->dg != 1 || K < 1 || K > 15 || g->C % 64 != 0 || Cout % DF_BN != 0 || (fmt != 1 && fmt != 2)) return 0;
+    if (g->dg != 1 || K < 1 || K > 15 || g->C % 64 != 0 || Cout % 128 != 0 || (fmt != 1 && fmt != 2)) return 0;
     if (has_mask && K != 9) return 0;
     return 1;
 }
@@ -564,36 +600,30 @@ extern "C" int stm_deform_conv_fused_planar_f32(const float* x, int x_ld, const 
     a.out_pstride = (out_plane_stride > 0 ? out_plane_stride : (long long)(Cout / 32) * a.out_np * 32) * 2;
     a.relu = relu; a.out_scale = out_scale > 0.0f ? out_scale : 1.0f; a.out_fmt = out_fmt;
     a.range_flag = stm_internal_range_flag();
+    // tile shape: 64 pixels x 256 channels where the layer has them (every pixel is then sampled once, not once per 128 channels); STM_DCN_FUSED_WIDE=0: always 128 x 128
+    const bool wide = Cout % 256 == 0 && STM_ENV_INT("STM_DCN_FUSED_WIDE", 1) != 0;
+    const int TP = wide ? DfShape<1>::TP : DfShape<0>::TP, BN = wide ? DfShape<1>::BN : DfShape<0>::BN;
     int th = STM_ENV_INT("STM_DCN_FUSED_TH", 0), tw = STM_ENV_INT("STM_DCN_FUSED_TW", 0);
-    if (th <= 0 || tw <= 0 || th * tw > DF_TP) pick_patch(g->Ho, g->Wo, th, tw);
+    if (th <= 0 || tw <= 0 || th * tw > TP) pick_patch(g->Ho, g->Wo, th, tw, TP);
     a.TH = th; a.TW = tw;
     a.tiles_y = stm_cdiv(g->Ho, th); a.tiles_x = stm_cdiv(g->Wo, tw);
-    a.m_tiles = g->B * a.tiles_y * a.tiles_x; a.n_tiles = Cout / DF_BN;
+    a.m_tiles = g->B * a.tiles_y * a.tiles_x; a.n_tiles = Cout / BN;
     a.K = K; a.cslabs = g->C / 32; a.slabs = K * a.cslabs;
     a.x_bytes = (unsigned)xb;
     const int npl = fmt == 1 ? 2 : 1;
-    size_t lds = (size_t)DF_KMAX * DF_TP * 32 + (size_t)DF_NS * npl * DF_BN * 64 + (size_t)DF_NS * npl * DF_TP * 64;   // coefficient tables, weight ring, operand ring
-    const size_t park = (size_t)DF_TP * DF_PARK_LD * sizeof(float);
+    size_t lds = (size_t)DF_KMAX * TP * 32 + (size_t)DF_NS * npl * BN * 64 + (size_t)DF_NS * npl * TP * 64;   // coefficient tables, weight ring, operand ring
+    const size_t park = (size_t)TP * (BN + 4) * sizeof(float);
     if (lds < park) lds = park;
-    const int which = (npl - 1) * 2 + (has_mask ? 1 : 0);
-    static std::atomic<int> reserved[4][32];
-    int dev = 0;
-    const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32;
-    const void* fn = which == 3 ? reinterpret_cast<const void*>(dcn_fused_kernel<2, true>)
-                   : which == 2 ? reinterpret_cast<const void*>(dcn_fused_kernel<2, false>)
-                   : which == 1 ? reinterpret_cast<const void*>(dcn_fused_kernel<1, true>)
-                                : reinterpret_cast<const void*>(dcn_fused_kernel<1, false>);
-    if (!have_dev || reserved[which][dev].load(std::memory_order_relaxed) < (int)lds) {
-        STM_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, STM_ELAUNCH,
-                    "%s: cannot reserve %zu bytes of LDS", who, lds);
-        if (have_dev) reserved[which][dev].store((int)lds, std::memory_order_relaxed);
+    int rc;
+    const hipStream_t hs = stm_hs(stream);
+    if (wide) {
+        if (npl == 2) rc = has_mask ? df_launch<2, true, 1>(a, lds, hs, who) : df_launch<2, false, 1>(a, lds, hs, who);
+        else rc = has_mask ? df_launch<1, true, 1>(a, lds, hs, who) : df_launch<1, false, 1>(a, lds, hs, who);
+    } else {
+        if (npl == 2) rc = has_mask ? df_launch<2, true, 0>(a, lds, hs, who) : df_launch<2, false, 0>(a, lds, hs, who);
+        else rc = has_mask ? df_launch<1, true, 0>(a, lds, hs, who) : df_launch<1, false, 0>(a, lds, hs, who);
     }
-    const dim3 grid(8 * stm_cdiv((int64_t)a.m_tiles * a.n_tiles, 8));
-    if (which == 3) hipLaunchKernelGGL((dcn_fused_kernel<2, true>), grid, dim3(512), lds, stm_hs(stream), a);
-    else if (which == 2) hipLaunchKernelGGL((dcn_fused_kernel<2, false>), grid, dim3(512), lds, stm_hs(stream), a);
-    else if (which == 1) hipLaunchKernelGGL((dcn_fused_kernel<1, true>), grid, dim3(512), lds, stm_hs(stream), a);
-    else hipLaunchKernelGGL((dcn_fused_kernel<1, false>), grid, dim3(512), lds, stm_hs(stream), a);
-    STM_CHECK_LAUNCH("dcn_fused_kernel");
+    if (rc != STM_OK) return rc;
     g_fused_launches.fetch_add(1, std::memory_order_relaxed);
     return STM_OK;
 }

@@ -5,6 +5,7 @@ and enqueues the hand-written gfx950 kernel on the current stream.  CPU tensors 
 no CPU fallback (oracle/ is test infrastructure and is never imported from here).
 """
 import ctypes
+import os
 
 import torch
 
@@ -1178,20 +1179,23 @@ def deform_conv_fused_supported(C, O, kernel_size, has_mask, fmt, deformable_gro
 
 
 def deform_conv_fused_tiles(B, Ho, Wo, O):
-    """Workgroups stm_deform_conv_fused_planar_f32 launches for B images of Ho x Wo output pixels and O channels (patches of <= 128
-    pixels chosen as csrc/dcn_fused.hip pick_patch does: fewest wasted tile pixels, then the squarest) -- the callers' small-grid rule."""
+    """Workgroups stm_deform_conv_fused_planar_f32 launches for B images of Ho x Wo output pixels and O channels: tiles of 64 pixels x 256 channels
+    where O is a multiple of 256 (STM_DCN_FUSED_WIDE, default on), 128 x 128 otherwise; patches chosen as csrc/dcn_fused.hip pick_patch does (fewest
+    wasted tile pixels, then the squarest) -- the callers' small-grid rule."""
+    wide = O % 256 == 0 and os.environ.get("STM_DCN_FUSED_WIDE", "1") != "0"
+    tp, bn = (64, 256) if wide else (128, 128)
     best, bt, bper = -1.0, 1, 1 << 30
-    for tw in range(4, 129):
-        th = 128 // tw
+    for tw in range(4, tp + 1):
+        th = tp // tw
         if th < 1:
             break
         thc, twc = min(th, Ho), min(tw, Wo)
         tiles = -(-Ho // thc) * -(-Wo // twc)
-        eff = Ho * Wo / (tiles * 128.0)
+        eff = Ho * Wo / (tiles * float(tp))
         per = thc + twc
         if eff > best + 1e-9 or (eff > best - 1e-9 and per < bper):
             best, bt, bper = eff, tiles, per
-    return B * bt * (O // 128)
+    return B * bt * (O // bn)
 
 
 def deform_conv_fused_planar(x_pix, B, H, W, C, om, packed, out_scale, bias, O, kernel_size=3, stride=1, padding=1, dilation=1, has_mask=True,

@@ -99,6 +99,22 @@ def test_fused_deform_conv_vs_oracle_and_pair(case):
         assert ((got - two).abs() / (mag + 1e-3)).max().item() < 2e-6   # same values and products, another summation order
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 14, 18, 256, 1), (1, 256, 24, 40, 512, 2), (2, 64, 5, 7, 256, 1)])
+def test_fused_deform_conv_wide_tiles_equal_narrow_tiles(shape, tunables):
+    """Layers with Cout a multiple of 256 run on 64-pixel x 256-channel tiles (every pixel sampled once); STM_DCN_FUSED_WIDE=0 keeps the 128 x 128 tiles.
+    Same sampled values, same products in the same order per accumulator: the two must agree bit for bit."""
+    B, C, H, W, O, s = shape
+    Ho, Wo = ops.conv_out_hw(H, W, 3, 3, s, s, 1, 1, 1, 1)
+    x = rnd(B, C, H, W, seed=31)
+    om = torch.cat([rnd(B, 18, Ho, Wo, seed=32, scale=2.0), rnd(B, 9, Ho, Wo, seed=33)], 1)
+    w = rnd(O, C, 3, 3, seed=34, scale=(C * 9) ** -0.5)
+    bias = rnd(O, seed=35)
+    wide = fused(x, om, w, bias, s, (1, 1), True, True)
+    tunables.set(STM_DCN_FUSED_WIDE=0)
+    narrow = fused(x, om, w, bias, s, (1, 1), True, True)
+    assert torch.equal(wide, narrow)
+
+
 def test_fused_deform_conv_dilation_two():
     """dilation 2 (the geometry struct's dh / dw; the reference's DCN keeps dilation 1, mmcv's DeformConv2d takes any): fused kernel vs the fp64 oracle."""
     B, C, H, W, O, s, pad, dil = 2, 64, 11, 14, 128, 1, (2, 2), 2
