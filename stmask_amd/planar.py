@@ -53,10 +53,10 @@ DCN_FUSED_MIN_TILES = int(os.environ.get("STM_DCN_FUSED_MIN_TILES", "200"))
 # which layers: 0 = every layer whose grid is large enough; 1 = only where the fused kernel wins in isolation (profiles/r05_dcn_fused_forms.txt section 0): one
 # 128-channel tile per pixel patch, or two at stride 2 -- with more channel tiles every tile samples the patch again
 DCN_FUSED_RULE = int(os.environ.get("STM_DCN_FUSED_RULE", "0"))   # (in the step both rules measure the same within 0.1 ms on R50 and R101: profiles/r05_dcn_fused_forms.txt)
-# ... the FCB class branch (FeatureAlign's DeformConv2d, 256 -> 256 channels, 9 / 15 / 15 taps over five levels) on the same kernel: built and tested, OFF by
-# default -- two 128-channel tiles per pixel patch sample every pixel twice and the sampler + product pair wins (R50 FCB-ada at 32 clips: 918 frames/s with
-# the pair, 764 fused; profiles/r05_dcn_fused_forms.txt)
-FCB_FUSED = os.environ.get("STM_FCB_FUSED", "0") != "0"
+# ... the FCB class branch (FeatureAlign's DeformConv2d, 256 -> 256 channels, 9 / 15 / 15 taps over five levels) on the same kernel.  ON by default since the
+# kernel has 64-pixel x 256-channel tiles (every pixel sampled once): R50 FCB-ada at 32 clips 36.6 -> 36.1 ms per step, R101 FCB-ali 34.5 -> 34.0; on the
+# 128 x 128 tiles (two channel tiles per patch, every pixel sampled twice) it lost, 764 vs 918 frames/s (profiles/r05_dcn_fused_forms.txt).  STM_FCB_FUSED=0: the pair
+FCB_FUSED = os.environ.get("STM_FCB_FUSED", "1") != "0"
 # Independent parts of the trunk on a second stream while a HIP graph is being captured (PlanarGraph.run): 0 off (default), 1 proto-net beside the
 # shared head, 2 also the P5 -> P6 -> P7 convolutions beside the finer FPN levels; only batches of at most BRANCH_MAX_IMAGES frames.  Bit-equal, and
 # SLOWER at every batch size it was meant for (profiles/r04_trunk_branches_ab.txt: 1 clip 478 -> 426-442 frames/s, 2 clips 728 -> 640-694, 4 clips
