@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and the parity block that needs it)")
     ap.add_argument("--no-extras", action="store_true", help="skip the 8-clip / 1-clip / bf16x3 side measurements")
+    ap.add_argument("--events-in-timed-region", action="store_true",
+                    help="record the per-launch HIP events of the roofline objects INSIDE the timed region (rounds 1-4 did; two event records around each of "
+                         "~190 launches cost ~1.1 ms per step at 32 clips, so by default they are taken in an eager pass of the same K steps right after it)")
     ap.add_argument("--no-sampler-pass", action="store_true",
                     help="skip the short eager pass with the fused deformable convolution switched off that only serves roofline_im2col (kernel traces: one kind of step)")
     ap.add_argument("--extras", default="realistic,clips8,clips1,bf16x3,per_class_nms,non_tf,e2e", help="which side measurements to run (comma-separated)")
@@ -680,7 +683,10 @@ def main():
     graphed = run.batched and run.pipe.use_graph
     if args.world2_one_gpu:
         run.keep = []
-    elapsed, out, timing, conv_t = run.timed(args.warmup, args.steps, use_dist, collect=not graphed and not args.world2_one_gpu)
+    # The timed region carries no instrumentation: the per-launch HIP events the roofline objects are built from are recorded in a second pass of the same
+    # K steps right after it (eager; under a trunk graph that was always so).  --events-in-timed-region puts them back inside.
+    events_inside = args.events_in_timed_region and not graphed and not args.world2_one_gpu
+    elapsed, out, timing, conv_t = run.timed(args.warmup, args.steps, use_dist, collect=events_inside)
     if args.world2_one_gpu:
         sys.exit(world2_report(args, run, dev, rank, world, elapsed, use_dist))
     coll_local = coll_delta = None
@@ -691,15 +697,18 @@ def main():
         coll_local = run.pipe._pack_outputs(dev).clone()
         saved_mode = run.gatherer.mode
         run.gatherer.mode = 2
-        el_nog, _, _, _ = run.timed(1, args.steps, use_dist)
+        el_nog, _, _, _ = run.timed(args.warmup, args.steps, use_dist)         # the same step indices as the timed region: same frames, same tracker phase
         run.gatherer.mode = saved_mode
         coll_delta = (elapsed - el_nog) / args.steps * 1e3
-    if graphed:
-        # a graph replay cannot be bracketed kernel by kernel: the per-kernel HIP-event timing of the roofline objects comes from
-        # a second, eager pass of the same K steps right after the timed region (same kernels, same shapes, same process)
-        run.pipe.use_graph = False
-        _, _, timing, conv_t = run.timed(1, args.steps, use_dist, collect=True)
-        run.pipe.use_graph = True
+    instrumented_s = None
+    if not events_inside and not args.world2_one_gpu:
+        # the per-kernel HIP-event timing of the roofline objects: a second, eager pass of the same K steps right after the timed region (same kernels,
+        # same shapes, same process; a graph replay cannot be bracketed kernel by kernel at all)
+        if graphed:
+            run.pipe.use_graph = False
+        instrumented_s, _, timing, conv_t = run.timed(args.warmup, args.steps, use_dist, collect=True)     # the same step indices: same frames, same tracker phase
+        if graphed:
+            run.pipe.use_graph = True
     if use_dist:
         tmax = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -725,6 +734,11 @@ def main():
             "value": round(frames / elapsed, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "timing": {"timed_region": "exactly K steps between barrier + synchronize pairs, " + ("per-launch HIP events recorded inside" if events_inside else
+                                       "no instrumentation inside"),
+                       "instrumented_pass_ms_per_step": round(instrumented_s / args.steps * 1e3, 3) if instrumented_s is not None else None,
+                       "note": "the roofline objects' per-launch durations come from HIP events recorded on the launch stream around every kernel launch; "
+                               "recorded inside the timed region (rounds 1-4, --events-in-timed-region) they add ~1.1 ms per step at 32 clips"},
             "vs_baseline": None, "dtype": "f32" if (args.planes != "fp16x1" or not planar_graph) else "f16-convs/f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {backbone_tag(cfg)} {heads_tag(cfg)}, {args.height}x{args.width} tensor "
                                    f"({img} image padded to /32), {args.clips} clips/GPU x 1 frame per step, clips of "
@@ -816,7 +830,8 @@ def main():
         if conv_t:
             tr_c, src_c = pmc_traffic("conv_planar") if default_wl else (None, None)
             res["roofline"] = conv_roofline(conv_t, args.steps, args.planes, tr_c, src_c,
-                                            "the timed region" if not graphed else "an eager pass of the same steps right after the timed region (which replays HIP graphs)")
+                                            "the timed region" if events_inside else "an eager pass of the same K steps right after the timed region (which "
+                                            + ("replays HIP graphs)" if graphed else "carries no per-launch events: they cost ~1 ms per step)"))
             res["frac_trunk_only"] = res["roofline"]["frac_trunk_only"]
             if fused_t:
                 # `roofline` keeps its definition of the earlier rounds -- the plane-split dense-convolution kernels -- so the deformable layers' products,
