@@ -79,10 +79,10 @@ def parse_args(argv=None):
     ap.add_argument("--extras", default="realistic,clips8,clips1,bf16x3,per_class_nms,non_tf,e2e", help="which side measurements to run (comma-separated)")
     ap.add_argument("--nchw", dest="channels_last", action="store_false", help="keep the dense convs in NCHW")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="keep BatchNorm / bias / ReLU as separate kernels")
-    ap.add_argument("--overlap", choices=("late", "early", "off"), default="late",
-                    help="next frame's trunk on a second stream: 'late' = after this frame's temporal-fusion convolutions are "
-                         "enqueued (default: big kernels never share the GPU, per-kernel timings stay clean), 'early' = at the "
-                         "start of the step, 'off'")
+    ap.add_argument("--overlap", choices=("late", "early", "off"), default="early",
+                    help="next frame's trunk on a second stream: 'early' = at the start of the step (default since round 5: +0.5 %% at 32 clips, +5.7 %% at 8, "
+                         "+13 %% single-stream; the passes that record per-launch events run 'late'), 'late' = after this frame's temporal-fusion "
+                         "convolutions are enqueued (the two big kernel groups never share the GPU: per-kernel timings stay clean), 'off'")
     ap.add_argument("--no-overlap", dest="overlap", action="store_const", const="off", help="same as --overlap off")
     ap.add_argument("--planes", choices=["fp16x2", "bf16x3", "fp16x1"], default="fp16x2",
                     help="operand format of the planar MFMA convolutions: two fp16 planes / 3 products (default, fp32-equivalent), "
@@ -706,7 +706,12 @@ def main():
         # same shapes, same process; a graph replay cannot be bracketed kernel by kernel at all)
         if graphed:
             run.pipe.use_graph = False
+        early = run.batched and run.pipe.prefetch_early
+        if early:
+            run.pipe.prefetch_early = False      # 'late': the trunk and the temporal-fusion convolutions never share the GPU, so a launch's events bracket that launch alone
         instrumented_s, _, timing, conv_t = run.timed(args.warmup, args.steps, use_dist, collect=True)     # the same step indices: same frames, same tracker phase
+        if early:
+            run.pipe.prefetch_early = True
         if graphed:
             run.pipe.use_graph = True
     if use_dist:
@@ -815,7 +820,12 @@ def main():
                 if run.batched:
                     run.pipe.use_graph = False
                 try:
+                    early_s = run.batched and run.pipe.prefetch_early
+                    if early_s:
+                        run.pipe.prefetch_early = False
                     _, _, timing, _ = run.timed(1, min(args.steps, 8), use_dist, collect=True)
+                    if early_s:
+                        run.pipe.prefetch_early = True
                 finally:
                     _plf.DCN_FUSED_MIN_TILES = saved_mt
                     if run.batched:
@@ -831,7 +841,8 @@ def main():
             tr_c, src_c = pmc_traffic("conv_planar") if default_wl else (None, None)
             res["roofline"] = conv_roofline(conv_t, args.steps, args.planes, tr_c, src_c,
                                             "the timed region" if events_inside else "an eager pass of the same K steps right after the timed region (which "
-                                            + ("replays HIP graphs)" if graphed else "carries no per-launch events: they cost ~1 ms per step)"))
+                                            + ("replays HIP graphs" if graphed else "carries no per-launch events: they cost ~0.8 ms per step") + "), next-trunk overlap 'late' so that "
+                                            "no two convolution launches share the GPU")
             res["frac_trunk_only"] = res["roofline"]["frac_trunk_only"]
             if fused_t:
                 # `roofline` keeps its definition of the earlier rounds -- the plane-split dense-convolution kernels -- so the deformable layers' products,
@@ -890,6 +901,7 @@ def main():
                         # this line's own roofline: per-launch HIP events need eager launches, so a short eager pass of the same
                         # pipeline right after its timed region (which replays HIP graphs up to 8 clips)
                         r2.pipe.use_graph = False
+                        r2.pipe.prefetch_early = False
                         rsteps = min(steps, 8)
                         _, _, _, ct = r2.timed(1, rsteps, collect=True)
                         if ct:

@@ -146,7 +146,8 @@ class BatchedClipPipeline:
         self.timer = _StageTimer()
         self._pending = None        # (frames, (fpn_outs, pred), event): trunk of the NEXT frame, running on the side stream
         self._side = None
-        self.prefetch_early = False  # True: start the next trunk at the beginning of step() instead of after the TF convolutions
+        self.prefetch_early = True   # start the next trunk at the beginning of step() (measured best at every batch size: +0.5 % at 32 clips, +5.7 % at 8, +13 % at 1);
+                                     # False: after the TF convolutions are enqueued (the two big kernel groups then never share the GPU: clean per-kernel timings)
         self.use_graph = False       # replay the trunk (forward_single) from captured HIP graphs: see _trunk
         self.graph_active = False
         self._graphs = []            # round-robin slots: (static input, graph, outputs)
