@@ -26,8 +26,8 @@ for k,v in d['extras'].items():
     else: print(k, v.get('value'), v.get('ms_per_step'), (v.get('roofline') or {}).get('frac'))
 print(d['parity']['matched_frac'], d['parity']['mask_l2'], d['cpu_baseline']['value'])
 PY
-echo "== 5. rocprofv3 kernel trace + stats"
-cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-sampler-pass > $OUT/prof.log 2>&1; echo "prof exit $?"; cd $R
+echo "== 5. rocprofv3 kernel trace + stats (--overlap late, like the pass bench.py records its per-launch events in: no two convolution launches share the GPU)"
+cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-sampler-pass --overlap late > $OUT/prof.log 2>&1; echo "prof exit $?"; cd $R
 f=$(ls $OUT/prof/*/*kernel_stats.csv $OUT/prof/*kernel_stats.csv 2>/dev/null | head -1); echo "stats: $f"; head -12 "$f" | cut -c1-200
 t=$(ls $OUT/prof/*/*kernel_trace.csv $OUT/prof/*kernel_trace.csv 2>/dev/null | head -1); python scripts/summarize_trace.py "$t" > $OUT/kernel_stats_final.md 2>&1; head -30 $OUT/kernel_stats_final.md | cut -c1-160
 cp "$f" $OUT/kernel_stats_final.csv; find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete
