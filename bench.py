@@ -390,7 +390,8 @@ class Runner:
         if self.batched and self.args.overlap != "off":
             # the next frame's trunk starts on a second stream while this frame's tracker logic (tiny launches, two host
             # reads) runs; every step still enqueues exactly one trunk
-            out = pipe.step(self.frames_t[t % T], is_first=(t % T == 0), next_frames=self.frames_t[(t + 1) % T])
+            # the frames of the next two calls: under graph replay (small batches) two trunks run ahead on two side streams (BatchedClipPipeline._prefetch_trunk)
+            out = pipe.step(self.frames_t[t % T], is_first=(t % T == 0), next_frames=[self.frames_t[(t + 1) % T], self.frames_t[(t + 2) % T]])
         else:
             out = pipe.step(self.frames_t[t % T], is_first=(t % T == 0))
         if self.batched:
@@ -408,6 +409,12 @@ class Runner:
         from stmask_amd import ops
         for t in range(warmup):
             self.step(t)
+        t_first = warmup
+        if self.batched and self.pipe.use_graph and not collect:
+            # the trunk graphs are captured lazily, one slot per trunk call (two eager calls first): keep the captures out of the timed region
+            while len(self.pipe._graphs) < self.pipe.N_GRAPH_SLOTS and t_first < warmup + self.pipe.N_GRAPH_SLOTS + 4:
+                self.step(t_first)
+                t_first += 1
         torch.cuda.synchronize()
         if use_dist:
             barrier()
@@ -422,7 +429,7 @@ class Runner:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = None
-        for t in range(warmup, warmup + steps):
+        for t in range(t_first, t_first + steps):
             out = self.step(t)
         self.gatherer.wait()
         torch.cuda.synchronize()

@@ -125,6 +125,53 @@ class _TrackedRows(dict):
         return dict.__contains__(self, key) or (key == "mask" and getattr(self, "_deferred", None) is not None)
 
 
+_SIDE_STREAMS = {}
+
+
+def concurrent_side_streams(dev, n=2):
+    """n streams that really run BESIDE the current stream and beside each other.  HIP maps streams onto a few hardware queues; two streams that land on
+    one queue run their work one after the other, silently -- measured: the same pipeline gives 780 frames/s single-stream with two trunk graphs in
+    flight, 560 when its side streams happen to share a queue (after another pipeline in the same process had used up some streams of torch's pool) and
+    440 when one of them shares the main stream's queue; GPU_MAX_HW_QUEUES only moves the collisions.  So the streams are picked by test, once per
+    process and main stream: a 0.5-ms spin kernel on the main stream, on the streams chosen so far and on the candidate -- the candidate is taken when
+    all of them finish in the time of one."""
+    import time
+    dev = torch.device(dev)
+    main = torch.cuda.current_stream(dev)
+    key = (dev.index, main.cuda_stream, n)
+    if key in _SIDE_STREAMS:
+        return _SIDE_STREAMS[key]
+    cands = [torch.cuda.Stream(device=dev) for _ in range(16)]
+    chosen = []
+    spin = getattr(torch.cuda, "_sleep", None)
+    if spin is not None and not torch.cuda.is_current_stream_capturing():
+        cycles = 1_000_000
+
+        def run(streams):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for s_ in streams:
+                with torch.cuda.stream(s_):
+                    spin(cycles)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t0
+
+        run([main])
+        base = min(run([main]) for _ in range(3))
+        for c in cands:
+            if len(chosen) == n:
+                break
+            if min(run([main] + chosen + [c]) for _ in range(2)) < 1.4 * base:
+                chosen.append(c)
+    for c in cands:                                  # (no spin kernel, or fewer independent queues than asked for: any streams will do -- results never depend on it)
+        if len(chosen) == n:
+            break
+        if c not in chosen:
+            chosen.append(c)
+    _SIDE_STREAMS[key] = chosen
+    return chosen
+
+
 class BatchedClipPipeline:
     """All clips' tracker state concatenated (rows sorted by clip); per-clip row ranges are host integers."""
 
@@ -144,17 +191,17 @@ class BatchedClipPipeline:
         self.has_prev = [False] * n_clips
         self.tracked = [[] for _ in range(n_clips)]  # host-side "frames since last match" counters
         self.timer = _StageTimer()
-        self._pending = None        # (frames, (fpn_outs, pred), event): trunk of the NEXT frame, running on the side stream
-        self._side = None
+        self._pending = []          # FIFO of (frames, (fpn_outs, pred), event): trunks of the NEXT frame(s), running on the side stream(s)
+        self._sides = []            # side streams of the prefetched trunks (two under graph replay: see _prefetch_trunk)
+        self._side_next = 0
         self.prefetch_early = True   # start the next trunk at the beginning of step() (measured best at every batch size: +0.5 % at 32 clips, +5.7 % at 8, +13 % at 1);
                                      # False: after the TF convolutions are enqueued (the two big kernel groups then never share the GPU: clean per-kernel timings)
         self.use_graph = False       # replay the trunk (forward_single) from captured HIP graphs: see _trunk
         self.graph_active = False
         self._graphs = []            # round-robin slots: (static input, graph, outputs)
         self._graph_next = 0
-        self._graph_pool = None
         self._graph_warm = 0
-        self._graph_ws = {}          # workspaces the captured graphs write into (kept alive here)
+        self._graph_ws = []          # per slot: the workspaces its captured graph writes into (kept alive here)
         # Workload knob of the benchmark ("a max_instances cap to study n ~ 5-10, the realistic regime"), NOT
         # a reference semantic: the reference's tracker never prunes (track_TF.py:132-165).  n > 0: at most n detections per frame
         # (the best-scoring ones: Fast NMS returns them sorted) and at most n tracked instances per clip (an unmatched detection
@@ -219,15 +266,20 @@ class BatchedClipPipeline:
             self.tracked[b] = [v + 1 for v in self.tracked[b]]
 
     # -- trunk, eager or from HIP graphs ---------------------------------------------------------------------------------
-    N_GRAPH_SLOTS = 3   # outputs of frame t-1 (previous-frame features of the temporal fusion) and t are live while t+1 is produced
+    # Outputs of frame t-1 (previous-frame features of the temporal fusion) and t are live while t+1 and t+2 are produced; a prefetched trunk that is
+    # dropped (the caller changed its mind about the next frames) still used up its slot: six slots cover two prefetched frames with two drops.
+    N_GRAPH_SLOTS = 6
+    PREFETCH_DEPTH = 2   # trunks in flight ahead of the current frame under graph replay (eager trunks: 1)
 
     def _trunk(self, frames):
         """forward_single(frames).  With use_graph the ~110 launches of the trunk (every one a Python -> ctypes call: ~25 us of
         host time each, i.e. more than the GPU needs for them at 1-8 clips) are captured once per slot into a HIP graph and
-        replayed: one copy of the frames into the slot's static input + one graph launch per step.  Three slots in round-robin,
-        because a step still reads the previous frame's P4 / T2S while the next frame's trunk is already running on the side
-        stream; a slot's outputs stay valid until it is replayed again, three steps later.  The graphs share one memory pool
-        (they are replayed in capture order and never concurrently)."""
+        replayed: one copy of the frames into the slot's static input + one graph launch per step.  Slots in round-robin,
+        because a step still reads the previous frame's P4 / T2S while the next frames' trunks are already running on the side
+        streams; a slot's outputs stay valid until it is replayed again, N_GRAPH_SLOTS trunks later.  Every slot has its own memory pool
+        and its own workspaces: two replays may run CONCURRENTLY on two side streams (a single-frame trunk is a chain of ~155 dependent
+        small launches -- 1.57 ms of GPU-side launch latency for half that in work; two chains overlap almost completely:
+        profiles/r05_two_trunks_probe.txt)."""
         net = self.net
         if not (self.use_graph and getattr(net, "_planar", None) is not None and not self.timer.on and ops._conv_timing is None
                 and ops._im2col_timing is None):
@@ -239,17 +291,17 @@ class BatchedClipPipeline:
         if len(self._graphs) < self.N_GRAPH_SLOTS:
             static_in = frames.clone(memory_format=torch.preserve_format)
             graph = torch.cuda.CUDAGraph()
-            if self._graph_pool is None:
-                self._graph_pool = torch.cuda.graph_pool_handle()
+            ws = {}
+            self._graph_ws.append(ws)
             cur = torch.cuda.current_stream()
             cap = torch.cuda.Stream(device=frames.device)
             cap.wait_stream(cur)
             # scratch buffers whose addresses the graph bakes in are owned by this pipeline (ops.workspace_scope), not by the
             # capture stream's slot of the global cache
-            with ops.workspace_scope(self._graph_ws):
+            with ops.workspace_scope(ws):
                 with torch.cuda.stream(cap):
                     net.forward_single(static_in)             # once more on the capture stream: sizes this scope's workspaces
-                with torch.cuda.graph(graph, pool=self._graph_pool, stream=cap):
+                with torch.cuda.graph(graph, stream=cap):
                     out = net.forward_single(static_in)
             cur.wait_stream(cap)
             self._graphs.append((static_in, graph, out))
@@ -263,31 +315,43 @@ class BatchedClipPipeline:
         return out
 
     def _prefetch_trunk(self, next_frames):
-        """Enqueue the trunk of the next frame on a second stream.  The trunk does not depend on the tracker, and the rest
+        """Enqueue the trunk(s) of the next frame(s) on side streams.  The trunk does not depend on the tracker, and the rest
         of this step is ~200 tiny launches around two host reads (latency-bound: the GPU idles 10-17 % of the step without
-        this).  Called after the temporal-fusion convolutions of this step are enqueued, so the two big kernel groups do
-        not share the GPU; the side stream waits for everything enqueued on the main stream so far."""
+        this).  next_frames: the frames of the next call, or a list [next, the one after, ...] -- under graph replay up to PREFETCH_DEPTH of
+        them are started (those not in flight yet), alternating between two side streams, so that two trunk graphs run beside each other and
+        beside this step's tracker tail; eager trunks (large batches fill the GPU by themselves) keep one frame of look-ahead.  A side stream
+        waits for everything enqueued on the main stream so far."""
         if next_frames is None or self.timer.on:
             return
+        nxt = list(next_frames) if isinstance(next_frames, (list, tuple)) else [next_frames]
+        depth = self.PREFETCH_DEPTH if (self.use_graph and self.graph_active) else 1
         main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=next_frames.device)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            out = self._trunk(next_frames)
-            ev = torch.cuda.Event()
-            ev.record()
-        self._pending = (next_frames, out, ev)
+        for f in nxt[:depth]:
+            if f is None or any(p[0] is f for p in self._pending):
+                continue
+            if not self._sides:
+                self._sides = concurrent_side_streams(f.device, 2)
+            side = self._sides[self._side_next]
+            self._side_next ^= 1
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                out = self._trunk(f)
+                ev = torch.cuda.Event()
+                ev.record()
+            self._pending.append((f, out, ev))
 
     def _take_trunk(self, frames):
-        """(fpn_outs, pred) of `frames`: the trunk started for them on the side stream by the previous step, or a fresh one.  Third value: a
+        """(fpn_outs, pred) of `frames`: the trunk started for them on a side stream by an earlier step, or a fresh one.  Third value: a
         prefetched trunk of OTHER frames was dropped."""
         net = self.net
-        pend, self._pending = self._pending, None
-        if pend is not None and pend[0] is frames:
-            fpn_outs, pred = pend[1]
-            torch.cuda.current_stream().wait_event(pend[2])
-            if not self.graph_active:                            # (graph outputs live in the graphs' own pool)
+        dropped = False
+        while self._pending and self._pending[0][0] is not frames:
+            torch.cuda.current_stream().wait_event(self._pending.pop(0)[2])   # a trunk nobody asked for: let it finish, drop it
+            dropped = True
+        if self._pending:
+            _, (fpn_outs, pred), ev = self._pending.pop(0)
+            torch.cuda.current_stream().wait_event(ev)
+            if not self.graph_active:                            # (graph outputs live in the graphs' own pools)
                 for t_ in list(pred.values()) + list(fpn_outs):  # allocated on the side stream, consumed on this one
                     if torch.is_tensor(t_):
                         t_.record_stream(torch.cuda.current_stream())
@@ -295,10 +359,8 @@ class BatchedClipPipeline:
                 if torch.is_tensor(t2s_):
                     t2s_.record_stream(torch.cuda.current_stream())
         else:
-            if pend is not None:
-                torch.cuda.current_stream().wait_event(pend[2])   # a trunk nobody asked for: let it finish, drop it
             fpn_outs, pred = self._trunk(frames)
-        return fpn_outs, pred, (pend is not None and pend[0] is not frames)
+        return fpn_outs, pred, dropped
 
     def _detect(self, pred):
         """Decode + confidence threshold + Fast NMS for every frame of the batch, no host sync -> (prior_idx [B, cap], cls, score, box, count [B]).
@@ -316,8 +378,9 @@ class BatchedClipPipeline:
     @torch.no_grad()
     def step(self, frames, is_first=None, next_frames=None):
         """frames [B,3,H,W] -> packed detections [B, top_k, 40] (stmask_amd.dist layout) without a final sync, plus the
-        per-clip tracked-instance counts (host ints).  next_frames (optional): the frames the NEXT call will be given;
-        their trunk is started on a second stream while this step's tracker logic runs.
+        per-clip tracked-instance counts (host ints).  next_frames (optional): the frames the NEXT call will be given -- or a list: those of the
+        next call, of the one after it, ... (the same tensor OBJECTS the later calls pass as `frames`); their trunks are started on side streams
+        while this step's tracker logic runs (_prefetch_trunk).
 
         fp16 plane graphs carry |activation| <= 65504 only; their producers raise a sticky device flag beyond that, which arrives with the step's
         first host read (ops.RangeError).  The step is then NOT lost: the tracker state it had touched is put back, the inference graph is rebuilt
@@ -353,7 +416,7 @@ class BatchedClipPipeline:
         import sys
         from . import fuse
         net = self.net
-        pend, self._pending = self._pending, None
+        self._pending = []
         torch.cuda.synchronize()                      # nothing enqueued on the fp16 graph may raise the flag after it has been cleared
         flag = ops._range_flags.get(torch.cuda.current_device())
         if flag is not None:
@@ -363,7 +426,7 @@ class BatchedClipPipeline:
         if getattr(net, "_planar_bf16x3", None) is None:
             net._planar_bf16x3 = fuse.build_planar(net, "bf16x3")
         fuse.attach_planar(net, net._planar_bf16x3)
-        self._graphs, self._graph_next, self.graph_active, self._graph_warm, self._graph_ws = [], 0, False, 0, {}
+        self._graphs, self._graph_next, self.graph_active, self._graph_warm, self._graph_ws = [], 0, False, 0, []
         rows, tracked, t = snap
         if rows is not None:
             for k, v in zip(("box", "mask_coeff", "score"), rows):

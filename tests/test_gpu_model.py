@@ -404,27 +404,32 @@ def test_fp16x1_backbone_config5_flavour(name, tag):
 
 
 def test_batched_pipeline_trunk_from_hip_graphs_equals_eager():
-    """use_graph: the trunk is replayed from three round-robin HIP graphs (static input, static outputs).  Eight steps of three
-    clips, with and without the next-frame prefetch on the side stream, a tracker reset in the middle: same packed detections
-    as the eager pipeline bit for bit (same kernels on the same data), and the graphs really are replayed."""
+    """use_graph: the trunk is replayed from round-robin HIP graphs (static input, static outputs, a memory pool and workspaces per slot).  Twelve
+    steps of three clips -- without look-ahead, with the next frame's trunk on a side stream, with the next TWO frames' trunks on two side streams
+    (two graph replays running beside each other and beside the tracker tail) -- tracker resets in the middle, and a caller that changes its mind
+    about the frames it announced: same packed detections as the eager pipeline bit for bit (same kernels on the same data), and the graphs
+    really are replayed."""
     from stmask_amd.pipeline import BatchedClipPipeline
     from stmask_amd.fuse import optimize_for_inference
     net = build("STMask_plus_resnet50_config")
     optimize_for_inference(net, planar=True)
     net = net.to(memory_format=torch.channels_last)
     net.TemporalNet = net.TemporalNet.to(memory_format=torch.contiguous_format)
-    T = 8
+    T = 12
     clips = torch.stack([synthetic.synthetic_clip(T, 128, 192, seed=s) for s in (0, 5, 9)]).cuda()
     frames = [clips[:, t].contiguous(memory_format=torch.channels_last) for t in range(T)]
-    for overlap in (False, True):
+    for depth in (0, 1, 2):
         eager, graphed = BatchedClipPipeline(net, 3), BatchedClipPipeline(net, 3)
         graphed.use_graph = True
         for t in range(T):
             first = t in (0, 5)
-            nxt = frames[t + 1] if (overlap and t + 1 < T) else None
-            ya = eager.step(frames[t], is_first=first, next_frames=nxt).clone()
+            nxt = [frames[u] for u in range(t + 1, min(t + 1 + depth, T))] or None
+            if depth == 2 and t == 8:
+                nxt = [frames[2], frames[3]]          # announced, never passed: both trunks are dropped by the next step
+            ya = eager.step(frames[t], is_first=first, next_frames=nxt[0] if nxt else None).clone()
             yb = graphed.step(frames[t], is_first=first, next_frames=nxt).clone()
             torch.cuda.synchronize()
-            assert torch.equal(ya, yb), (overlap, t, (ya - yb).abs().max().item())
+            assert torch.equal(ya, yb), (depth, t, (ya - yb).abs().max().item())
         assert graphed.graph_active and len(graphed._graphs) == BatchedClipPipeline.N_GRAPH_SLOTS
+        assert len(graphed._sides) == (0 if depth == 0 else 2)          # the look-ahead trunks alternate between two side streams
         assert not eager.graph_active

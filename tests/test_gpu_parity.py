@@ -168,8 +168,8 @@ def test_batched_graph_pipeline_matches_reference_every_frame(name, tag):
     """The pipeline bench.py times -- BatchedClipPipeline over the planar fp16x2 inference graph, trunk replayed from HIP graphs,
     next frame's trunk prefetched on the side stream, tracker kernels of csrc/tracker.hip, deferred masks -- DIRECTLY against the
     reference's clip goldens, every frame: instances matched one to one, tracker ids, boxes 3e-6, soft masks 1e-4 RMS.  Two clips
-    per step (the golden clip and another one: batching must not couple them); the clip is run three times so that the last
-    pass is replayed from the captured graphs on every frame (the first two trunks of a pipeline run eager, the next three
+    per step (the golden clip and another one: batching must not couple them); the clip is run as many times as it takes for the last
+    pass to be replayed from the captured graphs on every frame (the first two trunks of a pipeline run eager, the next N_GRAPH_SLOTS
     capture one slot each)."""
     from stmask_amd.pipeline import BatchedClipPipeline
     g = load_golden(f"model_{tag}.npz")
@@ -181,7 +181,8 @@ def test_batched_graph_pipeline_matches_reference_every_frame(name, tag):
     pipe = BatchedClipPipeline(net, 2)
     pipe.use_graph = True
     rep = {}
-    for rnd in range(3):
+    n_rounds = -(-(2 + BatchedClipPipeline.N_GRAPH_SLOTS) // T) + 1
+    for rnd in range(n_rounds):
         for t in range(T):
             nxt = frames[t + 1] if t + 1 < T else frames[0]            # the next pass starts with frame 0 again
             pipe.step(frames[t], is_first=(t == 0), next_frames=nxt)
@@ -193,7 +194,7 @@ def test_batched_graph_pipeline_matches_reference_every_frame(name, tag):
                 r["ids_checked"] = True
             rep[f"pass{rnd}_t{t}"] = r
     assert pipe.graph_active and len(pipe._graphs) == BatchedClipPipeline.N_GRAPH_SLOTS
-    assert any(r.get("ids_checked") for k, r in rep.items() if k.startswith("pass2"))
+    assert any(r.get("ids_checked") for k, r in rep.items() if k.startswith(f"pass{n_rounds - 1}"))
     report(f"batched_graph_{tag}", **rep)
 
 
@@ -425,6 +426,6 @@ def test_trunk_branches_in_the_graph_are_bit_equal_to_the_plain_order(monkeypatc
         assert run.pipe.graph_active, "the trunk was not replayed from a graph: the branches were not exercised"
         keeps.append([k.clone() for k in run.keep])
         del run
-    assert len(keeps[0]) == 9
+    assert len(keeps[0]) == len(keeps[1]) >= 9          # warm-up + timed steps (+ the untimed steps during which the remaining graph slots are captured)
     for t, (a, b) in enumerate(zip(*keeps)):
         assert torch.equal(a, b), f"step {t}: max abs diff {(a - b).abs().max().item()}"
