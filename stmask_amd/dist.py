@@ -89,7 +89,10 @@ class DetectionGatherer:
             self.n_collectives += 1
             return all_gather_detections(packed)
         if self._comm is None:
-            self._comm = torch.cuda.Stream(device=packed.device)
+            # a stream that runs beside the main stream AND beside the two trunk streams of the pipeline (streams that share a hardware queue
+            # serialise: pipeline.concurrent_side_streams) -- the exchange must not queue up behind the next frame's trunk
+            from .pipeline import concurrent_side_streams
+            self._comm = concurrent_side_streams(packed.device, 3)[2]
         main = torch.cuda.current_stream()
         self._comm.wait_stream(main)
         with torch.cuda.stream(self._comm):

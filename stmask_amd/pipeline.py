@@ -138,11 +138,12 @@ def concurrent_side_streams(dev, n=2):
     import time
     dev = torch.device(dev)
     main = torch.cuda.current_stream(dev)
-    key = (dev.index, main.cuda_stream, n)
-    if key in _SIDE_STREAMS:
-        return _SIDE_STREAMS[key]
+    key = (dev.index, main.cuda_stream)
+    have = _SIDE_STREAMS.get(key, [])
+    if len(have) >= n:
+        return have[:n]                              # (the list only grows: the first two are the trunk streams, a third serves the detection gather)
     cands = [torch.cuda.Stream(device=dev) for _ in range(16)]
-    chosen = []
+    chosen = list(have)
     spin = getattr(torch.cuda, "_sleep", None)
     if spin is not None and not torch.cuda.is_current_stream_capturing():
         cycles = 1_000_000
@@ -169,7 +170,7 @@ def concurrent_side_streams(dev, n=2):
         if c not in chosen:
             chosen.append(c)
     _SIDE_STREAMS[key] = chosen
-    return chosen
+    return chosen[:n]
 
 
 class BatchedClipPipeline:
