@@ -391,7 +391,7 @@ class Runner:
             # the next frame's trunk starts on a second stream while this frame's tracker logic (tiny launches, two host
             # reads) runs; every step still enqueues exactly one trunk
             # the frames of the next two calls: under graph replay (small batches) two trunks run ahead on two side streams (BatchedClipPipeline._prefetch_trunk)
-            out = pipe.step(self.frames_t[t % T], is_first=(t % T == 0), next_frames=[self.frames_t[(t + 1) % T], self.frames_t[(t + 2) % T]])
+            out = pipe.step(self.frames_t[t % T], is_first=(t % T == 0), next_frames=[self.frames_t[(t + k) % T] for k in range(1, 1 + max(2, pipe.PREFETCH_DEPTH))])
         else:
             out = pipe.step(self.frames_t[t % T], is_first=(t % T == 0))
         if self.batched:

@@ -12,6 +12,8 @@ tracker state, track_TF.py:52-54,96-100).  Two drivers:
                              TemporalNet / decode / lincomb chain for all tracked instances, one cross matrix for the
                              matching scores.  Two small device->host reads per STEP (detection counts, match ids).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -269,8 +271,10 @@ class BatchedClipPipeline:
     # -- trunk, eager or from HIP graphs ---------------------------------------------------------------------------------
     # Outputs of frame t-1 (previous-frame features of the temporal fusion) and t are live while t+1 and t+2 are produced; a prefetched trunk that is
     # dropped (the caller changed its mind about the next frames) still used up its slot: six slots cover two prefetched frames with two drops.
-    N_GRAPH_SLOTS = 6
-    PREFETCH_DEPTH = 2   # trunks in flight ahead of the current frame under graph replay (eager trunks: 1)
+    # trunks in flight ahead of the current frame under graph replay (eager trunks: 1).  Single stream: depth 1 543 frames/s, 2 777, 3 878, 4 793; 8 clips: 1 401 /
+    # 1 491 / 1 488 / 1 454 (profiles/r05_trunk_depth2_ab.txt)
+    PREFETCH_DEPTH = int(os.environ.get("STM_PREFETCH_DEPTH", "3"))
+    N_GRAPH_SLOTS = 2 * PREFETCH_DEPTH + 2
 
     def _trunk(self, frames):
         """forward_single(frames).  With use_graph the ~110 launches of the trunk (every one a Python -> ctypes call: ~25 us of
@@ -331,9 +335,9 @@ class BatchedClipPipeline:
             if f is None or any(p[0] is f for p in self._pending):
                 continue
             if not self._sides:
-                self._sides = concurrent_side_streams(f.device, 2)
+                self._sides = concurrent_side_streams(f.device, max(2, self.PREFETCH_DEPTH))
             side = self._sides[self._side_next]
-            self._side_next ^= 1
+            self._side_next = (self._side_next + 1) % len(self._sides)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 out = self._trunk(f)

@@ -415,21 +415,21 @@ def test_batched_pipeline_trunk_from_hip_graphs_equals_eager():
     optimize_for_inference(net, planar=True)
     net = net.to(memory_format=torch.channels_last)
     net.TemporalNet = net.TemporalNet.to(memory_format=torch.contiguous_format)
-    T = 12
+    T = 14
     clips = torch.stack([synthetic.synthetic_clip(T, 128, 192, seed=s) for s in (0, 5, 9)]).cuda()
     frames = [clips[:, t].contiguous(memory_format=torch.channels_last) for t in range(T)]
-    for depth in (0, 1, 2):
+    for depth in (0, 1, 2, 3):
         eager, graphed = BatchedClipPipeline(net, 3), BatchedClipPipeline(net, 3)
         graphed.use_graph = True
         for t in range(T):
             first = t in (0, 5)
             nxt = [frames[u] for u in range(t + 1, min(t + 1 + depth, T))] or None
-            if depth == 2 and t == 8:
-                nxt = [frames[2], frames[3]]          # announced, never passed: both trunks are dropped by the next step
+            if depth >= 2 and t == 8:
+                nxt = [frames[2], frames[3], frames[4]][:depth]          # announced, never passed: the trunks are dropped by the next step
             ya = eager.step(frames[t], is_first=first, next_frames=nxt[0] if nxt else None).clone()
             yb = graphed.step(frames[t], is_first=first, next_frames=nxt).clone()
             torch.cuda.synchronize()
             assert torch.equal(ya, yb), (depth, t, (ya - yb).abs().max().item())
         assert graphed.graph_active and len(graphed._graphs) == BatchedClipPipeline.N_GRAPH_SLOTS
-        assert len(graphed._sides) == (0 if depth == 0 else 2)          # the look-ahead trunks alternate between two side streams
+        assert len(graphed._sides) == (0 if depth == 0 else max(2, BatchedClipPipeline.PREFETCH_DEPTH))          # the look-ahead trunks rotate over the side streams
         assert not eager.graph_active
