@@ -269,9 +269,10 @@ class BatchedClipPipeline:
             self.tracked[b] = [v + 1 for v in self.tracked[b]]
 
     # -- trunk, eager or from HIP graphs ---------------------------------------------------------------------------------
-    # Outputs of frame t-1 (previous-frame features of the temporal fusion) and t are live while t+1 and t+2 are produced; a prefetched trunk that is
-    # dropped (the caller changed its mind about the next frames) still used up its slot: six slots cover two prefetched frames with two drops.
-    # trunks in flight ahead of the current frame under graph replay (eager trunks: 1).  Single stream: depth 1 543 frames/s, 2 777, 3 878, 4 793; 8 clips: 1 401 /
+    # Outputs of frame t-1 (previous-frame features of the temporal fusion) and t are live while t+1 .. t+D are produced; a prefetched trunk that is
+    # dropped (the caller changed its mind about the next frames) still used up its slot: 2 D + 2 slots cover D prefetched frames with D drops (the
+    # slot of frame f is replayed again by the (2 D + 2)-th trunk after it; at most 2 D + 1 start before step f + 1 has read its features).
+    # D = trunks in flight ahead of the current frame under graph replay (eager trunks: 1).  Single stream: depth 1 543 frames/s, 2 777, 3 878, 4 793; 8 clips: 1 401 /
     # 1 491 / 1 488 / 1 454 (profiles/r05_trunk_depth2_ab.txt)
     PREFETCH_DEPTH = int(os.environ.get("STM_PREFETCH_DEPTH", "3"))
     N_GRAPH_SLOTS = 2 * PREFETCH_DEPTH + 2
@@ -282,7 +283,7 @@ class BatchedClipPipeline:
         replayed: one copy of the frames into the slot's static input + one graph launch per step.  Slots in round-robin,
         because a step still reads the previous frame's P4 / T2S while the next frames' trunks are already running on the side
         streams; a slot's outputs stay valid until it is replayed again, N_GRAPH_SLOTS trunks later.  Every slot has its own memory pool
-        and its own workspaces: two replays may run CONCURRENTLY on two side streams (a single-frame trunk is a chain of ~155 dependent
+        and its own workspaces: replays may run CONCURRENTLY on different side streams (a single-frame trunk is a chain of ~155 dependent
         small launches -- 1.57 ms of GPU-side launch latency for half that in work; two chains overlap almost completely:
         profiles/r05_two_trunks_probe.txt)."""
         net = self.net
@@ -323,7 +324,7 @@ class BatchedClipPipeline:
         """Enqueue the trunk(s) of the next frame(s) on side streams.  The trunk does not depend on the tracker, and the rest
         of this step is ~200 tiny launches around two host reads (latency-bound: the GPU idles 10-17 % of the step without
         this).  next_frames: the frames of the next call, or a list [next, the one after, ...] -- under graph replay up to PREFETCH_DEPTH of
-        them are started (those not in flight yet), alternating between two side streams, so that two trunk graphs run beside each other and
+        them are started (those not in flight yet), rotating over as many side streams, so that the trunk graphs run beside each other and
         beside this step's tracker tail; eager trunks (large batches fill the GPU by themselves) keep one frame of look-ahead.  A side stream
         waits for everything enqueued on the main stream so far."""
         if next_frames is None or self.timer.on:
