@@ -72,3 +72,24 @@ def test_model_golden_fixtures_are_nontrivial():
         last = int(g["n_frames"]) - 1
         assert g["t0_box"].shape[0] >= 3 and g[f"t{last}_box"].shape[0] >= 3, tag
         assert np.isfinite(g["f0_proto"].numpy()).all()
+
+
+def test_fused_deform_conv_grid_helper_follows_the_tile_shapes(monkeypatch):
+    """ops.deform_conv_fused_tiles mirrors the launcher of csrc/dcn_fused.hip (pick_patch + the tile shape rule): 128-pixel x 128-channel tiles, or
+    64 x 256 where the layer has a multiple of 256 output channels (STM_DCN_FUSED_WIDE, default on).  The graph's small-grid rule rests on it."""
+    from stmask_amd import ops
+    monkeypatch.delenv("STM_DCN_FUSED_WIDE", raising=False)
+    assert ops.deform_conv_fused_tiles(32, 48, 80, 128) == 32 * 30                 # 8x16 patches: 6 x 5 per image, one channel tile
+    assert ops.deform_conv_fused_tiles(32, 24, 40, 256) == 32 * 15                 # 64-pixel patches (8x8): 3 x 5 per image, one 256-channel tile
+    assert ops.deform_conv_fused_tiles(32, 12, 20, 512) == 32 * 4 * 2              # 6x10 patches: 2 x 2 per image, two 256-channel tiles
+    assert ops.deform_conv_fused_tiles(1, 3, 5, 128) == 1                          # P7: one partial patch
+    monkeypatch.setenv("STM_DCN_FUSED_WIDE", "0")
+    assert ops.deform_conv_fused_tiles(32, 24, 40, 256) == 32 * 8 * 2              # 128-pixel patches, two 128-channel tiles: every pixel sampled twice
+
+
+def test_bench_defaults_of_round_5():
+    """The driver runs `python bench.py` bare: the next trunk starts early, the timed region carries no per-launch events, the roofline passes exist."""
+    import bench
+    a = bench.parse_args([])
+    assert a.overlap == "early" and not a.events_in_timed_region and not a.no_sampler_pass and a.gpus == 1
+    assert bench.parse_args(["--events-in-timed-region", "--overlap", "late"]).events_in_timed_region
