@@ -79,7 +79,7 @@ __device__ __forceinline__ float df_sigmoid(float v) { return 1.0f / (1.0f + exp
 // fmas), range maximum, split into the fp16 planes h = RN16(v), l = RN16((v - h) * 2048) -- planar_common.h split2_f16, value for value:
 // v * 2048 and h * 2048 are exact, so fma(h, -2048, v * 2048) is (v - h) * 2048 without a rounding of its own (v_fma_mixlo / mixhi_f16)
 template <int NPL, int Q>
-__device__ __forceinline__ void blend_part(const f32x4 (&X)[4][2], const f32x4 w, unsigned (&ph)[4], unsigned (&pl)[4], float& rmax)
+__device__ __forceinline__ void blend_part(const f32x4 (&X)[4][2], const f32x4 w, unsigned (&ph)[4], unsigned (&pl)[4], float& rmax, f32x2& rnan)
 {
     constexpr int h = Q >> 1, e = Q & 1;
     const f32x2 w1 = {w.x, w.x}, w2 = {w.y, w.y}, w3 = {w.z, w.z}, w4 = {w.w, w.w};
@@ -90,6 +90,7 @@ __device__ __forceinline__ void blend_part(const f32x4 (&X)[4][2], const f32x4 w
     v = __builtin_elementwise_fma(w3, x3, v);
     v = __builtin_elementwise_fma(w4, x4, v);
     rmax = __builtin_fmaxf(rmax, __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)));
+    rnan = __builtin_elementwise_fma(v, f32x2{0.0f, 0.0f}, rnan);      // v_max drops a NaN operand: 0 * v + r turns NaN AND inf samples into a sticky NaN (one v_pk_fma_f32)
     const f16x2 hh = __builtin_convertvector(v, f16x2);
     ph[Q] = __builtin_bit_cast(unsigned, hh);
     if constexpr (NPL == 2) {
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
 
     f32x4 acc[4][4], accl[4][4];                                  // consumer: [channel tile][pixel tile], main / correction products
     float rmax = 0.0f;
+    f32x2 rnan = {0.0f, 0.0f};       // stays (+-)0 while every sampled value is finite
     if (wave < 4) {
         // ================================================ producer =======================================================================
         // lane = 4 gp + gq: pixel gp of a 16-pixel unit, quarter gq; a corner's 128-byte channel slab arrives as two instructions of 64 contiguous
@@ -321,10 +323,10 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
             uint8_t* const bs_ = smem + (SLOT_) * BBUF;                                                                            \
             _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                                       \
                 unsigned ph[4], pl[4];                                                                                             \
-                blend_part<NPL, 0>(X_[u], W_[u], ph, pl, rmax);                                                                    \
-                blend_part<NPL, 1>(X_[u], W_[u], ph, pl, rmax);                                                                    \
-                blend_part<NPL, 2>(X_[u], W_[u], ph, pl, rmax);                                                                    \
-                blend_part<NPL, 3>(X_[u], W_[u], ph, pl, rmax);                                                                    \
+                blend_part<NPL, 0>(X_[u], W_[u], ph, pl, rmax, rnan);                                                                    \
+                blend_part<NPL, 1>(X_[u], W_[u], ph, pl, rmax, rnan);                                                                    \
+                blend_part<NPL, 2>(X_[u], W_[u], ph, pl, rmax, rnan);                                                                    \
+                blend_part<NPL, 3>(X_[u], W_[u], ph, pl, rmax, rnan);                                                                    \
                 *reinterpret_cast<u32x2_*>(bs_ + st_w0 + u * 1024) = u32x2_{ph[0], ph[1]};                                         \
                 *reinterpret_cast<u32x2_*>(bs_ + st_w1 + u * 1024) = u32x2_{ph[2], ph[3]};                                         \
                 if constexpr (NPL == 2) {                                                                                          \
@@ -378,7 +380,8 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
 #undef DF_PROD
 #undef DF_BLEND
 #undef DF_GATHER
-        if (rmax > 65504.0f && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
+        // the planes' range guard, same predicate as f16_range_check8 (|v| > 65504, inf or NaN)
+        if ((rmax > 65504.0f || !(rnan.x == 0.0f && rnan.y == 0.0f)) && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the rings' last (unused) slabs have landed before the LDS is reused
     } else {
         // ================================================ consumer =======================================================================

@@ -88,11 +88,7 @@ class DetectionGatherer:
         if self.mode == 3:
             self.n_collectives += 1
             return all_gather_detections(packed)
-        if self._comm is None:
-            # a stream that runs beside the main stream AND beside the two trunk streams of the pipeline (streams that share a hardware queue
-            # serialise: pipeline.concurrent_side_streams) -- the exchange must not queue up behind the next frame's trunk
-            from .pipeline import concurrent_side_streams
-            self._comm = concurrent_side_streams(packed.device, 3)[2]
+        self.comm_stream(packed.device)
         main = torch.cuda.current_stream()
         self._comm.wait_stream(main)
         with torch.cuda.stream(self._comm):
@@ -112,6 +108,15 @@ class DetectionGatherer:
         self._events = [ev]
         self.n_collectives += 1
         return out
+
+    def comm_stream(self, device):
+        """The communication stream: one that runs beside the main stream AND beside every trunk stream of the pipeline (streams that share a
+        hardware queue serialise: pipeline.concurrent_side_streams) -- the exchange must not queue up behind a prefetched trunk.  The pipelines
+        rotate their trunks over the first trunk_stream_count() streams of that list; the gather takes the one after them."""
+        if self._comm is None:
+            from .pipeline import concurrent_side_streams, trunk_stream_count
+            self._comm = concurrent_side_streams(device, trunk_stream_count() + 1)[-1]
+        return self._comm
 
     def wait(self):
         """Host-side: the last gather() has completed."""

@@ -117,6 +117,9 @@ class Detect_TF(object):
         self.nms_thresh, self.conf_thresh = nms_thresh, conf_thresh
         self.use_cross_class_nms = True
         self.use_fast_nms = True
+        # per-class Fast NMS ranks by conf * centerness in Detect_TF (detection_TF.py:139-141) but by the raw class confidences in the non-TF
+        # Detect (detection.py:211-212, no centerness argument, no 'centerness' key in its output): Detect clears this on its inner detector
+        self.pc_centerness = True
         self.cfg = cfg or _default_cfg
 
     def __call__(self, net, candidates, is_output_candidate=False):
@@ -162,6 +165,8 @@ class Detect_TF(object):
                  second_threshold=True):
         if not second_threshold:
             raise NotImplementedError("the reference always applies the second threshold")
+        if not self.pc_centerness:
+            centerness_scores = None
         idx, cls, score, _, count = ops.fast_nms(conf, boxes, centerness_scores, iou_threshold, top_k, self.conf_thresh,
                                                  self.cfg.max_num_detections)
         n = int(count)
@@ -280,6 +285,7 @@ class Detect(object):
         self.use_fast_nms = True
         self.cfg = cfg or _default_cfg
         self._tf = Detect_TF(num_classes, bkg_label, top_k, conf_thresh, nms_thresh, cfg=self.cfg)
+        self._tf.pc_centerness = False       # detection.py:130: fast_nms(boxes, masks_coeff, track, scores, ...) -- centerness only reaches cc_fast_nms
 
     def __call__(self, predictions, net):
         cfg = self.cfg

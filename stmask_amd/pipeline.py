@@ -143,7 +143,7 @@ def concurrent_side_streams(dev, n=2):
     key = (dev.index, main.cuda_stream)
     have = _SIDE_STREAMS.get(key, [])
     if len(have) >= n:
-        return have[:n]                              # (the list only grows: the first two are the trunk streams, a third serves the detection gather)
+        return have[:n]                              # (the list only grows: the first trunk_stream_count() are the trunk streams, the one after them serves the detection gather)
     cands = [torch.cuda.Stream(device=dev) for _ in range(16)]
     chosen = list(have)
     spin = getattr(torch.cuda, "_sleep", None)
@@ -173,6 +173,11 @@ def concurrent_side_streams(dev, n=2):
             chosen.append(c)
     _SIDE_STREAMS[key] = chosen
     return chosen[:n]
+
+
+def trunk_stream_count():
+    """How many of concurrent_side_streams()'s streams the pipelines rotate their prefetched trunks over (dist.DetectionGatherer takes the next one)."""
+    return max(2, BatchedClipPipeline.PREFETCH_DEPTH)
 
 
 class BatchedClipPipeline:
@@ -205,6 +210,7 @@ class BatchedClipPipeline:
         self._graph_next = 0
         self._graph_warm = 0
         self._graph_ws = []          # per slot: the workspaces its captured graph writes into (kept alive here)
+        self._graph_planes = None    # plane format of the net's inference graph when the slots were captured (a net may serve several pipelines: _trunk)
         # Workload knob of the benchmark ("a max_instances cap to study n ~ 5-10, the realistic regime"), NOT
         # a reference semantic: the reference's tracker never prunes (track_TF.py:132-165).  n > 0: at most n detections per frame
         # (the best-scoring ones: Fast NMS returns them sorted) and at most n tracked instances per clip (an unmatched detection
@@ -290,6 +296,13 @@ class BatchedClipPipeline:
         if not (self.use_graph and getattr(net, "_planar", None) is not None and not self.timer.on and ops._conv_timing is None
                 and ops._im2col_timing is None):
             return net.forward_single(frames)
+        planes = getattr(net, "_planar_planes", None)
+        if self._graphs and self._graph_planes != planes:
+            # another pipeline on the same net fell back to bf16x3 planes (_fall_back swaps the net's inference graph): this pipeline's captured trunks
+            # still replay the fp16 graph they were captured from -- drop them (with their private pools) and capture again on the net's current graph
+            self._pending = []
+            torch.cuda.synchronize()
+            self._graphs, self._graph_next, self.graph_active, self._graph_warm, self._graph_ws = [], 0, False, 0, []
         if self._graph_warm < 2:
             # eager first: packs the weights, sizes the workspaces, fills the prior cache, reserves the kernels' LDS
             self._graph_warm += 1
@@ -311,6 +324,7 @@ class BatchedClipPipeline:
                     out = net.forward_single(static_in)
             cur.wait_stream(cap)
             self._graphs.append((static_in, graph, out))
+            self._graph_planes = planes
             self.graph_active = True
         static_in, graph, out = self._graphs[self._graph_next]
         self._graph_next = (self._graph_next + 1) % self.N_GRAPH_SLOTS
@@ -336,7 +350,7 @@ class BatchedClipPipeline:
             if f is None or any(p[0] is f for p in self._pending):
                 continue
             if not self._sides:
-                self._sides = concurrent_side_streams(f.device, max(2, self.PREFETCH_DEPTH))
+                self._sides = concurrent_side_streams(f.device, trunk_stream_count())
             side = self._sides[self._side_next]
             self._side_next = (self._side_next + 1) % len(self._sides)
             side.wait_stream(main)
@@ -378,8 +392,10 @@ class BatchedClipPipeline:
         if getattr(det, "use_cross_class_nms", True):
             # (the softmax of STMask.py:314 is taken per row inside the candidate pass: no pass over the [B, N, 41] logits of its own)
             return ops.detect_cc(pred["loc"], priors, pred["conf"], pred["centerness"], cfg.eval_conf_thresh, cfg.nms_thresh, cfg.nms_top_k, logits=True)
-        return ops.detect_pc(pred["loc"], priors, F.softmax(pred["conf"], -1), pred["centerness"], cfg.eval_conf_thresh, cfg.nms_thresh, cfg.nms_top_k,
-                             cfg.max_num_detections)
+        # (per-class ranking: conf * centerness in Detect_TF.fast_nms, detection_TF.py:139-141; the raw confidences in the non-TF Detect.fast_nms,
+        # detection.py:211-212)
+        return ops.detect_pc(pred["loc"], priors, F.softmax(pred["conf"], -1), pred["centerness"] if self.tf else None, cfg.eval_conf_thresh, cfg.nms_thresh,
+                             cfg.nms_top_k, cfg.max_num_detections)
 
     @torch.no_grad()
     def step(self, frames, is_first=None, next_frames=None):

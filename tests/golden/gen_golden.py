@@ -169,6 +169,26 @@ def gen_postproc():
     save("postproc.npz", **out)
 
 
+def gen_postproc_nontf():
+    """Row a18's per-class Fast NMS: the reference's own Detect.fast_nms (detection.py:211-261) -- which, unlike Detect_TF.fast_nms, ranks by the
+    raw class confidences WITHOUT centerness -- on the stored inputs of postproc.npz (outputs only go into postproc_nontf.npz)."""
+    from datasets.config import cfg, set_cfg
+    set_cfg("STMask_plus_resnet50_config")
+    from layers.functions import Detect
+    z = np.load(os.path.join(HERE, "postproc.npz"))
+    out = {}
+    for case in range(3):
+        p = f"c{case}_"
+        conf, boxes = torch.from_numpy(z[p + "conf"]), torch.from_numpy(z[p + "boxes"])
+        coeff = torch.from_numpy(z[p + "mask_coeff"])
+        track = torch.nn.functional.normalize(torch.randn(conf.shape[0], 8), dim=-1)        # (carried along only)
+        keep = conf[:, 1:].max(1)[0] > cfg.nms_conf_thresh                                   # Detect.detect, detection.py:104-108
+        det = Detect(cfg.num_classes, bkg_label=0, top_k=cfg.nms_top_k, conf_thresh=cfg.nms_conf_thresh, nms_thresh=cfg.nms_thresh)
+        r = det.fast_nms(boxes[keep], coeff[keep], track[keep], conf[keep, 1:].t().contiguous(), det.nms_thresh, det.top_k)
+        out.update({p + "pcn_box": r["box"], p + "pcn_class": r["class"], p + "pcn_score": r["score"], p + "pcn_mask_coeff": r["mask_coeff"]})
+    save("postproc_nontf.npz", **out)
+
+
 def gen_priors():
     from datasets.config import cfg, set_cfg
     set_cfg("STMask_plus_resnet50_config")
@@ -333,6 +353,8 @@ def main():
     which = sys.argv[1:] or ["postproc", "priors", "fcb_ali", "model"]
     if "postproc" in which:
         gen_postproc()
+    if "postproc_nontf" in which:
+        gen_postproc_nontf()
     if "priors" in which:
         gen_priors()
     if "fcb_ali" in which:

@@ -472,6 +472,30 @@ def test_per_class_fast_nms_bit_exact(golden_postproc, p):
 
 
 @pytest.mark.parametrize("p", CASES)
+def test_per_class_fast_nms_non_tf_golden(golden_postproc, p):
+    """Row a18: Detect.fast_nms (detection.py:211-261) ranks WITHOUT centerness -- the layer API's non-TF detector and the batched op against the
+    reference's own outputs (tests/golden/postproc_nontf.npz)."""
+    from conftest import load_golden
+    from stmask_amd.config import get_cfg
+    from stmask_amd.layers.functions import Detect
+    g, gn = golden_postproc, load_golden("postproc_nontf.npz")
+    cfg = get_cfg("STMask_plus_resnet50_config")
+    det = Detect(cfg.num_classes, 0, cfg.nms_top_k, cfg.nms_conf_thresh, cfg.nms_thresh, cfg=cfg)
+    det.use_cross_class_nms = False
+    preds = {"loc": g[p + "loc"][None].to(DEV), "conf": g[p + "conf"][None].to(DEV), "priors": g["priors"][None].to(DEV),
+             "mask_coeff": g[p + "mask_coeff"][None].to(DEV), "track": torch.zeros(1, g[p + "loc"].shape[0], 8, device=DEV),
+             "centerness": g[p + "centerness"][None].to(DEV), "proto": g[p + "proto"][None].to(DEV)}
+    out = det(preds, None)[0]["detection"]
+    assert torch.equal(out["score"].cpu(), gn[p + "pcn_score"]) and torch.equal(out["class"].cpu(), gn[p + "pcn_class"])
+    assert torch.equal(out["mask_coeff"].cpu(), gn[p + "pcn_mask_coeff"])
+    assert (out["box"].cpu() - gn[p + "pcn_box"]).abs().max().item() <= 2.4e-7        # (decode: <= 4 ULP of w / h from the reference's MKL exp)
+    # the batched op with centerness = None: the same rows
+    idx, cls, sc, bx, cnt = ops.detect_pc(preds["loc"], preds["priors"][0], preds["conf"], None, 0.05, 0.5, 200, 100)
+    n = int(cnt[0])
+    assert n == len(gn[p + "pcn_class"]) and torch.equal(sc[0, :n].cpu(), gn[p + "pcn_score"]) and torch.equal(cls[0, :n].cpu(), gn[p + "pcn_class"])
+
+
+@pytest.mark.parametrize("p", CASES)
 def test_jaccard_bit_exact(golden_postproc, p):
     cb = golden_postproc[p + "cand_box"]
     got = ops.jaccard(cb[:64].to(DEV), cb[:96].to(DEV)).cpu()

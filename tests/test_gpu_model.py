@@ -433,3 +433,17 @@ def test_batched_pipeline_trunk_from_hip_graphs_equals_eager():
         assert graphed.graph_active and len(graphed._graphs) == BatchedClipPipeline.N_GRAPH_SLOTS
         assert len(graphed._sides) == (0 if depth == 0 else max(2, BatchedClipPipeline.PREFETCH_DEPTH))          # the look-ahead trunks rotate over the side streams
         assert not eager.graph_active
+
+
+def test_detection_gather_stream_is_not_a_trunk_stream():
+    """The all-gather's communication stream must be none of the streams the pipeline rotates its prefetched trunks over (at the default
+    look-ahead of three trunks the gather used to share a stream with every third trunk), nor the main stream."""
+    from stmask_amd.dist import DetectionGatherer
+    from stmask_amd.pipeline import concurrent_side_streams, trunk_stream_count
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sides = concurrent_side_streams(dev, trunk_stream_count())
+    comm = DetectionGatherer(dev).comm_stream(dev)
+    assert len(sides) == trunk_stream_count() >= 2
+    assert all(comm != s for s in sides) and comm != torch.cuda.current_stream(dev)
+    # asking for the trunk streams again (a second pipeline in the process) returns the same ones, still without the gather's
+    assert concurrent_side_streams(dev, trunk_stream_count()) == sides

@@ -40,3 +40,37 @@ def test_the_lint_sees_the_round3_sequence(tmp_path):
     lint = os.path.join(ROOT, "scripts", "lint_store_war.py")
     assert subprocess.run([sys.executable, lint, str(bad)], capture_output=True).returncode == 1
     assert subprocess.run([sys.executable, lint, str(good)], capture_output=True).returncode == 0
+
+
+# Kernels whose ring protocols count vector-memory operations by hand (`s_waitcnt vmcnt(N)` with N derived from the DMAs / gathers the source issues):
+# a compiler-inserted scratch spill or reload is a vector-memory operation nobody counted, and the protocol would then certify a slab that has
+# not landed -- silently.  Their code objects must therefore use no private segment at all (and the other hot kernels none either: a scratch
+# reload is a vmcnt(0)-class wait behind every store in flight, csrc/conv_chain.hip's history).
+COUNTED_WAIT_KERNELS = {"dcn_fused.s": ("dcn_fused_kernel",), "conv_chain.s": ("conv_chain_kernel",), "conv_kxr.s": ("conv_kxr_kernel",),
+                        "conv_bf16x.s": ("conv_planar_kernel", "conv_planar_kx3_kernel"), "stem_fused.s": ("stem_fused_kernel",)}
+
+
+def _kernel_metadata(path):
+    """(.name, {field: int}) for every kernel of the listing's amdhsa.kernels metadata."""
+    out, cur = [], None
+    for line in open(path):
+        t = line.strip()
+        if t.startswith(".name:") and "_Z" in t:
+            cur = (t.split(":", 1)[1].strip(), {})
+            out.append(cur)
+        elif cur is not None and ":" in t and t.split(":", 1)[0] in (".private_segment_fixed_size", ".sgpr_spill_count", ".vgpr_spill_count"):
+            cur[1][t.split(":", 1)[0]] = int(t.split(":", 1)[1])
+    return out
+
+
+def test_counted_wait_kernels_use_no_scratch():
+    files = {os.path.basename(f): f for f in _listings()}
+    seen = 0
+    for fname, kernels in COUNTED_WAIT_KERNELS.items():
+        for name, meta in _kernel_metadata(files[fname]):
+            if not any(k in name for k in kernels):
+                continue
+            seen += 1
+            # (SGPR spills go to VGPR lanes -- v_writelane / v_readlane, no memory operation -- and are not counted by vmcnt)
+            assert meta.get(".private_segment_fixed_size") == 0 and meta.get(".vgpr_spill_count") == 0, (name, meta)
+    assert seen >= 20        # (8 dcn_fused + 3 conv_chain + the conv_kxr / conv_planar instantiations)

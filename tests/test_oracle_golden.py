@@ -87,6 +87,19 @@ def test_per_class_fast_nms_bit_exact(golden_postproc, p):
 
 
 @pytest.mark.parametrize("p", CASES)
+def test_per_class_fast_nms_non_tf_ranks_without_centerness(golden_postproc, p):
+    """detection.py:211-261 (row a18): the non-TF Detect.fast_nms takes no centerness -- goldens from the reference's own method
+    (tests/golden/gen_golden.py postproc_nontf), and the host mirror's Detect must go the same way."""
+    from conftest import load_golden
+    g, gn = golden_postproc, load_golden("postproc_nontf.npz")
+    idx, cls, sc = oracle.fast_nms(g[p + "cand_conf"], g[p + "cand_box"], None, 0.5, 200, 0.05, 100)
+    assert len(idx) == len(gn[p + "pcn_class"]) and len(idx) > 0
+    assert torch.equal(sc, gn[p + "pcn_score"]) and torch.equal(cls, gn[p + "pcn_class"])
+    assert torch.equal(g[p + "cand_box"][idx], gn[p + "pcn_box"])
+    assert not torch.equal(sc[:8], g[p + "pc_score"][:8])             # (the Detect_TF variant scores differently: the two goldens are not the same test)
+
+
+@pytest.mark.parametrize("p", CASES)
 def test_generate_mask_within_tolerance(golden_postproc, p):
     """mask_utils.py:111-128; tolerance 1e-5 abs (reference matmul is fp32 MKL, oracle accumulates in double)."""
     g = golden_postproc
