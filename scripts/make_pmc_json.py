@@ -48,9 +48,9 @@ def main():
             return None
         return {"launches": nf, "fetch_bytes_per_launch": fb / nf, "write_bytes_per_launch": wb / nw, "traffic_bytes_per_launch": fb / nf + wb / nw}
 
-    g = group_any(("conv_planar_kernel", "conv_planar_kx3_kernel", "conv_kxr_kernel"))   # (bench.py pmc_traffic("conv_planar"))
+    g = group_any(("conv_planar_kernel", "conv_planar_kx3_kernel", "conv_kxr_kernel", "conv_chain_kernel"))   # (the launches of bench.py's roofline object: pmc_traffic("conv_planar"))
     if g:
-        doc["conv_planar"] = {"kernel": "conv_planar_kernel<*> + conv_planar_kx3_kernel + conv_kxr_kernel<*> (all launches of bench.py at batch 32, fp16x2 plane format)", **g}
+        doc["conv_planar"] = {"kernel": "conv_planar_kernel<*> + conv_planar_kx3_kernel + conv_kxr_kernel<*> + conv_chain_kernel<*> (all launches of bench.py at batch 32, fp16x2 plane format; the split-K finishing launches ride inside their layer's events and are not counted as launches)", **g}
     g = group("conv_planar_kx3_kernel")
     if g:
         doc["conv_planar_kx3"] = {"kernel": "conv_planar_kx3_kernel (stride-1 kw = 3 layers on 256-pixel tiles: head towers, proto-net, FPN 3x3; kx-reuse staging)", **g}
@@ -61,6 +61,22 @@ def main():
     g = group("stem_fused_kernel")
     if g:
         doc["stem_fused"] = {"kernel": "stem_fused_kernel (32 frames 384x640: 94 MB in, 126 MB of planes out)", **g}
+    # launches per step of the profiled run, from that run's own result line (the last JSON line of pmc_fetch.log): bench.py refuses the file when a
+    # later run's counts disagree (benchlib/roofline.py pmc_traffic)
+    line = None
+    try:
+        for ln in open(os.path.join(out, "pmc_fetch.log"), errors="replace"):
+            if ln.lstrip().startswith("{") and '"metric"' in ln:
+                line = json.loads(ln)
+    except (OSError, ValueError):
+        line = None
+    if line is not None:
+        for grp, key in (("conv_planar", "roofline"), ("dcn_fused", "roofline_dcn_fused"), ("dcn_sample_planar", "roofline_im2col")):
+            lps = (line.get(key) or {}).get("launches_per_step")
+            if grp in doc and lps is not None:
+                doc[grp]["launches_per_step"] = lps
+        doc["profiled_run"] = {"steps": line.get("steps"), "warmup": line.get("warmup"), "workload": line.get("config", {}).get("workload"),
+                               "value": line.get("value")}
     doc["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 4 --warmup 2` (scripts/gpu_round.sh pmc); "
                      "counters are KiB; FETCH_SIZE doubled per the gfx950 correction (MI355X guide, HBM section); WRITE_SIZE exact for 16-byte streaming stores")
     per = {}

@@ -321,6 +321,45 @@ def gen_model_full(cfg_name, tag, hw=(384, 640), row_step=16):
     save(f"model_full_{tag}.npz", **out)
 
 
+def gen_model_full_tf(cfg_name, tag, hw=(384, 640), n_frames=3, n_masks=32):
+    """frames 0..2 of a FULL-SIZE clip through the reference's eval forward (STMask.py:310-329) with the benchmark's weights:
+    frame 0 detects, frames 1-2 run CandidateShift (TF_utils.py:12-51: correlation, RoIAlign, TemporalNet, decode, lincomb on the current
+    prototypes) and Track_TF.track (track_TF.py:50-181: comp scores, greedy resolution, ids, keep rule) on ~100 tracked instances.  Stored per
+    frame: every tracked instance's box / score / class / id / coefficients / centerness, float64 checksums (sum, sum of squares, count of pixels
+    > 0.5) of EVERY soft mask, the first n_masks soft masks whole, and checksums of the frame's head outputs."""
+    from datasets.config import cfg, set_cfg
+    set_cfg(cfg_name)
+    cfg.temporal_fusion_module = True
+    import STMask as stmask_mod
+    net = stmask_mod.STMask()
+    net.eval()
+    synthetic.fill_state_dict(net, seed=0, bg_bias=synthetic.BENCH_BG_BIAS)
+    frames = synthetic.synthetic_clip(n_frames, hw[0], hw[1], seed=0)
+    out = {"frames_hw": np.array(hw), "n_frames": np.array(n_frames), "n_masks": np.array(n_masks)}
+    with torch.no_grad():
+        for t in range(n_frames):
+            _, po = net.forward_single(frames[t:t + 1])
+            for k in ("loc", "conf", "mask_coeff", "centerness", "proto"):
+                v = po[k][0].double()
+                out[f"t{t}_sum_{k}"] = np.array([v.sum().item(), v.abs().sum().item()])
+            res = net(frames[t:t + 1], img_meta=[{"is_first": t == 0, "video_id": 0, "frame_id": t}])[0]["detection"]
+            for k in ("box", "score", "class", "box_ids", "mask_coeff", "centerness"):
+                out[f"t{t}_{k}"] = res[k]
+            m = res["mask"].double()
+            out[f"t{t}_mask_sums"] = torch.stack([m.sum(dim=(1, 2)), m.pow(2).sum(dim=(1, 2)), (m > 0.5).double().sum(dim=(1, 2))], 1)
+            out[f"t{t}_mask"] = res["mask"][:n_masks]
+            # the tracker's whole state after the frame (row = instance id): what CandidateShift moved and Track_TF.track matched / appended,
+            # including the instances the keep rule (track_TF.py:168-178) holds back from the output
+            st = net.Track_TF.prev_candidate
+            for k in ("box", "score", "class", "mask_coeff", "tracked_mask"):
+                out[f"t{t}_state_{k}"] = st[k]
+            ms = st["mask"].double()
+            out[f"t{t}_state_mask_sums"] = torch.stack([ms.sum(dim=(1, 2)), ms.pow(2).sum(dim=(1, 2)), (ms > 0.5).double().sum(dim=(1, 2))], 1)
+            print(tag, "state rows", len(st["box"]))
+            print(tag, "full-size TF frame", t, "tracked", len(res["box"]), "ids", int(res["box_ids"].max()) + 1 if len(res["box"]) else 0)
+    save(f"model_full_tf_{tag}.npz", **out)
+
+
 from synth_results import synth_video_results  # noqa: E402  (tests/golden/synth_results.py, shared with the test)
 
 
@@ -371,6 +410,9 @@ def main():
         gen_model_full("STMask_plus_resnet50_config", "r50_fca")
         gen_model_full("STMask_plus_resnet50_ada_config", "r50_ada")
         gen_model_full("STMask_plus_base_ali_config", "r101_ali")
+    if "model_full_tf" in which:
+        gen_model_full_tf("STMask_plus_resnet50_config", "r50_fca")
+        gen_model_full_tf("STMask_plus_resnet50_ada_config", "r50_ada")
     if "model_full_720p" in which:
         gen_model_full("STMask_plus_base_ali_config", "r101_ali_736x1280", hw=(736, 1280), row_step=64)
     if "model_extra" in which:

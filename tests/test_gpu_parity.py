@@ -429,3 +429,55 @@ def test_trunk_branches_in_the_graph_are_bit_equal_to_the_plain_order(monkeypatc
     assert len(keeps[0]) == len(keeps[1]) >= 9          # warm-up + timed steps (+ the untimed steps during which the remaining graph slots are captured)
     for t, (a, b) in enumerate(zip(*keeps)):
         assert torch.equal(a, b), f"step {t}: max abs diff {(a - b).abs().max().item()}"
+
+
+# ------------------------------------------------------------------------------------------------- full-size temporal fusion
+FULL_TF = [("STMask_plus_resnet50_config", "r50_fca"), ("STMask_plus_resnet50_ada_config", "r50_ada")]
+
+
+@pytest.mark.parametrize("name,tag", FULL_TF)
+def test_full_size_temporal_fusion_clip_matches_reference(name, tag):
+    """Frames 0..2 of a FULL-SIZE 384x640 clip (the benchmark's weights) through the pipeline bench.py times, against the reference's own eval forward
+    (gen_golden.py model_full_tf): frame 0 detects, frames 1-2 run CandidateShift (TF_utils.py:12-51) and Track_TF.track (track_TF.py:50-181) on the
+    whole tracked set (~40 instances on R50-FCA, 120-200 on FCB-ada).  Checked per frame: the tracker's WHOLE state row by row (row = instance id:
+    classes and frames-since-match counters equal, boxes / scores 5e-6, every soft mask's float64 sum and > 0.5 pixel count), then the reported
+    instances (ids equal, boxes 5e-6, the stored soft masks 1e-4 RMS).  Two clips per step: batching must not couple them."""
+    from stmask_amd.pipeline import BatchedClipPipeline
+    g = load_golden(f"model_full_tf_{tag}.npz")
+    h, w = [int(v) for v in g["frames_hw"]]
+    T, n_masks = int(g["n_frames"]), int(g["n_masks"])
+    net = build(name, bg_bias=synthetic.BENCH_BG_BIAS, planar="fp16x2")
+    clips = torch.stack([synthetic.synthetic_clip(T, h, w, seed=s) for s in (0, 2)]).cuda()
+    frames = [clips[:, t].contiguous(memory_format=torch.channels_last) for t in range(T)]
+    pipe = BatchedClipPipeline(net, 2)
+    rep = {}
+    for t in range(T):
+        pipe.step(frames[t], is_first=(t == 0), next_frames=frames[t + 1] if t + 1 < T else None)
+        det = pipe.detections()[0]
+        # -- the tracker's state of clip 0: rows [0, prev_n[0])
+        n = pipe.prev_n[0]
+        ref_n = g[f"t{t}_state_box"].shape[0]
+        assert n == ref_n, (tag, t, n, ref_n)
+        st = {k: pipe.prev[k][:n].cpu() for k in ("box", "score", "class", "mask")}
+        assert st["class"].tolist() == g[f"t{t}_state_class"].tolist(), (tag, t)
+        assert list(pipe.tracked[0]) == [int(v) for v in g[f"t{t}_state_tracked_mask"].tolist()], (tag, t)
+        sb = (st["box"] - g[f"t{t}_state_box"]).abs().max().item()
+        ss = (st["score"] - g[f"t{t}_state_score"]).abs().max().item()
+        assert sb < 5e-6 and ss < 5e-6, (tag, t, sb, ss)
+        ms, ref_ms = st["mask"].double(), g[f"t{t}_state_mask_sums"]
+        area = ref_ms[:, 0].clamp(min=1.0)
+        d_sum = ((ms.sum(dim=(1, 2)) - ref_ms[:, 0]).abs() / area).max().item()
+        d_cnt = ((ms > 0.5).double().sum(dim=(1, 2)) - ref_ms[:, 2]).abs().max().item()
+        # a crop edge may move by one pixel row / column when a box moves by 1e-6 (soft_mask_delta): the sums get the perimeter's worth of slack
+        assert d_sum < 2e-2 and d_cnt <= 2 * (ms.shape[1] + ms.shape[2]), (tag, t, d_sum, d_cnt)
+        # -- the reported instances
+        assert det["box_ids"].cpu().tolist() == g[f"t{t}_box_ids"].tolist(), (tag, t)
+        assert det["class"].cpu().tolist() == g[f"t{t}_class"].tolist(), (tag, t)
+        bd = (det["box"].cpu() - g[f"t{t}_box"]).abs().max().item()
+        assert bd < 5e-6, (tag, t, bd)
+        rms, mx, edge = soft_mask_delta(det["mask"].cpu()[:n_masks], g[f"t{t}_mask"])
+        assert rms.max().item() < 1e-4 and mx.max().item() < 2e-4, (tag, t, rms.max().item(), mx.max().item())
+        rep[f"t{t}"] = dict(state_rows=n, reported=len(g[f"t{t}_box_ids"]), state_box=sb, state_score=ss, mask_sum_rel=d_sum, mask_count=d_cnt, box=bd,
+                            mask_rms=rms.max().item(), mask_abs=mx.max().item(), crop_edge_pixels=int(edge.max()))
+    assert rep[f"t{T - 1}"]["state_rows"] > rep["t0"]["state_rows"]          # the later frames DID run the temporal fusion on a grown tracked set
+    report(f"full_tf_{tag}", **rep)

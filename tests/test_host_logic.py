@@ -93,3 +93,48 @@ def test_bench_defaults_of_round_5():
     a = bench.parse_args([])
     assert a.overlap == "early" and not a.events_in_timed_region and not a.no_sampler_pass and a.gpus == 1
     assert bench.parse_args(["--events-in-timed-region", "--overlap", "late"]).events_in_timed_region
+
+
+def test_bench_defaults_of_round_6():
+    """The bare `python bench.py` also runs the sustained line and one short line per remaining BASELINE configuration."""
+    import bench
+    names = bench.parse_args([]).extras.split(",")
+    assert {"sustained", "config3", "config4", "config5", "clips1", "clips8", "realistic"} <= set(names)
+    from benchlib.extras import CONFIG_LINES
+    assert [c[0] for c in CONFIG_LINES] == ["config3", "config4", "config5"]
+    assert CONFIG_LINES[2][3:6] == (736, 1280, "fp16x1")                      # BASELINE config 5: 720x1280 (padded to /32), fp16 backbone convolutions
+
+
+def test_rank_cpu_binding_helpers(tmp_path):
+    """benchlib.launch: a rank takes its share of the cores local to its GPU's NUMA node."""
+    from benchlib import launch
+    assert launch.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert launch.parse_cpulist("") == []
+    cores = list(range(0, 16)) + list(range(128, 144))
+    slices = [launch.rank_core_slice(cores, i, 4) for i in range(4)]
+    assert sum(slices, []) == cores and all(len(s) == 8 for s in slices)
+    assert launch.rank_core_slice([5, 6], 3, 4) == [6]                         # fewer cores than ranks: shared, never empty
+    d = tmp_path / "0000:c1:00.0"
+    d.mkdir()
+    (d / "local_cpulist").write_text("96-111,224-239\n")
+    assert launch.gpu_local_cpulist(0, 0xc1, 0, sysfs=str(tmp_path)) == list(range(96, 112)) + list(range(224, 240))
+    assert launch.gpu_local_cpulist(0, 0xc2, 0, sysfs=str(tmp_path)) == []
+
+
+def test_pmc_traffic_file_is_refused_when_its_launch_counts_disagree(tmp_path, monkeypatch):
+    """bench.py reads the HBM traffic of its kernels from a committed counter file: one that was collected on other launches must not be quoted."""
+    import json
+    from benchlib import roofline as rf
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "x.json").write_text(json.dumps({"conv_planar": {"traffic_bytes_per_launch": 4.4e8, "launches_per_step": 70.0},
+                                             "old": {"traffic_bytes_per_launch": 1.0e8}}))
+    monkeypatch.setattr(rf, "ROOT", str(tmp_path))
+    t, src, why = rf.pmc_traffic("conv_planar", 70.6, pmc_file="x.json")
+    assert t == 440000000 and src == "x.json" and why is None
+    t, src, why = rf.pmc_traffic("conv_planar", 81.0, pmc_file="x.json")       # another tile rule / fusion threshold: refused
+    assert t is None and "differ" in why
+    t, src, why = rf.pmc_traffic("old", 3.0, pmc_file="x.json")                # a file from before the check existed
+    assert t is None and "launches_per_step" in why
+    t, src, why = rf.pmc_traffic("missing", 3.0, pmc_file="x.json")
+    assert t is None and src is None
