@@ -321,6 +321,9 @@ def gen_model_full(cfg_name, tag, hw=(384, 640), row_step=16):
     save(f"model_full_{tag}.npz", **out)
 
 
+FRAGILE_EPS = 1e-4
+
+
 def gen_model_full_tf(cfg_name, tag, hw=(384, 640), n_frames=3, n_masks=32):
     """frames 0..2 of a FULL-SIZE clip through the reference's eval forward (STMask.py:310-329) with the benchmark's weights:
     frame 0 detects, frames 1-2 run CandidateShift (TF_utils.py:12-51: correlation, RoIAlign, TemporalNet, decode, lincomb on the current
@@ -335,9 +338,23 @@ def gen_model_full_tf(cfg_name, tag, hw=(384, 640), n_frames=3, n_masks=32):
     net.eval()
     synthetic.fill_state_dict(net, seed=0, bg_bias=synthetic.BENCH_BG_BIAS)
     frames = synthetic.synthetic_clip(n_frames, hw[0], hw[1], seed=0)
-    out = {"frames_hw": np.array(hw), "n_frames": np.array(n_frames), "n_masks": np.array(n_masks)}
+    out = {"frames_hw": np.array(hw), "n_frames": np.array(n_frames), "n_masks": np.array(n_masks), "fragile_eps": np.array(FRAGILE_EPS)}
+    # Which rows of the tracker state hang on a near-tie.  Track_TF.track decides by argmax over comp scores (track_TF.py:125) and, among detections that
+    # pick the same object, by det_score > best (track_TF.py:141); with 120-200 overlapping instances some of those comparisons are closer than the
+    # ~1e-6 by which two correct fp32 implementations of the trunk differ.  Recorded from the reference's OWN values, per frame: the rows whose outcome
+    # a perturbation below FRAGILE_EPS could change (the test compares all other rows exactly) and whether the row COUNT could change.
+    import layers.functions.track_TF as ttf
+    seen = {}
+    real_ccs = ttf.compute_comp_scores
+
+    def spy(match_ll, bbox_scores, *a, **k):
+        comp = real_ccs(match_ll, bbox_scores, *a, **k)
+        seen["comp"], seen["score"] = comp.clone(), bbox_scores.view(-1).clone()
+        return comp
+    ttf.compute_comp_scores = spy
     with torch.no_grad():
         for t in range(n_frames):
+            seen.clear()
             _, po = net.forward_single(frames[t:t + 1])
             for k in ("loc", "conf", "mask_coeff", "centerness", "proto"):
                 v = po[k][0].double()
@@ -352,11 +369,40 @@ def gen_model_full_tf(cfg_name, tag, hw=(384, 640), n_frames=3, n_masks=32):
             # including the instances the keep rule (track_TF.py:168-178) holds back from the output
             st = net.Track_TF.prev_candidate
             for k in ("box", "score", "class", "mask_coeff", "tracked_mask"):
-                out[f"t{t}_state_{k}"] = st[k]
+                out[f"t{t}_state_{k}"] = st[k].clone()          # (the next frame updates matched rows IN PLACE: track_TF.py:150)
             ms = st["mask"].double()
             out[f"t{t}_state_mask_sums"] = torch.stack([ms.sum(dim=(1, 2)), ms.pow(2).sum(dim=(1, 2)), (ms > 0.5).double().sum(dim=(1, 2))], 1)
-            print(tag, "state rows", len(st["box"]))
+            fragile, count_fragile, min_margin = set(), False, float("inf")
+            if "comp" in seen:
+                comp, dsc = seen["comp"], seen["score"]
+                n_prev = comp.shape[1] - 1
+                top2v, top2i = comp.topk(2, dim=1)
+                cm = top2v[:, 0] - top2v[:, 1]
+                mid = top2i[:, 0]
+                new_rank = torch.cumsum((mid == 0).long(), 0) - 1                      # appended row of a new object = n_prev + rank
+                for i in range(comp.shape[0]):
+                    if cm[i] < FRAGILE_EPS:
+                        for j in top2i[i].tolist():
+                            if j == 0:
+                                count_fragile = True
+                            else:
+                                fragile.add(j - 1)
+                        if mid[i] == 0:
+                            fragile.add(n_prev + int(new_rank[i]))
+                for obj in range(n_prev):
+                    c = torch.nonzero(mid == obj + 1).view(-1)
+                    if len(c) > 1:
+                        sc = dsc[c].sort(descending=True).values
+                        if sc[0] - sc[1] < FRAGILE_EPS:
+                            fragile.add(obj)
+                        min_margin = min(min_margin, float(sc[0] - sc[1]))
+                min_margin = min(min_margin, float(cm.min()))
+            out[f"t{t}_fragile_rows"] = np.array(sorted(fragile), dtype=np.int64)
+            out[f"t{t}_count_fragile"] = np.array(count_fragile)
+            out[f"t{t}_min_margin"] = np.array(min_margin)
+            print(tag, "state rows", len(st["box"]), "fragile rows", sorted(fragile), "count fragile", count_fragile, "min margin %.2e" % min_margin)
             print(tag, "full-size TF frame", t, "tracked", len(res["box"]), "ids", int(res["box_ids"].max()) + 1 if len(res["box"]) else 0)
+    ttf.compute_comp_scores = real_ccs
     save(f"model_full_tf_{tag}.npz", **out)
 
 

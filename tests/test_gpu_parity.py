@@ -458,19 +458,27 @@ def test_full_size_temporal_fusion_clip_matches_reference(name, tag):
         n = pipe.prev_n[0]
         ref_n = g[f"t{t}_state_box"].shape[0]
         assert n == ref_n, (tag, t, n, ref_n)
+        # rows whose match hangs on a comparison closer than fragile_eps (1e-4) IN THE REFERENCE'S OWN VALUES are recorded in the golden and excused;
+        # with these weights there are none (smallest margin 8e-4), so every row is compared
+        fragile = set(int(v) for v in g[f"t{t}_fragile_rows"].tolist())
+        assert len(fragile) <= max(1, n // 50) and not bool(g[f"t{t}_count_fragile"]), (tag, t, sorted(fragile))
+        ok = torch.tensor([i not in fragile for i in range(n)])
         st = {k: pipe.prev[k][:n].cpu() for k in ("box", "score", "class", "mask")}
-        assert st["class"].tolist() == g[f"t{t}_state_class"].tolist(), (tag, t)
-        assert list(pipe.tracked[0]) == [int(v) for v in g[f"t{t}_state_tracked_mask"].tolist()], (tag, t)
-        sb = (st["box"] - g[f"t{t}_state_box"]).abs().max().item()
-        ss = (st["score"] - g[f"t{t}_state_score"]).abs().max().item()
+        assert st["class"][ok].tolist() == g[f"t{t}_state_class"][ok].tolist(), (tag, t)
+        assert [v for i, v in enumerate(pipe.tracked[0]) if i not in fragile] == [int(v) for i, v in enumerate(g[f"t{t}_state_tracked_mask"].tolist())
+                                                                                    if i not in fragile], (tag, t)
+        sb = (st["box"] - g[f"t{t}_state_box"])[ok].abs().max().item()
+        ss = (st["score"] - g[f"t{t}_state_score"])[ok].abs().max().item()
         assert sb < 5e-6 and ss < 5e-6, (tag, t, sb, ss)
         ms, ref_ms = st["mask"].double(), g[f"t{t}_state_mask_sums"]
         area = ref_ms[:, 0].clamp(min=1.0)
-        d_sum = ((ms.sum(dim=(1, 2)) - ref_ms[:, 0]).abs() / area).max().item()
-        d_cnt = ((ms > 0.5).double().sum(dim=(1, 2)) - ref_ms[:, 2]).abs().max().item()
+        d_sum = ((ms.sum(dim=(1, 2)) - ref_ms[:, 0]).abs() / area)[ok].max().item()
+        d_cnt = ((ms > 0.5).double().sum(dim=(1, 2)) - ref_ms[:, 2]).abs()[ok].max().item()
         # a crop edge may move by one pixel row / column when a box moves by 1e-6 (soft_mask_delta): the sums get the perimeter's worth of slack
         assert d_sum < 2e-2 and d_cnt <= 2 * (ms.shape[1] + ms.shape[2]), (tag, t, d_sum, d_cnt)
         # -- the reported instances
+        if fragile:
+            continue
         assert det["box_ids"].cpu().tolist() == g[f"t{t}_box_ids"].tolist(), (tag, t)
         assert det["class"].cpu().tolist() == g[f"t{t}_class"].tolist(), (tag, t)
         bd = (det["box"].cpu() - g[f"t{t}_box"]).abs().max().item()
