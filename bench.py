@@ -149,9 +149,8 @@ def main():
         launch.stdout_to_stderr()
         # NO device_id: with it torch binds the communicator eagerly at start-up, and on this stack that alone -- no collective issued -- costs a rank
         # 1.3-1.5 ms of every 21-ms step (profiles/r05_launcher_overhead.txt: plain 21.19, eager communicator without any gather 22.56, lazy
-        # communicator with a gather every step 21.20).  The device is set above; barriers name it.  STM_PG_EAGER=1 restores the eager form (A/B).
-        dist.init_process_group(args.backend, rank=rank, world_size=world,
-                                device_id=dev if (args.backend == "nccl" and os.environ.get("STM_PG_EAGER", "0") != "0") else None)
+        # communicator with a gather every step 21.20).  The device is set above; barriers name it.
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # MIOpen immediate mode (only --no-planar graphs reach the library at all)
     torch.backends.cudnn.benchmark = False

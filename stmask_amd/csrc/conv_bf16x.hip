@@ -84,7 +84,7 @@ struct PlanarArgs {
     int x_np, out_np, res_np;                        // pixels per channel slab of the planar buffers
     int relu;
     int M, n_tiles, m_tiles, slabs;
-    int nsub;                // 0, or the channel tiles of one pixel tile that run TOGETHER on an XCD (STM_CONV_NSUB; see the tile map)
+    int nsub;                // 0, or the channel tiles of one pixel tile that run TOGETHER on an XCD (see the tile map)
     unsigned plane_bytes;   // bytes of one input plane that may be addressed (buffer range)
     long long x_pstride, out_pstride, res_pstride;   // bytes between planes
     int groups, ntpg, cout_g;                        // grouped conv: n-tiles per group, output channels per group
@@ -1754,16 +1754,16 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const float* __r
 std::atomic<long long> g_kx3_launches{0};      // stm_debug_launch_count(0)
 struct ConvTunables {
     int ring = 3;          // STM_CONV_RING: 2 = two-buffer loop on the 128-wide tiles, 3 = three-buffer ring (fp16 formats)
-    int ring64_small = 512; // STM_CONV_RING64_SMALL: grids up to this many workgroups take the ring on 128 x 64 tiles whatever K
+    int ring64_small = 512; // grids up to this many workgroups take the ring on 128 x 64 tiles whatever K (round 2 sweep; a switch until round 6)
     int ring64 = 3;        // STM_CONV_RING64: 2 never / 4 always the ring on 128 x 64 tiles, 3 = by K length (rule below)
     int splitk = 0;        // STM_CONV_SPLITK: force this many K parts (0 = rule)
-    int sk_rule = 0;       // STM_CONV_SK_RULE: 1 = round 1's split-K rule of the 64-wide tiles for every layer (A/B runs)
-    int sk_target = 256;   // STM_CONV_SK_TARGET: workgroups the split-K rule of the 64-wide tiles aims at (one per CU)
+    int sk_rule = 0;       // 1 = round 1's split-K rule of the 64-wide tiles for every layer (kept for the record; a switch until round 6)
+    int sk_target = 256;   // workgroups the split-K rule of the 64-wide tiles aims at (one per CU; a switch until round 6)
     int mg = 0;            // STM_CONV_MG: force 128 (1) or 256 (2) pixel tiles
-    long long nt_mb = 0;   // STM_CONV_NT: nontemporal plane stores for outputs of at least this many MB (0 = off; no gain measured)
-    int scalar_epilogue = 0;   // STM_CONV_SCALAR_EPILOGUE: element-wise epilogue stores (tests)
+    long long nt_mb = 0;   // nontemporal plane stores for outputs of at least this many MB (0 = off: no gain measured in rounds 2-4)
+    int scalar_epilogue = 0;   // element-wise epilogue stores (a cross-check form)
     int abl = 0;           // STM_CONV_ABL (builds with -DSTM_ABLATE only)
-    int nsub = 0;          // STM_CONV_NSUB: 2 / 4 = channel tiles of a pixel tile that share an XCD's L2 at one time (tile map of conv_planar_kernel)
+    int nsub = 0;          // 2 / 4 = channel tiles of a pixel tile that share an XCD's L2 at one time (regrouped tile map: no effect measured in round 4)
     int kx3 = 1;           // STM_CONV_KX3: 0 = stride-1 kw = 3 layers on the 256 x 128 ring tiles stay on conv_planar_kernel (1: conv_planar_kx3_kernel, kx-reuse staging)
 };
 ConvTunables read_tunables()
@@ -1772,16 +1772,12 @@ ConvTunables read_tunables()
     auto geti = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
     t.ring = (int)geti("STM_CONV_RING", t.ring);
     t.ring64 = (int)geti("STM_CONV_RING64", t.ring64);
-    t.ring64_small = (int)geti("STM_CONV_RING64_SMALL", t.ring64_small);
     t.splitk = (int)geti("STM_CONV_SPLITK", 0);
-    t.sk_target = (int)geti("STM_CONV_SK_TARGET", t.sk_target);
-    t.sk_rule = (int)geti("STM_CONV_SK_RULE", t.sk_rule);
     t.mg = (int)geti("STM_CONV_MG", 0);
-    t.nt_mb = geti("STM_CONV_NT", 0);
-    t.scalar_epilogue = (int)geti("STM_CONV_SCALAR_EPILOGUE", 0);
     t.kx3 = (int)geti("STM_CONV_KX3", t.kx3);
+#ifdef STM_ABLATE
     t.abl = (int)geti("STM_CONV_ABL", 0);
-    t.nsub = (int)geti("STM_CONV_NSUB", 0);
+#endif
     return t;
 }
 const ConvTunables& tunables()
@@ -2355,7 +2351,7 @@ int conv2d_planar_impl(const void* x_planes, const void* packed_weight, const fl
     const int mg = tn.mg ? tn.mg : (t2 >= 192 ? 2 : 1);
     a.m_tiles = stm_cdiv(M, CV_BM * mg);
     plan_splitk(a.m_tiles * a.n_tiles);
-    // regrouped tile map (STM_CONV_NSUB): whole groups of 32 / nsub pixel tiles -- the padding tiles leave at once
+    // regrouped tile map (nsub > 0): whole groups of 32 / nsub pixel tiles -- the padding tiles leave at once
     a.nsub = ((tn.nsub == 2 || tn.nsub == 4) && a.splitk == 1 && a.n_tiles > tn.nsub && a.n_tiles % tn.nsub == 0 && g->groups == 1 &&
               a.m_tiles >= 4 * (32 / tn.nsub)) ? tn.nsub : 0;
     if (a.nsub) a.m_tiles = stm_cdiv(a.m_tiles, 32 / a.nsub) * (32 / a.nsub);

@@ -606,7 +606,7 @@ extern "C" int stm_deform_conv_fused_planar_f32(const float* x, int x_ld, const 
     // tile shape: 64 pixels x 256 channels where the layer has them (every pixel is then sampled once, not once per 128 channels); STM_DCN_FUSED_WIDE=0: always 128 x 128
     const bool wide = Cout % 256 == 0 && STM_ENV_INT("STM_DCN_FUSED_WIDE", 1) != 0;
     const int TP = wide ? DfShape<1>::TP : DfShape<0>::TP, BN = wide ? DfShape<1>::BN : DfShape<0>::BN;
-    int th = STM_ENV_INT("STM_DCN_FUSED_TH", 0), tw = STM_ENV_INT("STM_DCN_FUSED_TW", 0);
+    int th = 0, tw = 0;
     if (th <= 0 || tw <= 0 || th * tw > TP) pick_patch(g->Ho, g->Wo, th, tw, TP);
     a.TH = th; a.TW = tw;
     a.tiles_y = stm_cdiv(g->Ho, th); a.tiles_x = stm_cdiv(g->Wo, tw);

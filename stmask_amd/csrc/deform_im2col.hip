@@ -1201,9 +1201,8 @@ extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const floa
     a.out_pstride = (out_plane_stride > 0 ? out_plane_stride : (long long)(K * g->C / 32) * a.out_np * 32) * 2;
     const int ppw = 512 / g->C;                                  // pixels per wave
     const int nblk = stm_cdiv(M, 4 * ppw);
-    // A/B switches, read from the environment once: STM_DCN_XCD (XCD-contiguous block order), STM_DCN_NT (nontemporal column
-    // stores), STM_DCN_PREFETCH (centre-pixel touch); all on by default
-    const int env_xcd = STM_ENV_INT("STM_DCN_XCD", 1), env_nt = STM_ENV_INT("STM_DCN_NT", -1), env_prefetch = STM_ENV_INT("STM_DCN_PREFETCH", 1);
+    // XCD-contiguous block order, nontemporal column stores (-1: by size), centre-pixel touch: A/B switches until round 6, all on since round 2
+    const int env_xcd = 1, env_nt = -1, env_prefetch = 1;
     a.xcd = env_xcd;
     // nontemporal column stores: 248 -> 115 us on layer2 at batch 32 together with the XCD order (5.6 TB/s algorithmic), but
     // 34 -> 45 us with 512 channels (one pixel per wave, 1-KB runs per tap) -- so up to 256 channels only
@@ -1253,11 +1252,11 @@ extern "C" int stm_deform_sample_planar_f32(const float* x, int x_ld, const floa
         }
     }
     const dim3 grid(a.xcd ? 8 * a.per_xcd : nblk);
-    // STM_DCN_VARIANT: 0 = the run-time-format kernel (rounds 1-3: 64 registers, 8 waves per SIMD); the straight-line fp16x2 kernel: 1 = registers as
+    // Sampler form: 0 = the run-time-format kernel (rounds 1-3: 64 registers, 8 waves per SIMD); the straight-line fp16x2 kernel: 1 = registers as
     // the compiler likes (116: 4 waves per SIMD, it hoists the next taps' loads by itself), 2 = explicit one-tap look-ahead (143: 3 waves).  Default
     // (-1): form 2 on the stride-2 layers of 256 / 512 channels, form 0 elsewhere -- profiles/r04_dcn_sampler_forms.txt: 123 vs 127 us and 65 vs 77 us
     // there, 20-50 % slower on the stride-1 layers; forms capped to 6 / 8 waves per SIMD spilled (148 / 220 B per lane) and ran at half the rate.
-    int variant = STM_ENV_INT("STM_DCN_VARIANT", -1);
+    int variant = -1;        // (-1: the rule below; 0 / 1 / 2 forced one form everywhere -- an environment switch until round 6)
     if (variant < 0) variant = (g->sh == 2 && g->C >= 256) ? 2 : 0;
     if (variant && fmt == 1 && has_mask && K == 9 && (g->C == 128 || g->C == 256 || g->C == 512)) {
 #define STM_DSV(LPP_) \

@@ -358,14 +358,14 @@ static int gemm_dispatch(const float* A, const float* Bmat, const float* bias, f
     STM_REQUIRE(batch <= 65535, STM_EINVAL, "stm_gemm_bias_f32: batch %d > 65535", batch);
     STM_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)Bmat % 16 == 0) && (b_bstride % 4 == 0 || N % 4 != 0),
                 STM_EINVAL, "stm_gemm_bias_f32: A and B must be 16-byte aligned");
-    const int forced = STM_ENV_INT("STM_GEMM_TILE", 0);          // A/B: force the 256- or 64-wide kernel
+    const int forced = 0;          // (A/B until round 6: force the 256- or 64-wide kernel)
     // 128^2 double-buffered kernel: needs whole 128-row tiles, float4-loadable A and B rows
     const bool ok128 = (M % 128 == 0) && (K % 32 == 0) && (N % 4 == 0) && (N >= 4) && (c_bstride % 4 == 0) && ((uintptr_t)Cmat % 16 == 0);
     if ((forced == 0 || forced == 256) && ok128) {
         const int nt = stm_cdiv(N, G2_BN);
         const int64_t blocks = (int64_t)nt * (M / G2_BM) * batch;
         int splitk = 1;
-        const int fs = STM_ENV_INT("STM_GEMM_SPLITK", 0);
+        const int fs = 0;
         if (fs > 0) splitk = fs;
         else while (splitk < 8 && blocks * splitk < 224 && K / (splitk * 2) >= 256) splitk *= 2;
         if (splitk > 1 && (!ws || ws_bytes < (size_t)splitk * batch * M * N * sizeof(float))) splitk = 1;

@@ -354,7 +354,7 @@ extern "C" int stm_roi_align_avg_f32(const float* feat, const float* rois, float
     STM_REQUIRE(feat && rois && out, STM_ENULL, "stm_roi_align_avg_f32: feat/rois/out must be non-NULL");
     STM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0, STM_EINVAL, "stm_roi_align_avg_f32: bad sizes");
     int64_t total = (int64_t)n * C * PH * PW;
-    const int xcd = STM_ENV_INT("STM_XCD_ORDER", 1);
+    const int xcd = 1;        // XCD-contiguous block order (a switch until round 6)
     hipLaunchKernelGGL(roi_align_avg_kernel, dim3(xcd ? stm_xcd_grid(stm_cdiv(total, 256)) : stm_cdiv(total, 256)), dim3(256), 0, stm_hs(stream),
                        feat, rois, out, C, H, W, n, PH, PW, spatial_scale, sampling_ratio, aligned, xcd);
     STM_CHECK_LAUNCH("roi_align_avg_kernel");

@@ -67,15 +67,14 @@ class DetectionGatherer:
     (or a device synchronisation) has returned."""
 
     def __init__(self, device=None):
-        import os
         self.device = device
         self._comm = None
         self._events = []
         self.n_collectives = 0          # all-gathers enqueued on the communication stream (the RCCL branch)
-        # diagnosis (scripts/ab_launcher_overhead.sh): 0 = as described above; 1 = two persistent output buffers, the packed block kept alive by a
+        # diagnosis forms (an environment switch in round 5, profiles/r05_launcher_overhead.txt; bench.py sets 2 for its no-gather pass): 0 = as described above; 1 = two persistent output buffers, the packed block kept alive by a
         # reference instead of record_stream; 2 = no collective at all (the process group exists, nothing is gathered); 3 = the collective on the
         # CURRENT stream (no communication stream)
-        self.mode = int(os.environ.get("STM_GATHER_MODE", "0"))
+        self.mode = 0
         self._outs, self._hold = [None, None], None
 
     def gather(self, packed):

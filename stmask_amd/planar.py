@@ -36,23 +36,25 @@ FMT = 0
 # Format of the ResNet backbone's convolutions when it differs from FMT (fuse: planes="fp16x1" -> backbone 2, the rest 1)
 BACKBONE_FMT = None
 
-# A/B switches, read once at import (never per call)
-TILE64_MAX_SLABS = int(os.environ.get("STM_TILE64_MAX_SLABS", "8"))
-FCB_PLANAR = os.environ.get("STM_FCB_PLANAR", "1") != "0"
-STEM_PLANAR = os.environ.get("STM_STEM_PLANAR", "1") != "0"
-C3DS_FUSED = os.environ.get("STM_C3DS_FUSED", "1") != "0"    # conv3 + projection shortcut of a stage's first block as one two-source product
-STEM_FUSED = os.environ.get("STM_STEM_FUSED", "1") != "0"    # conv1 + ReLU + max-pool as one kernel (csrc/stem_fused.hip)
-CONV_KXR = os.environ.get("STM_CONV_KXR", "1") != "0"     # narrow stride-1 layers on the kx-reuse kernel (csrc/conv_kxr.hip)
-TN_BORDER = os.environ.get("STM_TN_BORDER", "1") != "0"     # TemporalNet's 3x3 layers as nine window launches without the zero taps of the RoI borders
-TN_POOL = os.environ.get("STM_TN_POOL", "1") != "0"         # ... and its AvgPool2d in conv3's epilogue, fc + fc_coeff as one launch (needs TN_BORDER)
-CONV_CHAIN = os.environ.get("STM_CONV_CHAIN", "1") != "0"
+# Graph-construction choices.  Plain module constants since round 6 (environment switches STM_* in rounds 2-5; every default has held since it was
+# measured -- DESIGN.md section 9 keeps the A/B figures): tests that want the other form of a layer set the attribute.
+TILE64_MAX_SLABS = 8      # K-slab limit of the short-K rule of the 128 x 64 tiles
+FCB_PLANAR = True         # FCB class branch on the planar kernels
+STEM_PLANAR = True        # stem on the planar kernels
+C3DS_FUSED = True         # conv3 + projection shortcut of a stage's first block as one two-source product
+STEM_FUSED = True         # conv1 + ReLU + max-pool as one kernel (csrc/stem_fused.hip)
+CONV_KXR = True           # narrow stride-1 layers on the kx-reuse kernel (csrc/conv_kxr.hip)
+TN_BORDER = True          # TemporalNet's 3x3 layers as nine window launches without the zero taps of the RoI borders
+TN_POOL = True            # ... and its AvgPool2d in conv3's epilogue, fc + fc_coeff as one launch (needs TN_BORDER)
+CONV_CHAIN = True         # layer1's bottlenecks on csrc/conv_chain.hip
+# Environment switches that remain (read once at import, never per call): the fused deformable convolution and the chain kernel's mode
 # the deformable 3x3 layers (and the FCB class branch) as ONE kernel -- sampler -> plane split -> MFMA product, no column buffer (csrc/dcn_fused.hip) --
 # from DCN_FUSED_MIN_TILES workgroups on (below that the grid leaves CUs idle and the sampler + split-K product pair is faster); 0 = the pair everywhere
 DCN_FUSED = os.environ.get("STM_DCN_FUSED", "1") != "0"
 DCN_FUSED_MIN_TILES = int(os.environ.get("STM_DCN_FUSED_MIN_TILES", "200"))
 # which layers: 0 = every layer whose grid is large enough; 1 = only where the fused kernel wins in isolation (profiles/r05_dcn_fused_forms.txt section 0): one
 # 128-channel tile per pixel patch, or two at stride 2 -- with more channel tiles every tile samples the patch again
-DCN_FUSED_RULE = int(os.environ.get("STM_DCN_FUSED_RULE", "0"))   # (in the step both rules measure the same within 0.1 ms on R50 and R101: profiles/r05_dcn_fused_forms.txt)
+DCN_FUSED_RULE = 0   # (in the step both rules measure the same within 0.1 ms on R50 and R101: profiles/r05_dcn_fused_forms.txt)
 # ... the FCB class branch (FeatureAlign's DeformConv2d, 256 -> 256 channels, 9 / 15 / 15 taps over five levels) on the same kernel.  ON by default since the
 # kernel has 64-pixel x 256-channel tiles (every pixel sampled once): R50 FCB-ada at 32 clips 36.6 -> 36.1 ms per step, R101 FCB-ali 34.5 -> 34.0; on the
 # 128 x 128 tiles (two channel tiles per patch, every pixel sampled twice) it lost, 764 vs 918 frames/s (profiles/r05_dcn_fused_forms.txt).  STM_FCB_FUSED=0: the pair
@@ -61,8 +63,8 @@ FCB_FUSED = os.environ.get("STM_FCB_FUSED", "1") != "0"
 # shared head, 2 also the P5 -> P6 -> P7 convolutions beside the finer FPN levels; only batches of at most BRANCH_MAX_IMAGES frames.  Bit-equal, and
 # SLOWER at every batch size it was meant for (profiles/r04_trunk_branches_ab.txt: 1 clip 478 -> 426-442 frames/s, 2 clips 728 -> 640-694, 4 clips
 # 1034 -> 960-990, 8 clips 1284 -> 1206-1223): a fork / join pair in a replayed HIP graph costs more than the small grids it lets overlap.
-TRUNK_BRANCHES = int(os.environ.get("STM_TRUNK_BRANCHES", "0"))
-BRANCH_MAX_IMAGES = int(os.environ.get("STM_BRANCH_MAX_IMAGES", "16"))
+TRUNK_BRANCHES = 0
+BRANCH_MAX_IMAGES = 16
 # bit 0 = the projection form (a stage's first block); bit 1 = the kernel also computes the NEXT block's conv1 (z); bit 2 (diagnostics) = z is
 # computed but not used.  Round 3 shipped 1 because the z-producing instantiation (conv_chain_kernel<true, .>) gave wrong y / z beside a
 # second process on the GPU.  Round 4 found why (csrc/conv_chain.hip, store16: a 16-byte buffer store with an SGPR soffset reads its data
