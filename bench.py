@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 from benchlib import launch  # noqa: E402
 from benchlib.launch import barrier, emit  # noqa: E402
 from benchlib.roofline import BF16_MFMA_PEAK_TF, HBM_PEAK_GBS, PMC_FILE  # noqa: E402,F401
+from benchlib.runner import Runner, build_net  # noqa: E402,F401  (tests/test_gpu_parity.py and scripts/gpu_hammer.py drive the benchmark's pipeline through these)
 
 DEFAULT_CLIPS = 32          # plateau of the throughput curve (999 frames/s at 8 clips, 1167 at 16, 1250-1280 at 32, 1300 at 64);
                             # SURVEY §8(d) names 8 clips/GPU: that line and the single-stream (1 clip) line ride along in `extras`

@@ -214,6 +214,9 @@ __device__ __forceinline__ void df_store_tile(const FusedArgs& a, const float* p
 #ifndef DF_PSCHED
 #define DF_PSCHED 6      // vector instructions between two gathers of the producer stream (0: the compiler's order)
 #endif
+#ifndef DF_WAUX
+#define DF_WAUX 0        // cache policy bits of the weight DMA (2 = nt) -- timing experiments
+#endif
 #ifndef DF_ABL
 #define DF_ABL 0         // timing builds (RESULTS WRONG): 1 no corner gathers, 2 no blend / split / staging, 4 no MFMAs, 8 no weight DMA, 16 no fragment reads
 #endif
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
             for (int j = 0; j < NPW; ++j) {
                 const int wi = pw + 4 * j;                                        // 1-KB piece of the ring slot
                 const int wh_ = wi / (WT / 1024), wp_ = wi - wh_ * (WT / 1024);   // weight tile, piece inside its K-slab
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(wb + wi * 1024), 16, lane16, (wh_ * a.slabs + slab) * WT + wp_ * 1024, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(wb + wi * 1024), 16, lane16, (wh_ * a.slabs + slab) * WT + wp_ * 1024, 0, DF_WAUX);
             }
         };
         const int cpix0 = (pw * 16 * NU + gp) * 16, cpix1 = cpix0 + 16 * 16;     // the lane's pixel of unit 0 / 1 inside a tap's coefficient block
