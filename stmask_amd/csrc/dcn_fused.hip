@@ -23,11 +23,11 @@
 //     into LDS (same expressions as dcn_sample_planar_kernel: the sampled values are bit-identical to the unfused sampler's).
 //   * epilogue: the consumers park their accumulators as fp32 [pixel][channel] in LDS, all eight waves apply out_scale, bias, ReLU and the
 //     plane split and write 1-KB runs (16 pixels x 64 B) per store instruction.
-// What bounds it (profiles/r05_dcn_fused_forms.txt): on this power-capped board the parts do not hide behind one another -- the consumers alone
-// (MFMAs on real data + fragment reads + weight DMA) take 83 us per layer at batch 32, the producers alone 110, both 180-205, the fixed part
-// of a tile (coefficients, 37 barriers, output pass) 28 of it -- in three different kernel structures (every wave sampling and multiplying;
-// that with the MFMA stream lagging a chunk; producer / consumer waves) the same total within 3 %: the kernel runs as long as the energy of its
-// gathers (2.3 GB through L1 per layer), its blend and its products takes at the board's 1.4 kW.  Against the pair it replaces: x1.25.
+// What bounds it (profiles/r05_dcn_fused_forms.txt, r06_dcn_fused_ablations.txt, r06_power_probe.txt): the consumers alone (MFMAs on real data + fragment reads + weight
+// DMA) take 101 us per 256-channel layer at batch 32, the producers alone 73, both 161 -- the sides add.  Not because of the power cap (round 5's reading): the kernel holds
+// 2.15-2.27 GHz at 1.36-1.39 kW where the planar kernels sit at 1.9 GHz.  They meet on the SIMD's issue port -- a producer VALU instruction costs ~18 clocks while the consumer
+// wave on the same SIMD issues MFMAs back to back: removing the 52-instruction blend saves more time than removing the gathers -- and on the LDS (fragment reads 64 KB + weight
+// DMA 32 KB per K-slab against 98 KB per 768 matrix clocks).  Against the pair it replaces: x1.25.
 #include "planar_common.h"
 #include <atomic>
 
@@ -76,10 +76,10 @@ struct FusedArgs {
 __device__ __forceinline__ float df_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }   // (deform_im2col.hip: sigmoidf_dev)
 
 // one quarter (two channels) of a lane's 8 sampled values of a K-slab: blend the four corners (deform_im2col.hip bilerp(): w1 v1, then three
-// fmas), range maximum, split into the fp16 planes h = RN16(v), l = RN16((v - h) * 2048) -- planar_common.h split2_f16, value for value:
+// fmas), split into the fp16 planes h = RN16(v), l = RN16((v - h) * 2048) -- planar_common.h split2_f16, value for value:
 // v * 2048 and h * 2048 are exact, so fma(h, -2048, v * 2048) is (v - h) * 2048 without a rounding of its own (v_fma_mixlo / mixhi_f16)
 template <int NPL, int Q>
-__device__ __forceinline__ void blend_part(const f32x4 (&X)[4][2], const f32x4 w, unsigned (&ph)[4], unsigned (&pl)[4], float& rmax, f32x2& rnan)
+__device__ __forceinline__ void blend_part(const f32x4 (&X)[4][2], const f32x4 w, unsigned (&ph)[4], unsigned (&pl)[4])
 {
     constexpr int h = Q >> 1, e = Q & 1;
     const f32x2 w1 = {w.x, w.x}, w2 = {w.y, w.y}, w3 = {w.z, w.z}, w4 = {w.w, w.w};
@@ -89,8 +89,8 @@ __device__ __forceinline__ void blend_part(const f32x4 (&X)[4][2], const f32x4 w
     v = __builtin_elementwise_fma(w2, x2, v);
     v = __builtin_elementwise_fma(w3, x3, v);
     v = __builtin_elementwise_fma(w4, x4, v);
-    rmax = __builtin_fmaxf(rmax, __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)));
-    rnan = __builtin_elementwise_fma(v, f32x2{0.0f, 0.0f}, rnan);      // v_max drops a NaN operand: 0 * v + r turns NaN AND inf samples into a sticky NaN (one v_pk_fma_f32)
+    // (No range bookkeeping here since round 6: a sampled value beyond fp16's range becomes inf / nan in the h plane, every product it enters is inf or nan, and the
+    // output pass tests the PRE-activation value -- df_store_tile.  Two vector instructions per pair less in a stream where each costs ~18 clocks beside the MFMA wave.)
     const f16x2 hh = __builtin_convertvector(v, f16x2);
     ph[Q] = __builtin_bit_cast(unsigned, hh);
     if constexpr (NPL == 2) {
@@ -189,12 +189,14 @@ __device__ __forceinline__ void df_store_tile(const FusedArgs& a, const float* p
         if (a.bias) { b0 = *reinterpret_cast<const f32x4*>(a.bias + co); b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4); }
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = __builtin_fmaf(v[e], a.out_scale, bb[e]);
+        for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], a.out_scale, bb[e]);
+        // the fp16 range guard on the PRE-activation value (a ReLU would turn a nan into 0): |v| > 65504, inf or nan -- which is also where a sampled value
+        // beyond fp16's range ends up (its h plane is inf: every product with it is inf or nan), so the producers carry no range bookkeeping of their own
+        if (live) f16_range_check8(v, a.range_flag);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
             if (a.relu) v[e] = __builtin_fmaxf(v[e], 0.0f);
-        }
         if (live) {
-            f16_range_check8(v, a.range_flag);
             unsigned q0[4], q1[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) split2_f16(f32x2{v[2 * e], v[2 * e + 1]}, q0[e], q1[e]);
@@ -266,8 +268,6 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
     __syncthreads();
 
     f32x4 acc[4][4], accl[4][4];                                  // consumer: [channel tile][pixel tile], main / correction products
-    float rmax = 0.0f;
-    f32x2 rnan = {0.0f, 0.0f};       // stays (+-)0 while every sampled value is finite
     if (wave < 4) {
         // ================================================ producer =======================================================================
         // lane = 4 gp + gq: pixel gp of a 16-pixel unit, quarter gq; a corner's 128-byte channel slab arrives as two instructions of 64 contiguous
@@ -326,10 +326,10 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
             uint8_t* const bs_ = smem + (SLOT_) * BBUF;                                                                            \
             _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                                       \
                 unsigned ph[4], pl[4];                                                                                             \
-                blend_part<NPL, 0>(X_[u], W_[u], ph, pl, rmax, rnan);                                                                    \
-                blend_part<NPL, 1>(X_[u], W_[u], ph, pl, rmax, rnan);                                                                    \
-                blend_part<NPL, 2>(X_[u], W_[u], ph, pl, rmax, rnan);                                                                    \
-                blend_part<NPL, 3>(X_[u], W_[u], ph, pl, rmax, rnan);                                                                    \
+                blend_part<NPL, 0>(X_[u], W_[u], ph, pl);                                                                    \
+                blend_part<NPL, 1>(X_[u], W_[u], ph, pl);                                                                    \
+                blend_part<NPL, 2>(X_[u], W_[u], ph, pl);                                                                    \
+                blend_part<NPL, 3>(X_[u], W_[u], ph, pl);                                                                    \
                 *reinterpret_cast<u32x2_*>(bs_ + st_w0 + u * 1024) = u32x2_{ph[0], ph[1]};                                         \
                 *reinterpret_cast<u32x2_*>(bs_ + st_w1 + u * 1024) = u32x2_{ph[2], ph[3]};                                         \
                 if constexpr (NPL == 2) {                                                                                          \
@@ -383,8 +383,6 @@ __global__ __launch_bounds__(512, 1) void dcn_fused_kernel(const FusedArgs a)
 #undef DF_PROD
 #undef DF_BLEND
 #undef DF_GATHER
-        // the planes' range guard, same predicate as f16_range_check8 (|v| > 65504, inf or NaN)
-        if ((rmax > 65504.0f || !(rnan.x == 0.0f && rnan.y == 0.0f)) && a.range_flag) *reinterpret_cast<volatile int*>(a.range_flag) = 1;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the rings' last (unused) slabs have landed before the LDS is reused
     } else {
         // ================================================ consumer =======================================================================

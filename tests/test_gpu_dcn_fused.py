@@ -230,3 +230,36 @@ def test_fused_deform_conv_rejects_bad_arguments():
     with pytest.raises(StmError):
         ops.deform_conv_fused_planar(x, 1, 8, 8, 64, om, packed, sc, None, 128, fmt=0)                      # bf16 x 3: the pair stays
     assert not ops.deform_conv_fused_supported(48, 128, 3, True, 1) and ops.deform_conv_fused_supported(256, 256, (3, 5), False, 1)
+
+
+@pytest.mark.parametrize("O", [128, 256])                     # 128 x 128 and 64 x 256 tiles
+def test_fused_deform_conv_raises_the_fp16_range_flag(O):
+    """A sampled value beyond fp16's range (|v| > 65504, inf, nan) must raise the sticky range flag even though the layer's ReLU would turn a nan output
+    into 0: since round 6 the fused kernel tests the PRE-activation outputs (a sample whose h plane is inf makes every product it enters inf or nan) and
+    its producer waves carry no range bookkeeping.  Also with weights that are all zero (0 * inf = nan), and not for in-range inputs."""
+    flag = ops.planar_range_flag()
+    flag.zero_()
+
+    def raised():
+        torch.cuda.synchronize()
+        v = int(flag.item())
+        flag.zero_()
+        return v
+
+    B, C, H, W = 1, 64, 8, 8
+    x = rnd(B, C, H, W, seed=3)
+    om = torch.cat([rnd(B, 18, H, W, seed=4), rnd(B, 9, H, W, seed=5)], 1)
+    w = rnd(O, C, 3, 3, seed=6, scale=0.05)
+    y = fused(x, om, w, None, 1, (1, 1), True, True)
+    assert raised() == 0 and torch.isfinite(y).all()
+    for bad in (1e5, -3e38, float("inf"), float("-inf"), float("nan")):
+        xb = x.clone()
+        xb[0, 7, 4, 4] = bad
+        for wt in (w, torch.zeros_like(w), -w.abs()):             # (-|w|: the ReLU would hide a -inf / nan output)
+            fused(xb, om, wt, None, 1, (1, 1), True, True)
+            assert raised() == 1, (bad, float(wt.abs().max()))
+    # a value fp16 can hold leaves the flag alone
+    xb = x.clone()
+    xb[0, 7, 4, 4] = 6.0e4
+    fused(xb, om, w, None, 1, (1, 1), True, True)
+    assert raised() == 0
