@@ -86,9 +86,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-planar", dest="planar", action="store_false",
                     help="dense convolutions through MIOpen instead of the planar matrix-core kernel")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="replay the trunk from captured HIP graphs (stmask_amd/pipeline.py _trunk).  auto = up to 8 clips per GPU, "
-                         "where the ~110 Python-driven launches of the trunk cost more host time than GPU time; at 32 clips the step is "
-                         "GPU-bound and the eager launches keep the per-kernel HIP-event timing of the roofline inside the timed region")
+                    help="replay the trunk from captured HIP graphs (stmask_amd/pipeline.py _trunk).  auto = on (round 6; until round 5: up to 8 clips per GPU, "
+                         "where the ~110 Python-driven launches of the trunk cost more host time than GPU time -- at 32 clips two replayed trunks in flight "
+                         "are worth +2 %%); the roofline objects' per-launch HIP events come from an eager pass right after the timed region either way")
     ap.add_argument("--pipeline", default="batched", choices=["batched", "per-clip"],
                     help="batched: all clips' post-processing in concatenated tensors; per-clip: reference-shaped layer API")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" is RCCL on ROCm; gloo for the CPU launch test')

@@ -62,7 +62,8 @@ class Runner:
             self.pipe.max_instances = args.max_instances if max_instances is None else max_instances
             self.pipe.prefetch_early = args.overlap == "early"
             gm = getattr(args, "graph", "auto")
-            self.pipe.use_graph = (gm == "on" or (gm == "auto" and clips <= 8)) and args.fuse and args.planar and args.channels_last
+            # (round 6: graphs at every batch size -- at 32 clips two replayed trunks in flight are +2 % over the eager trunk, pipeline.BatchedClipPipeline.LARGE_BATCH)
+            self.pipe.use_graph = gm in ("on", "auto") and args.fuse and args.planar and args.channels_last
         self.tracked_sum = 0.0
         self.tracked_steps = 0
         from stmask_amd.dist import DetectionGatherer
@@ -97,7 +98,7 @@ class Runner:
         t_first = warmup
         if self.batched and self.pipe.use_graph and not collect:
             # the trunk graphs are captured lazily, one slot per trunk call (two eager calls first): keep the captures out of the timed region
-            while len(self.pipe._graphs) < self.pipe.N_GRAPH_SLOTS and t_first < warmup + self.pipe.N_GRAPH_SLOTS + 4:
+            while len(self.pipe._graphs) < self.pipe.n_graph_slots and t_first < warmup + self.pipe.n_graph_slots + 4:
                 self.step(t_first)
                 t_first += 1
         torch.cuda.synchronize()

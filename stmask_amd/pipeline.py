@@ -282,6 +282,18 @@ class BatchedClipPipeline:
     # 1 491 / 1 488 / 1 454 (profiles/r05_trunk_depth2_ab.txt)
     PREFETCH_DEPTH = int(os.environ.get("STM_PREFETCH_DEPTH", "3"))
     N_GRAPH_SLOTS = 2 * PREFETCH_DEPTH + 2
+    # Large batches (round 6): a 32-clip trunk fills the GPU by itself, but not at its two ends (the stem and layer1 ramp up, the small FPN levels, P6 / P7 and the head's
+    # last launches run on few workgroups) -- two replayed trunks in flight overlap those: 1 599 (eager, one frame ahead) -> 1 587-1 593 (graphs, depth 1) -> 1 630-1 633
+    # (depth 2) -> 1 627-1 628 (depth 3) frames/s at 32 clips, same box, alternating.  Above LARGE_BATCH clips the depth is capped at 2 (a slot's private pool is ~10 GB there).
+    LARGE_BATCH = 8
+
+    @property
+    def prefetch_depth(self):
+        return self.PREFETCH_DEPTH if self.B <= self.LARGE_BATCH else min(self.PREFETCH_DEPTH, 2)
+
+    @property
+    def n_graph_slots(self):
+        return 2 * self.prefetch_depth + 2
 
     def _trunk(self, frames):
         """forward_single(frames).  With use_graph the ~110 launches of the trunk (every one a Python -> ctypes call: ~25 us of
@@ -307,7 +319,7 @@ class BatchedClipPipeline:
             # eager first: packs the weights, sizes the workspaces, fills the prior cache, reserves the kernels' LDS
             self._graph_warm += 1
             return net.forward_single(frames)
-        if len(self._graphs) < self.N_GRAPH_SLOTS:
+        if len(self._graphs) < self.n_graph_slots:
             static_in = frames.clone(memory_format=torch.preserve_format)
             graph = torch.cuda.CUDAGraph()
             ws = {}
@@ -327,7 +339,7 @@ class BatchedClipPipeline:
             self._graph_planes = planes
             self.graph_active = True
         static_in, graph, out = self._graphs[self._graph_next]
-        self._graph_next = (self._graph_next + 1) % self.N_GRAPH_SLOTS
+        self._graph_next = (self._graph_next + 1) % self.n_graph_slots
         if static_in.shape != frames.shape:
             raise ops.StmError("BatchedClipPipeline: the frame batch changed shape under a captured trunk graph")
         static_in.copy_(frames)
@@ -344,7 +356,7 @@ class BatchedClipPipeline:
         if next_frames is None or self.timer.on:
             return
         nxt = list(next_frames) if isinstance(next_frames, (list, tuple)) else [next_frames]
-        depth = self.PREFETCH_DEPTH if (self.use_graph and self.graph_active) else 1
+        depth = self.prefetch_depth if (self.use_graph and self.graph_active) else 1
         main = torch.cuda.current_stream()
         for f in nxt[:depth]:
             if f is None or any(p[0] is f for p in self._pending):
