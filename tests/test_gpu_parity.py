@@ -382,14 +382,17 @@ def test_decode_difference_from_reference_is_counted_and_harmless(golden_postpro
     assert int(f_cnt[0]) == n and f_idx[0, :n].cpu().tolist() == keep_idx[torch.tensor(ref_keep)].tolist()
 
 
-def test_pipeline_is_bit_reproducible_run_to_run():
-    """Two passes of the benchmark's pipeline (16 clips, eager trunk on the side stream beside the tracker tail) over the same clips on one
-    net give bit-equal detection blocks at every step.  Round 3's chain kernel once failed this one pass in ten (a counted wait on its
-    LDS-DMA ring: DESIGN section 4, "Bottleneck chain"); `bench.py --world2-one-gpu` is the stricter form with a second process."""
+@pytest.mark.parametrize("graph", ["off", "auto"])
+def test_pipeline_is_bit_reproducible_run_to_run(graph):
+    """Two passes of the benchmark's pipeline (16 clips) over the same clips on one net give bit-equal detection blocks at every step -- with the eager
+    trunk on the side stream beside the tracker tail (rounds 3-5's default at this size) and with the trunk replayed from HIP graphs, two trunks in
+    flight on two side streams (round 6's default: every slot has its own pool and workspaces, so concurrent replays share nothing).  Round 3's chain
+    kernel once failed this one pass in ten (a counted wait on its LDS-DMA ring: DESIGN section 4, "Bottleneck chain"); `bench.py --world2-one-gpu`
+    is the stricter form with a second process."""
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    args = bench.parse_args(["--clips", "16", "--steps", "6", "--warmup", "2"])
+    args = bench.parse_args(["--clips", "16", "--steps", "6", "--warmup", "2", "--graph", graph])
     dev = torch.device("cuda:0")
     net = bench.build_net(args, dev)
     keeps = []
@@ -398,9 +401,10 @@ def test_pipeline_is_bit_reproducible_run_to_run():
         run.keep = []
         run.timed(args.warmup, args.steps)
         torch.cuda.synchronize()
+        assert run.pipe.graph_active == (graph == "auto") and (graph == "off" or run.pipe.prefetch_depth == 2)
         keeps.append([k.clone() for k in run.keep])
         del run
-    assert len(keeps[0]) == 8
+    assert len(keeps[0]) == len(keeps[1]) >= 8          # (under graphs the runner adds capture steps in front of the timed region)
     for t, (a, b) in enumerate(zip(*keeps)):
         assert torch.equal(a, b), f"step {t}: max abs diff {(a - b).abs().max().item()}"
 
