@@ -230,6 +230,7 @@ def main():
                        "detections_last_step": n_det,
                        "tracked_instances_mean": round(run.tracked_sum / max(run.tracked_steps, 1), 1),
                        "parallelism": f"clip-dp{world}", "cpu_binding": binding,
+                       "hbm_reserved_gb_after_timed_region": round(torch.cuda.memory_reserved(dev) / 1e9, 1),
                        "pipeline": args.pipeline + (f"+next-trunk-overlap-{args.overlap}" if (run.batched and args.overlap != "off") else "")
                                    + ("+trunk-hip-graph" if getattr(run.pipe, "graph_active", False) else ""),
                        "inference_graph": ("bn-folded+fused-epilogues" + ("+planar-%s-convs" % args.planes if planar_graph else ""))
