@@ -138,3 +138,27 @@ def test_pmc_traffic_file_is_refused_when_its_launch_counts_disagree(tmp_path, m
     assert t is None and "launches_per_step" in why
     t, src, why = rf.pmc_traffic("missing", 3.0, pmc_file="x.json")
     assert t is None and src is None
+
+
+def test_board_sampler_reads_hwmon_files_and_summarises_windows(tmp_path, monkeypatch):
+    """benchlib.extras.BoardSampler (extras.sustained, scripts/power_probe.py): power1_input in microwatts and freq1_input in Hz of the device's hwmon
+    directory, sampled on a host thread; summary per named time window; no source -> no thread, an empty summary."""
+    import time
+    from benchlib import extras
+    pw, ck = tmp_path / "power1_input", tmp_path / "freq1_input"
+    pw.write_text("1320000000\n")
+    ck.write_text("1930000000\n")
+    monkeypatch.setattr(extras.BoardSampler, "_find_hwmon", staticmethod(lambda i: {"power_uw": str(pw), "sclk_hz": str(ck)}))
+    with extras.BoardSampler(0, 0.005) as smp:
+        time.sleep(0.06)
+        pw.write_text("1400000000\n")
+        time.sleep(0.06)
+    s = smp.summary([("late", 0.07, 10.0)])
+    assert s["samples"] >= 8 and s["source"].startswith("sysfs hwmon")
+    assert s["power_w"]["min"] == 1320.0 and s["power_w"]["max"] == 1400.0 and s["sclk_mhz"]["mean"] == 1930.0
+    assert s["late"]["samples"] >= 2 and s["late"]["power_w"]["min"] == 1400.0
+    monkeypatch.setattr(extras.BoardSampler, "_find_hwmon", staticmethod(lambda i: {}))
+    monkeypatch.setattr("shutil.which", lambda name: None)
+    with extras.BoardSampler(0, 0.005) as none:
+        pass
+    assert none.source is None and none.summary()["samples"] == 0
