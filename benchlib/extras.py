@@ -349,8 +349,10 @@ CONFIG_LINES = (
 )
 
 
-def config_lines(args, dev, rank, world, which, steps=10, warmup=3):
-    """One short line each for the other BASELINE configurations, in this process (their own nets and clips, built and dropped one at a time), each
+def config_lines(args, dev, rank, world, which, steps=16, warmup=3):
+    """(steps = one whole clip cycle of T = 16 frames: the tracked set, and with it TemporalNet's share, grows over a clip, so a shorter window would depend on
+    where in the cycle it falls -- under graph replay the runner puts capture steps in front of the timed region.)
+    One short line each for the other BASELINE configurations, in this process (their own nets and clips, built and dropped one at a time), each
     with the roofline objects of a short eager pass.  datasets/config.py:789-798 (ada), :757-766 (R101 ali)."""
     import argparse
     from stmask_amd import planar as _pl

@@ -33,7 +33,14 @@ def _p(t):
     return c_p(t.data_ptr()) if t is not None else c_p(0)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a C pointer.  torch.cuda.current_stream() builds a Stream object through four Python layers
+    (8 us a call, ~22 calls per single-stream step: 16 % of it, profiles/r06_prof_host_clips1.txt); the raw getter is one C call."""
+    if _raw_stream is not None:
+        return c_p(_raw_stream(torch.cuda.current_device()))
     return c_p(torch.cuda.current_stream().cuda_stream)
 
 
