@@ -162,3 +162,18 @@ def test_board_sampler_reads_hwmon_files_and_summarises_windows(tmp_path, monkey
     with extras.BoardSampler(0, 0.005) as none:
         pass
     assert none.source is None and none.summary()["samples"] == 0
+
+
+def test_look_ahead_depth_and_graph_slots_by_batch_size():
+    """Round 6: trunk graphs at every batch size; up to LARGE_BATCH clips three trunks run ahead (launch-latency-bound chains), above it two (a 32-clip trunk
+    fills the GPU except at its ends); 2 D + 2 graph slots either way; the detection gather's stream comes after the trunk streams."""
+    from stmask_amd import pipeline
+
+    class Net:
+        cfg = type("C", (), {"temporal_fusion_module": True})()
+
+    P = pipeline.BatchedClipPipeline
+    small, large = P(Net(), 8), P(Net(), 32)
+    assert small.prefetch_depth == P.PREFETCH_DEPTH == 3 and small.n_graph_slots == P.N_GRAPH_SLOTS == 8
+    assert large.prefetch_depth == 2 and large.n_graph_slots == 6
+    assert pipeline.trunk_stream_count() == 3
