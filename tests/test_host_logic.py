@@ -177,3 +177,19 @@ def test_look_ahead_depth_and_graph_slots_by_batch_size():
     assert small.prefetch_depth == P.PREFETCH_DEPTH == 3 and small.n_graph_slots == P.N_GRAPH_SLOTS == 8
     assert large.prefetch_depth == 2 and large.n_graph_slots == 6
     assert pipeline.trunk_stream_count() == 3
+
+
+def test_committed_pmc_traffic_file_is_checkable():
+    """The counter file bench.py quotes (benchlib.roofline.PMC_FILE) exists, names the run it was collected on and carries launches per step for the three
+    kernel groups the line quotes traffic for -- without them bench.py refuses it (test above) and the line's `traffic` would be null."""
+    import json
+    import os
+    from benchlib import roofline as rf
+    path = os.path.join(rf.ROOT, "profiles", rf.PMC_FILE)
+    assert os.path.exists(path), path
+    d = json.load(open(path))
+    for grp in ("conv_planar", "dcn_fused", "dcn_sample_planar"):
+        assert d[grp]["launches_per_step"] > 0 and d[grp]["traffic_bytes_per_launch"] > 1e6, grp
+        t, src, why = rf.pmc_traffic(grp, d[grp]["launches_per_step"])
+        assert t == int(d[grp]["traffic_bytes_per_launch"]) and src == rf.PMC_FILE and why is None
+    assert "32 clips/GPU" in d["profiled_run"]["workload"] and "STMask_plus_resnet50_config" in d["profiled_run"]["workload"]
