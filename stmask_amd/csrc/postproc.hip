@@ -19,6 +19,10 @@ namespace {
 constexpr int NMS_THREADS = 1024;
 constexpr int NMS_WAVES = NMS_THREADS / STM_WAVE;
 constexpr int NMS_MAX_KEYS = 16384;
+#ifndef NMS_SELECT_FROM
+#define NMS_SELECT_FROM 4096    // candidates from which cc_nms_kernel selects the top_k before sorting: the selection costs ~70 us flat at 32 frames, the sort 30 / 60 / 115 / 240 us for up to
+                                // 2 048 / 4 096 / 6 000 / 12 000 candidates (profiles/r06_cc_nms_select.txt; timing builds: make variant ... VFLAGS=-DNMS_SELECT_FROM=n)
+#endif
 constexpr int NMS_MAX_TOPK = 512;
 
 // ------------------------------------------------------------------------------------------ decode
@@ -280,8 +284,10 @@ __global__ __launch_bounds__(NMS_THREADS) void cc_nms_kernel(const float* __rest
             }
         }
         __syncthreads();
-        if (n_cand > Kp) {
-            // More candidates than the LDS sort holds (only possible with N > NMS_MAX_KEYS priors, e.g. 58 860 at 736x1280).
+        if (n_cand > Kp || n_cand > max(NMS_SELECT_FROM, top_k)) {
+            // More candidates than the LDS sort holds (only possible with N > NMS_MAX_KEYS priors, e.g. 58 860 at 736x1280) -- or, since round 6, simply
+            // MANY: the bitonic sort of 2 048-8 192 keys is 66-91 barrier-separated stages of one workgroup (most of this kernel's 190-490 us per step at
+            // 32 clips), and only the top_k best are ever read, so from NMS_SELECT_FROM candidates on the same exact selection runs first and 256 keys are sorted.
             // Only the top_k best (score descending, row ascending) ever matter, so select exactly those: a radix select
             // (four 8-bit passes over the rows) finds the score key of the top_k-th best candidate; all strictly better
             // candidates enter the sort, and of the candidates that tie with that key the first ones in row order.
