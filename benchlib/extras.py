@@ -312,10 +312,17 @@ def sustained_block(args, dev, rank, world, net, headline_ms, min_seconds=10.0, 
     clock sampled every 100 ms: the 20-step timed region is 0.4 s, and every "board at its power limit" argument needs a window longer than the
     board's thermal / power-management time constants."""
     r2 = Runner(args, dev, rank, world, args.clips, net=net)
-    for t in range(args.warmup):
+    t = 0
+    for _ in range(args.warmup):
         r2.step(t)
+        t += 1
+    # (the trunk graphs are captured lazily, one slot per trunk call after two eager ones: keep the captures out of the first chunk, as Runner.timed does)
+    pipe = r2.pipe
+    while r2.batched and pipe.use_graph and len(pipe._graphs) < pipe.n_graph_slots and t < args.warmup + pipe.n_graph_slots + 4:
+        r2.step(t)
+        t += 1
     torch.cuda.synchronize()
-    chunks, t = [], args.warmup
+    chunks = []
     with BoardSampler(dev.index or 0, 0.1) as smp:
         t_begin = time.perf_counter()
         while len(chunks) < min_chunks or (time.perf_counter() - t_begin < min_seconds and len(chunks) < max_chunks):
