@@ -297,8 +297,9 @@ __global__ __launch_bounds__(NMS_THREADS) void cc_nms_kernel(const float* __rest
         __syncthreads();
         if (n_cand > Kp || n_cand > max(NMS_SELECT_FROM, top_k)) {
             // More candidates than the LDS sort holds (only possible with N > NMS_MAX_KEYS priors, e.g. 58 860 at 736x1280) -- or, since round 6, simply
-            // MANY: the bitonic sort of 2 048-8 192 keys is 66-91 barrier-separated stages of one workgroup (most of this kernel's 190-490 us per step at
-            // 32 clips), and only the top_k best are ever read, so from NMS_SELECT_FROM candidates on the same exact selection runs first and 256 keys are sorted.
+            // MANY: the bitonic sort of 8 192-16 384 keys is 91-105 barrier-separated stages of one workgroup, and only the top_k best are ever read, so
+            // from NMS_SELECT_FROM candidates on the same exact selection runs first and 256 keys are sorted (the benchmark's frames have ~40 candidates and
+            // never get here; a frame with 12 000: 240 -> 70 us).
             // Only the top_k best (score descending, row ascending) ever matter, so select exactly those: a radix select
             // (four 8-bit passes over the rows) finds the score key of the top_k-th best candidate; all strictly better
             // candidates enter the sort, and of the candidates that tie with that key the first ones in row order.
