@@ -218,7 +218,8 @@ class BoardSampler:
         self.source = None
         self._files = self._find_hwmon(device_index)
         if self._files:
-            self.source = "sysfs hwmon (" + ", ".join(os.path.basename(f) for f in self._files.values()) + ")"
+            self.source = ("sysfs hwmon (" + ", ".join(os.path.basename(f) for f in self._files.values()) + ") of "
+                           + os.path.dirname(next(iter(self._files.values()))))
         else:
             import shutil
             self._smi = shutil.which("rocm-smi")
@@ -244,25 +245,25 @@ class BoardSampler:
             for key, names in (("power_uw", ("power1_average", "power1_input")), ("sclk_hz", ("freq1_input",))):
                 for n in names:
                     f = os.path.join(r, n)
-                    try:
-                        int(open(f).read().strip())
+                    if BoardSampler._read_int(f) is not None:
                         files[key] = f
                         break
-                    except (OSError, ValueError):
-                        continue
             if "power_uw" in files or "sclk_hz" in files:
                 return files
         return {}
 
+    @staticmethod
+    def _read_int(path):
+        try:
+            with open(path) as fh:
+                return int(fh.read().strip())
+        except (OSError, ValueError):
+            return None
+
     def _read(self):
         if self._files:
-            out = {}
-            for key, f in self._files.items():
-                try:
-                    out[key] = int(open(f).read().strip())
-                except (OSError, ValueError):
-                    pass
-            return (out.get("power_uw", 0) / 1e6 or None, out.get("sclk_hz", 0) / 1e6 or None)
+            out = {key: self._read_int(f) for key, f in self._files.items()}
+            return ((out.get("power_uw") or 0) / 1e6 or None, (out.get("sclk_hz") or 0) / 1e6 or None)
         if getattr(self, "_smi", None):
             import subprocess
             try:
