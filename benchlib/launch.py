@@ -123,14 +123,22 @@ def parse_cpulist(text):
 
 
 def rank_core_slice(cores, idx, n):
-    """The idx-th of n contiguous, equally long slices of `cores` (never empty while cores is not: with fewer cores than ranks they share)."""
-    cores = list(cores)
+    """Rank idx's share of `cores` among n ranks: the idx-th n-th of EVERY run of consecutive core numbers -- a node's list is usually its physical
+    cores followed by their SMT siblings ('0-63,128-191'), and a rank should get cores together with their own siblings, not another rank's.  Never
+    empty while cores is not (with fewer cores than ranks they share)."""
+    cores = sorted(cores)
     if not cores or n <= 0:
         return cores
-    per = len(cores) // n
-    if per == 0:
-        return [cores[idx % len(cores)]]
-    return cores[idx * per:(idx + 1) * per]
+    runs, start = [], 0
+    for i in range(1, len(cores) + 1):
+        if i == len(cores) or cores[i] != cores[i - 1] + 1:
+            runs.append(cores[start:i])
+            start = i
+    out = []
+    for run in runs:
+        per = len(run) // n
+        out += run[idx * per:(idx + 1) * per]
+    return out if out else [cores[idx % len(cores)]]
 
 
 def gpu_local_cpulist(pci_domain, pci_bus, pci_device, sysfs="/sys/bus/pci/devices"):

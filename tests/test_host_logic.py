@@ -110,9 +110,11 @@ def test_rank_cpu_binding_helpers(tmp_path):
     from benchlib import launch
     assert launch.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
     assert launch.parse_cpulist("") == []
-    cores = list(range(0, 16)) + list(range(128, 144))
+    cores = list(range(0, 16)) + list(range(128, 144))                        # physical cores, then their SMT siblings
     slices = [launch.rank_core_slice(cores, i, 4) for i in range(4)]
-    assert sum(slices, []) == cores and all(len(s) == 8 for s in slices)
+    assert sorted(sum(slices, [])) == cores and all(len(s) == 8 for s in slices)
+    assert slices[1] == [4, 5, 6, 7, 132, 133, 134, 135]                        # a rank's cores come with their own siblings
+    assert launch.rank_core_slice(list(range(8)), 1, 2) == [4, 5, 6, 7]
     assert launch.rank_core_slice([5, 6], 3, 4) == [6]                         # fewer cores than ranks: shared, never empty
     d = tmp_path / "0000:c1:00.0"
     d.mkdir()
