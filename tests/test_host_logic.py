@@ -195,3 +195,61 @@ def test_committed_pmc_traffic_file_is_checkable():
         t, src, why = rf.pmc_traffic(grp, d[grp]["launches_per_step"])
         assert t == int(d[grp]["traffic_bytes_per_launch"]) and src == rf.PMC_FILE and why is None
     assert "32 clips/GPU" in d["profiled_run"]["workload"] and "STMask_plus_resnet50_config" in d["profiled_run"]["workload"]
+
+
+def test_sustained_and_config_lines_glue_with_a_fake_runner(monkeypatch):
+    """benchlib.extras.sustained_block / config_lines without a GPU: chunking (>= 500 steps AND >= min_seconds, bounded), graph captures kept out of the
+    first chunk, frames/s arithmetic, one line per BASELINE configuration with its own arguments, a failing configuration reported instead of raised."""
+    import argparse
+    import types
+    import torch
+    from benchlib import extras
+
+    made = []
+
+    class FakeRunner:
+        def __init__(self, args, dev, rank, world, clips, planes=None, net=None, max_instances=None):
+            if args.config == "STMask_plus_base_ali_config" and args.height == 736:
+                raise RuntimeError("out of memory (pretend)")
+            self.args, self.clips, self.planes = args, clips, planes
+            self.batched, self.tracked_sum, self.tracked_steps, self.steps_run = True, 50.0, 10, 0
+            self.gatherer = types.SimpleNamespace(wait=lambda: None)
+            self.pipe = types.SimpleNamespace(use_graph=True, _graphs=[], n_graph_slots=3, prefetch_early=True)
+            self.net = types.SimpleNamespace(cfg=types.SimpleNamespace(backbone_layers=(3, 4, 6, 3), backbone_dcn_layers=(0, 4, 6, 3), use_pred_offset=True,
+                                                                      use_dcn_class=True, temporal_fusion_module=True))
+            made.append(self)
+
+        def step(self, t):
+            import time
+            time.sleep(0.0005)
+            self.steps_run += 1
+            if len(self.pipe._graphs) < self.pipe.n_graph_slots and self.steps_run > 2:
+                self.pipe._graphs.append(object())
+
+        def timed(self, warmup, steps, use_dist=False, collect=False):
+            return (0.5, None, None, [] if collect else None)
+
+    monkeypatch.setattr(extras, "Runner", FakeRunner)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    monkeypatch.setattr(extras.BoardSampler, "_find_hwmon", staticmethod(lambda i: {}))
+    monkeypatch.setattr("shutil.which", lambda name: None)
+    args = argparse.Namespace(clips=32, warmup=2, steps=20, frames=16, config="STMask_plus_resnet50_config", height=384, width=640, planes="fp16x2", max_instances=0)
+    s = extras.sustained_block(args, torch.device("cpu"), 0, 1, None, headline_ms=20.0, min_seconds=0.0, chunk=100, min_chunks=5, max_chunks=6)
+    assert s["steps"] == 500 and len(s["frames_per_s_by_100_steps"]) == 5 and s["board"]["samples"] == 0 and s["board"]["source"] is None
+    assert made[0].steps_run == 500 + 2 + 3 and len(made[0].pipe._graphs) == 3            # warm-up 2, three more steps until every graph slot exists, then the chunks
+    assert abs(s["value"] - 32 * 500 / s["seconds"]) / s["value"] < 0.05 and s["first_100"] == s["frames_per_s_by_100_steps"][0]
+
+    class _Pl:
+        FMT, BACKBONE_FMT = 1, None
+        set_format = staticmethod(lambda *a: None)
+    monkeypatch.setitem(__import__("sys").modules, "stmask_amd.planar", _Pl)
+    import stmask_amd
+    monkeypatch.setattr(stmask_amd, "planar", _Pl, raising=False)
+    made.clear()
+    out = extras.config_lines(args, torch.device("cpu"), 0, 1, ["config3", "config4", "config5"], steps=16, warmup=3)
+    assert set(out) == {"config3", "config4", "config5"}
+    assert out["config3"]["value"] == round(32 * 16 / 0.5, 2) and out["config3"]["planes"] == "fp16x2" and "FCB(ada)" in out["config3"]["workload"]
+    assert out["config4"]["clips_per_gpu"] == 32 and made[1].args.config == "STMask_plus_base_ali_config" and made[1].args.height == 384
+    assert "error" in out["config5"] and "out of memory" in out["config5"]["error"]        # a failing side line is reported, never raised
+    assert args.config == "STMask_plus_resnet50_config" and args.clips == 32                 # the headline's arguments are untouched
