@@ -100,6 +100,10 @@ def parse_args(argv=None):
                     help="run TWO ranks of the real model path on ONE GPU (both map to device 0, gloo all-gather through host staging): "
                          "executes Runner + clip sharding + all-gather + max-over-ranks timing for real where only one GPU exists; "
                          "writes profiles-style JSON with gather_ok and a comparison against the N = 1 run of the same clips")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="ranks under a launcher map to device local_rank %% device_count (with --backend gloo: RCCL refuses two ranks on one device): the "
+                         "WHOLE N-rank flow of this file -- every pass, barrier, all-gather and the result line -- on a box with fewer GPUs than ranks "
+                         "(tests/test_gpu_bench_ranks.py); a plumbing check, not a throughput figure")
     ap.add_argument("--launch-check", action="store_true",
                     help="host-only check of the multi-rank plumbing (self-launch, rendezvous, clip sharding, all-gather, max-over-"
                          "ranks timing, JSON relay) with synthetic detection rows instead of the model; needs no GPU")
@@ -139,13 +143,13 @@ def main():
     from benchlib import checks, extras as bx, roofline as rf
     from benchlib.runner import Runner, backbone_tag, heads_tag, image_tag
     from stmask_amd import ops  # noqa: F401  (fails loudly here when the HIP library is missing)
-    if args.world2_one_gpu:
+    if args.world2_one_gpu or args.share_gpu:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)     # both ranks on device 0 of a 1-GPU box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # a rank under a launcher keeps to the cores of its GPU's NUMA node (its share of them); the plain N = 1 run keeps every core: its CPU baseline
     # leg wants them
-    binding = launch.bind_rank_to_gpu_cores(local_rank, world) if (use_dist and world > 1 and not args.world2_one_gpu) else {"bound": False, "why": "single process"}
+    binding = launch.bind_rank_to_gpu_cores(local_rank, world) if (use_dist and world > 1 and not args.world2_one_gpu and not args.share_gpu) else {"bound": False, "why": "single process or shared GPU"}
     if use_dist:
         launch.stdout_to_stderr()
         # NO device_id: with it torch binds the communicator eagerly at start-up, and on this stack that alone -- no collective issued -- costs a rank
@@ -165,6 +169,7 @@ def main():
     # K steps right after it (eager; under a trunk graph that was always so).  --events-in-timed-region puts them back inside.
     events_inside = args.events_in_timed_region and not graphed and not args.world2_one_gpu
     elapsed, out, timing, conv_t = run.timed(args.warmup, args.steps, use_dist, collect=events_inside)
+    tracked_mean = round(run.tracked_sum / max(run.tracked_steps, 1), 1)      # of the timed region (the later passes reset the counters)
     if args.world2_one_gpu:
         sys.exit(checks.world2_report(args, run, dev, rank, world, elapsed, use_dist))
     coll_local = coll_delta = None
@@ -197,6 +202,30 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # EVERY rank runs the passes below: they contain barriers and the per-step all-gather (a pass on rank 0 alone would wait for ranks that have left)
+    fused_t = getattr(run, "fused_t", None) or []
+    im2col_in = None
+    if fused_t and not timing and not args.no_sampler_pass:
+        # the sampler the north star names did not run in that pass (every DCN layer took the fused kernel): its own figure from a short eager
+        # pass of the same pipeline with fusion switched off (same process, right after; nothing of it enters the headline)
+        from stmask_amd import planar as _plf
+        saved_mt, saved_g = _plf.DCN_FUSED_MIN_TILES, (run.pipe.use_graph if run.batched else None)
+        _plf.DCN_FUSED_MIN_TILES = 1 << 30
+        if run.batched:
+            run.pipe.use_graph = False
+        try:
+            early_s = run.batched and run.pipe.prefetch_early
+            if early_s:
+                run.pipe.prefetch_early = False
+            _, _, timing, _ = run.timed(1, min(args.steps, 8), use_dist, collect=True)
+            if early_s:
+                run.pipe.prefetch_early = True
+        finally:
+            _plf.DCN_FUSED_MIN_TILES = saved_mt
+            if run.batched:
+                run.pipe.use_graph = saved_g
+        im2col_in = "a short eager pass with STM_DCN_FUSED off right after the timed region (the timed region runs the fused kernel: roofline_dcn_fused)"
+
     tm = getattr(run.pipe, "timer", None)
     if tm is not None and tm.on and rank == 0:
         print("stage ms/step:", {k: round(v / args.steps * 1e3, 2) for k, v in tm.acc.items()}, file=sys.stderr, flush=True)
@@ -228,7 +257,7 @@ def main():
                                    f"T={args.frames} frames, random seeded weights",
                        "clips_per_gpu": args.clips, "frames_per_clip": args.frames, "frames_per_step": world * args.clips,
                        "detections_last_step": n_det,
-                       "tracked_instances_mean": round(run.tracked_sum / max(run.tracked_steps, 1), 1),
+                       "tracked_instances_mean": tracked_mean,
                        "parallelism": f"clip-dp{world}", "cpu_binding": binding,
                        "hbm_reserved_gb_after_timed_region": round(torch.cuda.memory_reserved(dev) / 1e9, 1),
                        "pipeline": args.pipeline + (f"+next-trunk-overlap-{args.overlap}" if (run.batched and args.overlap != "off") else "")
@@ -256,32 +285,10 @@ def main():
                                  "last_gather_equals_local_block": (bool(torch.equal(out[rank * args.clips:(rank + 1) * args.clips], coll_local))
                                                                     if coll_local is not None else None)}
         default_wl = args.clips == DEFAULT_CLIPS and args.config == "STMask_plus_resnet50_config" and args.planes == "fp16x2"
-        fused_t = getattr(run, "fused_t", None) or []
         f_ms = f_fl = 0.0
         if fused_t:
             tr_f, src_f, why_f = rf.pmc_traffic("dcn_fused", len(fused_t) / args.steps) if default_wl else (None, None, "not the profiled workload")
             res["roofline_dcn_fused"], f_ms, f_fl = rf.dcn_fused_roofline(fused_t, args.steps, tr_f, src_f, why_f)
-        im2col_in = None
-        if fused_t and not timing and not args.no_sampler_pass:
-            # the sampler the north star names did not run in that pass (every DCN layer took the fused kernel): its own figure from a short eager
-            # pass of the same pipeline with fusion switched off (same process, right after; nothing of it enters the headline)
-            from stmask_amd import planar as _plf
-            saved_mt, saved_g = _plf.DCN_FUSED_MIN_TILES, (run.pipe.use_graph if run.batched else None)
-            _plf.DCN_FUSED_MIN_TILES = 1 << 30
-            if run.batched:
-                run.pipe.use_graph = False
-            try:
-                early_s = run.batched and run.pipe.prefetch_early
-                if early_s:
-                    run.pipe.prefetch_early = False
-                _, _, timing, _ = run.timed(1, min(args.steps, 8), use_dist, collect=True)
-                if early_s:
-                    run.pipe.prefetch_early = True
-            finally:
-                _plf.DCN_FUSED_MIN_TILES = saved_mt
-                if run.batched:
-                    run.pipe.use_graph = saved_g
-            im2col_in = "a short eager pass with STM_DCN_FUSED off right after the timed region (the timed region runs the fused kernel: roofline_dcn_fused)"
         n_samp_steps = min(args.steps, 8) if im2col_in else args.steps
         tr_s, src_s, why_s = (rf.pmc_traffic("dcn_sample_planar", len(timing) / n_samp_steps) if (default_wl and planar_graph and timing)
                               else (None, None, "not the profiled workload"))
