@@ -32,3 +32,14 @@ def test_two_ranks_run_the_whole_bench_flow_and_print_one_line():
     assert c["backend"] == "gloo" and c["world_size"] == 2 and c["gathered_shape"][0] == 4 and c["last_gather_equals_local_block"] is True
     assert "roofline" in d and d["roofline_im2col"]["launches"] > 0            # the sampler pass ran (on BOTH ranks) and rank 0 reported it
     assert "extras" not in d and "cpu_baseline" not in d                       # N = 1 only
+
+
+def test_bench_as_typed_with_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2 ...` without a launcher: the parent (which touches no GPU API) starts the two ranks as a child process and relays rank 0's line."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--clips", "1", "--steps", "3", "--warmup", "2"]
+    out = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "clip-dp2" and d["collective"]["world_size"] == 2
