@@ -320,6 +320,7 @@ class BatchedClipPipeline:
             self._graph_warm += 1
             return net.forward_single(frames)
         if len(self._graphs) < self.n_graph_slots:
+            reserved0 = torch.cuda.memory_reserved(frames.device)
             static_in = frames.clone(memory_format=torch.preserve_format)
             graph = torch.cuda.CUDAGraph()
             ws = {}
@@ -335,6 +336,21 @@ class BatchedClipPipeline:
                 with torch.cuda.graph(graph, stream=cap):
                     out = net.forward_single(static_in)
             cur.wait_stream(cap)
+            if not self._graphs:
+                # every slot keeps a private pool the size of a trunk's activations (~8 GB at 32 clips of 384x640): before the ring is built, make sure
+                # the other 2 D + 1 slots fit beside what the process holds -- else this pipeline keeps the eager trunk (one frame of look-ahead)
+                slot_bytes = max(torch.cuda.memory_reserved(frames.device) - reserved0, 0)
+                free = torch.cuda.mem_get_info(frames.device)[0] + torch.cuda.memory_reserved(frames.device) - torch.cuda.memory_allocated(frames.device)
+                if (self.n_graph_slots - 1) * slot_bytes > 0.9 * free:
+                    import sys
+                    sys.stderr.write(f"stmask_amd: {self.n_graph_slots} trunk-graph slots of {slot_bytes / 1e9:.1f} GB do not fit in {free / 1e9:.1f} GB of free HBM: "
+                                     "this pipeline keeps the eager trunk\n")
+                    del graph, out, static_in
+                    self._graph_ws.pop()
+                    self.use_graph = False
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                    return net.forward_single(frames)
             self._graphs.append((static_in, graph, out))
             self._graph_planes = planes
             self.graph_active = True

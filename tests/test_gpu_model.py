@@ -447,3 +447,28 @@ def test_detection_gather_stream_is_not_a_trunk_stream():
     assert all(comm != s for s in sides) and comm != torch.cuda.current_stream(dev)
     # asking for the trunk streams again (a second pipeline in the process) returns the same ones, still without the gather's
     assert concurrent_side_streams(dev, trunk_stream_count()) == sides
+
+
+def test_trunk_graph_ring_is_not_built_when_it_would_not_fit(monkeypatch, capsys):
+    """Every trunk-graph slot keeps a private pool of a trunk's activations; when the 2 D + 1 further slots would not fit in the free HBM the pipeline says so once
+    and keeps the eager trunk -- same results."""
+    from stmask_amd.pipeline import BatchedClipPipeline
+    from stmask_amd.fuse import optimize_for_inference
+    net = build("STMask_plus_resnet50_config")
+    optimize_for_inference(net, planar=True)
+    net = net.to(memory_format=torch.channels_last)
+    net.TemporalNet = net.TemporalNet.to(memory_format=torch.contiguous_format)
+    T = 6
+    clips = torch.stack([synthetic.synthetic_clip(T, 128, 192, seed=s) for s in (0, 5)]).cuda()
+    frames = [clips[:, t].contiguous(memory_format=torch.channels_last) for t in range(T)]
+    eager, tight = BatchedClipPipeline(net, 2), BatchedClipPipeline(net, 2)
+    tight.use_graph = True
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (-(1 << 50), 1 << 38))          # "no free memory at all"
+    for t in range(T):
+        nxt = [frames[u] for u in range(t + 1, min(t + 3, T))] or None
+        ya = eager.step(frames[t], is_first=(t == 0), next_frames=nxt[0] if nxt else None).clone()
+        yb = tight.step(frames[t], is_first=(t == 0), next_frames=nxt).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), t
+    assert not tight.use_graph and not tight.graph_active and tight._graphs == [] and tight._graph_ws == []
+    assert "do not fit" in capsys.readouterr().err
