@@ -43,16 +43,12 @@ def e2e_block(args, dev, net, cap, steps, warmup=3):
     pipe = BatchedClipPipeline(net, clips)
     pipe.max_instances = cap or 0
     pipe.prefetch_early = args.overlap == "early"
-    # as the headline: the trunk replayed from HIP graphs, the trunks of the next two frames in flight (their pre-processing runs two frames ahead)
-    pipe.use_graph = getattr(args, "graph", "auto") != "off" and args.fuse and args.planar and args.channels_last
-    if pipe.use_graph:
-        warmup = max(warmup, pipe.n_graph_slots + 3)          # the slots are captured lazily, one per trunk call after two eager ones
     thr = net.cfg.eval_conf_thresh
     acc = {"pre": 0.0, "step": 0.0, "keep": 0.0, "rle": 0.0, "host": 0.0}
     n_masks = n_bytes = 0
     tracked_sum = 0.0
     crop_h = crop_w = 0
-    ahead = [pre(0), pre(1)]
+    x_next = pre(0)
     torch.cuda.synchronize()
     t0 = None
     for t in range(warmup + steps):
@@ -61,10 +57,9 @@ def e2e_block(args, dev, net, cap, steps, warmup=3):
             t0 = time.perf_counter()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
-        x = ahead.pop(0)
-        ahead.append(pre(t + 2))
+        x, x_next = x_next, pre(t + 1)
         ev[1].record()
-        pipe.step(x, is_first=(t % T == 0), next_frames=list(ahead) if args.overlap != "off" else None)
+        pipe.step(x, is_first=(t % T == 0), next_frames=x_next if args.overlap != "off" else None)
         ev[2].record()
         prev = pipe.prev
         n = 0
